@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- columnSums over a 1e9-nnz CSC dgCMatrix on N MI355X GPUs.
+
+Contract (one JSON line from rank 0):
+    python bench.py --gpus N --steps K --warmup W
+    N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+               --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one columnSums pass over the whole matrix: the hot path of reference
+src/example.cpp:26-32, here `rsp_column_sums_device` (hand-written HIP, called
+through the C ABI of include/rcppsparse_hip.h) on inputs already resident in HBM.
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 1e7 x 1e6,
+nnz = 1e9, uniform ("rsparsematrix-like") -- synthetic, seeded, generated in HBM.
+With N > 1 the SAME matrix is split into N nnz-balanced contiguous column ranges
+(strong scaling: total work fixed), each rank sums its range, and the per-rank
+slices are gathered to rank 0 with an RCCL gatherv over xGMI inside every step.
+
+`value` = nnz of the whole matrix x K / wall time of the K steps (max over ranks).
+`roofline.achieved` = algorithmic bytes of one launch (8 B/nnz + 12 B/column,
+SURVEY.md 8d; i[] is never read) / mean launch duration from HIP events recorded
+on the launch stream around every launch of the timed region.
+`cpu_baseline` = the oracle (1-thread C restatement of the reference loop) timed
+on this box's host on a bounded prefix of the same matrix (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+SEED = 42
+
+WORKLOADS = {
+    # name: (nrow, ncol, nnz, shape)
+    "c2": (1_000_000, 1_000_000, 10_000_000, "uniform"),
+    "c3": (10_000_000, 1_000_000, 1_000_000_000, "uniform"),
+    "c5": (10_000_000, 1_000_000, 1_000_000_000, "zipf"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--nnz", type=int, default=0, help="override nnz (experiments)")
+    ap.add_argument("--kind", type=int, default=0, help="0 signed two-decimal, 1 U(0,1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk-rows", type=int, default=0)
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` typed by hand: start the N ranks as a child."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def build_offsets(name, nnz_override):
+    from rcppsparse_amd import synth
+    nrow, ncol, nnz, shape = WORKLOADS[name]
+    if nnz_override:
+        nnz = nnz_override
+    if shape == "uniform":
+        counts = synth.uniform_counts(ncol, nnz, SEED, nrow)
+    else:
+        counts = synth.zipf_counts(ncol, nnz, SEED, nrow)
+    return nrow, ncol, nnz, shape, synth.offsets_from_counts(counts)
+
+
+def cpu_baseline(p, kind, target_nnz=200_000_000, reps=5):
+    """Oracle (kind "port": restatement of reference src/example.cpp:26-32), 1 thread,
+    on a prefix of the same matrix: the first columns holding ~target_nnz nonzeros."""
+    import numpy as np
+    import oracle
+    ncol_s = int(np.searchsorted(p, target_nnz, side="right")) - 1
+    ncol_s = max(1, min(ncol_s, len(p) - 1))
+    nnz_s = int(p[ncol_s])
+    x = oracle.gen_values(nnz_s, SEED, 0, kind)
+    ps = np.ascontiguousarray(p[:ncol_s + 1])
+    oracle.column_sums(x, ps)            # warm-up
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.column_sums(x, ps)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": nnz_s / med, "unit": "nnz/s", "cores": 1, "kind": "port",
+        "sample": f"first {ncol_s} columns ({nnz_s} nnz) of the same matrix, "
+                  f"{reps} reps, median; best {nnz_s / times[0]:.3e} nnz/s; host has {os.cpu_count()} cpus",
+    }
+
+
+def parity_spot_check(got, p, kind, first_idx=0, ncheck=400):
+    """A few column ranges of the result vs the oracle (outside the timed region)."""
+    import numpy as np
+    import oracle
+    ncol = len(p) - 1
+    worst = 0.0
+    for c0 in sorted({0, ncol // 2, max(0, ncol - ncheck)}):
+        c1 = min(ncol, c0 + ncheck)
+        lo, hi = int(p[c0]), int(p[c1])
+        xs = oracle.gen_values(hi - lo, SEED, first_idx + lo, kind)
+        pl = (p[c0:c1 + 1] - lo).astype(np.int32)
+        ref = oracle.column_sums(xs, pl)
+        scale = np.maximum(oracle.column_abs_sums(xs, pl), 1e-300)
+        worst = max(worst, float(np.max(np.abs(got[c0:c1] - ref) / scale)))
+    return worst
+
+
+def traffic_from_profiles(workload):
+    """HBM bytes per launch from the committed PMC passes (profiles/*traffic*.json)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("workload") == workload:
+                best = d.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rcppsparse_amd import capi, sharded
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    capi.load()
+    capi.set_tuning(args.chunk_rows)
+
+    nrow, ncol, nnz, shape, p = build_offsets(args.workload, args.nnz)
+    shard = sharded.make_shard(p, rank, world)
+    counts, displs = sharded.gather_layout(shard.bounds)
+
+    # inputs resident in HBM before anything is timed
+    xt = torch.empty(shard.nnz, dtype=torch.float64, device=dev)
+    capi.gen_values_device(xt, SEED, shard.x0, args.kind)
+    pt = torch.from_numpy(shard.p_local).to(dev)
+    out_local = torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=dev)[:shard.ncol]
+    ws = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
+    recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None
+    comm = None
+    if world > 1:
+        uid = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+
+    def step(ev_a=None, ev_b=None):
+        if ev_a is not None:
+            ev_a.record()
+        capi.column_sums_device(xt, pt, out_local, ws)
+        if ev_b is not None:
+            ev_b.record()
+        if comm is not None:
+            comm.gatherv(out_local, recv, counts, displs, 0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(*ev[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    stats = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_max = float(stats[0]), float(stats[1])
+
+    result = None
+    if rank == 0:
+        full = (recv if world > 1 else out_local).cpu().numpy()
+        worst = parity_spot_check(full, p, args.kind)
+        if not worst <= 1e-12:
+            raise SystemExit(f"parity spot check failed: max |gpu-ref|/sum|x| = {worst:.3e}")
+        # the launch rank 0 timed processed its own shard
+        algo_bytes = 8 * shard.nnz + 4 * (shard.ncol + 1) + 8 * shard.ncol
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        value = nnz * args.steps / elapsed
+        result = {
+            "metric": "columnSums nnz/s + achieved HBM GB/s vs roofline, 1e9-nnz CSC at 1/2/4/8 GPUs",
+            "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, "
+                            f"values kind {args.kind}, seed {SEED}",
+                "parallelism": ("single GPU" if world == 1 else
+                                f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0"),
+                "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
+                "chunk_rows": args.chunk_rows,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
+                "kernel": "colsums_chunks_kernel (+ colsums_fixup_kernel)",
+                "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+            "parity": {"max_abs_err_over_l1": worst, "tolerance": 1e-12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(p, args.kind)
+        elif world == 1:
+            result["cpu_baseline"] = None
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

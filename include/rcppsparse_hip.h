@@ -1,0 +1,165 @@
+/*
+ * rcppsparse_hip.h -- C ABI of librcppsparse_hip.so (MI355X / gfx950).
+ *
+ * This is the device boundary inserted *inside* the reference's columnSums:
+ * everything above it (R wrapper, Rcpp glue, RcppSparse::Matrix, the Exporter)
+ * keeps its shape; the double loop of reference src/example.cpp:28-30, which
+ * drives Matrix::InnerIterator (reference inst/include/RcppSparse.h:218-233)
+ * over the dgCMatrix slots x / p, is replaced by one call below.
+ *
+ * Rules of the boundary:
+ *   - plain C types only; no Rcpp / R / torch types; no exceptions cross it;
+ *   - every entry point returns an int status (RSP_OK == 0); the text of the
+ *     last failure on the calling thread is rsp_last_error();
+ *   - host pointers are *borrowed* for the duration of one call and never
+ *     retained or freed; handles own device copies only;
+ *   - output buffers are allocated by the caller (the Rcpp side allocates the
+ *     NumericVector on the R main thread before calling in);
+ *   - no entry point calls any R API; all are safe to call sequentially from
+ *     one thread; they return only when `out` is completely written (host
+ *     variants) or when the work is enqueued on `stream` (device variants);
+ *   - there is NO CPU fallback in this library: with no usable HIP device the
+ *     compute entry points fail with RSP_ERR_NO_DEVICE.
+ *
+ * Index types follow the reference: p[] and i[] are 32-bit int
+ * (RcppSparse.h:30, :232), so nnz <= 2^31-1; byte offsets are 64-bit inside.
+ * Contract on p (what Matrix::dgCMatrix guarantees and the reference assumes
+ * without checking): p[0] == 0, p non-decreasing, p[ncol] == nnz.  The host
+ * entry points verify this and return RSP_ERR_BAD_ARG otherwise; the device
+ * entry points trust the caller (their reads and writes stay in bounds for
+ * any p, but the sums are then unspecified).
+ */
+#ifndef RCPPSPARSE_HIP_H
+#define RCPPSPARSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSP_OK              0
+#define RSP_ERR_NO_DEVICE   1   /* no HIP device / runtime unusable            */
+#define RSP_ERR_BAD_ARG     2   /* null pointer, negative size, invalid p[]    */
+#define RSP_ERR_HIP         3   /* a HIP runtime call failed                   */
+#define RSP_ERR_WORKSPACE   4   /* workspace too small                         */
+#define RSP_ERR_RCCL        5   /* an RCCL call failed                         */
+#define RSP_ERR_ALLOC       6   /* host or device allocation failed            */
+
+/* ---- library / device queries ------------------------------------------ */
+
+/* "rcppsparse_hip <semver> gfx950". */
+const char *rsp_version(void);
+/* Message of the last non-OK status returned on this thread ("" if none). */
+const char *rsp_last_error(void);
+/* Number of visible HIP devices; 0 (and RSP_OK) when there are none. */
+int rsp_device_count(int *count);
+
+/* ---- one-shot path: replaces reference src/example.cpp:28-30 ------------ */
+/*
+ * sums[c] = sum_{j = p[c]}^{p[c+1]-1} x[j]   for c in [0, ncol)
+ * x: REAL(A@x), p: INTEGER(A@p) (host memory, borrowed), ncol = A@Dim[1]
+ * (RcppSparse.h:45 cols()), nnz = length(A@x) (RcppSparse.h:48 n_nonzero()).
+ * `sums` is the caller-allocated NumericVector storage of example.cpp:27 (it
+ * need not be zero-filled).  Uploads x and p to `device`, runs the segmented
+ * sum there, copies the ncol doubles back.  i[] is not needed: the reference
+ * never reads it on this path (RcppSparse.h:227 row() is not called).
+ */
+int rsp_column_sums_host(const double *x, const int32_t *p, int32_t ncol,
+                         int64_t nnz, double *sums, int device);
+
+/* ---- device-resident dgCMatrix handle (upload once, sum many) ---------- */
+/* The slot layout x / i / p / Dim of reference RcppSparse.h:29-30 is the wire
+ * format; i may be NULL (it is only kept for the row-wise "next" entries). */
+typedef struct rsp_csc *rsp_csc_t;
+
+int rsp_csc_upload(const double *x, const int32_t *i, const int32_t *p,
+                   int32_t nrow, int32_t ncol, int64_t nnz, int device,
+                   rsp_csc_t *handle);
+/* columnSums on the resident copy; `sums` is host memory, ncol doubles. */
+int rsp_csc_column_sums(rsp_csc_t handle, double *sums);
+/* Matrix::colMeans (RcppSparse.h:145-150): column sums divided by Dim[0]. */
+int rsp_csc_column_means(rsp_csc_t handle, double *means);
+int rsp_csc_free(rsp_csc_t handle);
+
+/* ---- device-pointer path (inputs already in HBM) ----------------------- */
+/*
+ * Same computation on device pointers; everything is enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream) and nothing
+ * synchronises.  d_x must be 16-byte aligned.  d_workspace is scratch of at
+ * least rsp_column_sums_workspace_bytes(ncol, nnz) bytes, 16-byte aligned; it
+ * carries no state between calls.  Graph-capture safe (no allocation, no
+ * synchronisation inside).
+ */
+size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz);
+int rsp_column_sums_device(const double *d_x, const int32_t *d_p, int32_t ncol,
+                           int64_t nnz, double *d_sums, void *d_workspace,
+                           size_t workspace_bytes, void *stream);
+/* As above, then sums[c] /= nrow (RcppSparse.h:145-150), fused in the same
+ * launches. */
+int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
+                            int32_t ncol, int64_t nnz, double *d_means,
+                            void *d_workspace, size_t workspace_bytes,
+                            void *stream);
+/*
+ * Measurement helper: enqueue `reps` back-to-back rsp_column_sums_device calls
+ * on `stream`, bracketed by hipEvents recorded on that same stream, wait for
+ * the last, and return the mean milliseconds per call in *ms_per_call.
+ */
+int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
+                                 int32_t ncol, int64_t nnz, double *d_sums,
+                                 void *d_workspace, size_t workspace_bytes,
+                                 void *stream, int reps, float *ms_per_call);
+
+/* ---- column-range partitioner (multi-GPU; pure integer, host) ---------- */
+/*
+ * nnz-balanced contiguous column ranges: bounds[k] = first column c with
+ * p[c] >= k*nnz/nparts (k = 1..nparts-1), bounds[0] = 0, bounds[nparts] = ncol.
+ * No column is split.  Part k owns columns [bounds[k], bounds[k+1]) and the
+ * x range [p[bounds[k]], p[bounds[k+1]]).  p is host memory.
+ */
+int rsp_partition_columns(const int32_t *p, int32_t ncol, int32_t nparts,
+                          int32_t *bounds);
+/* p_local[j] = p[c0 + j] - p[c0] for j in [0, c1-c0] (rebased shard offsets). */
+int rsp_rebase_offsets(const int32_t *p, int32_t c0, int32_t c1, int32_t *p_local);
+
+/* ---- RCCL gatherv of per-shard sums over xGMI -------------------------- */
+/* One communicator per process (one process per GPU).  The 128-byte unique id
+ * is created on rank 0 and distributed by the caller (e.g. a torch.distributed
+ * broadcast or a file), then every rank calls rsp_comm_init. */
+#define RSP_UNIQUE_ID_BYTES 128
+typedef struct rsp_comm *rsp_comm_t;
+
+int rsp_comm_unique_id(void *id_bytes);
+int rsp_comm_init(const void *id_bytes, int nranks, int rank, int device,
+                  rsp_comm_t *comm);
+/*
+ * Gather counts[r] doubles from every rank r into d_recv + displs[r] on `root`
+ * (grouped ncclSend / ncclRecv; RCCL has no native gatherv).  d_recv, counts
+ * and displs are only read on root (counts/displs are host arrays of nranks
+ * entries); other ranks pass their own send_count.  Enqueued on `stream`.
+ */
+int rsp_comm_gatherv(rsp_comm_t comm, const double *d_send, int64_t send_count,
+                     double *d_recv, const int64_t *counts, const int64_t *displs,
+                     int root, void *stream);
+int rsp_comm_destroy(rsp_comm_t comm);
+
+/* ---- synthetic inputs (bench / tests) ---------------------------------- */
+/*
+ * d_x[k] = value(seed, first_idx + k) for k in [0, n): a counter-based
+ * generator using integer arithmetic only, so any slice can be regenerated
+ * bit-identically on the host.  kind 0: signed two-decimal values in
+ * [-5.10, 5.10] ("rsparsematrix-like"); kind 1: U(0,1), all positive.
+ */
+int rsp_gen_values_device(double *d_x, int64_t n, uint64_t seed,
+                          uint64_t first_idx, int kind, void *stream);
+
+/* ---- tuning knobs (experiments; defaults are chosen per problem size) --- */
+/* chunk_rows: 128-element rows of x owned by one wavefront (0 = automatic). */
+int rsp_set_tuning(int chunk_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCPPSPARSE_HIP_H */

@@ -1,0 +1,162 @@
+"""oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement of RcppSparse's ``columnSums`` hot path (reference
+``src/example.cpp:26-32`` driving ``Matrix::InnerIterator``,
+``inst/include/RcppSparse.h:218-233``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  Nothing under ``rcppsparse_amd/`` imports it.
+
+Parity status: **unpinned by the reference's own tests** (it has none for this
+path).  Pinned here by the one reference-derived known
+answer (``vignettes/Documentation.Rmd:213-216``) plus a SciPy cross-check of
+the restatement; see ``tests/test_oracle.py`` and ``tests/golden/``.
+
+Two restatements are provided:
+
+* ``column_sums`` etc. -- ctypes into ``liboracle.so`` (C, ``-O2``, no
+  fast-math), the one used for anything bigger than toy sizes and as the timed
+  CPU baseline (1 thread: the reference path has no OpenMP);
+* ``column_sums_py`` -- a pure-Python loop for tiny cases, an independent
+  second transcription of the same seven lines.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with the committed Makefile (gcc, no fast-math)."""
+    src = os.path.join(_HERE, "colsums_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        try:
+            build()
+        except Exception:
+            # no compiler / read-only tree (GPU box): use the prebuilt file
+            if not os.path.exists(_LIB_PATH):
+                raise
+        L = ctypes.CDLL(_LIB_PATH)
+        dp = ctypes.POINTER(ctypes.c_double)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        i32, u64 = ctypes.c_int32, ctypes.c_uint64
+        L.oracle_column_sums.argtypes = [dp, ip, ip, i32, i32, dp]
+        L.oracle_col_sums.argtypes = [dp, ip, i32, dp]
+        L.oracle_col_means.argtypes = [dp, ip, i32, i32, dp]
+        L.oracle_row_sums.argtypes = [dp, ip, ip, i32, i32, dp]
+        L.oracle_row_means.argtypes = [dp, ip, ip, i32, i32, dp]
+        L.oracle_column_abs_sums.argtypes = [dp, ip, i32, dp]
+        L.oracle_gen_values.argtypes = [dp, u64, u64, u64, ctypes.c_int]
+        L.oracle_gen_value.argtypes = [u64, u64, ctypes.c_int]
+        L.oracle_gen_value.restype = ctypes.c_double
+        for f in ("oracle_column_sums", "oracle_col_sums", "oracle_col_means",
+                  "oracle_row_sums", "oracle_row_means", "oracle_column_abs_sums",
+                  "oracle_gen_values"):
+            getattr(L, f).restype = None
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def _prep(x, p, i=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    if i is not None:
+        i = np.ascontiguousarray(i, dtype=np.int32)
+    return x, p, i
+
+
+def column_sums(x, p, ncol=None, i=None, nrow=0) -> np.ndarray:
+    """example.cpp:26-32 via the InnerIterator restatement.  ``i`` is never read."""
+    x, p, i = _prep(x, p, i)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    ii = _ip(i) if i is not None else ctypes.POINTER(ctypes.c_int32)()
+    lib().oracle_column_sums(_dp(x), ii, _ip(p), int(nrow), ncol, _dp(out))
+    return out
+
+
+def col_sums(x, p, ncol=None) -> np.ndarray:
+    """RcppSparse.h:131-137."""
+    x, p, _ = _prep(x, p)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    lib().oracle_col_sums(_dp(x), _ip(p), ncol, _dp(out))
+    return out
+
+
+def col_means(x, p, nrow, ncol=None) -> np.ndarray:
+    """RcppSparse.h:145-150."""
+    x, p, _ = _prep(x, p)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    lib().oracle_col_means(_dp(x), _ip(p), int(nrow), ncol, _dp(out))
+    return out
+
+
+def row_sums(x, i, p, nrow, ncol=None) -> np.ndarray:
+    """RcppSparse.h:138-144."""
+    x, p, i = _prep(x, p, i)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(int(nrow), dtype=np.float64)
+    lib().oracle_row_sums(_dp(x), _ip(i), _ip(p), int(nrow), ncol, _dp(out))
+    return out
+
+
+def row_means(x, i, p, nrow, ncol=None) -> np.ndarray:
+    """RcppSparse.h:151-156."""
+    x, p, i = _prep(x, p, i)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(int(nrow), dtype=np.float64)
+    lib().oracle_row_means(_dp(x), _ip(i), _ip(p), int(nrow), ncol, _dp(out))
+    return out
+
+
+def column_abs_sums(x, p, ncol=None) -> np.ndarray:
+    """Per-column 1-norm: the scale of the 1e-12 tolerance."""
+    x, p, _ = _prep(x, p)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    lib().oracle_column_abs_sums(_dp(x), _ip(p), ncol, _dp(out))
+    return out
+
+
+def column_sums_py(x, p, ncol=None):
+    """Pure-Python second transcription of example.cpp:26-32 (tiny inputs only)."""
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    sums = [0.0] * ncol                      # NumericVector sums(A.cols())
+    for col in range(ncol):                  # for (col = 0; col < A.cols(); ++col)
+        index, max_index = int(p[col]), int(p[col + 1])   # InnerIterator ctor
+        while index < max_index:             # operator bool
+            sums[col] += float(x[index])     # sums(col) += it.value()
+            index += 1                       # ++it
+    return np.array(sums, dtype=np.float64)
+
+
+def gen_values(n, seed, first_idx=0, kind=0) -> np.ndarray:
+    """Counter-based synthetic x[]; bit-identical to the device generator."""
+    out = np.empty(int(n), dtype=np.float64)
+    lib().oracle_gen_values(_dp(out), int(n), int(seed), int(first_idx), int(kind))
+    return out

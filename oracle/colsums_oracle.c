@@ -1,0 +1,143 @@
+/*
+ * oracle/colsums_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the RcppSparse column-iteration hot path, over raw
+ * pointers instead of Rcpp vectors.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; the product path
+ * (rcppsparse_amd/csrc) never links or calls it.
+ *
+ * PARITY PINNING: the reference ships no tests, golden vectors or fixtures for
+ * columnSums, and it cannot be compiled here (needs
+ * Rcpp/R headers that the image lacks), so there is no oracle/_ref build.  The
+ * only reference-derived known answer is the literal 5x5 matrix printed in
+ * vignettes/Documentation.Rmd:213-216; everything else is pinned by this
+ * restatement cross-checked against SciPy.  => "parity unpinned" by the
+ * reference's own tests; pinned by KAT + SciPy cross-check only.
+ *
+ * Build: see oracle/Makefile.  Must be compiled WITHOUT -ffast-math /
+ * -fassociative-math so the adds stay sequential, one rounding per add.
+ *
+ * What is restated (reference file:line):
+ *   src/example.cpp:26-32                 columnSums()
+ *   inst/include/RcppSparse.h:218-233     Matrix::InnerIterator
+ *   inst/include/RcppSparse.h:44-48       rows()/cols()/n_nonzero()
+ *   inst/include/RcppSparse.h:131-137     Matrix::colSums()   (same sums, no iterator)
+ *   inst/include/RcppSparse.h:145-150     Matrix::colMeans()
+ *   inst/include/RcppSparse.h:138-144     Matrix::rowSums()   (scatter form; "next" row f1)
+ *   inst/include/RcppSparse.h:151-156     Matrix::rowMeans()
+ */
+#include <stddef.h>
+#include <stdint.h>
+
+/* A dgCMatrix seen as raw slots (RcppSparse.h:29-30: x, i, p, Dim). */
+typedef struct {
+    const double  *x;
+    const int32_t *i;
+    const int32_t *p;
+    int32_t        dim[2];
+} oracle_csc;
+
+/* RcppSparse.h:218-233 -- const column cursor; all state is 32-bit int (:232). */
+typedef struct {
+    const oracle_csc *m;
+    int32_t col_, index, max_index;
+} oracle_inner_it;
+
+static void it_begin(oracle_inner_it *it, const oracle_csc *m, int32_t col) {
+    /* :220  index(ptr.p[col]), max_index(ptr.p[col + 1]) */
+    it->m = m;
+    it->col_ = col;
+    it->index = m->p[col];
+    it->max_index = m->p[col + 1];
+}
+static int it_valid(const oracle_inner_it *it) { return it->index < it->max_index; } /* :221 */
+static void it_next(oracle_inner_it *it) { ++it->index; }                             /* :222-225 */
+static double it_value(const oracle_inner_it *it) { return it->m->x[it->index]; }     /* :226 */
+
+/*
+ * src/example.cpp:26-32.  `sums` plays the zero-filled NumericVector(A.cols())
+ * of :27; the double loop is :28-30; accumulation is a plain `+=` into
+ * sums[col] in ascending storage order starting from +0.0.
+ */
+void oracle_column_sums(const double *x, const int32_t *i, const int32_t *p,
+                        int32_t nrow, int32_t ncol, double *sums) {
+    oracle_csc A = {x, i, p, {nrow, ncol}};
+    uint32_t cols = (uint32_t)A.dim[1]; /* RcppSparse.h:45 cols() -> unsigned int */
+    for (size_t col = 0; col < cols; ++col) sums[col] = 0.0; /* example.cpp:27 */
+    for (size_t col = 0; col < cols; ++col) {                /* example.cpp:28 */
+        oracle_inner_it it;
+        for (it_begin(&it, &A, (int32_t)col); it_valid(&it); it_next(&it)) /* :29 */
+            sums[col] += it_value(&it);                                     /* :30 */
+    }
+}
+
+/* RcppSparse.h:131-137 -- same reduction, direct p/x loop with int indices. */
+void oracle_col_sums(const double *x, const int32_t *p, int32_t ncol, double *sums) {
+    for (int32_t col = 0; col < ncol; ++col) sums[col] = 0.0;
+    for (int32_t col = 0; col < ncol; ++col)
+        for (int32_t j = p[col]; j < p[col + 1]; ++j)
+            sums[col] += x[j];
+}
+
+/* RcppSparse.h:145-150 -- colSums() then divide each by Dim[0]. */
+void oracle_col_means(const double *x, const int32_t *p, int32_t nrow, int32_t ncol,
+                      double *means) {
+    oracle_col_sums(x, p, ncol, means);
+    for (int32_t c = 0; c < ncol; ++c) means[c] = means[c] / nrow;
+}
+
+/* RcppSparse.h:138-144 -- scatter-add by row index, column-major visiting order. */
+void oracle_row_sums(const double *x, const int32_t *i, const int32_t *p,
+                     int32_t nrow, int32_t ncol, double *sums) {
+    for (int32_t r = 0; r < nrow; ++r) sums[r] = 0.0;
+    for (int32_t col = 0; col < ncol; ++col)
+        for (int32_t j = p[col]; j < p[col + 1]; ++j)
+            sums[i[j]] += x[j];
+}
+
+/* RcppSparse.h:151-156 -- rowSums() then divide each by Dim[1]. */
+void oracle_row_means(const double *x, const int32_t *i, const int32_t *p,
+                      int32_t nrow, int32_t ncol, double *means) {
+    oracle_row_sums(x, i, p, nrow, ncol, means);
+    for (int32_t r = 0; r < nrow; ++r) means[r] = means[r] / ncol;
+}
+
+/*
+ * Per-column 1-norms, Sum_j |x_j|: the scale of the parity tolerance
+ * (|gpu - ref| <= 1e-12 * Sum|x|).  Not in the reference.
+ */
+void oracle_column_abs_sums(const double *x, const int32_t *p, int32_t ncol, double *sums) {
+    for (int32_t col = 0; col < ncol; ++col) {
+        double s = 0.0;
+        for (int32_t j = p[col]; j < p[col + 1]; ++j) s += (x[j] < 0 ? -x[j] : x[j]);
+        sums[col] = s;
+    }
+}
+
+/*
+ * Synthetic value generators shared bit-for-bit with the device generator in
+ * rcppsparse_amd/csrc (integer hash -> exactly representable double), so the
+ * host can rebuild any slice of a device-generated x[] without copying it.
+ * splitmix64 finaliser keyed by (seed, global nnz index).
+ *   kind 0: "rsparsematrix-like" signed values with two decimals in [-5.10, 5.10]
+ *           (sum of four 8-bit uniforms, centred, /100 -- a bell-shaped stand-in
+ *           for Matrix::rsparsematrix's rounded rnorm default)
+ *   kind 1: all-positive U(0,1) with 53 random bits
+ */
+static uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+double oracle_gen_value(uint64_t seed, uint64_t idx, int kind) {
+    uint64_t h = mix64(seed * 0xD1342543DE82EF95ull + idx);
+    if (kind == 1) return (double)(h >> 11) * 0x1.0p-53;
+    int s = (int)(h & 255) + (int)((h >> 8) & 255) + (int)((h >> 16) & 255) + (int)((h >> 24) & 255);
+    return (double)(s - 510) / 100.0;
+}
+
+void oracle_gen_values(double *x, uint64_t n, uint64_t seed, uint64_t first_idx, int kind) {
+    for (uint64_t k = 0; k < n; ++k) x[k] = oracle_gen_value(seed, first_idx + k, kind);
+}

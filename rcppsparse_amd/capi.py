@@ -1,0 +1,274 @@
+"""ctypes binding of ``include/rcppsparse_hip.h`` (librcppsparse_hip.so).
+
+This is plumbing for tests, ``bench.py`` and the multi-GPU driver: the product
+is the C ABI itself (what an Rcpp ``columnSums`` would call, see
+INTEGRATION.md).  torch is used only as the owner of device memory and streams;
+no torch type crosses the ABI -- tensors are passed as raw ``data_ptr()``.
+
+There is no CPU fallback here: if the library is missing or no HIP device is
+usable, calls raise ``RspError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+RSP_OK = 0
+RSP_ERR_NO_DEVICE = 1
+RSP_ERR_BAD_ARG = 2
+RSP_ERR_HIP = 3
+RSP_ERR_WORKSPACE = 4
+RSP_ERR_RCCL = 5
+RSP_ERR_ALLOC = 6
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/rcppsparse_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTED_SYMBOLS = (
+    "rsp_version", "rsp_last_error", "rsp_device_count",
+    "rsp_column_sums_host",
+    "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
+    "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
+    "rsp_column_sums_device_timed",
+    "rsp_partition_columns", "rsp_rebase_offsets",
+    "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
+    "rsp_gen_values_device", "rsp_set_tuning",
+)
+
+
+class RspError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rcppsparse_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load(build: bool = True) -> ctypes.CDLL:
+    """dlopen librcppsparse_hip.so (building it first when hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch ships its own libamdhip64 / librccl with the same sonames; importing it
+    # first makes this library share that one HIP runtime (so tensor pointers and
+    # streams are valid on both sides).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for pure-host use
+        pass
+    path = _build.LIB_PATH
+    if build and _build.have_hipcc():
+        try:
+            _build.build_library()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    if not os.path.exists(path):
+        raise RspError(RSP_ERR_NO_DEVICE, f"{path} is missing and cannot be built (no hipcc)")
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    c = ctypes
+    dp, ip = c.POINTER(c.c_double), c.POINTER(c.c_int32)
+    vp, i32, i64, u64 = c.c_void_p, c.c_int32, c.c_int64, c.c_uint64
+    L.rsp_version.restype = c.c_char_p
+    L.rsp_last_error.restype = c.c_char_p
+    L.rsp_device_count.argtypes = [c.POINTER(c.c_int)]
+    L.rsp_column_sums_host.argtypes = [dp, ip, i32, i64, dp, c.c_int]
+    L.rsp_csc_upload.argtypes = [dp, ip, ip, i32, i32, i64, c.c_int, c.POINTER(vp)]
+    L.rsp_csc_column_sums.argtypes = [vp, dp]
+    L.rsp_csc_column_means.argtypes = [vp, dp]
+    L.rsp_csc_free.argtypes = [vp]
+    L.rsp_column_sums_workspace_bytes.argtypes = [i32, i64]
+    L.rsp_column_sums_workspace_bytes.restype = c.c_size_t
+    L.rsp_column_sums_device.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp]
+    L.rsp_column_means_device.argtypes = [vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
+    L.rsp_column_sums_device_timed.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp, c.c_int,
+                                               c.POINTER(c.c_float)]
+    L.rsp_partition_columns.argtypes = [ip, i32, i32, ip]
+    L.rsp_rebase_offsets.argtypes = [ip, i32, i32, ip]
+    L.rsp_comm_unique_id.argtypes = [vp]
+    L.rsp_comm_init.argtypes = [vp, c.c_int, c.c_int, c.c_int, c.POINTER(vp)]
+    L.rsp_comm_gatherv.argtypes = [vp, vp, i64, vp, c.POINTER(i64), c.POINTER(i64), c.c_int, vp]
+    L.rsp_comm_destroy.argtypes = [vp]
+    L.rsp_gen_values_device.argtypes = [vp, i64, u64, u64, c.c_int, vp]
+    L.rsp_set_tuning.argtypes = [c.c_int]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != RSP_OK:
+        raise RspError(rc, load().rsp_last_error().decode("utf-8", "replace"))
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _ip(a):
+    if a is None:
+        return ctypes.POINTER(ctypes.c_int32)()
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def version() -> str:
+    return load().rsp_version().decode()
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    _check(load().rsp_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def set_tuning(chunk_rows: int = 0) -> None:
+    _check(load().rsp_set_tuning(int(chunk_rows)))
+
+
+# ---------------------------------------------------------------- host paths
+def column_sums_host(x, p, ncol=None, device: int = 0) -> np.ndarray:
+    """One-shot host->device->host columnSums (what the Rcpp columnSums calls)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    _check(load().rsp_column_sums_host(_dp(x), _ip(p), ncol, x.size, _dp(out), device))
+    return out
+
+
+class DeviceCSC:
+    """Device-resident dgCMatrix (slots x / i / p / Dim): upload once, sum many."""
+
+    def __init__(self, x, p, dim, i=None, device: int = 0):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.int32)
+        i = None if i is None else np.ascontiguousarray(i, dtype=np.int32)
+        self.nrow, self.ncol = int(dim[0]), int(dim[1])
+        self.nnz = int(x.size)
+        self._h = ctypes.c_void_p()
+        _check(load().rsp_csc_upload(_dp(x), _ip(i), _ip(p), self.nrow, self.ncol, self.nnz,
+                                     device, ctypes.byref(self._h)))
+
+    def column_sums(self) -> np.ndarray:
+        out = np.empty(self.ncol, dtype=np.float64)
+        _check(load().rsp_csc_column_sums(self._h, _dp(out)))
+        return out
+
+    def column_means(self) -> np.ndarray:
+        out = np.empty(self.ncol, dtype=np.float64)
+        _check(load().rsp_csc_column_means(self._h, _dp(out)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            load().rsp_csc_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# -------------------------------------------------------------- device paths
+def _stream_ptr(stream=None):
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def workspace_bytes(ncol: int, nnz: int) -> int:
+    return int(load().rsp_column_sums_workspace_bytes(int(ncol), int(nnz)))
+
+
+def alloc_workspace(ncol: int, nnz: int, device="cuda"):
+    import torch
+    return torch.empty(workspace_bytes(ncol, nnz), dtype=torch.uint8, device=device)
+
+
+def column_sums_device(x_t, p_t, out_t=None, workspace=None, stream=None, nrow_for_means=None):
+    """columnSums on torch-owned HBM buffers; enqueued on the current torch stream."""
+    import torch
+    assert x_t.dtype == torch.float64 and p_t.dtype == torch.int32
+    assert x_t.is_cuda and p_t.is_cuda and x_t.is_contiguous() and p_t.is_contiguous()
+    ncol, nnz = p_t.numel() - 1, x_t.numel()
+    if out_t is None:
+        out_t = torch.empty(ncol, dtype=torch.float64, device=x_t.device)
+    if workspace is None:
+        workspace = alloc_workspace(ncol, nnz, x_t.device)
+    L = load()
+    if nrow_for_means is None:
+        _check(L.rsp_column_sums_device(x_t.data_ptr(), p_t.data_ptr(), ncol, nnz, out_t.data_ptr(),
+                                        workspace.data_ptr(), workspace.numel(), _stream_ptr(stream)))
+    else:
+        _check(L.rsp_column_means_device(x_t.data_ptr(), p_t.data_ptr(), int(nrow_for_means), ncol,
+                                         nnz, out_t.data_ptr(), workspace.data_ptr(),
+                                         workspace.numel(), _stream_ptr(stream)))
+    return out_t
+
+
+def column_sums_device_timed(x_t, p_t, out_t, workspace, reps: int, stream=None) -> float:
+    """Mean ms per call, hipEvents recorded on the launch stream inside the library."""
+    ms = ctypes.c_float(0)
+    ncol, nnz = p_t.numel() - 1, x_t.numel()
+    _check(load().rsp_column_sums_device_timed(x_t.data_ptr(), p_t.data_ptr(), ncol, nnz,
+                                               out_t.data_ptr(), workspace.data_ptr(),
+                                               workspace.numel(), _stream_ptr(stream), int(reps),
+                                               ctypes.byref(ms)))
+    return float(ms.value)
+
+
+def gen_values_device(x_t, seed: int, first_idx: int = 0, kind: int = 0, stream=None):
+    _check(load().rsp_gen_values_device(x_t.data_ptr(), x_t.numel(), int(seed), int(first_idx),
+                                        int(kind), _stream_ptr(stream)))
+    return x_t
+
+
+# ------------------------------------------------------------- partitioning
+def partition_columns(p, nparts: int) -> np.ndarray:
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    bounds = np.empty(nparts + 1, dtype=np.int32)
+    _check(load().rsp_partition_columns(_ip(p), len(p) - 1, int(nparts), _ip(bounds)))
+    return bounds
+
+
+def rebase_offsets(p, c0: int, c1: int) -> np.ndarray:
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    out = np.empty(c1 - c0 + 1, dtype=np.int32)
+    _check(load().rsp_rebase_offsets(_ip(p), int(c0), int(c1), _ip(out)))
+    return out
+
+
+# --------------------------------------------------------------------- RCCL
+def comm_unique_id() -> bytes:
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(load().rsp_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One RCCL communicator per process (one process per GPU)."""
+
+    def __init__(self, unique_id: bytes, nranks: int, rank: int, device: int):
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        self.nranks, self.rank = nranks, rank
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        _check(load().rsp_comm_init(buf, nranks, rank, device, ctypes.byref(self._h)))
+
+    def gatherv(self, send_t, recv_t, counts, displs, root: int = 0, stream=None) -> None:
+        n = self.nranks
+        c_arr = (ctypes.c_int64 * n)(*[int(v) for v in counts])
+        d_arr = (ctypes.c_int64 * n)(*[int(v) for v in displs])
+        _check(load().rsp_comm_gatherv(self._h, send_t.data_ptr(), send_t.numel(),
+                                       recv_t.data_ptr() if recv_t is not None else None,
+                                       c_arr, d_arr, root, _stream_ptr(stream)))
+
+    def close(self) -> None:
+        if self._h:
+            load().rsp_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()

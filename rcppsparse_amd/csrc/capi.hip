@@ -1,0 +1,304 @@
+// capi.hip -- the extern "C" shim declared in include/rcppsparse_hip.h.
+//
+// Sits directly under the Rcpp-side columnSums (reference src/example.cpp:26-32):
+// the caller hands over REAL(x), INTEGER(p), ncol, nnz and a pre-allocated
+// output; nothing here knows about R, Rcpp or torch.  No CPU fallback: without
+// a HIP device every compute entry fails with RSP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/rcppsparse_hip.h"
+#include "colsums_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_chunk_rows_override = 0;   // rsp_set_tuning / RSP_CHUNK_ROWS
+
+}  // namespace
+
+namespace rsp {
+// records the message for rsp_last_error() on this thread and returns `code`
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace rsp
+
+namespace {
+using rsp::fail;
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(RSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+int chunk_rows_setting() {
+    if (g_chunk_rows_override > 0) return g_chunk_rows_override;
+    static int env = -1;
+    if (env < 0) {
+        const char* s = getenv("RSP_CHUNK_ROWS");
+        env = s ? atoi(s) : 0;
+        if (env < 0) env = 0;
+    }
+    return env;
+}
+
+// Chunking policy: enough chunks to keep every CU busy with several waves and
+// to let the hardware dispatcher balance the tail, but chunks long enough to
+// amortise the per-chunk column search.  Always a whole number of 128-element
+// rows so every chunk starts 1 KiB-aligned.
+rsp::LaunchPlan make_plan(int64_t nnz) {
+    rsp::LaunchPlan plan;
+    int rows = chunk_rows_setting();
+    if (rows <= 0) {
+        const int64_t total_rows = (nnz + rsp::kRowElems - 1) / rsp::kRowElems;
+        const int64_t target_chunks = 256 * 32;   // 256 CUs x 32 waves
+        int64_t r = (total_rows + target_chunks - 1) / target_chunks;
+        if (r < rsp::kBatchRows) r = rsp::kBatchRows;
+        if (r > 256) r = 256;
+        rows = (int)r;
+    }
+    plan.chunk_elems = rows * rsp::kRowElems;
+    plan.nchunks = nnz > 0 ? (int32_t)((nnz + plan.chunk_elems - 1) / plan.chunk_elems) : 0;
+    return plan;
+}
+
+int check_sizes(int32_t ncol, int64_t nnz) {
+    if (ncol < 0) return fail(RSP_ERR_BAD_ARG, "ncol is negative (%d)", ncol);
+    if (nnz < 0 || nnz > INT32_MAX)
+        return fail(RSP_ERR_BAD_ARG,
+                    "nnz = %lld is outside [0, 2^31-1] (p[] is 32-bit, RcppSparse.h:30)",
+                    (long long)nnz);
+    return RSP_OK;
+}
+
+// What Matrix::dgCMatrix validity guarantees and the reference loop assumes.
+int check_offsets_host(const int32_t* p, int32_t ncol, int64_t nnz) {
+    if (p[0] != 0) return fail(RSP_ERR_BAD_ARG, "p[0] = %d, expected 0", p[0]);
+    int bad = 0;
+    for (int32_t c = 0; c < ncol; ++c) bad |= (p[c + 1] < p[c]);
+    if (bad) return fail(RSP_ERR_BAD_ARG, "p[] is not non-decreasing");
+    if (p[ncol] != nnz)
+        return fail(RSP_ERR_BAD_ARG, "p[ncol] = %d but nnz = %lld", p[ncol], (long long)nnz);
+    return RSP_OK;
+}
+
+int require_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_NO_DEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= n)
+        return fail(RSP_ERR_BAD_ARG, "device %d out of range [0, %d)", device, n);
+    return RSP_OK;
+}
+
+int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out,
+            void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (ncol == 0) return RSP_OK;
+    if (!d_p || !d_out || (nnz > 0 && !d_x))
+        return fail(RSP_ERR_BAD_ARG, "null device pointer");
+    if (((uintptr_t)d_x & 15) != 0)
+        return fail(RSP_ERR_BAD_ARG, "d_x must be 16-byte aligned");
+    const rsp::LaunchPlan plan = make_plan(nnz);
+    const size_t need = rsp::workspace_bytes_for(plan.nchunks);
+    if (nnz > 0 && (!d_ws || ws_bytes < need))
+        return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+    HIP_TRY(rsp::launch_column_sums(d_x, d_p, ncol, (int32_t)nnz, d_out, plan, d_ws, divisor, means,
+                                    stream));
+    return RSP_OK;
+}
+
+}  // namespace
+
+struct rsp_csc {
+    int device;
+    int32_t nrow, ncol;
+    int64_t nnz;
+    double* d_x;
+    int32_t* d_i;
+    int32_t* d_p;
+    double* d_out;
+    void* d_ws;
+    size_t ws_bytes;
+    hipStream_t stream;
+};
+
+extern "C" {
+
+const char* rsp_version(void) { return "rcppsparse_hip 0.1.0 gfx950"; }
+
+const char* rsp_last_error(void) { return g_err; }
+
+int rsp_device_count(int* count) {
+    if (!count) return fail(RSP_ERR_BAD_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return RSP_OK;
+}
+
+int rsp_set_tuning(int chunk_rows) {
+    if (chunk_rows < 0) return fail(RSP_ERR_BAD_ARG, "chunk_rows is negative");
+    g_chunk_rows_override = chunk_rows;
+    return RSP_OK;
+}
+
+size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz) {
+    (void)ncol;
+    if (nnz <= 0 || nnz > INT32_MAX) return 256;
+    // sized for the chunking in force now; changing rsp_set_tuning afterwards to
+    // smaller chunks makes the launch fail with RSP_ERR_WORKSPACE, never overrun
+    return rsp::workspace_bytes_for(make_plan(nnz).nchunks);
+}
+
+int rsp_column_sums_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,
+                           double* d_sums, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return enqueue(d_x, d_p, ncol, nnz, d_sums, d_workspace, workspace_bytes, 1.0, false,
+                   (hipStream_t)stream);
+}
+
+int rsp_column_means_device(const double* d_x, const int32_t* d_p, int32_t nrow, int32_t ncol,
+                            int64_t nnz, double* d_means, void* d_workspace, size_t workspace_bytes,
+                            void* stream) {
+    return enqueue(d_x, d_p, ncol, nnz, d_means, d_workspace, workspace_bytes, (double)nrow, true,
+                   (hipStream_t)stream);
+}
+
+int rsp_column_sums_device_timed(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,
+                                 double* d_sums, void* d_workspace, size_t workspace_bytes,
+                                 void* stream, int reps, float* ms_per_call) {
+    if (reps <= 0 || !ms_per_call) return fail(RSP_ERR_BAD_ARG, "reps <= 0 or null result");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = RSP_OK;
+    hipError_t he = hipEventRecord(e0, s);
+    for (int r = 0; r < reps && rc == RSP_OK && he == hipSuccess; ++r)
+        rc = enqueue(d_x, d_p, ncol, nnz, d_sums, d_workspace, workspace_bytes, 1.0, false, s);
+    if (he == hipSuccess) he = hipEventRecord(e1, s);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != RSP_OK) return rc;
+    if (he != hipSuccess) return fail(RSP_ERR_HIP, "timing failed: %s", hipGetErrorString(he));
+    *ms_per_call = ms / (float)reps;
+    return RSP_OK;
+}
+
+int rsp_gen_values_device(double* d_x, int64_t n, uint64_t seed, uint64_t first_idx, int kind,
+                          void* stream) {
+    if (n < 0 || (n > 0 && !d_x)) return fail(RSP_ERR_BAD_ARG, "bad buffer");
+    if (kind != 0 && kind != 1) return fail(RSP_ERR_BAD_ARG, "kind must be 0 or 1");
+    HIP_TRY(rsp::launch_gen_values(d_x, n, seed, first_idx, kind, (hipStream_t)stream));
+    return RSP_OK;
+}
+
+// ---- device-resident dgCMatrix -------------------------------------------
+
+int rsp_csc_free(rsp_csc_t h) {
+    if (!h) return RSP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->d_x) (void)hipFree(h->d_x);
+    if (h->d_i) (void)hipFree(h->d_i);
+    if (h->d_p) (void)hipFree(h->d_p);
+    if (h->d_out) (void)hipFree(h->d_out);
+    if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RSP_OK;
+}
+
+int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t nrow, int32_t ncol,
+                   int64_t nnz, int device, rsp_csc_t* handle) {
+    if (!handle) return fail(RSP_ERR_BAD_ARG, "handle is null");
+    *handle = nullptr;
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
+    if (!p || (nnz > 0 && !x)) return fail(RSP_ERR_BAD_ARG, "x or p is null");
+    if (int rc = check_offsets_host(p, ncol, nnz)) return rc;
+    if (int rc = require_device(device)) return rc;
+    HIP_TRY(hipSetDevice(device));
+
+    rsp_csc* h = new (std::nothrow) rsp_csc();
+    if (!h) return fail(RSP_ERR_ALLOC, "out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    h->nrow = nrow;
+    h->ncol = ncol;
+    h->nnz = nnz;
+    h->ws_bytes = rsp_column_sums_workspace_bytes(ncol, nnz);
+    // x is padded to a whole 16-byte pair so the device copy never ends mid-load
+    const size_t xbytes = ((size_t)nnz * 8 + 15) & ~(size_t)15;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_x, xbytes ? xbytes : 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_p, ((size_t)ncol + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, ncol ? (size_t)ncol * 8 : 8);
+    if (e == hipSuccess) e = hipMalloc(&h->d_ws, h->ws_bytes);
+    if (e == hipSuccess && i && nnz > 0) e = hipMalloc((void**)&h->d_i, (size_t)nnz * 4);
+    if (e == hipSuccess && nnz > 0)
+        e = hipMemcpyAsync(h->d_x, x, (size_t)nnz * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h->d_p, p, ((size_t)ncol + 1) * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && h->d_i)
+        e = hipMemcpyAsync(h->d_i, i, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);   // host buffers are only borrowed
+    if (e != hipSuccess) {
+        rsp_csc_free(h);
+        return fail(RSP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    }
+    *handle = h;
+    return RSP_OK;
+}
+
+static int csc_run(rsp_csc_t h, double* host_out, bool means) {
+    if (!h || !host_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->ncol == 0) return RSP_OK;
+    if (int rc = enqueue(h->d_x, h->d_p, h->ncol, h->nnz, h->d_out, h->d_ws, h->ws_bytes,
+                         means ? (double)h->nrow : 1.0, means, h->stream))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(host_out, h->d_out, (size_t)h->ncol * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RSP_OK;
+}
+
+int rsp_csc_column_sums(rsp_csc_t h, double* sums) { return csc_run(h, sums, false); }
+int rsp_csc_column_means(rsp_csc_t h, double* means) { return csc_run(h, means, true); }
+
+int rsp_column_sums_host(const double* x, const int32_t* p, int32_t ncol, int64_t nnz, double* sums,
+                         int device) {
+    if (!sums && ncol > 0) return fail(RSP_ERR_BAD_ARG, "sums is null");
+    rsp_csc_t h = nullptr;
+    if (int rc = rsp_csc_upload(x, nullptr, p, 0, ncol, nnz, device, &h)) return rc;
+    const int rc = rsp_csc_column_sums(h, sums);
+    rsp_csc_free(h);
+    return rc;
+}
+
+}  // extern "C"

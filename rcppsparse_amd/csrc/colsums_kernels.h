@@ -1,0 +1,37 @@
+// colsums_kernels.h -- shared constants and launcher prototypes (internal).
+#ifndef RSP_COLSUMS_KERNELS_H
+#define RSP_COLSUMS_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsp {
+
+constexpr int kRowElems = 128;    // one wave instruction: 64 lanes x 16 B = 128 doubles
+constexpr int kBatchRows = 16;    // rows (1 KiB loads) kept in flight per wavefront
+constexpr int kWavesPerWG = 4;    // independent wavefronts per workgroup
+constexpr int kPWin = 256;        // p[] entries staged in LDS per wavefront
+constexpr int kHistPad = 132;     // 129 histogram slots, padded to a 16-byte multiple
+constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed once)
+
+// How a column-sum call is cut into chunks (one wavefront each).
+struct LaunchPlan {
+    int32_t chunk_elems;   // multiple of kRowElems
+    int32_t nchunks;       // ceil(nnz / chunk_elems), >= 1 when nnz > 0
+};
+
+inline size_t workspace_bytes_for(int32_t nchunks) {
+    // carry_head[nchunks] + carry_tail[nchunks] (double) + carry_info[nchunks] (int2)
+    size_t b = (size_t)nchunks * (8 + 8 + 8);
+    return (b + 255) & ~(size_t)255;
+}
+
+hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t nnz,
+                              double* d_out, const LaunchPlan& plan, void* d_workspace,
+                              double divisor, bool means, hipStream_t stream);
+
+hipError_t launch_gen_values(double* d_x, int64_t n, uint64_t seed, uint64_t first_idx, int kind,
+                             hipStream_t stream);
+
+}  // namespace rsp
+#endif

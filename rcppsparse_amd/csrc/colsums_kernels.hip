@@ -1,0 +1,435 @@
+// colsums_kernels.hip -- CDNA4 (gfx950) segmented column-sum kernels.
+//
+// Replaces the double loop of reference src/example.cpp:28-30 (one
+// Matrix::InnerIterator per column, reference inst/include/RcppSparse.h:218-233):
+//
+//     sums[c] = sum_{j = p[c]}^{p[c+1]-1} x[j]
+//
+// Design (MI355X-first):
+//   * The unit of work is a *chunk* of x[] (a fixed number of 128-element rows),
+//     not a set of columns, so skewed column lengths cannot unbalance the chip.
+//     One wavefront owns one chunk and streams it with 16-byte-per-lane
+//     buffer loads (1 KiB per wave instruction), BATCH_ROWS of them always in
+//     flight in a rolling register pipeline.  i[] is never read.
+//   * Column offsets p[] are staged per wave in an LDS window; a second small
+//     LDS histogram turns the offsets that fall inside one 128-element row into
+//     per-element column ranks (this also handles empty columns).
+//   * Rows that contain no column end take the fast path: two v_add_f64 per
+//     lane.  Rows that do contain column ends take a segmented wave scan
+//     (DPP / ds_bpermute lane exchange) and write finished columns directly.
+//   * Columns that cross chunk edges leave a head / tail partial per chunk; a
+//     tiny second kernel adds those in ascending chunk order.  There are no
+//     floating-point atomics anywhere, so results are bit-stable run to run.
+//   * No MFMA: 1 FP64 add per 8 bytes, the bound is HBM bandwidth.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "colsums_kernels.h"
+
+namespace rsp {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// lane-exchange helpers (wave64)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_up_f64(double v, int d) { return __shfl_up(v, d, 64); }
+__device__ __forceinline__ int shfl_up_i32(int v, int d) { return __shfl_up(v, d, 64); }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    // one DPP move per 32-bit half; bound_ctrl = true -> lanes with no source read 0
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over all 64 lanes, returned in every lane.  Fixed tree: bit-stable.
+__device__ __forceinline__ double wave_allreduce_sum(double v) {
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]  : xor 1
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  : xor 2
+    v += dpp_f64<0x141>(v);   // row_half_mirror      : combines the two quads of 8
+    v += dpp_f64<0x140>(v);   // row_mirror           : combines the two halves of 16
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Inclusive prefix sum over the 64 lanes (int).
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = shfl_up_i32(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// per-wave LDS window over p[]
+// ---------------------------------------------------------------------------
+// win[k] = p[min(wbase + k, ncol)] for k in [0, kPWin).  Consumers must check
+// idx <= ncol themselves (entries past ncol repeat p[ncol]).
+__device__ __forceinline__ void fill_window(int32_t* win, const int32_t* __restrict__ p,
+                                            int wbase, int ncol, int lane) {
+    int32_t t[kPWin / 64];
+#pragma unroll
+    for (int j = 0; j < kPWin / 64; ++j) {
+        uint32_t idx = (uint32_t)wbase + (uint32_t)(j * 64 + lane);
+        if (idx > (uint32_t)ncol) idx = (uint32_t)ncol;
+        t[j] = p[idx];
+    }
+    __builtin_amdgcn_wave_barrier();   // earlier reads of the old window stay above
+#pragma unroll
+    for (int j = 0; j < kPWin / 64; ++j) win[j * 64 + lane] = t[j];
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveState {
+    int ccur;            // column that owns the current stream position
+    int qnext;           // p[ccur + 1]  (end of that column); valid iff has_next
+    int wbase;           // p-index of win[0]
+    bool has_next;       // ccur + 1 <= ncol
+    bool head_open;      // no column end seen in this chunk yet
+    bool head_complete;  // the chunk starts exactly at p[c0]
+};
+
+// Make sure win covers p-indices [k, k + need).
+__device__ __forceinline__ void ensure_window(WaveState& st, int32_t* win,
+                                              const int32_t* __restrict__ p, int k, int need,
+                                              int ncol, int lane) {
+    if (k < st.wbase || k + need > st.wbase + kPWin) {
+        st.wbase = k;
+        fill_window(win, p, k, ncol, lane);
+    }
+}
+
+template <bool MEANS>
+__device__ __forceinline__ double finish(double v, double divisor) {
+    v += 0.0;   // a sum of -0.0 terms must come out +0.0 like the reference's 0.0-initialised accumulator
+    if (MEANS) v = v / divisor;   // RcppSparse.h:147-148  sums[i] / Dim[0]
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// slow path: one 128-element row that contains >= 1 column end
+// ---------------------------------------------------------------------------
+// Lane l holds elements e0 = rs + 2l (v0) and e1 = e0 + 1 (v1).  On entry
+// acc0/acc1 are the per-lane partial sums of column st.ccur from earlier rows.
+template <bool MEANS>
+__device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane, WaveState& st,
+                                      double& acc0, double& acc1, int32_t* win, int32_t* hist,
+                                      const int32_t* __restrict__ p, int ncol, int w,
+                                      double* __restrict__ out, double* __restrict__ carry_head,
+                                      double divisor) {
+    // 1. fold the running per-lane partials into the first element of the row
+    const double A = wave_allreduce_sum(acc0 + acc1);
+    if (lane == 0) v0 += A;
+
+    // 2. histogram of column ends q in (rs, rs + 128]:  hist[q - rs]++
+    *(int2*)&hist[2 * lane] = make_int2(0, 0);
+    if (lane == 0) hist[128] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int k = st.ccur + 1;
+    for (;;) {
+        ensure_window(st, win, p, k, 64, ncol, lane);
+        const uint32_t idx = (uint32_t)k + (uint32_t)lane;
+        const bool valid = idx <= (uint32_t)ncol;
+        const int q = win[(valid ? (int)idx : k) - st.wbase];
+        const uint32_t d = (uint32_t)q - (uint32_t)rs;
+        const bool inrow = valid && (d - 1u) < 128u;
+        if (inrow) atomicAdd(&hist[d], 1);
+        const int n = __popcll(__ballot(inrow));
+        k += n;
+        if (n < 64) break;
+    }
+    const int tot = k - (st.ccur + 1);   // column ends in this row
+    __builtin_amdgcn_wave_barrier();
+
+    // 3. rank of each element = number of ends at or before it
+    const int2 h = *(const int2*)&hist[2 * lane];
+    const int S = wave_inclusive_scan_i32(h.x + h.y, lane);
+    const int kR = S;          // rank of e1
+    const int kL = S - h.y;    // rank of e0
+
+    // 4. segmented inclusive scan (key kR) of each lane's open-right part
+    const bool split = kL != kR;              // a column ends between e0 and e1
+    double X = split ? v1 : (v0 + v1);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double Xd = shfl_up_f64(X, d);
+        const int kd = shfl_up_i32(kR, d);
+        if (lane >= d && kd == kR) X += Xd;
+    }
+
+    // 5. finished segments
+    const double Xp = shfl_up_f64(X, 1);
+    const int kp = shfl_up_i32(kR, 1);
+    const double totalL = v0 + ((lane > 0 && kp == kL) ? Xp : 0.0);   // segment ending at e0
+    int kN = __shfl_down(kL, 1, 64);
+    if (lane == 63) kN = tot;
+    const bool endR = kN > kR;                                         // segment ending at e1
+    const int cbase = st.ccur;
+
+    if (split) {
+        const int c = cbase + kL;
+        if (st.head_open && kL == 0) {
+            carry_head[w] = totalL;
+            if (st.head_complete && c < ncol) out[c] = finish<MEANS>(totalL, divisor);
+        } else if (c < ncol) {
+            out[c] = finish<MEANS>(totalL, divisor);
+        }
+    }
+    if (endR) {
+        const int c = cbase + kR;
+        if (st.head_open && kR == 0) {
+            carry_head[w] = X;
+            if (st.head_complete && c < ncol) out[c] = finish<MEANS>(X, divisor);
+        } else if (c < ncol) {
+            out[c] = finish<MEANS>(X, divisor);
+        }
+    }
+
+    // empty columns (rank jumps by more than one): zero-fill, whole wave per gap
+    const int gapL = split ? (kR - kL - 1) : 0;
+    const int gapR = endR ? (kN - kR - 1) : 0;
+    uint64_t mL = __ballot(gapL > 0);
+    uint64_t mR = __ballot(gapR > 0);
+    while (mL) {
+        const int l = __builtin_ctzll(mL);
+        mL &= mL - 1;
+        const int start = __shfl(cbase + kL + 1, l, 64);
+        const int cnt = __shfl(gapL, l, 64);
+        for (int c = lane; c < cnt; c += 64)
+            if (start + c < ncol) out[start + c] = 0.0;
+    }
+    while (mR) {
+        const int l = __builtin_ctzll(mR);
+        mR &= mR - 1;
+        const int start = __shfl(cbase + kR + 1, l, 64);
+        const int cnt = __shfl(gapR, l, 64);
+        for (int c = lane; c < cnt; c += 64)
+            if (start + c < ncol) out[start + c] = 0.0;
+    }
+
+    // 6. carry the open tail of the row and advance the column cursor
+    acc0 = (lane == 63 && !endR) ? X : 0.0;
+    acc1 = 0.0;
+    st.ccur = cbase + tot;
+    st.head_open = false;
+    st.has_next = (uint32_t)k <= (uint32_t)ncol;
+    if (st.has_next) {
+        ensure_window(st, win, p, k, 1, ncol, lane);
+        st.qnext = __builtin_amdgcn_readfirstlane(win[k - st.wbase]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// main kernel: one wavefront per chunk
+// ---------------------------------------------------------------------------
+template <int BATCH_ROWS, bool MEANS>
+__global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel(
+    const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
+    int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
+    double* __restrict__ carry_head, double* __restrict__ carry_tail,
+    int2* __restrict__ carry_info, double divisor) {
+    __shared__ __attribute__((aligned(16))) int32_t s_win[kWavesPerWG][kPWin];
+    __shared__ __attribute__((aligned(16))) int32_t s_hist[kWavesPerWG][kHistPad];
+
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = blockIdx.x * kWavesPerWG + wave_in_wg;   // chunk id (wave-uniform)
+    if (w >= nchunks) return;
+    int32_t* win = s_win[wave_in_wg];
+    int32_t* hist = s_hist[wave_in_wg];
+
+    const int32_t cs = w * chunk_elems;
+    const int64_t ce64 = (int64_t)cs + chunk_elems;
+    const int32_t ce = ce64 < (int64_t)nnz ? (int32_t)ce64 : nnz;
+    const int32_t nrows = (int32_t)(((int64_t)ce - cs + 127) >> 7);
+
+    // wave-uniform buffer descriptor over this chunk of x (hardware bounds check:
+    // reads past the chunk return 0, and a sum is unchanged by extra +0.0 terms)
+    const double* xb = x + cs;
+    const uint32_t xbytes = (uint32_t)(ce - cs) * 8u;
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)xbytes, 0x00020000);
+    const int voff = lane * 16;
+
+    d2 v[BATCH_ROWS];
+#pragma unroll
+    for (int r = 0; r < BATCH_ROWS; ++r)
+        v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, r * 1024, kLoadAux));
+
+    // ---- locate the column that owns element cs: c0 = upper_bound(p, cs) - 1,
+    //      64-ary search (each round one strided load + ballot) -------------
+    int lo = 0, hi = ncol;   // invariant: p[lo] <= cs < p[hi]
+    while (hi - lo > 1) {
+        const int step = (int)(((int64_t)hi - lo + 63) >> 6);
+        const int64_t j = (int64_t)lo + (int64_t)(lane + 1) * step;
+        const bool valid = j < hi;
+        const int pv = p[valid ? j : hi];
+        const bool le = valid && pv <= cs;
+        const int n = __popcll(__ballot(le));
+        const int64_t nlo = (int64_t)lo + (int64_t)n * step;
+        const int64_t nhi = nlo + step;
+        lo = (int)nlo;
+        hi = nhi < hi ? (int)nhi : hi;
+    }
+    const int c0 = lo;
+
+    // leading empty columns (p[c+1] == 0) belong to chunk 0
+    if (w == 0)
+        for (int c = lane; c < c0; c += 64) out[c] = 0.0;
+
+    WaveState st;
+    st.ccur = c0;
+    st.wbase = c0;
+    fill_window(win, p, c0, ncol, lane);
+    st.head_open = true;
+    st.head_complete = __builtin_amdgcn_readfirstlane(win[0]) >= cs;
+    st.has_next = c0 + 1 <= ncol;
+    st.qnext = __builtin_amdgcn_readfirstlane(win[1]);
+
+    double acc0 = 0.0, acc1 = 0.0;
+    const int nbatches = (nrows + BATCH_ROWS - 1) / BATCH_ROWS;
+    for (int b = 0; b < nbatches; ++b) {
+#pragma unroll
+        for (int r = 0; r < BATCH_ROWS; ++r) {
+            const int row = b * BATCH_ROWS + r;
+            if (row < nrows) {
+                const int rs = cs + row * kRowElems;
+                const uint32_t dq = (uint32_t)st.qnext - (uint32_t)rs;
+                if (st.has_next && (dq - 1u) < 128u) {
+                    slow_row<MEANS>(v[r].x, v[r].y, rs, lane, st, acc0, acc1, win, hist, p, ncol, w,
+                                    out, carry_head, divisor);
+                } else {
+                    acc0 += v[r].x;
+                    acc1 += v[r].y;
+                }
+            }
+            // refill this register pair with the same row of the next batch:
+            // BATCH_ROWS loads stay in flight for the whole chunk
+            v[r] = __builtin_bit_cast(
+                d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, kLoadAux));
+        }
+    }
+
+    const double T = wave_allreduce_sum(acc0 + acc1);
+    if (lane == 0) {
+        if (st.head_open) {
+            carry_head[w] = T;
+            carry_tail[w] = 0.0;
+        } else {
+            carry_tail[w] = T;
+        }
+        carry_info[w] = make_int2(c0, st.ccur - c0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fix-up: columns that cross chunk edges, summed in ascending chunk order
+// ---------------------------------------------------------------------------
+template <bool MEANS>
+__global__ __launch_bounds__(256) void colsums_fixup_kernel(
+    const int32_t* __restrict__ p, int32_t ncol, int32_t chunk_elems, int32_t nchunks,
+    double* __restrict__ out, const double* __restrict__ carry_head,
+    const double* __restrict__ carry_tail, const int2* __restrict__ carry_info, double divisor) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nchunks) return;
+    const int2 inf = carry_info[w];
+    if (inf.y == 0) return;             // no column ends in chunk w
+    const int c = inf.x;
+    if (c >= ncol) return;
+    const int pc = p[c];
+    if (pc >= w * chunk_elems) return;  // the head column started in this chunk: already written
+    const int ts = pc / chunk_elems;    // chunk holding the column's first element
+    double acc = (pc == ts * chunk_elems) ? carry_head[ts] : carry_tail[ts];
+    for (int t = ts + 1; t <= w; ++t) acc += carry_head[t];
+    out[c] = finish<MEANS>(acc, divisor);
+}
+
+// nnz == 0: every column is empty
+__global__ void colsums_zero_kernel(double* __restrict__ out, int32_t ncol) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncol) out[c] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic values (bench / tests); mirrors oracle_gen_value bit for bit
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void gen_values_kernel(double* __restrict__ x, int64_t n, uint64_t seed,
+                                  uint64_t first_idx, int kind) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const uint64_t h = mix64(seed * 0xD1342543DE82EF95ull + (first_idx + (uint64_t)k));
+        double val;
+        if (kind == 1) {
+            val = (double)(h >> 11) * 0x1.0p-53;
+        } else {
+            const int s = (int)(h & 255) + (int)((h >> 8) & 255) + (int)((h >> 16) & 255) +
+                          (int)((h >> 24) & 255);
+            val = (double)(s - 510) / 100.0;
+        }
+        x[k] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t nnz,
+                              double* d_out, const LaunchPlan& plan, void* d_workspace,
+                              double divisor, bool means, hipStream_t stream) {
+    if (ncol <= 0) return hipSuccess;
+    if (nnz <= 0) {
+        hipLaunchKernelGGL(colsums_zero_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_out,
+                           ncol);
+        return hipGetLastError();
+    }
+    char* ws = (char*)d_workspace;
+    double* carry_head = (double*)ws;
+    double* carry_tail = carry_head + plan.nchunks;
+    int2* carry_info = (int2*)(carry_tail + plan.nchunks);
+    const dim3 grid((plan.nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
+    if (means)
+        hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, true>), grid, block, 0, stream, d_x, d_p,
+                           ncol, nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail,
+                           carry_info, divisor);
+    else
+        hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false>), grid, block, 0, stream, d_x, d_p,
+                           ncol, nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail,
+                           carry_info, divisor);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const dim3 fgrid((plan.nchunks + 255) / 256), fblock(256);
+    if (means)
+        hipLaunchKernelGGL((colsums_fixup_kernel<true>), fgrid, fblock, 0, stream, d_p, ncol,
+                           plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info,
+                           divisor);
+    else
+        hipLaunchKernelGGL((colsums_fixup_kernel<false>), fgrid, fblock, 0, stream, d_p, ncol,
+                           plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info,
+                           divisor);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_values(double* d_x, int64_t n, uint64_t seed, uint64_t first_idx, int kind,
+                             hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(gen_values_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_x, n, seed,
+                       first_idx, kind);
+    return hipGetLastError();
+}
+
+}  // namespace rsp

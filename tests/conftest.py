@@ -1,0 +1,31 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(f))[0]
+                  for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return {n: load_golden(n) for n in golden_names()}

@@ -1,0 +1,294 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI of include/rcppsparse_hip.h, against the oracle (CPU restatement of
+reference src/example.cpp:26-32) on the same seeded inputs.
+
+Bar (BASELINE.json north_star / SURVEY.md 8d):
+  * integer side -- output length, column boundaries, empty columns: bit-exact
+    (an empty column is exactly +0.0);
+  * FP64 sums: |gpu - ref| <= 1e-12 * sum_j |x_j| per column, and on the
+    all-positive variant plain |gpu - ref| <= 1e-12 * |ref|;
+  * bit-identical run to run (no float atomics).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_names, load_golden
+from rcppsparse_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12   # the tolerance north_star states, relative to the column's 1-norm
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked tests need a GPU: the HIP path has no CPU fallback")
+    capi.load()
+    yield torch
+    capi.set_tuning(0)
+
+
+def assert_parity(got, x, p, positive=False):
+    ref = oracle.column_sums(x, p)
+    assert got.shape == ref.shape and got.dtype == np.float64
+    scale = oracle.column_abs_sums(x, p)
+    finite = np.isfinite(ref) & np.isfinite(scale)
+    err = np.abs(got[finite] - ref[finite])
+    assert np.all(err <= RTOL * scale[finite]), float((err / np.maximum(scale[finite], 1e-300)).max())
+    # non-finite columns: same class (NaN stays NaN, +-Inf keeps its sign)
+    nf = ~finite
+    assert np.array_equal(np.isnan(got[nf]), np.isnan(ref[nf]))
+    inf = nf & ~np.isnan(ref)
+    assert np.array_equal(got[inf], ref[inf])
+    # empty columns are exactly +0.0
+    empty = np.diff(p) == 0
+    assert np.all(got[empty] == 0.0) and not np.any(np.signbit(got[empty]))
+    # a column whose terms are all zeros (of either sign) is +0.0 like the reference
+    zero_ref = finite & (scale == 0.0)
+    assert not np.any(np.signbit(got[zero_ref]))
+    if positive:
+        assert np.all(np.abs(got - ref) <= RTOL * np.abs(ref))
+
+
+def dev_colsums(torch, x, p, **kw):
+    xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+    pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int32)).cuda()
+    if xt.numel() == 0:
+        xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
+    out = capi.column_sums_device(xt, pt, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+# ------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_all_three_entry_points(torch_cuda, name):
+    g = load_golden(name)
+    x, p, dim = g["x"], g["p"], g["Dim"]
+    positive = "positive" in name
+    host = capi.column_sums_host(x, p, int(dim[1]))
+    assert_parity(host, x, p, positive)
+    h = capi.DeviceCSC(x, p, dim, i=g["i"])
+    resident = h.column_sums()
+    assert_parity(resident, x, p, positive)
+    means = h.column_means()
+    h.close()
+    dev = dev_colsums(torch_cuda, x, p)
+    assert_parity(dev, x, p, positive)
+    # same kernel, same chunking -> identical bits through every entry point
+    assert host.tobytes() == resident.tobytes() == dev.tobytes()
+    if dim[0] > 0:
+        want = resident / dim[0]          # RcppSparse.h:147-148 divides the sums
+        same = (means == want) | (np.isnan(means) & np.isnan(want))
+        assert np.all(same)
+
+
+def test_kat_vignette_matches_reference_bits(torch_cuda):
+    # columns this short are summed in storage order on the GPU too: exact bits
+    g = load_golden("kat_vignette")
+    got = capi.column_sums_host(g["x"], g["p"])
+    assert [float.hex(float(v)) for v in got] == [
+        "0x0.0p+0", "0x1.a3d70a3d70a3dp-2", "0x1.6666666666666p-2",
+        "0x1.35c28f5c28f5cp+0", "0x1.0a3d70a3d70a4p-2"]
+
+
+# -------------------------------------------------------- column-length regimes
+REGIMES = [
+    # (label, ncol, mean nnz/col)
+    ("short3", 20000, 3),
+    ("short10", 30000, 10),       # BASELINE C2 regime
+    ("mid100", 5000, 100),
+    ("long1000", 900, 1000),      # BASELINE C3 regime
+    ("long5000", 150, 5000),
+    ("sparse_cols", 50000, 0.2),  # most columns empty
+]
+
+
+@pytest.mark.parametrize("label,ncol,mean", REGIMES)
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("chunk_rows", [0, 1, 3, 64])
+def test_uniform_regimes(torch_cuda, label, ncol, mean, kind, chunk_rows):
+    nnz = int(ncol * mean)
+    counts = synth.uniform_counts(ncol, nnz, seed=sum(map(ord, label)), nrow=None)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(nnz, seed=7, kind=kind)
+    capi.set_tuning(chunk_rows)
+    try:
+        got = dev_colsums(torch_cuda, x, p)
+    finally:
+        capi.set_tuning(0)
+    assert_parity(got, x, p, positive=(kind == 1))
+
+
+@pytest.mark.parametrize("order", ["shuffled", "descending"])
+@pytest.mark.parametrize("chunk_rows", [0, 2, 16])
+def test_zipf_skew(torch_cuda, order, chunk_rows):
+    counts = synth.zipf_counts(20000, 3_000_001, seed=5, nrow=400_000, order=order)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=9, kind=1)
+    capi.set_tuning(chunk_rows)
+    try:
+        got = dev_colsums(torch_cuda, x, p)
+    finally:
+        capi.set_tuning(0)
+    assert_parity(got, x, p, positive=True)
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("nnz", [1, 2, 3, 127, 128, 129, 255, 256, 257, 2047, 2048, 2049, 4097, 70001])
+@pytest.mark.parametrize("ncol", [1, 2, 7])
+def test_sizes_around_row_and_chunk_edges(torch_cuda, nnz, ncol):
+    rng = np.random.default_rng(nnz * 31 + ncol)
+    cuts = np.sort(rng.integers(0, nnz + 1, size=ncol - 1)) if ncol > 1 else np.array([], dtype=np.int64)
+    p = np.concatenate([[0], cuts, [nnz]]).astype(np.int32)
+    x = synth.gen_values(nnz, seed=nnz, kind=0)
+    for rows in (0, 1):
+        capi.set_tuning(rows)
+        try:
+            got = dev_colsums(torch_cuda, x, p)
+        finally:
+            capi.set_tuning(0)
+        assert_parity(got, x, p)
+
+
+def test_column_ends_exactly_on_row_and_chunk_edges(torch_cuda):
+    # every column is a whole number of 128-element rows; chunk = 1 row
+    counts = np.array([128, 256, 0, 128, 384, 0, 0, 128, 2048, 128], dtype=np.int64)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=3, kind=1)
+    for rows in (1, 2, 16):
+        capi.set_tuning(rows)
+        try:
+            got = dev_colsums(torch_cuda, x, p)
+        finally:
+            capi.set_tuning(0)
+        assert_parity(got, x, p, positive=True)
+
+
+def test_leading_trailing_and_runs_of_empty_columns(torch_cuda):
+    counts = np.concatenate([np.zeros(300), [5], np.zeros(1000), [700, 1], np.zeros(129), [64],
+                             np.zeros(5000)]).astype(np.int64)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=4, kind=0)
+    got = dev_colsums(torch_cuda, x, p)
+    assert_parity(got, x, p)
+
+
+def test_all_empty_and_zero_columns(torch_cuda):
+    p = np.zeros(1001, dtype=np.int32)
+    got = dev_colsums(torch_cuda, np.array([], dtype=np.float64), p)
+    assert got.shape == (1000,) and np.all(got == 0.0) and not np.any(np.signbit(got))
+    assert capi.column_sums_host(np.array([], dtype=np.float64), np.zeros(1, dtype=np.int32)).shape == (0,)
+
+
+def test_nonfinite_values_do_not_leak_between_columns(torch_cuda):
+    counts = np.full(200, 37, dtype=np.int64)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=6, kind=0)
+    x[p[10]] = np.nan
+    x[p[50] + 3] = np.inf
+    x[p[51] - 1] = -np.inf         # same column as +inf -> NaN
+    x[p[90] + 1] = -np.inf
+    got = dev_colsums(torch_cuda, x, p)
+    assert_parity(got, x, p)
+    assert np.isnan(got[10]) and np.isnan(got[50]) and got[90] == -np.inf
+    assert np.isfinite(np.delete(got, [10, 50, 90])).all()
+
+
+def test_bit_stable_run_to_run(torch_cuda):
+    torch = torch_cuda
+    counts = synth.zipf_counts(5000, 2_000_000, seed=1, nrow=300_000)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=2, kind=0)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    first = capi.column_sums_device(xt, pt).cpu().numpy().tobytes()
+    for _ in range(5):
+        assert capi.column_sums_device(xt, pt).cpu().numpy().tobytes() == first
+
+
+def test_device_generator_matches_oracle_bits(torch_cuda):
+    torch = torch_cuda
+    for kind in (0, 1):
+        t = torch.empty(100_003, dtype=torch.float64, device="cuda")
+        capi.gen_values_device(t, seed=42, first_idx=999_999_999_000, kind=kind)
+        torch.cuda.synchronize()
+        want = oracle.gen_values(100_003, 42, 999_999_999_000, kind)
+        assert t.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_workspace_too_small_is_an_error_not_an_overrun(torch_cuda):
+    torch = torch_cuda
+    xt = torch.ones(100_000, dtype=torch.float64, device="cuda")
+    pt = torch.tensor([0, 100_000], dtype=torch.int32, device="cuda")
+    ws = torch.empty(8, dtype=torch.uint8, device="cuda")
+    with pytest.raises(capi.RspError) as e:
+        capi.column_sums_device(xt, pt, workspace=ws)
+    assert e.value.code == capi.RSP_ERR_WORKSPACE
+
+
+# ---------------------------------------------------- BASELINE C2 at full size
+def test_c2_full_size_against_oracle(torch_cuda):
+    """1e6 x 1e6, nnz 1e7 uniform (BASELINE config 2): whole matrix vs the oracle."""
+    torch = torch_cuda
+    ncol, nnz = 1_000_000, 10_000_000
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=42, nrow=1_000_000))
+    for kind in (0, 1):
+        xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+        capi.gen_values_device(xt, seed=42, kind=kind)
+        got = capi.column_sums_device(xt, torch.from_numpy(p).cuda()).cpu().numpy()
+        x = oracle.gen_values(nnz, 42, 0, kind)
+        assert_parity(got, x, p, positive=(kind == 1))
+
+
+# ------------------------------------- BASELINE C3 at full size: properties
+@pytest.mark.parametrize("shape", ["uniform", "zipf"])
+def test_c3_full_size_properties(torch_cuda, shape):
+    """1e7 x 1e6, nnz 1e9 (BASELINE configs 3 and 5, one GPU).  x (8 GB) is generated
+    in HBM; the oracle checks column ranges whose x slices are regenerated on the
+    host from the same counter-based generator, plus size-independent properties:
+    checksum of checksums, exact linearity under x -> 2x, bit-stability."""
+    torch = torch_cuda
+    nrow, ncol, nnz = 10_000_000, 1_000_000, 1_000_000_000
+    if torch.cuda.get_device_properties(0).total_memory < 24 * 2**30:
+        pytest.skip("needs >= 24 GB of HBM")
+    if shape == "uniform":
+        counts = synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow)
+    else:
+        counts = synth.zipf_counts(ncol, nnz, seed=42, nrow=nrow)
+    p = synth.offsets_from_counts(counts)
+    assert p[-1] == nnz
+    pt = torch.from_numpy(p).cuda()
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    capi.gen_values_device(xt, seed=42, kind=1)
+    ws = capi.alloc_workspace(ncol, nnz)
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    capi.column_sums_device(xt, pt, out, ws)
+    got = out.cpu().numpy()
+
+    # (1) oracle on column ranges spread over the matrix (incl. both ends and the longest column)
+    longest = int(np.argmax(counts))
+    starts = sorted({0, ncol // 3, (2 * ncol) // 3, ncol - 600, max(0, min(longest - 1, ncol - 3))})
+    for c0 in starts:
+        c1 = min(ncol, c0 + (3 if c0 == max(0, min(longest - 1, ncol - 3)) else 600))
+        lo, hi = int(p[c0]), int(p[c1])
+        xs = oracle.gen_values(hi - lo, 42, lo, 1)
+        pl = (p[c0:c1 + 1] - lo).astype(np.int32)
+        ref = oracle.column_sums(xs, pl)
+        assert np.all(np.abs(got[c0:c1] - ref) <= RTOL * np.abs(ref)), (shape, c0)
+    # (2) empty columns exact; length exact
+    assert got.shape == (ncol,)
+    assert np.all(got[counts == 0] == 0.0)
+    # (3) checksum of checksums: sum of column sums == sum of x (all positive -> tight)
+    total = float(torch.sum(xt).item())
+    assert abs(float(np.sum(got)) - total) <= 1e-10 * total
+    # (4) bit-stable
+    out2 = torch.empty_like(out)
+    capi.column_sums_device(xt, pt, out2, ws)
+    assert torch.equal(out, out2)
+    # (5) exact linearity: scaling by 2 is exact in binary floating point
+    xt.mul_(2.0)
+    capi.column_sums_device(xt, pt, out2, ws)
+    assert torch.equal(out2, out * 2.0)

@@ -1,0 +1,85 @@
+"""CPU-only: pins the oracle (CPU restatement of reference src/example.cpp:26-32).
+
+The reference holds no golden vectors for columnSums; the pins
+are (1) the literal matrix of reference vignettes/Documentation.Rmd:213-216 with
+hand-derived exact IEEE sums, (2) SciPy as an independent second opinion,
+(3) a pure-Python second transcription of the same loop.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from conftest import golden_names, load_golden
+from rcppsparse_amd import synth
+
+
+def test_kat_vignette_exact_bits():
+    # Documentation.Rmd:213-216: x, i, p, Dim literal; sequential += from +0.0
+    x = [0.41, 0.35, 0.84, 0.37, 0.26]
+    p = [0, 0, 1, 2, 4, 5]
+    got = oracle.column_sums(x, p)
+    want_hex = ["0x0.0p+0", "0x1.a3d70a3d70a3dp-2", "0x1.6666666666666p-2",
+                "0x1.35c28f5c28f5cp+0", "0x1.0a3d70a3d70a4p-2"]
+    assert [float.hex(float(v)) for v in got] == want_hex
+    assert np.array_equal(got, np.array([0.0, 0.41, 0.35, 0.84 + 0.37, 0.26]))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixtures_bit_exact(name):
+    g = load_golden(name)
+    ncol = int(g["Dim"][1])
+    got = oracle.column_sums(g["x"], g["p"], ncol, i=g["i"], nrow=int(g["Dim"][0]))
+    assert got.shape == (ncol,)
+    assert got.tobytes() == g["sums"].tobytes()          # bit-exact incl. NaN / signed zero
+    # the iterator-free form RcppSparse.h:131-137 gives the same bits
+    assert oracle.col_sums(g["x"], g["p"], ncol).tobytes() == g["sums"].tobytes()
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "3000x700" not in n])
+def test_python_transcription_agrees(name):
+    g = load_golden(name)
+    got = oracle.column_sums_py(g["x"], g["p"], int(g["Dim"][1]))
+    assert got.tobytes() == g["sums"].tobytes()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_scipy_cross_check(seed):
+    m = synth.rsparsematrix(400, 300, density=0.03, seed=seed)
+    A = sp.csc_matrix((m["x"], m["i"], m["p"]), shape=(400, 300))
+    ref = np.asarray(A.sum(axis=0)).ravel()
+    got = oracle.column_sums(m["x"], m["p"])
+    scale = np.maximum(oracle.column_abs_sums(m["x"], m["p"]), 1e-300)
+    assert np.all(np.abs(got - ref) <= 1e-13 * scale)
+    red = np.add.reduceat(np.append(m["x"], 0.0), np.minimum(m["p"][:-1], len(m["x"])))
+    red[np.diff(m["p"]) == 0] = 0.0
+    assert np.all(np.abs(got - red) <= 1e-13 * scale)
+
+
+def test_empty_columns_are_positive_zero():
+    g = load_golden("stored_zeros")
+    s = oracle.column_sums(g["x"], g["p"])
+    assert not np.signbit(s[1]) and s[1] == 0.0     # column of -0.0 only -> +0.0
+    assert not np.signbit(s[2]) and s[2] == 0.0     # empty column
+
+
+def test_row_and_mean_variants():
+    m = synth.rsparsematrix(50, 40, density=0.2, seed=5)
+    A = sp.csc_matrix((m["x"], m["i"], m["p"]), shape=(50, 40)).toarray()
+    assert np.allclose(oracle.row_sums(m["x"], m["i"], m["p"], 50), A.sum(axis=1), atol=1e-12)
+    assert np.allclose(oracle.col_means(m["x"], m["p"], 50), A.sum(axis=0) / 50, atol=1e-13)
+    assert np.allclose(oracle.row_means(m["x"], m["i"], m["p"], 50), A.sum(axis=1) / 40, atol=1e-13)
+    # colMeans divides the sums (RcppSparse.h:147-148), bit for bit
+    assert np.array_equal(oracle.col_means(m["x"], m["p"], 50), oracle.col_sums(m["x"], m["p"]) / 50)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_generators_agree_bitwise(kind):
+    a = oracle.gen_values(5000, seed=42, first_idx=123456789012, kind=kind)
+    b = synth.gen_values(5000, seed=42, first_idx=123456789012, kind=kind)
+    assert a.tobytes() == b.tobytes()
+    if kind == 0:
+        assert a.min() >= -5.1 and a.max() <= 5.1
+        assert np.array_equal(a, np.round(a * 100) / 100.0)   # two decimals, correctly rounded
+    else:
+        assert a.min() >= 0.0 and a.max() < 1.0
