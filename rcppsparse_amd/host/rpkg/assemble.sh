@@ -1,0 +1,9 @@
+#!/bin/bash
+# Copies the canonical headers into inst/include so the directory is a self-contained
+# R package source tree:  bash assemble.sh && R CMD INSTALL .
+set -e
+here=$(cd "$(dirname "$0")" && pwd)
+cp "$here/../RcppSparse.h" "$here/../rcppsparse_core.hpp" "$here/../columnsums_impl.hpp" "$here/inst/include/"
+cp "$here/../../../include/rcppsparse_hip.h" "$here/inst/include/"
+sed -i 's#"../../include/rcppsparse_hip.h"#"rcppsparse_hip.h"#' "$here/inst/include/columnsums_impl.hpp"
+echo "assembled: $(ls $here/inst/include | tr '\n' ' ')"

@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: world_size-2 (and 4) gloo runs of the column-range sharded
+driver (rcppsparse_amd/sharded.py).  The per-shard compute is injected: here the
+oracle stands in for the HIP kernel (there is no GPU in this container), the
+gather goes over gloo instead of RCCL; partitioning, rebasing, slice layout and
+reassembly are the code the GPU ranks run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from rcppsparse_amd import sharded, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _matrix(shape):
+    if shape == "uniform":
+        counts = synth.uniform_counts(3000, 120_000, seed=11, nrow=None)
+    elif shape == "zipf":
+        counts = synth.zipf_counts(3000, 120_000, seed=11, nrow=20_000)
+    else:   # leading/trailing empties and one giant column
+        counts = np.concatenate([np.zeros(50), [90_000], np.full(100, 3), np.zeros(75)]).astype(np.int64)
+    p = synth.offsets_from_counts(counts)
+    return p, synth.gen_values(int(p[-1]), seed=12, kind=0)
+
+
+def _worker(rank, world, port, shape, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p, x = _matrix(shape)
+        shard = sharded.make_shard(p, rank, world)
+        counts, _ = sharded.gather_layout(shard.bounds)
+
+        def compute(sh):   # stand-in for rsp_column_sums_device on this rank's HBM shard
+            return torch.from_numpy(oracle.column_sums(x[sh.x0:sh.x1], sh.p_local))
+
+        recv = torch.empty(len(p) - 1, dtype=torch.float64) if rank == 0 else None
+        driver = sharded.ShardedColumnSums(shard, compute, sharded.GlooGather(counts))
+        local = driver.step(recv)
+        assert local.numel() == shard.ncol
+        if rank == 0:
+            ref = oracle.column_sums(x, p)
+            q.put(("ok", bool(recv.numpy().tobytes() == ref.tobytes()), sharded.imbalance(p, shard.bounds)))
+    except Exception as e:   # pragma: no cover
+        if rank == 0:
+            q.put(("err", repr(e), 0.0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("shape", ["uniform", "zipf", "giant"])
+def test_sharded_columnsums_over_gloo(world, shape):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_worker, args=(world, _free_port(), shape, q), nprocs=world, join=True)
+    status, same, imb = q.get()
+    assert status == "ok" and same
+    if shape == "uniform":
+        assert imb < 1.05
+
+
+def test_shards_tile_the_matrix_exactly():
+    p, _ = _matrix("zipf")
+    for world in (1, 2, 3, 8):
+        shards = [sharded.make_shard(p, r, world) for r in range(world)]
+        assert shards[0].c0 == 0 and shards[-1].c1 == len(p) - 1
+        assert shards[0].x0 == 0 and shards[-1].x1 == p[-1]
+        for a, b in zip(shards, shards[1:]):
+            assert a.c1 == b.c0 and a.x1 == b.x0
+        counts, displs = sharded.gather_layout(shards[0].bounds)
+        assert counts.sum() == len(p) - 1 and np.array_equal(displs, np.cumsum(counts) - counts)
