@@ -42,6 +42,10 @@ WORKLOADS = {
     "c2": (1_000_000, 1_000_000, 10_000_000, "uniform"),
     "c3": (10_000_000, 1_000_000, 1_000_000_000, "uniform"),
     "c5": (10_000_000, 1_000_000, 1_000_000_000, "zipf"),
+    # experiments (not BASELINE configs): one shard of C4, and a single 1e9-long column
+    # (no column ends inside the stream: the ceiling of the streaming fast path)
+    "c4shard": (10_000_000, 125_000, 125_000_000, "uniform"),
+    "stream": (2_000_000_000, 1, 1_000_000_000, "uniform"),
 }
 
 
@@ -55,6 +59,9 @@ def parse_args():
     ap.add_argument("--kind", type=int, default=0, help="0 signed two-decimal, 1 U(0,1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk-rows", type=int, default=0)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N=1 only: still create the RCCL communicator and run the 2-stream "
+                         "gather pipeline (rehearsal of the N>1 code path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -168,23 +175,43 @@ def main():
     pt = torch.from_numpy(shard.p_local).to(dev)
     out_local = torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=dev)[:shard.ncol]
     ws = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
-    recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None
+    use_comm = world > 1 or args.force_comm
+    recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (use_comm and rank == 0) else None
     comm = None
-    if world > 1:
+    if use_comm:
         uid = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
+        if world > 1:
+            dist.broadcast(uid, 0)
         comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
 
+    # N > 1: the gatherv of step k runs on its own stream and overlaps the kernel of
+    # step k+1 (double-buffered per-shard output); every step's gather completes
+    # inside the timed region.  N = 1: one stream, no collective.
+    s_compute = torch.cuda.current_stream()
+    s_comm = torch.cuda.Stream() if comm is not None else None
+    outs = [out_local, torch.empty_like(out_local)] if comm is not None else [out_local]
+    kernel_done = [torch.cuda.Event() for _ in outs]
+    gather_done = [None for _ in outs]
+    step_no = [0]
+
     def step(ev_a=None, ev_b=None):
+        k = step_no[0] % len(outs)
+        step_no[0] += 1
+        if gather_done[k] is not None:
+            s_compute.wait_event(gather_done[k])       # the buffer's previous gather has drained
         if ev_a is not None:
-            ev_a.record()
-        capi.column_sums_device(xt, pt, out_local, ws)
+            ev_a.record(s_compute)
+        capi.column_sums_device(xt, pt, outs[k], ws, stream=s_compute)
         if ev_b is not None:
-            ev_b.record()
+            ev_b.record(s_compute)
         if comm is not None:
-            comm.gatherv(out_local, recv, counts, displs, 0)
+            kernel_done[k].record(s_compute)
+            s_comm.wait_event(kernel_done[k])
+            comm.gatherv(outs[k], recv, counts, displs, 0, stream=s_comm)
+            gather_done[k] = torch.cuda.Event()
+            gather_done[k].record(s_comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -211,7 +238,7 @@ def main():
 
     result = None
     if rank == 0:
-        full = (recv if world > 1 else out_local).cpu().numpy()
+        full = (recv if comm is not None else out_local).cpu().numpy()   # the last step's gathered result
         worst = parity_spot_check(full, p, args.kind)
         if not worst <= 1e-12:
             raise SystemExit(f"parity spot check failed: max |gpu-ref|/sum|x| = {worst:.3e}")
@@ -229,7 +256,8 @@ def main():
                 "workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, "
                             f"values kind {args.kind}, seed {SEED}",
                 "parallelism": ("single GPU" if world == 1 else
-                                f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0"),
+                                f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0 "
+                                "(gather of step k on a second stream, overlapping the kernel of step k+1)"),
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
             },

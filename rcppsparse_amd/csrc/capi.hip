@@ -71,6 +71,12 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
         if (r > 256) r = 256;
         rows = (int)r;
     }
+    static int variant = -1;
+    if (variant < 0) {
+        const char* v = getenv("RSP_VARIANT");
+        variant = v ? atoi(v) : 0;
+    }
+    plan.variant = variant;
     plan.chunk_elems = rows * rsp::kRowElems;
     plan.nchunks = nnz > 0 ? (int32_t)((nnz + plan.chunk_elems - 1) / plan.chunk_elems) : 0;
     return plan;

@@ -18,6 +18,7 @@ constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed 
 struct LaunchPlan {
     int32_t chunk_elems;   // multiple of kRowElems
     int32_t nchunks;       // ceil(nnz / chunk_elems), >= 1 when nnz > 0
+    int variant;           // 0 = production kernel; >0 = experiment variants (env RSP_VARIANT)
 };
 
 inline size_t workspace_bytes_for(int32_t nchunks) {

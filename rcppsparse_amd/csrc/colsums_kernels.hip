@@ -16,7 +16,7 @@
 //     per-element column ranks (this also handles empty columns).
 //   * Rows that contain no column end take the fast path: two v_add_f64 per
 //     lane.  Rows that do contain column ends take a segmented wave scan
-//     (DPP / ds_bpermute lane exchange) and write finished columns directly.
+//     (DPP lane exchange, no LDS) and write finished columns directly.
 //   * Columns that cross chunk edges leave a head / tail partial per chunk; a
 //     tiny second kernel adds those in ascending chunk order.  There are no
 //     floating-point atomics anywhere, so results are bit-stable run to run.
@@ -32,38 +32,70 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
-// lane-exchange helpers (wave64)
+// lane-exchange helpers (wave64, DPP only: no LDS round trips)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double shfl_up_f64(double v, int d) { return __shfl_up(v, d, 64); }
-__device__ __forceinline__ int shfl_up_i32(int v, int d) { return __shfl_up(v, d, 64); }
+// DPP controls used (gfx9 family encodings):
+//   0xB1 quad_perm[1,0,3,2]   0x4E quad_perm[2,3,0,1]   0x141 row_half_mirror   0x140 row_mirror
+//   0x111/0x112/0x114/0x118 row_shr:1/2/4/8 (inside each row of 16 lanes)
+//   0x142 row_bcast:15 (lane 15 of a row -> every lane of the next row; row_mask 0xA = rows 1,3)
+//   0x143 row_bcast:31 (lane 31 -> rows 2,3; row_mask 0xC)
+//   0x138 wave_shr:1, 0x130 wave_shl:1 (whole-wave shift by one lane)
+template <int CTRL, int ROWMASK = 0xF, bool ZERO_FILL = true>
+__device__ __forceinline__ int dpp_i32(int v, int old = 0) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWMASK, 0xF, ZERO_FILL);
+}
 
-template <int CTRL>
+template <int CTRL, int ROWMASK = 0xF, bool ZERO_FILL = true>
 __device__ __forceinline__ double dpp_f64(double v) {
-    // one DPP move per 32-bit half; bound_ctrl = true -> lanes with no source read 0
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    // one DPP move per 32-bit half; lanes with no source (or a masked row) read +0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, ZERO_FILL);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, ZERO_FILL);
     return __hiloint2double(hi, lo);
 }
 
-// Sum over all 64 lanes, returned in every lane.  Fixed tree: bit-stable.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Sum over all 64 lanes, returned wave-uniform.  Fixed tree: bit-stable.
 __device__ __forceinline__ double wave_allreduce_sum(double v) {
-    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]  : xor 1
-    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  : xor 2
-    v += dpp_f64<0x141>(v);   // row_half_mirror      : combines the two quads of 8
-    v += dpp_f64<0x140>(v);   // row_mirror           : combines the two halves of 16
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v += dpp_f64<0xB1>(v);    // xor 1
+    v += dpp_f64<0x4E>(v);    // xor 2
+    v += dpp_f64<0x141>(v);   // the two quads of each 8
+    v += dpp_f64<0x140>(v);   // the two halves of each row of 16: every lane holds its row's sum
+    return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
+}
+
+// Inclusive prefix sum over the 64 lanes (int): 4 in-row steps + 2 row broadcasts.
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
+    v += dpp_i32<0x111>(v);
+    v += dpp_i32<0x112>(v);
+    v += dpp_i32<0x114>(v);
+    v += dpp_i32<0x118>(v);
+    v += dpp_i32<0x142, 0xA, false>(v);
+    v += dpp_i32<0x143, 0xC, false>(v);
     return v;
 }
 
-// Inclusive prefix sum over the 64 lanes (int).
-__device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = shfl_up_i32(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
+// One step of the segmented inclusive scan: add the source lane's running sum when it
+// carries the same key.  Keys are non-negative and non-decreasing across lanes; a lane
+// with no source sees key -1 (never equal).
+template <int CTRL, int ROWMASK, bool ZERO_FILL>
+__device__ __forceinline__ void seg_scan_step(double& X, int key) {
+    const double Xs = dpp_f64<CTRL, ROWMASK, ZERO_FILL>(X);
+    const int ks = __builtin_amdgcn_update_dpp(-1, key, CTRL, ROWMASK, 0xF, false);
+    if (ks == key) X += Xs;
+}
+
+__device__ __forceinline__ double wave_segmented_inclusive_scan(double X, int key) {
+    seg_scan_step<0x111, 0xF, true>(X, key);
+    seg_scan_step<0x112, 0xF, true>(X, key);
+    seg_scan_step<0x114, 0xF, true>(X, key);
+    seg_scan_step<0x118, 0xF, true>(X, key);
+    seg_scan_step<0x142, 0xA, false>(X, key);   // previous row's last lane
+    seg_scan_step<0x143, 0xC, false>(X, key);   // lane 31 into rows 2 and 3
+    return X;
 }
 
 // ---------------------------------------------------------------------------
@@ -149,25 +181,19 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
 
     // 3. rank of each element = number of ends at or before it
     const int2 h = *(const int2*)&hist[2 * lane];
-    const int S = wave_inclusive_scan_i32(h.x + h.y, lane);
+    const int S = wave_inclusive_scan_i32(h.x + h.y);
     const int kR = S;          // rank of e1
     const int kL = S - h.y;    // rank of e0
 
     // 4. segmented inclusive scan (key kR) of each lane's open-right part
     const bool split = kL != kR;              // a column ends between e0 and e1
-    double X = split ? v1 : (v0 + v1);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double Xd = shfl_up_f64(X, d);
-        const int kd = shfl_up_i32(kR, d);
-        if (lane >= d && kd == kR) X += Xd;
-    }
+    const double X = wave_segmented_inclusive_scan(split ? v1 : (v0 + v1), kR);
 
     // 5. finished segments
-    const double Xp = shfl_up_f64(X, 1);
-    const int kp = shfl_up_i32(kR, 1);
-    const double totalL = v0 + ((lane > 0 && kp == kL) ? Xp : 0.0);   // segment ending at e0
-    int kN = __shfl_down(kL, 1, 64);
+    const double Xp = dpp_f64<0x138>(X);                               // lane - 1
+    const int kp = __builtin_amdgcn_update_dpp(-1, kR, 0x138, 0xF, 0xF, false);
+    const double totalL = v0 + ((kp == kL) ? Xp : 0.0);                // segment ending at e0
+    int kN = dpp_i32<0x130>(kL);                                       // lane + 1
     if (lane == 63) kN = tot;
     const bool endR = kN > kR;                                         // segment ending at e1
     const int cbase = st.ccur;
@@ -199,16 +225,16 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
     while (mL) {
         const int l = __builtin_ctzll(mL);
         mL &= mL - 1;
-        const int start = __shfl(cbase + kL + 1, l, 64);
-        const int cnt = __shfl(gapL, l, 64);
+        const int start = __builtin_amdgcn_readlane(cbase + kL + 1, l);
+        const int cnt = __builtin_amdgcn_readlane(gapL, l);
         for (int c = lane; c < cnt; c += 64)
             if (start + c < ncol) out[start + c] = 0.0;
     }
     while (mR) {
         const int l = __builtin_ctzll(mR);
         mR &= mR - 1;
-        const int start = __shfl(cbase + kR + 1, l, 64);
-        const int cnt = __shfl(gapR, l, 64);
+        const int start = __builtin_amdgcn_readlane(cbase + kR + 1, l);
+        const int cnt = __builtin_amdgcn_readlane(gapR, l);
         for (int c = lane; c < cnt; c += 64)
             if (start + c < ncol) out[start + c] = 0.0;
     }
@@ -228,7 +254,7 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
 // ---------------------------------------------------------------------------
 // main kernel: one wavefront per chunk
 // ---------------------------------------------------------------------------
-template <int BATCH_ROWS, bool MEANS>
+template <int BATCH_ROWS, bool MEANS, int AUX>
 __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel(
     d2 v[BATCH_ROWS];
 #pragma unroll
     for (int r = 0; r < BATCH_ROWS; ++r)
-        v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, r * 1024, kLoadAux));
+        v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, r * 1024, AUX));
 
     // ---- locate the column that owns element cs: c0 = upper_bound(p, cs) - 1,
     //      64-ary search (each round one strided load + ballot) -------------
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel(
             // refill this register pair with the same row of the next batch:
             // BATCH_ROWS loads stay in flight for the whole chunk
             v[r] = __builtin_bit_cast(
-                d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, kLoadAux));
+                d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, AUX));
         }
     }
 
@@ -329,14 +355,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// fix-up: columns that cross chunk edges, summed in ascending chunk order
+// fix-up: columns that cross chunk edges
 // ---------------------------------------------------------------------------
+// One wavefront per chunk w.  If a column that started in an earlier chunk ends in
+// chunk w, its sum is   first + head[ts+1] + ... + head[w]   where ts is the chunk
+// holding the column's first element and `first` is that chunk's tail (or its head
+// when the column starts exactly on the chunk edge).  The lanes take the terms in a
+// fixed strided assignment and a fixed DPP tree combines them: deterministic, and a
+// column spanning tens of thousands of chunks (one 1e9-long column) costs a few
+// microseconds instead of a serial walk.
 template <bool MEANS>
 __global__ __launch_bounds__(256) void colsums_fixup_kernel(
     const int32_t* __restrict__ p, int32_t ncol, int32_t chunk_elems, int32_t nchunks,
     double* __restrict__ out, const double* __restrict__ carry_head,
     const double* __restrict__ carry_tail, const int2* __restrict__ carry_info, double divisor) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (w >= nchunks) return;
     const int2 inf = carry_info[w];
     if (inf.y == 0) return;             // no column ends in chunk w
@@ -345,9 +379,21 @@ __global__ __launch_bounds__(256) void colsums_fixup_kernel(
     const int pc = p[c];
     if (pc >= w * chunk_elems) return;  // the head column started in this chunk: already written
     const int ts = pc / chunk_elems;    // chunk holding the column's first element
-    double acc = (pc == ts * chunk_elems) ? carry_head[ts] : carry_tail[ts];
-    for (int t = ts + 1; t <= w; ++t) acc += carry_head[t];
-    out[c] = finish<MEANS>(acc, divisor);
+    double acc = 0.0;
+    if (lane == 0) acc = (pc == ts * chunk_elems) ? carry_head[ts] : carry_tail[ts];
+    // 8 independent loads in flight per lane; adds stay in ascending t order per lane
+    for (int t0 = ts + 1 + lane; t0 <= w; t0 += 64 * 8) {
+        double h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + 64 * u;
+            h[u] = (t <= w) ? carry_head[t] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += h[u];
+    }
+    const double total = wave_allreduce_sum(acc);
+    if (lane == 0) out[c] = finish<MEANS>(total, divisor);
 }
 
 // nnz == 0: every column is empty
@@ -400,17 +446,28 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     double* carry_tail = carry_head + plan.nchunks;
     int2* carry_info = (int2*)(carry_tail + plan.nchunks);
     const dim3 grid((plan.nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
-    if (means)
-        hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, true>), grid, block, 0, stream, d_x, d_p,
-                           ncol, nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail,
-                           carry_info, divisor);
-    else
-        hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false>), grid, block, 0, stream, d_x, d_p,
-                           ncol, nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail,
-                           carry_info, divisor);
+#define RSP_LAUNCH(BR, MEANS_, AUX_)                                                                \
+    hipLaunchKernelGGL((colsums_chunks_kernel<BR, MEANS_, AUX_>), grid, block, 0, stream, d_x, d_p,  \
+                       ncol, nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail,    \
+                       carry_info, divisor)
+    if (means) {
+        RSP_LAUNCH(kBatchRows, true, kLoadAux);
+    } else if (plan.variant == 0) {
+        RSP_LAUNCH(kBatchRows, false, kLoadAux);
+    } else {   // experiment variants (RSP_VARIANT): batch depth x cache policy
+        switch (plan.variant) {
+            case 1: RSP_LAUNCH(8, false, 2); break;
+            case 2: RSP_LAUNCH(32, false, 2); break;
+            case 3: RSP_LAUNCH(8, false, 0); break;
+            case 4: RSP_LAUNCH(16, false, 0); break;
+            case 5: RSP_LAUNCH(32, false, 0); break;
+            default: RSP_LAUNCH(kBatchRows, false, kLoadAux); break;
+        }
+    }
+#undef RSP_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const dim3 fgrid((plan.nchunks + 255) / 256), fblock(256);
+    const dim3 fgrid((plan.nchunks + 3) / 4), fblock(256);   // one wavefront per chunk
     if (means)
         hipLaunchKernelGGL((colsums_fixup_kernel<true>), fgrid, fblock, 0, stream, d_p, ncol,
                            plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info,

@@ -292,3 +292,18 @@ def test_c3_full_size_properties(torch_cuda, shape):
     xt.mul_(2.0)
     capi.column_sums_device(xt, pt, out2, ws)
     assert torch.equal(out2, out * 2.0)
+
+
+# ------------------------------------------------------------------ RCCL plumbing
+def test_rccl_single_rank_gatherv_roundtrip(torch_cuda):
+    """One-rank communicator on the one GPU of this box: unique id, init, gatherv (root's own
+    slice is a device copy on the stream), destroy.  Multi-rank behaviour is covered by the
+    gloo tests (same driver, same layout) and by the driver's 8-GPU run."""
+    torch = torch_cuda
+    comm = capi.Comm(capi.comm_unique_id(), 1, 0, 0)
+    send = torch.arange(1000, dtype=torch.float64, device="cuda")
+    recv = torch.zeros(1500, dtype=torch.float64, device="cuda")
+    comm.gatherv(send, recv, [1000], [250], 0)
+    torch.cuda.synchronize()
+    assert torch.equal(recv[250:1250], send) and recv[:250].abs().sum() == 0 and recv[1250:].abs().sum() == 0
+    comm.close()
