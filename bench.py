@@ -127,6 +127,32 @@ def parity_spot_check(got, p, kind, first_idx=0, ncheck=400):
     return worst
 
 
+class TorchGather:
+    """Same gatherv (grouped RCCL send/recv) issued through torch.distributed's own
+    communicator; used only if the C-ABI communicator cannot be created."""
+    name = "torch.distributed batch_isend_irecv (RCCL)"
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def gatherv(self, send_t, recv_t, counts, displs, root=0, stream=None):
+        import torch
+        dist = self.dist
+        with torch.cuda.stream(stream):
+            if self.rank == root:
+                ops = [dist.P2POp(dist.irecv, recv_t[int(displs[r]):int(displs[r] + counts[r])], r)
+                       for r in range(self.world) if r != root and counts[r] > 0]
+                recv_t[int(displs[root]):int(displs[root] + counts[root])].copy_(send_t, non_blocking=True)
+            else:
+                ops = [dist.P2POp(dist.isend, send_t, root)] if send_t.numel() > 0 else []
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+
+    def close(self):
+        pass
+
+
 def traffic_from_profiles(workload):
     """HBM bytes per launch from the committed PMC passes (profiles/*traffic*.json)."""
     import glob
@@ -184,7 +210,21 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
         if world > 1:
             dist.broadcast(uid, 0)
-        comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+        try:
+            comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+            ok = 1
+        except Exception as e:   # plumbing failure of the C-ABI communicator (never a compute fallback)
+            print(f"[rank {rank}] rsp_comm_init failed: {e}", file=sys.stderr, flush=True)
+            comm, ok = None, 0
+        if world > 1:   # every rank must take the same gather path
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = TorchGather(dist, rank, world)
+        elif comm is None:
+            raise SystemExit("--force-comm: communicator creation failed")
 
     # N > 1: the gatherv of step k runs on its own stream and overlaps the kernel of
     # step k+1 (double-buffered per-shard output); every step's gather completes
@@ -260,6 +300,7 @@ def main():
                                 "(gather of step k on a second stream, overlapping the kernel of step k+1)"),
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
+                "gather": (None if comm is None else getattr(comm, "name", "rsp_comm_gatherv (C ABI, RCCL)")),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -158,6 +158,10 @@ int rsp_gen_values_device(double *d_x, int64_t n, uint64_t seed,
 /* ---- tuning knobs (experiments; defaults are chosen per problem size) --- */
 /* chunk_rows: 128-element rows of x owned by one wavefront (0 = automatic). */
 int rsp_set_tuning(int chunk_rows);
+/* Selects an alternative build of the main kernel for A/B measurements
+ * (0 = production; see launch_column_sums in csrc/colsums_kernels.hip).  Not for
+ * production use; results stay within the documented tolerance for every value. */
+int rsp_set_experiment(int variant);
 
 #ifdef __cplusplus
 }

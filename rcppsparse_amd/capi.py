@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_device_timed",
     "rsp_partition_columns", "rsp_rebase_offsets",
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
-    "rsp_gen_values_device", "rsp_set_tuning",
+    "rsp_gen_values_device", "rsp_set_tuning", "rsp_set_experiment",
 )
 
 
@@ -95,6 +95,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_comm_destroy.argtypes = [vp]
     L.rsp_gen_values_device.argtypes = [vp, i64, u64, u64, c.c_int, vp]
     L.rsp_set_tuning.argtypes = [c.c_int]
+    L.rsp_set_experiment.argtypes = [c.c_int]
     _lib = L
     return L
 
@@ -126,6 +127,10 @@ def device_count() -> int:
 
 def set_tuning(chunk_rows: int = 0) -> None:
     _check(load().rsp_set_tuning(int(chunk_rows)))
+
+
+def set_experiment(variant: int = 0) -> None:
+    _check(load().rsp_set_experiment(int(variant)))
 
 
 # ---------------------------------------------------------------- host paths

@@ -20,6 +20,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 int g_chunk_rows_override = 0;   // rsp_set_tuning / RSP_CHUNK_ROWS
+int g_variant = -1;              // rsp_set_experiment / RSP_VARIANT (-1 = read the env once)
 
 }  // namespace
 
@@ -67,16 +68,15 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
         const int64_t total_rows = (nnz + rsp::kRowElems - 1) / rsp::kRowElems;
         const int64_t target_chunks = 256 * 32;   // 256 CUs x 32 waves
         int64_t r = (total_rows + target_chunks - 1) / target_chunks;
-        if (r < rsp::kBatchRows) r = rsp::kBatchRows;
+        if (r < rsp::kMinChunkRows) r = rsp::kMinChunkRows;
         if (r > 256) r = 256;
         rows = (int)r;
     }
-    static int variant = -1;
-    if (variant < 0) {
+    if (g_variant < 0) {
         const char* v = getenv("RSP_VARIANT");
-        variant = v ? atoi(v) : 0;
+        g_variant = v ? atoi(v) : 0;
     }
-    plan.variant = variant;
+    plan.variant = g_variant;
     plan.chunk_elems = rows * rsp::kRowElems;
     plan.nchunks = nnz > 0 ? (int32_t)((nnz + plan.chunk_elems - 1) / plan.chunk_elems) : 0;
     return plan;
@@ -168,6 +168,12 @@ int rsp_device_count(int* count) {
 int rsp_set_tuning(int chunk_rows) {
     if (chunk_rows < 0) return fail(RSP_ERR_BAD_ARG, "chunk_rows is negative");
     g_chunk_rows_override = chunk_rows;
+    return RSP_OK;
+}
+
+int rsp_set_experiment(int variant) {
+    if (variant < 0) return fail(RSP_ERR_BAD_ARG, "variant is negative");
+    g_variant = variant;
     return RSP_OK;
 }
 

@@ -8,11 +8,17 @@
 namespace rsp {
 
 constexpr int kRowElems = 128;    // one wave instruction: 64 lanes x 16 B = 128 doubles
-constexpr int kBatchRows = 16;    // rows (1 KiB loads) kept in flight per wavefront
+constexpr int kBatchRows = 8;     // rows (1 KiB loads) kept in flight per wavefront
+constexpr int kMinChunkRows = 16; // automatic chunking never goes below this many rows per wave
 constexpr int kWavesPerWG = 4;    // independent wavefronts per workgroup
 constexpr int kPWin = 256;        // p[] entries staged in LDS per wavefront
 constexpr int kHistPad = 132;     // 129 histogram slots, padded to a 16-byte multiple
 constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed once)
+constexpr int kGroupRows = 4;     // rows per dense group (512 elements, 8 per lane)
+constexpr int kGroupElems = kGroupRows * kRowElems;
+constexpr int kStageSlots = kGroupElems + kGroupElems / 8;   // LDS staging, one pad per 8 elements
+constexpr int kFewEnds = 3;       // rows with <= this many column ends use the masked-reduce loop
+constexpr int kDenseMinEnds = 8;  // groups with >= this many column ends use the dense path
 
 // How a column-sum call is cut into chunks (one wavefront each).
 struct LaunchPlan {

@@ -252,6 +252,305 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
 }
 
 // ---------------------------------------------------------------------------
+// v2 paths: rows with only a few column ends, and groups of rows with many
+// ---------------------------------------------------------------------------
+// Per-lane view of the next 64 column ends: lane j holds q = p[k + j] (valid iff
+// k + j <= ncol), read from the LDS window.
+__device__ __forceinline__ int load_next_ends(WaveState& st, int32_t* win,
+                                              const int32_t* __restrict__ p, int k, int ncol, int lane,
+                                              bool& valid) {
+    ensure_window(st, win, p, k, 64, ncol, lane);
+    const uint32_t idx = (uint32_t)k + (uint32_t)lane;
+    valid = idx <= (uint32_t)ncol;
+    return win[(valid ? (int)idx : k) - st.wbase];
+}
+
+// After `k - 1` became the current column: refresh qnext / has_next.
+__device__ __forceinline__ void refresh_next(WaveState& st, int32_t* win, const int32_t* __restrict__ p,
+                                             int k, int ncol, int lane) {
+    st.has_next = (uint32_t)k <= (uint32_t)ncol;
+    if (st.has_next) {
+        ensure_window(st, win, p, k, 1, ncol, lane);
+        st.qnext = __builtin_amdgcn_readfirstlane(win[k - st.wbase]);
+    }
+}
+
+template <bool MEANS>
+__device__ __forceinline__ void emit_column(const WaveState& st, int c, int rel, double total, int ncol,
+                                            int w, double* __restrict__ out,
+                                            double* __restrict__ carry_head, double divisor) {
+    // rel = index of this column end counted from st.ccur; the chunk's first end is the head
+    if (st.head_open && rel == 0) {
+        carry_head[w] = total;
+        if (st.head_complete && c < ncol) out[c] = finish<MEANS>(total, divisor);
+    } else if (c < ncol) {
+        out[c] = finish<MEANS>(total, divisor);
+    }
+}
+
+// Row with n in [1, kFewEnds] column ends: one masked wave reduction per end (about 40
+// instructions each) instead of the general rank + segmented-scan machinery.
+template <bool MEANS>
+__device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int lane, int n, int wq,
+                                             WaveState& st, double& acc0, double& acc1, int32_t* win,
+                                             const int32_t* __restrict__ p, int ncol, int w,
+                                             double* __restrict__ out, double* __restrict__ carry_head,
+                                             double divisor) {
+    const int o0 = 2 * lane;   // row-relative offsets of this lane's two elements
+    int lo = 0;                // row-relative start of the segment being closed
+    double a = acc0 + acc1;
+    for (int j = 0; j < n; ++j) {
+        const int d = __builtin_amdgcn_readlane(wq, j) - rs;   // end offset in (0, 128], uniform
+        const double t0 = (o0 >= lo && o0 < d) ? v0 : 0.0;
+        const double t1 = (o0 + 1 >= lo && o0 + 1 < d) ? v1 : 0.0;
+        const double total = wave_allreduce_sum(a + (t0 + t1));
+        if (lane == 0) emit_column<MEANS>(st, st.ccur + j, j, total, ncol, w, out, carry_head, divisor);
+        a = 0.0;
+        lo = d;
+    }
+    acc0 = (o0 >= lo) ? v0 : 0.0;
+    acc1 = (o0 + 1 >= lo) ? v1 : 0.0;
+    st.ccur += n;
+    st.head_open = false;
+    refresh_next(st, win, p, st.ccur + 1, ncol, lane);
+}
+
+// Dense group: kGroupRows consecutive rows (512 elements) holding many column ends.
+// The rows are staged in LDS (padded: slot = e + e/8, conflict-free for the strided
+// reads below), every lane then owns 8 *consecutive* elements and sums them in storage
+// order, closing columns as it meets their last element; only the first column closed by
+// a lane needs data from other lanes, which one segmented wave scan per group provides.
+// A bitmap of "last element of a column" positions (ds_or) replaces the per-row
+// histogram.  Groups containing empty columns (duplicate ends) are left to the row paths.
+// Returns false (nothing consumed) when the group must be handled row by row.
+template <bool MEANS>
+__device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, uint32_t glim, int lane,
+                                            WaveState& st,
+                                            double& acc0, double& acc1, int32_t* win, double* stage,
+                                            uint32_t* bitmap, const int32_t* __restrict__ p, int ncol,
+                                            int w, double* __restrict__ out,
+                                            double* __restrict__ carry_head, double divisor) {
+    // bitmap of last-element positions; bail out on duplicate ends
+    if (lane < 16) bitmap[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    int k = st.ccur + 1;
+    int prev_last = -1;
+    bool dup = false;
+    int nends = 0;
+    for (;;) {
+        bool valid;
+        const int q = load_next_ends(st, win, p, k, ncol, lane, valid);
+        const uint32_t d = (uint32_t)q - (uint32_t)gs;
+        const bool ing = valid && (d - 1u) < glim;   // glim: elements of the group this chunk owns
+        int qprev = __builtin_amdgcn_update_dpp(0, q, 0x138, 0xF, 0xF, false);   // lane - 1
+        if (lane == 0) qprev = prev_last;
+        dup = dup || (ing && q == qprev);
+        if (ing) atomicOr(&bitmap[(d - 1u) >> 5], 1u << ((d - 1u) & 31u));
+        const int n = __popcll(__ballot(ing));
+        nends += n;
+        k += n;
+        if (n < 64) break;
+        prev_last = __builtin_amdgcn_readlane(q, 63);
+    }
+    if (__ballot(dup) != 0ull) return false;
+
+    // stage the rows (lane holds elements e, e+1 of each row; e is even so both share a pad group)
+#pragma unroll
+    for (int r = 0; r < kGroupRows; ++r) {
+        const int e = r * kRowElems + 2 * lane;
+        const int slot = e + (e >> 3);
+        stage[slot] = v[r].x;
+        stage[slot + 1] = v[r].y;
+    }
+    const double A = wave_allreduce_sum(acc0 + acc1);   // open column's partial from earlier rows
+    __builtin_amdgcn_wave_barrier();
+
+    // this lane's 8 flags (positions 8*lane .. 8*lane+7) and its ranks
+    const uint32_t f = (bitmap[lane >> 2] >> ((lane & 3) * 8)) & 0xFFu;
+    const int cnt = __popc(f);
+    const int rank_incl = wave_inclusive_scan_i32(cnt);
+    const int rank_excl = rank_incl - cnt;
+
+    double e8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e8[j] = stage[9 * lane + j];
+
+    // storage-order sums; a lane's first closed column waits for the carry-in
+    double s = 0.0, head = 0.0;
+    bool seen = false;
+    int c = st.ccur + rank_excl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s += e8[j];
+        if ((f >> j) & 1u) {
+            if (!seen) {
+                head = s;
+                seen = true;
+            } else if (c < ncol) {
+                out[c] = finish<MEANS>(s, divisor);   // never the chunk head: a lane's 2nd+ end
+            }
+            ++c;
+            s = 0.0;
+        }
+    }
+    if (lane == 0) {   // fold the incoming partial into the first segment of the group
+        if (seen) head += A; else s += A;
+    }
+    // s = this lane's open tail (or its whole 8-element sum if it closed nothing)
+    const double X = wave_segmented_inclusive_scan(s, rank_incl);
+    const double Xp = dpp_f64<0x138>(X);   // lane - 1 (lane 0 reads +0.0)
+    if (seen)
+        emit_column<MEANS>(st, st.ccur + rank_excl, rank_excl, head + Xp, ncol, w, out, carry_head, divisor);
+
+    acc0 = (lane == 63) ? X : 0.0;
+    acc1 = 0.0;
+    st.ccur += nends;
+    if (nends > 0) st.head_open = false;
+    refresh_next(st, win, p, st.ccur + 1, ncol, lane);
+    return true;
+}
+
+// One row through the v2 row paths.
+template <bool MEANS>
+__device__ __forceinline__ void row_v2(double v0, double v1, int rs, int lane, WaveState& st,
+                                       double& acc0, double& acc1, int32_t* win, int32_t* hist,
+                                       const int32_t* __restrict__ p, int ncol, int w,
+                                       double* __restrict__ out, double* __restrict__ carry_head,
+                                       double divisor) {
+    const uint32_t dq = (uint32_t)st.qnext - (uint32_t)rs;
+    if (st.has_next && (dq - 1u) < 128u) {
+        bool valid;
+        const int wq = load_next_ends(st, win, p, st.ccur + 1, ncol, lane, valid);
+        const uint32_t d = (uint32_t)wq - (uint32_t)rs;
+        const int n = __popcll(__ballot(valid && (d - 1u) < 128u));
+        if (n <= kFewEnds)
+            few_ends_row<MEANS>(v0, v1, rs, lane, n, wq, st, acc0, acc1, win, p, ncol, w, out, carry_head,
+                                divisor);
+        else
+            slow_row<MEANS>(v0, v1, rs, lane, st, acc0, acc1, win, hist, p, ncol, w, out, carry_head,
+                            divisor);
+    } else {
+        acc0 += v0;
+        acc1 += v1;
+    }
+}
+
+template <int BATCH_ROWS, bool MEANS, int AUX>
+__global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel_v2(
+    const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
+    int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
+    double* __restrict__ carry_head, double* __restrict__ carry_tail,
+    int2* __restrict__ carry_info, double divisor) {
+    static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
+    __shared__ __attribute__((aligned(16))) double s_stage[kWavesPerWG][kStageSlots];
+    __shared__ __attribute__((aligned(16))) int32_t s_win[kWavesPerWG][kPWin];
+    __shared__ __attribute__((aligned(16))) int32_t s_hist[kWavesPerWG][kHistPad];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bitmap[kWavesPerWG][16];
+
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = blockIdx.x * kWavesPerWG + wave_in_wg;
+    if (w >= nchunks) return;
+    int32_t* win = s_win[wave_in_wg];
+    int32_t* hist = s_hist[wave_in_wg];
+    double* stage = s_stage[wave_in_wg];
+    uint32_t* bitmap = s_bitmap[wave_in_wg];
+
+    const int32_t cs = w * chunk_elems;
+    const int64_t ce64 = (int64_t)cs + chunk_elems;
+    const int32_t ce = ce64 < (int64_t)nnz ? (int32_t)ce64 : nnz;
+    const int32_t nrows = (int32_t)(((int64_t)ce - cs + 127) >> 7);
+
+    const double* xb = x + cs;
+    const uint32_t xbytes = (uint32_t)(ce - cs) * 8u;
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)xbytes, 0x00020000);
+    const int voff = lane * 16;
+
+    d2 v[BATCH_ROWS];
+#pragma unroll
+    for (int r = 0; r < BATCH_ROWS; ++r)
+        v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, r * 1024, AUX));
+
+    int lo = 0, hi = ncol;   // invariant: p[lo] <= cs < p[hi]
+    while (hi - lo > 1) {
+        const int step = (int)(((int64_t)hi - lo + 63) >> 6);
+        const int64_t j = (int64_t)lo + (int64_t)(lane + 1) * step;
+        const bool valid = j < hi;
+        const int pv = p[valid ? j : hi];
+        const bool le = valid && pv <= cs;
+        const int n = __popcll(__ballot(le));
+        const int64_t nlo = (int64_t)lo + (int64_t)n * step;
+        const int64_t nhi = nlo + step;
+        lo = (int)nlo;
+        hi = nhi < hi ? (int)nhi : hi;
+    }
+    const int c0 = lo;
+    if (w == 0)
+        for (int c = lane; c < c0; c += 64) out[c] = 0.0;
+
+    WaveState st;
+    st.ccur = c0;
+    st.wbase = c0;
+    fill_window(win, p, c0, ncol, lane);
+    st.head_open = true;
+    st.head_complete = __builtin_amdgcn_readfirstlane(win[0]) >= cs;
+    st.has_next = c0 + 1 <= ncol;
+    st.qnext = __builtin_amdgcn_readfirstlane(win[1]);
+
+    double acc0 = 0.0, acc1 = 0.0;
+    const int nbatches = (nrows + BATCH_ROWS - 1) / BATCH_ROWS;
+    for (int b = 0; b < nbatches; ++b) {
+#pragma unroll
+        for (int g = 0; g < BATCH_ROWS / kGroupRows; ++g) {
+            const int row0 = b * BATCH_ROWS + g * kGroupRows;
+            const int gs = cs + row0 * kRowElems;
+            bool done = false;
+            if (row0 < nrows) {
+                // how many column ends fall inside this group of rows?
+                // (only ends up to the chunk's own end count: later ones belong to other chunks)
+                const uint32_t left = (uint32_t)(ce - gs);
+                const uint32_t glim = left < (uint32_t)kGroupElems ? left : (uint32_t)kGroupElems;
+                const uint32_t dq = (uint32_t)st.qnext - (uint32_t)gs;
+                if (st.has_next && (dq - 1u) < glim) {
+                    bool valid;
+                    const int wq = load_next_ends(st, win, p, st.ccur + 1, ncol, lane, valid);
+                    const uint32_t d = (uint32_t)wq - (uint32_t)gs;
+                    const int n4 = __popcll(__ballot(valid && (d - 1u) < glim));
+                    if (n4 >= kDenseMinEnds) {
+                        const d2 grp[kGroupRows] = {v[g * kGroupRows + 0], v[g * kGroupRows + 1],
+                                                    v[g * kGroupRows + 2], v[g * kGroupRows + 3]};
+                        done = dense_group<MEANS>(grp, gs, glim, lane, st, acc0, acc1, win, stage, bitmap, p,
+                                                  ncol, w, out, carry_head, divisor);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < kGroupRows; ++rr) {
+                const int r = g * kGroupRows + rr;
+                const int row = row0 + rr;
+                if (!done && row < nrows)
+                    row_v2<MEANS>(v[r].x, v[r].y, cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p, ncol,
+                                  w, out, carry_head, divisor);
+                v[r] = __builtin_bit_cast(
+                    d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, AUX));
+            }
+        }
+    }
+
+    const double T = wave_allreduce_sum(acc0 + acc1);
+    if (lane == 0) {
+        if (st.head_open) {
+            carry_head[w] = T;
+            carry_tail[w] = 0.0;
+        } else {
+            carry_tail[w] = T;
+        }
+        carry_info[w] = make_int2(c0, st.ccur - c0);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // main kernel: one wavefront per chunk
 // ---------------------------------------------------------------------------
 template <int BATCH_ROWS, bool MEANS, int AUX>
@@ -446,25 +745,27 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     double* carry_tail = carry_head + plan.nchunks;
     int2* carry_info = (int2*)(carry_tail + plan.nchunks);
     const dim3 grid((plan.nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
-#define RSP_LAUNCH(BR, MEANS_, AUX_)                                                                \
-    hipLaunchKernelGGL((colsums_chunks_kernel<BR, MEANS_, AUX_>), grid, block, 0, stream, d_x, d_p,  \
-                       ncol, nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail,    \
-                       carry_info, divisor)
-    if (means) {
-        RSP_LAUNCH(kBatchRows, true, kLoadAux);
-    } else if (plan.variant == 0) {
-        RSP_LAUNCH(kBatchRows, false, kLoadAux);
-    } else {   // experiment variants (RSP_VARIANT): batch depth x cache policy
-        switch (plan.variant) {
-            case 1: RSP_LAUNCH(8, false, 2); break;
-            case 2: RSP_LAUNCH(32, false, 2); break;
-            case 3: RSP_LAUNCH(8, false, 0); break;
-            case 4: RSP_LAUNCH(16, false, 0); break;
-            case 5: RSP_LAUNCH(32, false, 0); break;
-            default: RSP_LAUNCH(kBatchRows, false, kLoadAux); break;
-        }
+#define RSP_LAUNCH_K(KERNEL, BR, AUX_)                                                              \
+    do {                                                                                           \
+        if (means)                                                                                 \
+            hipLaunchKernelGGL((KERNEL<BR, true, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,   \
+                               nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, \
+                               carry_info, divisor);                                               \
+        else                                                                                       \
+            hipLaunchKernelGGL((KERNEL<BR, false, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,  \
+                               nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, \
+                               carry_info, divisor);                                               \
+    } while (0)
+    switch (plan.variant) {   // 0 = production; others are experiment variants (env RSP_VARIANT)
+        case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 8, 2); break;
+        case 2: RSP_LAUNCH_K(colsums_chunks_kernel, 32, 2); break;
+        case 3: RSP_LAUNCH_K(colsums_chunks_kernel, 8, 0); break;
+        case 4: RSP_LAUNCH_K(colsums_chunks_kernel, 16, 0); break;
+        case 5: RSP_LAUNCH_K(colsums_chunks_kernel, 16, 2); break;      // round-1 first kernel (v1)
+        case 7: RSP_LAUNCH_K(colsums_chunks_kernel_v2, 16, 2); break;
+        default: RSP_LAUNCH_K(colsums_chunks_kernel_v2, kBatchRows, kLoadAux); break;
     }
-#undef RSP_LAUNCH
+#undef RSP_LAUNCH_K
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 fgrid((plan.nchunks + 3) / 4), fblock(256);   // one wavefront per chunk
