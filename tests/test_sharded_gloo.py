@@ -84,3 +84,31 @@ def test_shards_tile_the_matrix_exactly():
             assert a.c1 == b.c0 and a.x1 == b.x0
         counts, displs = sharded.gather_layout(shards[0].bounds)
         assert counts.sum() == len(p) - 1 and np.array_equal(displs, np.cumsum(counts) - counts)
+
+
+def _torch_gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        counts = [5, 0, 7][:world] if world == 3 else [4, 9]
+        displs = np.cumsum([0] + counts[:-1])
+        send = torch.full((counts[rank],), float(rank + 1), dtype=torch.float64)
+        recv = torch.zeros(sum(counts), dtype=torch.float64) if rank == 0 else None
+        bench.TorchGather(dist, rank, world).gatherv(send, recv, counts, displs, 0, stream=None)
+        if rank == 0:
+            want = np.concatenate([np.full(c, r + 1.0) for r, c in enumerate(counts)])
+            q.put(bool(np.array_equal(recv.numpy(), want)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_fallback_gatherv_layout(world):
+    """bench.py's torch.distributed gatherv (used only if the C-ABI communicator cannot be
+    created) fills the same counts/displacements layout, including an empty slice."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_torch_gather_worker, args=(world, _free_port(), q), nprocs=world, join=True)
+    assert q.get()
