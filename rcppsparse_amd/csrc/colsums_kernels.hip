@@ -656,43 +656,64 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel(
 // ---------------------------------------------------------------------------
 // fix-up: columns that cross chunk edges
 // ---------------------------------------------------------------------------
-// One wavefront per chunk w.  If a column that started in an earlier chunk ends in
+// One thread per chunk w.  If a column that started in an earlier chunk ends in
 // chunk w, its sum is   first + head[ts+1] + ... + head[w]   where ts is the chunk
 // holding the column's first element and `first` is that chunk's tail (or its head
-// when the column starts exactly on the chunk edge).  The lanes take the terms in a
-// fixed strided assignment and a fixed DPP tree combines them: deterministic, and a
-// column spanning tens of thousands of chunks (one 1e9-long column) costs a few
-// microseconds instead of a serial walk.
+// when the column starts exactly on the chunk edge).  Short spans (the common case:
+// a column spilling over one or two chunk edges) are added by the owning thread in
+// ascending order; a span longer than 64 chunks (a giant column) is summed by the
+// whole wavefront with a fixed lane-strided assignment and a fixed DPP tree, so one
+// 1e9-long column costs microseconds instead of a serial walk.  Deterministic.
 template <bool MEANS>
 __global__ __launch_bounds__(256) void colsums_fixup_kernel(
     const int32_t* __restrict__ p, int32_t ncol, int32_t chunk_elems, int32_t nchunks,
     double* __restrict__ out, const double* __restrict__ carry_head,
     const double* __restrict__ carry_tail, const int2* __restrict__ carry_info, double divisor) {
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (w >= nchunks) return;
-    const int2 inf = carry_info[w];
-    if (inf.y == 0) return;             // no column ends in chunk w
-    const int c = inf.x;
-    if (c >= ncol) return;
-    const int pc = p[c];
-    if (pc >= w * chunk_elems) return;  // the head column started in this chunk: already written
-    const int ts = pc / chunk_elems;    // chunk holding the column's first element
-    double acc = 0.0;
-    if (lane == 0) acc = (pc == ts * chunk_elems) ? carry_head[ts] : carry_tail[ts];
-    // 8 independent loads in flight per lane; adds stay in ascending t order per lane
-    for (int t0 = ts + 1 + lane; t0 <= w; t0 += 64 * 8) {
-        double h[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0 + 64 * u;
-            h[u] = (t <= w) ? carry_head[t] : 0.0;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    bool need = false;
+    int c = 0, ts = 0;
+    double first = 0.0;
+    if (w < nchunks) {
+        const int2 inf = carry_info[w];
+        c = inf.x;
+        if (inf.y != 0 && c < ncol) {          // a column ends in chunk w ...
+            const int pc = p[c];
+            if (pc < w * chunk_elems) {        // ... and it started in an earlier chunk
+                need = true;
+                ts = pc / chunk_elems;         // chunk holding the column's first element
+                first = (pc == ts * chunk_elems) ? carry_head[ts] : carry_tail[ts];
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += h[u];
     }
-    const double total = wave_allreduce_sum(acc);
-    if (lane == 0) out[c] = finish<MEANS>(total, divisor);
+    const int span = w - ts;
+    if (need && span <= 64) {
+        double acc = first;
+        for (int t = ts + 1; t <= w; ++t) acc += carry_head[t];
+        out[c] = finish<MEANS>(acc, divisor);
+    }
+    // giant columns: whole wave per column, one after the other
+    uint64_t m = __ballot(need && span > 64);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int wl = __builtin_amdgcn_readlane(w, l);
+        const int tl = __builtin_amdgcn_readlane(ts, l);
+        double acc = 0.0;
+        // 8 independent loads in flight per lane; adds stay in ascending t order per lane
+        for (int t0 = tl + 1 + lane; t0 <= wl; t0 += 64 * 8) {
+            double h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 64 * u;
+                h[u] = (t <= wl) ? carry_head[t] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += h[u];
+        }
+        const double total = readlane_f64(first, l) + wave_allreduce_sum(acc);
+        if (lane == l) out[c] = finish<MEANS>(total, divisor);
+    }
 }
 
 // nnz == 0: every column is empty
@@ -768,7 +789,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 #undef RSP_LAUNCH_K
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const dim3 fgrid((plan.nchunks + 3) / 4), fblock(256);   // one wavefront per chunk
+    const dim3 fgrid((plan.nchunks + 255) / 256), fblock(256);   // one thread per chunk
     if (means)
         hipLaunchKernelGGL((colsums_fixup_kernel<true>), fgrid, fblock, 0, stream, d_p, ncol,
                            plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info,
