@@ -42,10 +42,17 @@ class Shard:
         return self.x1 - self.x0
 
 
-def make_shard(p: np.ndarray, rank: int, world: int) -> Shard:
-    """nnz-balanced contiguous column range of `rank` (pure integer, host)."""
+def make_shard(p: np.ndarray, rank: int, world: int, balance: str = "nnz") -> Shard:
+    """Contiguous column range of `rank` (pure integer, host): nnz-balanced
+    (rsp_partition_columns) or, as the naive comparator, equal column counts."""
     p = np.ascontiguousarray(p, dtype=np.int32)
-    bounds = capi.partition_columns(p, world)
+    if balance == "nnz":
+        bounds = capi.partition_columns(p, world)
+    elif balance == "cols":
+        ncol = len(p) - 1
+        bounds = np.array([(k * ncol) // world for k in range(world + 1)], dtype=np.int32)
+    else:
+        raise ValueError(balance)
     c0, c1 = int(bounds[rank]), int(bounds[rank + 1])
     return Shard(rank, world, c0, c1, int(p[c0]), int(p[c1]), capi.rebase_offsets(p, c0, c1), bounds)
 
