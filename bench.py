@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--partition", default="nnz", choices=["nnz", "cols"],
                     help="N>1: nnz-balanced column ranges (default) or the naive equal-column-count split")
+    ap.add_argument("--gather-buffers", type=int, default=4,
+                    help="N>1: per-shard output buffers in the kernel/gather pipeline")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: still create the RCCL communicator and run the 2-stream "
                          "gather pipeline (rehearsal of the N>1 code path on a 1-GPU box)")
@@ -240,36 +242,47 @@ def main():
     # inside the timed region.  N = 1: one stream, no collective.
     s_compute = torch.cuda.current_stream()
     s_comm = torch.cuda.Stream() if comm is not None else None
-    outs = [out_local, torch.empty_like(out_local)] if comm is not None else [out_local]
-    kernel_done = [torch.cuda.Event() for _ in outs]
-    gather_done = [None for _ in outs]
+    outs = ([out_local] + [torch.empty_like(out_local) for _ in range(args.gather_buffers - 1)]
+            if comm is not None else [out_local])
+    nbuf = len(outs)
+    # everything the hot loop touches is created up front (host time per step must stay
+    # well under the ~155 us a 1/8 shard takes on the GPU)
+    launch = [capi.prepared_column_sums(xt, pt, o, ws, stream=s_compute) for o in outs]
+    if comm is None:
+        gather = [None] * nbuf
+    elif hasattr(comm, "prepared_gatherv"):
+        gather = [comm.prepared_gatherv(o, recv, counts, displs, 0, stream=s_comm) for o in outs]
+    else:
+        gather = [(lambda o=o: comm.gatherv(o, recv, counts, displs, 0, stream=s_comm)) for o in outs]
+    total_steps = args.warmup + args.steps
+    kernel_done = [torch.cuda.Event() for _ in range(total_steps)]
+    gather_done = [torch.cuda.Event() for _ in range(total_steps)]
+    gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)] if comm is not None else []
     step_no = [0]
 
-    gev = []
-
-    def step(ev_a=None, ev_b=None):
-        k = step_no[0] % len(outs)
-        step_no[0] += 1
-        if gather_done[k] is not None:
-            s_compute.wait_event(gather_done[k])       # the buffer's previous gather has drained
+    def step(ev_a=None, ev_b=None, gpair=None):
+        n = step_no[0]
+        k = n % nbuf
+        step_no[0] = n + 1
+        if comm is not None and n >= nbuf and not gather_done[n - nbuf].query():
+            s_compute.wait_event(gather_done[n - nbuf])   # this buffer's previous gather must have drained
         if ev_a is not None:
             ev_a.record(s_compute)
-        capi.column_sums_device(xt, pt, outs[k], ws, stream=s_compute)
+        launch[k]()
         if ev_b is not None:
             ev_b.record(s_compute)
         if comm is not None:
-            kernel_done[k].record(s_compute)
-            s_comm.wait_event(kernel_done[k])
-            ga = gb = None
-            if ev_a is not None:
-                ga, gb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ga.record(s_comm)
-            comm.gatherv(outs[k], recv, counts, displs, 0, stream=s_comm)
-            if gb is not None:
-                gb.record(s_comm)
-            gev.append((ga, gb))
-            gather_done[k] = torch.cuda.Event()
-            gather_done[k].record(s_comm)
+            done = ev_b if ev_b is not None else kernel_done[n]
+            if ev_b is None:
+                done.record(s_compute)
+            s_comm.wait_event(done)
+            if gpair is not None:
+                gpair[0].record(s_comm)
+            gather[k]()
+            if gpair is not None:
+                gpair[1].record(s_comm)
+            gather_done[n].record(s_comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -283,14 +296,21 @@ def main():
           for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
+    # N > 1: a shard's kernel is ~0.15 ms, so the timing events themselves (one queue packet
+    # each) are only placed on every 4th step; N = 1 times every launch
+    stride = 4 if comm is not None else 1
     for k in range(args.steps):
-        step(*ev[k])
+        if k % stride == 0:
+            step(ev[k][0], ev[k][1], gev[k] if gev else None)
+        else:
+            step()
     fence()
     elapsed = time.perf_counter() - t0
 
-    ktimes = sorted(a.elapsed_time(b) for a, b in ev)
-    kernel_ms = sum(ktimes) / args.steps
-    gather_ms = (sum(a.elapsed_time(b) for a, b in gev if a is not None) / max(1, sum(a is not None for a, b in gev))
+    timed = range(0, args.steps, stride)
+    ktimes = sorted(ev[k][0].elapsed_time(ev[k][1]) for k in timed)
+    kernel_ms = sum(ktimes) / len(ktimes)
+    gather_ms = (sum(gev[k][0].elapsed_time(gev[k][1]) for k in timed) / len(ktimes)
                  if comm is not None else 0.0)
     stats = torch.tensor([elapsed, kernel_ms, gather_ms], dtype=torch.float64, device=dev)
     if world > 1:

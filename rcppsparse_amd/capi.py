@@ -216,6 +216,23 @@ def column_sums_device(x_t, p_t, out_t=None, workspace=None, stream=None, nrow_f
     return out_t
 
 
+def prepared_column_sums(x_t, p_t, out_t, workspace, stream=None):
+    """Pre-bound launcher of rsp_column_sums_device for hot loops (bench): the ctypes
+    arguments are converted once, each call is a single foreign call."""
+    L = load()
+    ncol, nnz = p_t.numel() - 1, x_t.numel()
+    fn = L.rsp_column_sums_device
+    args = (ctypes.c_void_p(x_t.data_ptr()), ctypes.c_void_p(p_t.data_ptr()), ctypes.c_int32(ncol),
+            ctypes.c_int64(nnz), ctypes.c_void_p(out_t.data_ptr()), ctypes.c_void_p(workspace.data_ptr()),
+            ctypes.c_size_t(workspace.numel()), _stream_ptr(stream))
+
+    def launch():
+        rc = fn(*args)
+        if rc != RSP_OK:
+            _check(rc)
+    return launch
+
+
 def column_sums_device_timed(x_t, p_t, out_t, workspace, reps: int, stream=None) -> float:
     """Mean ms per call, hipEvents recorded on the launch stream inside the library."""
     ms = ctypes.c_float(0)
@@ -272,6 +289,22 @@ class Comm:
         _check(load().rsp_comm_gatherv(self._h, send_t.data_ptr(), send_t.numel(),
                                        recv_t.data_ptr() if recv_t is not None else None,
                                        c_arr, d_arr, root, _stream_ptr(stream)))
+
+    def prepared_gatherv(self, send_t, recv_t, counts, displs, root: int = 0, stream=None):
+        """Pre-bound gatherv for hot loops: argument conversion happens once."""
+        n = self.nranks
+        c_arr = (ctypes.c_int64 * n)(*[int(v) for v in counts])
+        d_arr = (ctypes.c_int64 * n)(*[int(v) for v in displs])
+        fn = load().rsp_comm_gatherv
+        args = (self._h, ctypes.c_void_p(send_t.data_ptr()), ctypes.c_int64(send_t.numel()),
+                ctypes.c_void_p(recv_t.data_ptr() if recv_t is not None else None), c_arr, d_arr,
+                ctypes.c_int(root), _stream_ptr(stream))
+
+        def run():
+            rc = fn(*args)
+            if rc != RSP_OK:
+                _check(rc)
+        return run
 
     def close(self) -> None:
         if self._h:
