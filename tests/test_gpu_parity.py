@@ -294,6 +294,28 @@ def test_c3_full_size_properties(torch_cuda, shape):
     assert torch.equal(out2, out * 2.0)
 
 
+# ------------------------------------------- "next" row f1: colSums / colMeans on device
+@pytest.mark.parametrize("label,ncol,mean", REGIMES)
+def test_column_means_follow_reference_division(torch_cuda, label, ncol, mean):
+    """Matrix::colMeans (RcppSparse.h:145-150) = colSums()[c] / Dim[0]: the device path fuses the
+    divide into the same launches, so means must equal sums / nrow bit for bit (IEEE division),
+    and the sums must match the oracle's col_sums within tolerance."""
+    torch = torch_cuda
+    nnz = int(ncol * mean)
+    nrow = 12345
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=3, nrow=None))
+    x = synth.gen_values(nnz, seed=11, kind=0)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    if nnz == 0:
+        xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
+    sums = capi.column_sums_device(xt, pt).cpu().numpy()
+    means = capi.column_sums_device(xt, pt, nrow_for_means=nrow).cpu().numpy()
+    assert means.tobytes() == (sums / nrow).tobytes()
+    ref = oracle.col_means(x, p, nrow)
+    scale = oracle.column_abs_sums(x, p) / nrow
+    assert np.all(np.abs(means - ref) <= RTOL * scale)
+
+
 # ------------------------------------------------------------------ RCCL plumbing
 def test_rccl_single_rank_gatherv_roundtrip(torch_cuda):
     """One-rank communicator on the one GPU of this box: unique id, init, gatherv (root's own
