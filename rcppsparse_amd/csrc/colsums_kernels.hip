@@ -435,21 +435,21 @@ __device__ __forceinline__ void row_v2(double v0, double v1, int rs, int lane, W
     }
 }
 
-template <int BATCH_ROWS, bool MEANS, int AUX>
-__global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel_v2(
+template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG>
+__global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel_v2(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
     double* __restrict__ carry_head, double* __restrict__ carry_tail,
     int2* __restrict__ carry_info, double divisor) {
     static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
-    __shared__ __attribute__((aligned(16))) double s_stage[kWavesPerWG][kStageSlots];
-    __shared__ __attribute__((aligned(16))) int32_t s_win[kWavesPerWG][kPWin];
-    __shared__ __attribute__((aligned(16))) int32_t s_hist[kWavesPerWG][kHistPad];
-    __shared__ __attribute__((aligned(16))) uint32_t s_bitmap[kWavesPerWG][16];
+    __shared__ __attribute__((aligned(16))) double s_stage[WPG][kStageSlots];
+    __shared__ __attribute__((aligned(16))) int32_t s_win[WPG][kPWin];
+    __shared__ __attribute__((aligned(16))) int32_t s_hist[WPG][kHistPad];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bitmap[WPG][16];
 
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int w = blockIdx.x * kWavesPerWG + wave_in_wg;
+    const int w = blockIdx.x * WPG + wave_in_wg;
     if (w >= nchunks) return;
     int32_t* win = s_win[wave_in_wg];
     int32_t* hist = s_hist[wave_in_wg];
@@ -777,6 +777,13 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                                nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, \
                                carry_info, divisor);                                               \
     } while (0)
+#define RSP_LAUNCH_W(WPG_)                                                                              \
+    do {                                                                                               \
+        const dim3 g2((plan.nchunks + (WPG_) - 1) / (WPG_)), b2((WPG_) * 64);                          \
+        hipLaunchKernelGGL((colsums_chunks_kernel_v2<kBatchRows, false, kLoadAux, WPG_>), g2, b2, 0,   \
+                           stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,         \
+                           carry_head, carry_tail, carry_info, divisor);                               \
+    } while (0)
     switch (plan.variant) {   // 0 = production; others are experiment variants (env RSP_VARIANT)
         case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 8, 2); break;
         case 2: RSP_LAUNCH_K(colsums_chunks_kernel, 32, 2); break;
@@ -784,9 +791,12 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         case 4: RSP_LAUNCH_K(colsums_chunks_kernel, 16, 0); break;
         case 5: RSP_LAUNCH_K(colsums_chunks_kernel, 16, 2); break;      // round-1 first kernel (v1)
         case 7: RSP_LAUNCH_K(colsums_chunks_kernel_v2, 16, 2); break;
+        case 8: RSP_LAUNCH_W(1); break;     // one wavefront per workgroup
+        case 9: RSP_LAUNCH_W(2); break;     // two
         default: RSP_LAUNCH_K(colsums_chunks_kernel_v2, kBatchRows, kLoadAux); break;
     }
 #undef RSP_LAUNCH_K
+#undef RSP_LAUNCH_W
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 fgrid((plan.nchunks + 255) / 256), fblock(256);   // one thread per chunk
