@@ -112,6 +112,27 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
                                  void *d_workspace, size_t workspace_bytes,
                                  void *stream, int reps, float *ms_per_call);
 
+/* ---- row-wise "next" entries: Matrix::rowSums / rowMeans ----------------- */
+/*
+ * Reference RcppSparse.h:138-144 / :151-156: sums[i[j]] += x[j] over all stored
+ * entries (rowMeans divides by Dim[1]).  Computed as columnSums(t(A)): a stable
+ * device radix sort of (i, x) by row keeps every row's values in ascending
+ * storage order, then the column-sum kernels reduce them.  Deterministic, no
+ * float atomics.  The handle variants build the row-major form on first use and
+ * keep it (the handle must have been uploaded with i[]); the device variants
+ * rebuild it in the caller's workspace on every call.
+ * rsp_row_sums_workspace_bytes needs a usable device (it asks rocPRIM); 0 = error.
+ */
+int rsp_csc_row_sums(rsp_csc_t handle, double *sums);     /* nrow doubles, host */
+int rsp_csc_row_means(rsp_csc_t handle, double *means);
+size_t rsp_row_sums_workspace_bytes(int32_t nrow, int64_t nnz);
+int rsp_row_sums_device(const double *d_x, const int32_t *d_i, int32_t nrow,
+                        int64_t nnz, double *d_sums, void *d_workspace,
+                        size_t workspace_bytes, void *stream);
+int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
+                         int32_t ncol, int64_t nnz, double *d_means,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- column-range partitioner (multi-GPU; pure integer, host) ---------- */
 /*
  * nnz-balanced contiguous column ranges: bounds[k] = first column c with
@@ -154,6 +175,12 @@ int rsp_comm_destroy(rsp_comm_t comm);
  */
 int rsp_gen_values_device(double *d_x, int64_t n, uint64_t seed,
                           uint64_t first_idx, int kind, void *stream);
+
+/* d_i[p[c] + r] = floor(nrow * (r + u) / k) for the k entries of column c (u in [0,1) from
+ * the same hash): ascending, distinct rows -- valid dgCMatrix row indices for synthetic
+ * matrices, reproducible on the host. */
+int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
+                               int32_t ncol, uint64_t seed, void *stream);
 
 /* ---- tuning knobs (experiments; defaults are chosen per problem size) --- */
 /* chunk_rows: 128-element rows of x owned by one wavefront (0 = automatic). */

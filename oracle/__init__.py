@@ -62,6 +62,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_row_means.argtypes = [dp, ip, ip, i32, i32, dp]
         L.oracle_column_abs_sums.argtypes = [dp, ip, i32, dp]
         L.oracle_gen_values.argtypes = [dp, u64, u64, u64, ctypes.c_int]
+        L.oracle_gen_row_indices.argtypes = [ip, ip, i32, i32, i32, u64]
+        L.oracle_gen_row_indices.restype = None
         L.oracle_gen_value.argtypes = [u64, u64, ctypes.c_int]
         L.oracle_gen_value.restype = ctypes.c_double
         for f in ("oracle_column_sums", "oracle_col_sums", "oracle_col_means",
@@ -159,4 +161,13 @@ def gen_values(n, seed, first_idx=0, kind=0) -> np.ndarray:
     """Counter-based synthetic x[]; bit-identical to the device generator."""
     out = np.empty(int(n), dtype=np.float64)
     lib().oracle_gen_values(_dp(out), int(n), int(seed), int(first_idx), int(kind))
+    return out
+
+
+def gen_row_indices(p, nrow, seed, c_first=0, c_last=None) -> np.ndarray:
+    """Row indices of columns [c_first, c_last); bit-identical to the device generator."""
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    c_last = len(p) - 1 if c_last is None else int(c_last)
+    out = np.empty(int(p[c_last] - p[c_first]), dtype=np.int32)
+    lib().oracle_gen_row_indices(_ip(out), _ip(p), int(nrow), int(c_first), c_last, int(seed))
     return out

@@ -141,3 +141,23 @@ double oracle_gen_value(uint64_t seed, uint64_t idx, int kind) {
 void oracle_gen_values(double *x, uint64_t n, uint64_t seed, uint64_t first_idx, int kind) {
     for (uint64_t k = 0; k < n; ++k) x[k] = oracle_gen_value(seed, first_idx + k, kind);
 }
+
+/* Twin of the device generator gen_row_indices_kernel: rows of column c. */
+void oracle_gen_row_indices(int32_t *i, const int32_t *p, int32_t nrow, int32_t c_first,
+                            int32_t c_last, uint64_t seed) {
+    /* writes i[p[c] - p[c_first] + r] for c in [c_first, c_last) */
+    const int32_t base = p[c_first];
+    for (int32_t c = c_first; c < c_last; ++c) {
+        const int32_t lo = p[c], k = p[c + 1] - p[c];
+        for (int32_t r = 0; r < k; ++r) {
+            const uint64_t h = mix64(seed * 0xD1342543DE82EF95ull + 0x5bd1e995ull + (uint64_t)(lo + r));
+            const double u = (double)(h >> 11) * 0x1.0p-53;
+            volatile double t = (double)r + u;
+            t = t * (double)nrow;
+            t = t / (double)k;
+            int32_t row = (int32_t)t;
+            if (row >= nrow) row = nrow - 1;
+            i[lo - base + r] = row;
+        }
+    }
+}

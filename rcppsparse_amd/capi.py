@@ -33,9 +33,11 @@ EXPORTED_SYMBOLS = (
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed",
+    "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
+    "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
-    "rsp_gen_values_device", "rsp_set_tuning", "rsp_set_experiment",
+    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_experiment",
 )
 
 
@@ -87,6 +89,12 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_means_device.argtypes = [vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_column_sums_device_timed.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp, c.c_int,
                                                c.POINTER(c.c_float)]
+    L.rsp_csc_row_sums.argtypes = [vp, dp]
+    L.rsp_csc_row_means.argtypes = [vp, dp]
+    L.rsp_row_sums_workspace_bytes.argtypes = [i32, i64]
+    L.rsp_row_sums_workspace_bytes.restype = c.c_size_t
+    L.rsp_row_sums_device.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp]
+    L.rsp_row_means_device.argtypes = [vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_partition_columns.argtypes = [ip, i32, i32, ip]
     L.rsp_rebase_offsets.argtypes = [ip, i32, i32, ip]
     L.rsp_comm_unique_id.argtypes = [vp]
@@ -94,6 +102,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_comm_gatherv.argtypes = [vp, vp, i64, vp, c.POINTER(i64), c.POINTER(i64), c.c_int, vp]
     L.rsp_comm_destroy.argtypes = [vp]
     L.rsp_gen_values_device.argtypes = [vp, i64, u64, u64, c.c_int, vp]
+    L.rsp_gen_row_indices_device.argtypes = [vp, vp, i32, i32, u64, vp]
     L.rsp_set_tuning.argtypes = [c.c_int]
     L.rsp_set_experiment.argtypes = [c.c_int]
     _lib = L
@@ -167,6 +176,16 @@ class DeviceCSC:
         _check(load().rsp_csc_column_means(self._h, _dp(out)))
         return out
 
+    def row_sums(self) -> np.ndarray:
+        out = np.empty(self.nrow, dtype=np.float64)
+        _check(load().rsp_csc_row_sums(self._h, _dp(out)))
+        return out
+
+    def row_means(self) -> np.ndarray:
+        out = np.empty(self.nrow, dtype=np.float64)
+        _check(load().rsp_csc_row_means(self._h, _dp(out)))
+        return out
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             load().rsp_csc_free(self._h)
@@ -216,6 +235,29 @@ def column_sums_device(x_t, p_t, out_t=None, workspace=None, stream=None, nrow_f
     return out_t
 
 
+def row_sums_device(x_t, i_t, nrow: int, out_t=None, workspace=None, stream=None, ncol_for_means=None):
+    """Matrix::rowSums / rowMeans on torch-owned HBM buffers (x, i); p is not needed."""
+    import torch
+    assert x_t.dtype == torch.float64 and i_t.dtype == torch.int32 and x_t.numel() == i_t.numel()
+    nnz = x_t.numel()
+    L = load()
+    if out_t is None:
+        out_t = torch.empty(nrow, dtype=torch.float64, device=x_t.device)
+    if workspace is None:
+        nbytes = int(L.rsp_row_sums_workspace_bytes(int(nrow), int(nnz)))
+        if nbytes == 0:
+            _check(RSP_ERR_HIP)
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)
+    if ncol_for_means is None:
+        _check(L.rsp_row_sums_device(x_t.data_ptr(), i_t.data_ptr(), int(nrow), nnz, out_t.data_ptr(),
+                                     workspace.data_ptr(), workspace.numel(), _stream_ptr(stream)))
+    else:
+        _check(L.rsp_row_means_device(x_t.data_ptr(), i_t.data_ptr(), int(nrow), int(ncol_for_means), nnz,
+                                      out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                                      _stream_ptr(stream)))
+    return out_t
+
+
 def prepared_column_sums(x_t, p_t, out_t, workspace, stream=None):
     """Pre-bound launcher of rsp_column_sums_device for hot loops (bench): the ctypes
     arguments are converted once, each call is a single foreign call."""
@@ -248,6 +290,12 @@ def gen_values_device(x_t, seed: int, first_idx: int = 0, kind: int = 0, stream=
     _check(load().rsp_gen_values_device(x_t.data_ptr(), x_t.numel(), int(seed), int(first_idx),
                                         int(kind), _stream_ptr(stream)))
     return x_t
+
+
+def gen_row_indices_device(i_t, p_t, nrow: int, seed: int, stream=None):
+    _check(load().rsp_gen_row_indices_device(i_t.data_ptr(), p_t.data_ptr(), int(nrow), p_t.numel() - 1,
+                                             int(seed), _stream_ptr(stream)))
+    return i_t
 
 
 # ------------------------------------------------------------- partitioning

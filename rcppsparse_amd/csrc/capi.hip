@@ -145,6 +145,11 @@ struct rsp_csc {
     void* d_ws;
     size_t ws_bytes;
     hipStream_t stream;
+    // row-wise path: row-major values + offsets, built on the first rowSums and kept
+    void* d_row_persist;
+    double* d_row_out;
+    rsp::RowSumsLayout row_layout;
+    bool row_ready;
 };
 
 extern "C" {
@@ -230,6 +235,13 @@ int rsp_gen_values_device(double* d_x, int64_t n, uint64_t seed, uint64_t first_
     return RSP_OK;
 }
 
+int rsp_gen_row_indices_device(int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,
+                               uint64_t seed, void* stream) {
+    if (ncol < 0 || nrow < 0 || (ncol > 0 && (!d_i || !d_p))) return fail(RSP_ERR_BAD_ARG, "bad buffer");
+    HIP_TRY(rsp::launch_gen_row_indices(d_i, d_p, nrow, ncol, seed, (hipStream_t)stream));
+    return RSP_OK;
+}
+
 // ---- device-resident dgCMatrix -------------------------------------------
 
 int rsp_csc_free(rsp_csc_t h) {
@@ -241,6 +253,8 @@ int rsp_csc_free(rsp_csc_t h) {
     if (h->d_p) (void)hipFree(h->d_p);
     if (h->d_out) (void)hipFree(h->d_out);
     if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_row_persist) (void)hipFree(h->d_row_persist);
+    if (h->d_row_out) (void)hipFree(h->d_row_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return RSP_OK;
@@ -302,6 +316,91 @@ static int csc_run(rsp_csc_t h, double* host_out, bool means) {
 
 int rsp_csc_column_sums(rsp_csc_t h, double* sums) { return csc_run(h, sums, false); }
 int rsp_csc_column_means(rsp_csc_t h, double* means) { return csc_run(h, means, true); }
+
+// ---- row-wise "next" entries (Matrix::rowSums / rowMeans, RcppSparse.h:138-156) ----------
+
+static int row_plan(int32_t nrow, int64_t nnz, rsp::RowSumsLayout* L) {
+    if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
+    if (int rc = check_sizes(0, nnz)) return rc;
+    const size_t cs = rsp::workspace_bytes_for(make_plan(nnz).nchunks);
+    hipError_t e = rsp::plan_row_sums(nrow, nnz, cs, L);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_HIP, "planning the row-wise path failed: %s", hipGetErrorString(e));
+    }
+    return RSP_OK;
+}
+
+size_t rsp_row_sums_workspace_bytes(int32_t nrow, int64_t nnz) {
+    rsp::RowSumsLayout L;
+    if (row_plan(nrow, nnz, &L) != RSP_OK) return 0;
+    return L.persistent_bytes + L.scratch_bytes;
+}
+
+static int row_enqueue(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz, double* d_out,
+                       void* ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+    if (nrow == 0) return RSP_OK;
+    if (!d_out || (nnz > 0 && (!d_x || !d_i))) return fail(RSP_ERR_BAD_ARG, "null device pointer");
+    rsp::RowSumsLayout L;
+    if (int rc = row_plan(nrow, nnz, &L)) return rc;
+    if (!ws || ws_bytes < L.persistent_bytes + L.scratch_bytes)
+        return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes,
+                    L.persistent_bytes + L.scratch_bytes);
+    char* persist = (char*)ws;
+    char* scratch = persist + L.persistent_bytes;
+    HIP_TRY(rsp::launch_row_transpose_values(d_x, d_i, nrow, nnz, L, persist, scratch, stream));
+    // rowSums(A) = columnSums(t(A)): same kernels, row offsets in place of p
+    const rsp::LaunchPlan plan = make_plan(nnz);
+    HIP_TRY(rsp::launch_column_sums((const double*)(persist + L.vals_off), (const int32_t*)(persist + L.prow_off),
+                                    nrow, (int32_t)nnz, d_out, plan, persist + L.colsums_off, divisor, means,
+                                    stream));
+    return RSP_OK;
+}
+
+int rsp_row_sums_device(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz, double* d_sums,
+                        void* d_workspace, size_t workspace_bytes, void* stream) {
+    return row_enqueue(d_x, d_i, nrow, nnz, d_sums, d_workspace, workspace_bytes, 1.0, false,
+                       (hipStream_t)stream);
+}
+
+int rsp_row_means_device(const double* d_x, const int32_t* d_i, int32_t nrow, int32_t ncol, int64_t nnz,
+                         double* d_means, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return row_enqueue(d_x, d_i, nrow, nnz, d_means, d_workspace, workspace_bytes, (double)ncol, true,
+                       (hipStream_t)stream);
+}
+
+static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
+    if (!h || !host_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->nrow == 0) return RSP_OK;
+    if (h->nnz > 0 && !h->d_i)
+        return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: rowSums needs the row indices");
+    if (!h->row_ready) {   // build the row-major form once; the scratch is released right after
+        if (int rc = row_plan(h->nrow, h->nnz, &h->row_layout)) return rc;
+        void* scratch = nullptr;
+        HIP_TRY(hipMalloc(&h->d_row_persist, h->row_layout.persistent_bytes));
+        HIP_TRY(hipMalloc((void**)&h->d_row_out, (size_t)h->nrow * 8));
+        hipError_t e = hipMalloc(&scratch, h->row_layout.scratch_bytes);
+        if (e == hipSuccess)
+            e = rsp::launch_row_transpose_values(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout,
+                                                 h->d_row_persist, scratch, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (scratch) (void)hipFree(scratch);
+        if (e != hipSuccess) return fail(RSP_ERR_HIP, "building the row-major form failed: %s", hipGetErrorString(e));
+        h->row_ready = true;
+    }
+    const rsp::RowSumsLayout& L = h->row_layout;
+    char* persist = (char*)h->d_row_persist;
+    HIP_TRY(rsp::launch_column_sums((const double*)(persist + L.vals_off), (const int32_t*)(persist + L.prow_off),
+                                    h->nrow, (int32_t)h->nnz, h->d_row_out, make_plan(h->nnz),
+                                    persist + L.colsums_off, means ? (double)h->ncol : 1.0, means, h->stream));
+    HIP_TRY(hipMemcpyAsync(host_out, h->d_row_out, (size_t)h->nrow * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RSP_OK;
+}
+
+int rsp_csc_row_sums(rsp_csc_t h, double* sums) { return csc_rows(h, sums, false); }
+int rsp_csc_row_means(rsp_csc_t h, double* means) { return csc_rows(h, means, true); }
 
 int rsp_column_sums_host(const double* x, const int32_t* p, int32_t ncol, int64_t nnz, double* sums,
                          int device) {

@@ -37,6 +37,19 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
                               double divisor, bool means, hipStream_t stream);
 
+// Workspace layout of the row-wise path (rowsums.hip); offsets in bytes, 256-aligned.
+// persistent = row-major values + row offsets + carries; scratch = sort keys + rocPRIM temp.
+struct RowSumsLayout {
+    size_t vals_off, prow_off, colsums_off, persistent_bytes;
+    size_t keys_off, temp_off, temp_bytes, scratch_bytes;
+};
+hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, RowSumsLayout* L);
+hipError_t launch_row_transpose_values(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
+                                       const RowSumsLayout& L, void* persist, void* scratch,
+                                       hipStream_t stream);
+
+hipError_t launch_gen_row_indices(int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,
+                                  uint64_t seed, hipStream_t stream);
 hipError_t launch_gen_values(double* d_x, int64_t n, uint64_t seed, uint64_t first_idx, int kind,
                              hipStream_t stream);
 

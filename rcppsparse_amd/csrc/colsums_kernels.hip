@@ -749,6 +749,27 @@ __global__ void gen_values_kernel(double* __restrict__ x, int64_t n, uint64_t se
     }
 }
 
+// Row indices for synthetic matrices: column c with k entries gets rows
+// floor(nrow * (r + u) / k), r = 0..k-1, u in [0,1) from the hash -- ascending and (for
+// k <= nrow) distinct, i.e. a valid dgCMatrix column.  One thread per column.  Mirrors
+// oracle_gen_row_indices bit for bit (plain IEEE double add / mul / div, no contraction).
+__global__ void gen_row_indices_kernel(int32_t* __restrict__ i, const int32_t* __restrict__ p,
+                                       int32_t nrow, int32_t ncol, uint64_t seed) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    const int lo = p[c], k = p[c + 1] - p[c];
+    for (int r = 0; r < k; ++r) {
+        const uint64_t h = mix64(seed * 0xD1342543DE82EF95ull + 0x5bd1e995ull + (uint64_t)(lo + r));
+        const double u = (double)(h >> 11) * 0x1.0p-53;
+        double t = (double)r + u;
+        t = t * (double)nrow;
+        t = t / (double)k;
+        int row = (int)t;
+        if (row >= nrow) row = nrow - 1;
+        i[lo + r] = row;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -808,6 +829,14 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         hipLaunchKernelGGL((colsums_fixup_kernel<false>), fgrid, fblock, 0, stream, d_p, ncol,
                            plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info,
                            divisor);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_row_indices(int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,
+                                  uint64_t seed, hipStream_t stream) {
+    if (ncol <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gen_row_indices_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_i, d_p, nrow,
+                       ncol, seed);
     return hipGetLastError();
 }
 
