@@ -69,6 +69,18 @@ int rsp_device_count(int *count);
 int rsp_column_sums_host(const double *x, const int32_t *p, int32_t ncol,
                          int64_t nnz, double *sums, int device);
 
+/*
+ * The same one-shot call spread over several GPUs of the node: the columns are cut
+ * into nnz-balanced contiguous ranges, every range is uploaded over its own GPU's
+ * host link by its own host thread, summed there, and its slice of the sums is
+ * copied straight into `sums` (no collective: the result lives in host memory).
+ * `devices` lists one device ordinal per shard (an ordinal may repeat); NULL / 0
+ * means one shard on every visible device.  Same contract on x, p, sums as above.
+ */
+int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol,
+                               int64_t nnz, double *sums, const int *devices,
+                               int ndevices);
+
 /* ---- device-resident dgCMatrix handle (upload once, sum many) ---------- */
 /* The slot layout x / i / p / Dim of reference RcppSparse.h:29-30 is the wire
  * format; i may be NULL (it is only kept for the row-wise "next" entries). */

@@ -29,7 +29,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/rcppsparse_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (
     "rsp_version", "rsp_last_error", "rsp_device_count",
-    "rsp_column_sums_host",
+    "rsp_column_sums_host", "rsp_column_sums_host_multi",
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed",
@@ -79,6 +79,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_last_error.restype = c.c_char_p
     L.rsp_device_count.argtypes = [c.POINTER(c.c_int)]
     L.rsp_column_sums_host.argtypes = [dp, ip, i32, i64, dp, c.c_int]
+    L.rsp_column_sums_host_multi.argtypes = [dp, ip, i32, i64, dp, c.POINTER(c.c_int), c.c_int]
     L.rsp_csc_upload.argtypes = [dp, ip, ip, i32, i32, i64, c.c_int, c.POINTER(vp)]
     L.rsp_csc_column_sums.argtypes = [vp, dp]
     L.rsp_csc_column_means.argtypes = [vp, dp]
@@ -150,6 +151,22 @@ def column_sums_host(x, p, ncol=None, device: int = 0) -> np.ndarray:
     ncol = len(p) - 1 if ncol is None else int(ncol)
     out = np.empty(ncol, dtype=np.float64)
     _check(load().rsp_column_sums_host(_dp(x), _ip(p), ncol, x.size, _dp(out), device))
+    return out
+
+
+def column_sums_host_multi(x, p, ncol=None, devices=None) -> np.ndarray:
+    """One-shot host columnSums over several GPUs (one shard per entry of `devices`;
+    None = every visible device)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.int32)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    if devices is None:
+        arr, n = None, 0
+    else:
+        n = len(devices)
+        arr = (ctypes.c_int * n)(*[int(d) for d in devices])
+    _check(load().rsp_column_sums_host_multi(_dp(x), _ip(p), ncol, x.size, _dp(out), arr, n))
     return out
 
 

@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/rcppsparse_hip.h"
 
@@ -51,6 +54,95 @@ int rsp_rebase_offsets(const int32_t* p, int32_t c0, int32_t c1, int32_t* p_loca
         return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_rebase_offsets");
     const int32_t base = p[c0];
     for (int32_t j = 0; j <= c1 - c0; ++j) p_local[j] = p[c0 + j] - base;
+    return RSP_OK;
+}
+
+// ---- one-shot host path over several GPUs -----------------------
+// The one-shot call is PCIe-bound, so with G GPUs the columns are cut
+// into nnz-balanced ranges and every range travels over its own GPU's host link: one host
+// thread per shard uploads x[p[c0]:p[c1]] and the rebased offsets, runs the same kernels,
+// and copies its slice of the sums straight into sums + c0.  No collective is needed: the
+// result lives in host memory.  `devices` may repeat an ordinal (several shards on one GPU).
+int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, int64_t nnz, double* sums,
+                               const int* devices, int ndevices) {
+    if (!p || (nnz > 0 && !x) || (ncol > 0 && !sums) || ncol < 0 || nnz < 0)
+        return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_column_sums_host_multi");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_NO_DEVICE, "no HIP device available");
+    }
+    std::vector<int> devs;
+    if (devices && ndevices > 0) {
+        devs.assign(devices, devices + ndevices);
+    } else {
+        for (int d = 0; d < visible; ++d) devs.push_back(d);
+    }
+    for (int d : devs)
+        if (d < 0 || d >= visible) return fail(RSP_ERR_BAD_ARG, "device %d out of range [0, %d)", d, visible);
+    if (ncol == 0) return RSP_OK;
+    // same contract on p as the single-device entry point
+    if (p[0] != 0 || p[ncol] != nnz) return fail(RSP_ERR_BAD_ARG, "p[0] must be 0 and p[ncol] must equal nnz");
+    int bad = 0;
+    for (int32_t c = 0; c < ncol; ++c) bad |= (p[c + 1] < p[c]);
+    if (bad) return fail(RSP_ERR_BAD_ARG, "p[] is not non-decreasing");
+
+    const int G = (int)devs.size();
+    std::vector<int32_t> bounds((size_t)G + 1);
+    if (int rc = rsp_partition_columns(p, ncol, G, bounds.data())) return rc;
+
+    std::vector<int> status((size_t)G, RSP_OK);
+    std::vector<std::string> message((size_t)G);
+    auto work = [&](int k) {
+        const int32_t c0 = bounds[k], c1 = bounds[k + 1];
+        const int32_t nc = c1 - c0;
+        if (nc == 0) return;
+        const int64_t n0 = p[c0], nk = (int64_t)p[c1] - p[c0];
+        double *d_x = nullptr, *d_out = nullptr;
+        int32_t* d_p = nullptr;
+        void* d_ws = nullptr;
+        hipStream_t st = nullptr;
+        std::vector<int32_t> pk((size_t)nc + 1);
+        for (int32_t j = 0; j <= nc; ++j) pk[j] = p[c0 + j] - (int32_t)n0;
+        auto check = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && status[k] == RSP_OK) {
+                status[k] = RSP_ERR_HIP;
+                message[k] = std::string(what) + ": " + hipGetErrorString(e);
+            }
+            return e == hipSuccess;
+        };
+        const size_t xbytes = (((size_t)nk * 8 + 15) & ~(size_t)15) + 16;
+        bool ok = check(hipSetDevice(devs[k]), "hipSetDevice");
+        const size_t wsb = rsp_column_sums_workspace_bytes(nc, nk);
+        ok = ok && check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+        ok = ok && check(hipMalloc((void**)&d_x, xbytes), "hipMalloc x");
+        ok = ok && check(hipMalloc((void**)&d_p, ((size_t)nc + 1) * 4), "hipMalloc p");
+        ok = ok && check(hipMalloc((void**)&d_out, (size_t)nc * 8), "hipMalloc out");
+        ok = ok && check(hipMalloc(&d_ws, wsb), "hipMalloc workspace");
+        if (ok && nk > 0) ok = check(hipMemcpyAsync(d_x, x + n0, (size_t)nk * 8, hipMemcpyHostToDevice, st), "H2D x");
+        ok = ok && check(hipMemcpyAsync(d_p, pk.data(), ((size_t)nc + 1) * 4, hipMemcpyHostToDevice, st), "H2D p");
+        if (ok) {
+            const int rc = rsp_column_sums_device(d_x, d_p, nc, nk, d_out, d_ws, wsb, st);
+            if (rc != RSP_OK) {
+                status[k] = rc;
+                message[k] = rsp_last_error();   // this thread's message
+                ok = false;
+            }
+        }
+        ok = ok && check(hipMemcpyAsync(sums + c0, d_out, (size_t)nc * 8, hipMemcpyDeviceToHost, st), "D2H sums");
+        if (st) check(hipStreamSynchronize(st), "hipStreamSynchronize");
+        if (d_x) (void)hipFree(d_x);
+        if (d_p) (void)hipFree(d_p);
+        if (d_out) (void)hipFree(d_out);
+        if (d_ws) (void)hipFree(d_ws);
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < G; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (int k = 0; k < G; ++k)
+        if (status[k] != RSP_OK) return fail(status[k], "shard %d on device %d: %s", k, devs[k], message[k].c_str());
     return RSP_OK;
 }
 

@@ -1,0 +1,70 @@
+/* Plain-C caller of the C ABI (no Python, no torch, no C++): what a foreign host
+ * language sees.  Builds the 5x5 matrix of reference vignettes/Documentation.Rmd:213-216,
+ * calls the one-shot and the handle entry points, checks the exact expected bits, then a
+ * 3e6-nnz ragged matrix against a plain C loop (the reference loop restated inline here so
+ * this file has no dependency on oracle/).  Exit code 0 = pass.
+ *   gcc cabi_smoke.c -I../../include -L../../rcppsparse_amd -lrcppsparse_hip -Wl,-rpath,... */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rcppsparse_hip.h"
+
+static int fail(const char *what) {
+    fprintf(stderr, "FAIL %s: %s\n", what, rsp_last_error());
+    return 1;
+}
+
+int main(void) {
+    int ndev = -1;
+    if (rsp_device_count(&ndev) != RSP_OK) return fail("device_count");
+    printf("%s, %d device(s)\n", rsp_version(), ndev);
+    if (ndev <= 0) { fprintf(stderr, "no GPU: the library has no CPU fallback\n"); return 2; }
+
+    const double x[5] = {0.41, 0.35, 0.84, 0.37, 0.26};
+    const int32_t i[5] = {0, 2, 0, 1, 1};
+    const int32_t p[6] = {0, 0, 1, 2, 4, 5};
+    const double want[5] = {0.0, 0.41, 0.35, 0.84 + 0.37, 0.26};
+    double got[5];
+    if (rsp_column_sums_host(x, p, 5, 5, got, 0) != RSP_OK) return fail("column_sums_host");
+    if (memcmp(got, want, sizeof want) != 0) { fprintf(stderr, "KAT bits differ\n"); return 1; }
+
+    rsp_csc_t h = NULL;
+    if (rsp_csc_upload(x, i, p, 5, 5, 5, 0, &h) != RSP_OK) return fail("upload");
+    double means[5], rows[5];
+    if (rsp_csc_column_sums(h, got) != RSP_OK || memcmp(got, want, sizeof want) != 0) return fail("csc_column_sums");
+    if (rsp_csc_column_means(h, means) != RSP_OK) return fail("csc_column_means");
+    for (int c = 0; c < 5; ++c) if (means[c] != want[c] / 5) { fprintf(stderr, "means differ\n"); return 1; }
+    if (rsp_csc_row_sums(h, rows) != RSP_OK) return fail("csc_row_sums");
+    const double want_rows[5] = {0.41 + 0.84, 0.37 + 0.26, 0.35, 0.0, 0.0};
+    for (int r = 0; r < 5; ++r) if (fabs(rows[r] - want_rows[r]) > 1e-15) { fprintf(stderr, "rows differ\n"); return 1; }
+    rsp_csc_free(h);
+
+    /* error behaviour: invalid offsets are rejected, nothing is computed */
+    const int32_t bad[6] = {0, 2, 1, 3, 4, 5};
+    if (rsp_column_sums_host(x, bad, 5, 5, got, 0) != RSP_ERR_BAD_ARG) { fprintf(stderr, "bad p accepted\n"); return 1; }
+
+    /* ragged matrix, 3e6 nnz */
+    const int ncol = 70001;
+    int32_t *pp = malloc(sizeof(int32_t) * (ncol + 1));
+    unsigned long long s = 88172645463325252ull;
+    pp[0] = 0;
+    for (int c = 0; c < ncol; ++c) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        int len = (c % 11 == 0) ? 0 : (int)(s % 90);
+        if (c == 1234) len = 250000;
+        pp[c + 1] = pp[c] + len;
+    }
+    const long nnz = pp[ncol];
+    double *xx = malloc(sizeof(double) * nnz), *ref = malloc(sizeof(double) * ncol), *out = malloc(sizeof(double) * ncol);
+    for (long k = 0; k < nnz; ++k) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; xx[k] = (double)((long)(s % 2001) - 1000) / 100.0; }
+    for (int c = 0; c < ncol; ++c) { double a = 0.0; for (int j = pp[c]; j < pp[c + 1]; ++j) a += xx[j]; ref[c] = a; }
+    if (rsp_column_sums_host(xx, pp, ncol, nnz, out, 0) != RSP_OK) return fail("ragged");
+    for (int c = 0; c < ncol; ++c) {
+        double l1 = 0.0; for (int j = pp[c]; j < pp[c + 1]; ++j) l1 += fabs(xx[j]);
+        if (fabs(out[c] - ref[c]) > 1e-12 * l1) { fprintf(stderr, "column %d: %.17g vs %.17g\n", c, out[c], ref[c]); return 1; }
+    }
+    printf("cabi_smoke ok (%ld nnz, %d columns)\n", nnz, ncol);
+    return 0;
+}

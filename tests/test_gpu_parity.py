@@ -316,6 +316,27 @@ def test_column_means_follow_reference_division(torch_cuda, label, ncol, mean):
     assert np.all(np.abs(means - ref) <= RTOL * scale)
 
 
+# ------------------------------------------- "next" row f2: one-shot host path over several GPUs
+@pytest.mark.parametrize("devices", [None, [0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
+def test_host_multi_shards_reassemble(torch_cuda, devices):
+    """rsp_column_sums_host_multi: nnz-balanced column ranges, one host thread per shard, slices
+    written straight into the host result.  On this 1-GPU box the shards share device 0."""
+    counts = synth.zipf_counts(30_000, 4_000_003, seed=8, nrow=600_000)
+    counts[::13] = 0
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=8, kind=0)
+    got = capi.column_sums_host_multi(x, p, devices=devices)
+    assert_parity(got, x, p)
+    # more shards than columns, and an empty matrix
+    tiny = capi.column_sums_host_multi(np.array([1.0, 2.0, 3.0]), np.array([0, 1, 3], dtype=np.int32),
+                                       devices=[0] * 5)
+    assert np.array_equal(tiny, [1.0, 5.0])
+    assert capi.column_sums_host_multi(np.array([], dtype=np.float64), np.zeros(4, dtype=np.int32),
+                                       devices=devices).tolist() == [0.0, 0.0, 0.0]
+    with pytest.raises(capi.RspError):
+        capi.column_sums_host_multi(x, p, devices=[99])
+
+
 # ------------------------------------------------------------------ RCCL plumbing
 def test_rccl_single_rank_gatherv_roundtrip(torch_cuda):
     """One-rank communicator on the one GPU of this box: unique id, init, gatherv (root's own

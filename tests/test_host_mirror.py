@@ -133,3 +133,20 @@ def test_exported_columnSums_readme_example():
     A = synth.rsparsematrix(10, 10, density=0.1, seed=1)
     got = hostseam.columnSums(A)
     assert got.shape == (10,) and got.tobytes() == oracle.column_sums(A["x"], A["p"]).tobytes()
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_of_the_abi(tmp_path):
+    """A C program (gcc, no Python/torch/C++ in the process) drives the C ABI: one-shot, handle,
+    means, rowSums, error status.  Also proves the library runs on the system HIP runtime."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rcppsparse_amd")
+    exe = str(tmp_path / "cabi_smoke")
+    subprocess.run(["gcc", "-O1", "-o", exe, os.path.join(root, "tests", "c", "cabi_smoke.c"),
+                    "-I", os.path.join(root, "include"), "-L", libdir, "-lrcppsparse_hip", "-lm",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cabi_smoke ok" in r.stdout
