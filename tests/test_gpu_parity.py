@@ -316,6 +316,51 @@ def test_column_means_follow_reference_division(torch_cuda, label, ncol, mean):
     assert np.all(np.abs(means - ref) <= RTOL * scale)
 
 
+# ------------------------------------------------------------- maximum size, graph capture
+def test_maximum_nnz_int32_limit(torch_cuda):
+    """nnz = 2^31 - 1, the largest matrix the reference's 32-bit p[] / iterator state can address
+    (RcppSparse.h:30, :232): 17.2 GB of x.  Checked against torch's own reductions of the same
+    slices (all-positive data, so plain relative error), plus an odd tail and a 1-element column."""
+    torch = torch_cuda
+    nnz = 2**31 - 1
+    if torch.cuda.get_device_properties(0).total_memory < 40 * 2**30:
+        pytest.skip("needs >= 40 GB of HBM")
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    capi.gen_values_device(xt, seed=5, kind=1)
+    cuts = [0, 1, 700_000_001, 700_000_001, 2_000_000_000, nnz - 1, nnz]
+    p = torch.tensor(cuts, dtype=torch.int32, device="cuda")
+    got = capi.column_sums_device(xt, p).cpu().numpy()
+    want = np.array([float(torch.sum(xt[a:b]).item()) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert got[2] == 0.0                                   # empty column in the middle
+    assert got[0] == float(xt[0].item()) and got[5] == float(xt[nnz - 1].item())
+    assert np.all(np.abs(got - want) <= 1e-12 * np.abs(want))
+
+
+def test_device_entry_is_graph_capture_safe(torch_cuda):
+    """rsp_column_sums_device allocates nothing and never synchronises, so it can be captured
+    into a HIP graph and replayed (include/rcppsparse_hip.h): replay must reproduce the bits."""
+    torch = torch_cuda
+    counts = synth.uniform_counts(20_000, 2_000_000, seed=2, nrow=None)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=2, kind=0)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.zeros(20_000, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(20_000, xt.numel())
+    eager = capi.column_sums_device(xt, pt, out.clone(), ws).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        capi.column_sums_device(xt, pt, out, ws)      # enqueued on the capturing stream
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    xt.mul_(2.0)                                       # same graph, new data in the same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager * 2.0)
+
+
 # ------------------------------------------- "next" row f2: one-shot host path over several GPUs
 @pytest.mark.parametrize("devices", [None, [0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
 def test_host_multi_shards_reassemble(torch_cuda, devices):
