@@ -43,6 +43,9 @@ WORKLOADS = {
     "c3": (10_000_000, 1_000_000, 1_000_000_000, "uniform"),
     "c5": (10_000_000, 1_000_000, 1_000_000_000, "zipf"),
     "c5desc": (10_000_000, 1_000_000, 1_000_000_000, "zipf-descending"),   # worst-case column order
+    # the shape of the reference's own vignette benchmark: rsparsematrix(100000, 1000, 0.1)
+    # (vignettes/Documentation.Rmd:425), 1e7 nnz in 1000 columns of ~1e4
+    "vignette": (100_000, 1_000, 10_000_000, "uniform"),
     # experiments (not BASELINE configs): one shard of C4, and a single 1e9-long column
     # (no column ends inside the stream: the ceiling of the streaming fast path)
     "c4shard": (10_000_000, 125_000, 125_000_000, "uniform"),

@@ -198,8 +198,9 @@ int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
 /* chunk_rows: 128-element rows of x owned by one wavefront (0 = automatic). */
 int rsp_set_tuning(int chunk_rows);
 /* Selects an alternative build of the main kernel for A/B measurements
- * (0 = production; see launch_column_sums in csrc/colsums_kernels.hip).  Not for
- * production use; results stay within the documented tolerance for every value. */
+ * (0 = production; 1 = 16 rows in flight; 2 / 3 = 1 / 2 wavefronts per workgroup;
+ * 4 = default cache policy instead of nt loads).  Not for production use; results
+ * stay within the documented tolerance for every value. */
 int rsp_set_experiment(int variant);
 
 #ifdef __cplusplus

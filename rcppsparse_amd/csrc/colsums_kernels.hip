@@ -29,7 +29,6 @@
 namespace rsp {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
-typedef int i4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
 // lane-exchange helpers (wave64, DPP only: no LDS round trips)
@@ -252,7 +251,7 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
 }
 
 // ---------------------------------------------------------------------------
-// v2 paths: rows with only a few column ends, and groups of rows with many
+// rows with only a few column ends, and groups of rows with many
 // ---------------------------------------------------------------------------
 // Per-lane view of the next 64 column ends: lane j holds q = p[k + j] (valid iff
 // k + j <= ncol), read from the LDS window.
@@ -410,9 +409,9 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
     return true;
 }
 
-// One row through the v2 row paths.
+// One row: fast path, few-ends path or the general slow path.
 template <bool MEANS>
-__device__ __forceinline__ void row_v2(double v0, double v1, int rs, int lane, WaveState& st,
+__device__ __forceinline__ void process_row(double v0, double v1, int rs, int lane, WaveState& st,
                                        double& acc0, double& acc1, int32_t* win, int32_t* hist,
                                        const int32_t* __restrict__ p, int ncol, int w,
                                        double* __restrict__ out, double* __restrict__ carry_head,
@@ -435,8 +434,11 @@ __device__ __forceinline__ void row_v2(double v0, double v1, int rs, int lane, W
     }
 }
 
+// ---------------------------------------------------------------------------
+// main kernel: one wavefront per chunk
+// ---------------------------------------------------------------------------
 template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG>
-__global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel_v2(
+__global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
     double* __restrict__ carry_head, double* __restrict__ carry_tail,
@@ -530,114 +532,11 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel_v2(
                 const int r = g * kGroupRows + rr;
                 const int row = row0 + rr;
                 if (!done && row < nrows)
-                    row_v2<MEANS>(v[r].x, v[r].y, cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p, ncol,
+                    process_row<MEANS>(v[r].x, v[r].y, cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p, ncol,
                                   w, out, carry_head, divisor);
                 v[r] = __builtin_bit_cast(
                     d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, AUX));
             }
-        }
-    }
-
-    const double T = wave_allreduce_sum(acc0 + acc1);
-    if (lane == 0) {
-        if (st.head_open) {
-            carry_head[w] = T;
-            carry_tail[w] = 0.0;
-        } else {
-            carry_tail[w] = T;
-        }
-        carry_info[w] = make_int2(c0, st.ccur - c0);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// main kernel: one wavefront per chunk
-// ---------------------------------------------------------------------------
-template <int BATCH_ROWS, bool MEANS, int AUX>
-__global__ __launch_bounds__(kWavesPerWG * 64) void colsums_chunks_kernel(
-    const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
-    int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
-    double* __restrict__ carry_head, double* __restrict__ carry_tail,
-    int2* __restrict__ carry_info, double divisor) {
-    __shared__ __attribute__((aligned(16))) int32_t s_win[kWavesPerWG][kPWin];
-    __shared__ __attribute__((aligned(16))) int32_t s_hist[kWavesPerWG][kHistPad];
-
-    const int lane = threadIdx.x & 63;
-    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int w = blockIdx.x * kWavesPerWG + wave_in_wg;   // chunk id (wave-uniform)
-    if (w >= nchunks) return;
-    int32_t* win = s_win[wave_in_wg];
-    int32_t* hist = s_hist[wave_in_wg];
-
-    const int32_t cs = w * chunk_elems;
-    const int64_t ce64 = (int64_t)cs + chunk_elems;
-    const int32_t ce = ce64 < (int64_t)nnz ? (int32_t)ce64 : nnz;
-    const int32_t nrows = (int32_t)(((int64_t)ce - cs + 127) >> 7);
-
-    // wave-uniform buffer descriptor over this chunk of x (hardware bounds check:
-    // reads past the chunk return 0, and a sum is unchanged by extra +0.0 terms)
-    const double* xb = x + cs;
-    const uint32_t xbytes = (uint32_t)(ce - cs) * 8u;
-    const __amdgpu_buffer_rsrc_t xr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)xbytes, 0x00020000);
-    const int voff = lane * 16;
-
-    d2 v[BATCH_ROWS];
-#pragma unroll
-    for (int r = 0; r < BATCH_ROWS; ++r)
-        v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, r * 1024, AUX));
-
-    // ---- locate the column that owns element cs: c0 = upper_bound(p, cs) - 1,
-    //      64-ary search (each round one strided load + ballot) -------------
-    int lo = 0, hi = ncol;   // invariant: p[lo] <= cs < p[hi]
-    while (hi - lo > 1) {
-        const int step = (int)(((int64_t)hi - lo + 63) >> 6);
-        const int64_t j = (int64_t)lo + (int64_t)(lane + 1) * step;
-        const bool valid = j < hi;
-        const int pv = p[valid ? j : hi];
-        const bool le = valid && pv <= cs;
-        const int n = __popcll(__ballot(le));
-        const int64_t nlo = (int64_t)lo + (int64_t)n * step;
-        const int64_t nhi = nlo + step;
-        lo = (int)nlo;
-        hi = nhi < hi ? (int)nhi : hi;
-    }
-    const int c0 = lo;
-
-    // leading empty columns (p[c+1] == 0) belong to chunk 0
-    if (w == 0)
-        for (int c = lane; c < c0; c += 64) out[c] = 0.0;
-
-    WaveState st;
-    st.ccur = c0;
-    st.wbase = c0;
-    fill_window(win, p, c0, ncol, lane);
-    st.head_open = true;
-    st.head_complete = __builtin_amdgcn_readfirstlane(win[0]) >= cs;
-    st.has_next = c0 + 1 <= ncol;
-    st.qnext = __builtin_amdgcn_readfirstlane(win[1]);
-
-    double acc0 = 0.0, acc1 = 0.0;
-    const int nbatches = (nrows + BATCH_ROWS - 1) / BATCH_ROWS;
-    for (int b = 0; b < nbatches; ++b) {
-#pragma unroll
-        for (int r = 0; r < BATCH_ROWS; ++r) {
-            const int row = b * BATCH_ROWS + r;
-            if (row < nrows) {
-                const int rs = cs + row * kRowElems;
-                const uint32_t dq = (uint32_t)st.qnext - (uint32_t)rs;
-                if (st.has_next && (dq - 1u) < 128u) {
-                    slow_row<MEANS>(v[r].x, v[r].y, rs, lane, st, acc0, acc1, win, hist, p, ncol, w,
-                                    out, carry_head, divisor);
-                } else {
-                    acc0 += v[r].x;
-                    acc1 += v[r].y;
-                }
-            }
-            // refill this register pair with the same row of the next batch:
-            // BATCH_ROWS loads stay in flight for the whole chunk
-            v[r] = __builtin_bit_cast(
-                d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, AUX));
         }
     }
 
@@ -801,20 +700,21 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 #define RSP_LAUNCH_W(WPG_)                                                                              \
     do {                                                                                               \
         const dim3 g2((plan.nchunks + (WPG_) - 1) / (WPG_)), b2((WPG_) * 64);                          \
-        hipLaunchKernelGGL((colsums_chunks_kernel_v2<kBatchRows, false, kLoadAux, WPG_>), g2, b2, 0,   \
-                           stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,         \
-                           carry_head, carry_tail, carry_info, divisor);                               \
+        if (means)                                                                                     \
+            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, true, kLoadAux, WPG_>), g2, b2, 0,   \
+                               stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,     \
+                               carry_head, carry_tail, carry_info, divisor);                           \
+        else                                                                                           \
+            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_>), g2, b2, 0,  \
+                               stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,     \
+                               carry_head, carry_tail, carry_info, divisor);                           \
     } while (0)
-    switch (plan.variant) {   // 0 = production; others are experiment variants (env RSP_VARIANT)
-        case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 8, 2); break;
-        case 2: RSP_LAUNCH_K(colsums_chunks_kernel, 32, 2); break;
-        case 3: RSP_LAUNCH_K(colsums_chunks_kernel, 8, 0); break;
-        case 4: RSP_LAUNCH_K(colsums_chunks_kernel, 16, 0); break;
-        case 5: RSP_LAUNCH_K(colsums_chunks_kernel, 16, 2); break;      // round-1 first kernel (v1)
-        case 7: RSP_LAUNCH_K(colsums_chunks_kernel_v2, 16, 2); break;
-        case 8: RSP_LAUNCH_W(1); break;     // one wavefront per workgroup
-        case 9: RSP_LAUNCH_W(2); break;     // two
-        default: RSP_LAUNCH_K(colsums_chunks_kernel_v2, kBatchRows, kLoadAux); break;
+    switch (plan.variant) {   // 0 = production; the rest are A/B builds (rsp_set_experiment)
+        case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 16, kLoadAux); break;   // 16 rows in flight
+        case 2: RSP_LAUNCH_W(1); break;                                     // 1 wavefront per workgroup
+        case 3: RSP_LAUNCH_W(2); break;                                     // 2 wavefronts per workgroup
+        case 4: RSP_LAUNCH_K(colsums_chunks_kernel, kBatchRows, 0); break;  // default cache policy
+        default: RSP_LAUNCH_K(colsums_chunks_kernel, kBatchRows, kLoadAux); break;
     }
 #undef RSP_LAUNCH_K
 #undef RSP_LAUNCH_W

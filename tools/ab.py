@@ -17,7 +17,7 @@ from rcppsparse_amd import capi
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="c3")
-    ap.add_argument("--variants", default="0,5")
+    ap.add_argument("--variants", default="0,1")
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--per-round", type=int, default=5)
