@@ -115,6 +115,18 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
                             void *d_workspace, size_t workspace_bytes,
                             void *stream);
 /*
+ * Generic column reduction ("next" row f3): the same column-iteration loop with a
+ * different per-element body, out[c] = sum_j f(x[j]) over column c's stored entries --
+ * what a user writes with Matrix::InnerIterator for column norms
+ * (for (InnerIterator it(A, c); it; ++it) acc += f(it.value());).
+ */
+#define RSP_OP_SUM          0   /* f(v) = v      (== rsp_column_sums_device) */
+#define RSP_OP_SUM_SQUARES  1   /* f(v) = v * v  (squared column 2-norms)     */
+#define RSP_OP_SUM_ABS      2   /* f(v) = |v|    (column 1-norms)             */
+int rsp_column_reduce_device(const double *d_x, const int32_t *d_p, int32_t ncol,
+                             int64_t nnz, int op, double *d_out, void *d_workspace,
+                             size_t workspace_bytes, void *stream);
+/*
  * Measurement helper: enqueue `reps` back-to-back rsp_column_sums_device calls
  * on `stream`, bracketed by hipEvents recorded on that same stream, wait for
  * the last, and return the mean milliseconds per call in *ms_per_call.

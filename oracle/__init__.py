@@ -62,6 +62,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_row_means.argtypes = [dp, ip, ip, i32, i32, dp]
         L.oracle_column_abs_sums.argtypes = [dp, ip, i32, dp]
         L.oracle_gen_values.argtypes = [dp, u64, u64, u64, ctypes.c_int]
+        L.oracle_column_reduce.argtypes = [dp, ip, i32, ctypes.c_int, dp]
+        L.oracle_column_reduce.restype = None
         L.oracle_gen_row_indices.argtypes = [ip, ip, i32, i32, i32, u64]
         L.oracle_gen_row_indices.restype = None
         L.oracle_gen_value.argtypes = [u64, u64, ctypes.c_int]
@@ -170,4 +172,13 @@ def gen_row_indices(p, nrow, seed, c_first=0, c_last=None) -> np.ndarray:
     c_last = len(p) - 1 if c_last is None else int(c_last)
     out = np.empty(int(p[c_last] - p[c_first]), dtype=np.int32)
     lib().oracle_gen_row_indices(_ip(out), _ip(p), int(nrow), int(c_first), c_last, int(seed))
+    return out
+
+
+def column_reduce(x, p, op, ncol=None) -> np.ndarray:
+    """InnerIterator loop with body acc += f(value): op 0 v, 1 v*v, 2 |v|."""
+    x, p, _ = _prep(x, p)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    lib().oracle_column_reduce(_dp(x), _ip(p), ncol, int(op), _dp(out))
     return out

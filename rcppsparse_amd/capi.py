@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_host", "rsp_column_sums_host_multi",
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
-    "rsp_column_sums_device_timed",
+    "rsp_column_sums_device_timed", "rsp_column_reduce_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
@@ -88,6 +88,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_workspace_bytes.restype = c.c_size_t
     L.rsp_column_sums_device.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_column_means_device.argtypes = [vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
+    L.rsp_column_reduce_device.argtypes = [vp, vp, i32, i64, c.c_int, vp, vp, c.c_size_t, vp]
     L.rsp_column_sums_device_timed.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp, c.c_int,
                                                c.POINTER(c.c_float)]
     L.rsp_csc_row_sums.argtypes = [vp, dp]
@@ -272,6 +273,23 @@ def row_sums_device(x_t, i_t, nrow: int, out_t=None, workspace=None, stream=None
         _check(L.rsp_row_means_device(x_t.data_ptr(), i_t.data_ptr(), int(nrow), int(ncol_for_means), nnz,
                                       out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),
                                       _stream_ptr(stream)))
+    return out_t
+
+
+OP_SUM, OP_SUM_SQUARES, OP_SUM_ABS = 0, 1, 2
+
+
+def column_reduce_device(x_t, p_t, op: int, out_t=None, workspace=None, stream=None):
+    """out[c] = sum over column c of f(x): f = identity / square / abs (rsp_column_reduce_device)."""
+    import torch
+    ncol, nnz = p_t.numel() - 1, x_t.numel()
+    if out_t is None:
+        out_t = torch.empty(ncol, dtype=torch.float64, device=x_t.device)
+    if workspace is None:
+        workspace = alloc_workspace(ncol, nnz, x_t.device)
+    _check(load().rsp_column_reduce_device(x_t.data_ptr(), p_t.data_ptr(), ncol, nnz, int(op),
+                                           out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                                           _stream_ptr(stream)))
     return out_t
 
 

@@ -116,7 +116,8 @@ int require_device(int device) {
 }
 
 int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out,
-            void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+            void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream,
+            int op = rsp::kOpSum) {
     if (int rc = check_sizes(ncol, nnz)) return rc;
     if (ncol == 0) return RSP_OK;
     if (!d_p || !d_out || (nnz > 0 && !d_x))
@@ -128,7 +129,7 @@ int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, do
     if (nnz > 0 && (!d_ws || ws_bytes < need))
         return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
     HIP_TRY(rsp::launch_column_sums(d_x, d_p, ncol, (int32_t)nnz, d_out, plan, d_ws, divisor, means,
-                                    stream));
+                                    stream, op));
     return RSP_OK;
 }
 
@@ -201,6 +202,14 @@ int rsp_column_means_device(const double* d_x, const int32_t* d_p, int32_t nrow,
                             void* stream) {
     return enqueue(d_x, d_p, ncol, nnz, d_means, d_workspace, workspace_bytes, (double)nrow, true,
                    (hipStream_t)stream);
+}
+
+int rsp_column_reduce_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, int op,
+                             double* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (op != RSP_OP_SUM && op != RSP_OP_SUM_SQUARES && op != RSP_OP_SUM_ABS)
+        return fail(RSP_ERR_BAD_ARG, "unknown reduction op %d", op);
+    return enqueue(d_x, d_p, ncol, nnz, d_out, d_workspace, workspace_bytes, 1.0, false,
+                   (hipStream_t)stream, op);
 }
 
 int rsp_column_sums_device_timed(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,

@@ -20,6 +20,11 @@ constexpr int kStageSlots = kGroupElems + kGroupElems / 8;   // LDS staging, one
 constexpr int kFewEnds = 3;       // rows with <= this many column ends use the masked-reduce loop
 constexpr int kDenseMinEnds = 8;  // groups with >= this many column ends use the dense path
 
+// per-element transforms of the generic column reduction (values of rsp_column_reduce_device's op)
+constexpr int kOpSum = 0;
+constexpr int kOpSumSquares = 1;
+constexpr int kOpSumAbs = 2;
+
 // How a column-sum call is cut into chunks (one wavefront each).
 struct LaunchPlan {
     int32_t chunk_elems;   // multiple of kRowElems
@@ -35,7 +40,7 @@ inline size_t workspace_bytes_for(int32_t nchunks) {
 
 hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t nnz,
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
-                              double divisor, bool means, hipStream_t stream);
+                              double divisor, bool means, hipStream_t stream, int op = kOpSum);
 
 // Workspace layout of the row-wise path (rowsums.hip); offsets in bytes, 256-aligned.
 // persistent = row-major values + row offsets + carries; scratch = sort keys + rocPRIM temp.

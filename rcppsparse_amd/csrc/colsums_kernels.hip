@@ -136,6 +136,16 @@ __device__ __forceinline__ void ensure_window(WaveState& st, int32_t* win,
     }
 }
 
+// Per-element transform of the generic column reduction: the same
+// InnerIterator-shaped loop with a different body -- sum, sum of squares, sum of |x|.
+// f(0) = 0 for all of them, so the zero-filled out-of-range lanes stay harmless.
+template <int OP>
+__device__ __forceinline__ double xf(double v) {
+    if (OP == kOpSumSquares) return v * v;
+    if (OP == kOpSumAbs) return __builtin_fabs(v);
+    return v;
+}
+
 template <bool MEANS>
 __device__ __forceinline__ double finish(double v, double divisor) {
     v += 0.0;   // a sum of -0.0 terms must come out +0.0 like the reference's 0.0-initialised accumulator
@@ -437,7 +447,7 @@ __device__ __forceinline__ void process_row(double v0, double v1, int rs, int la
 // ---------------------------------------------------------------------------
 // main kernel: one wavefront per chunk
 // ---------------------------------------------------------------------------
-template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG>
+template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG, int OP = kOpSum>
 __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
@@ -520,8 +530,12 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                     const uint32_t d = (uint32_t)wq - (uint32_t)gs;
                     const int n4 = __popcll(__ballot(valid && (d - 1u) < glim));
                     if (n4 >= kDenseMinEnds) {
-                        const d2 grp[kGroupRows] = {v[g * kGroupRows + 0], v[g * kGroupRows + 1],
-                                                    v[g * kGroupRows + 2], v[g * kGroupRows + 3]};
+                        d2 grp[kGroupRows];
+#pragma unroll
+                        for (int rr = 0; rr < kGroupRows; ++rr) {
+                            grp[rr].x = xf<OP>(v[g * kGroupRows + rr].x);
+                            grp[rr].y = xf<OP>(v[g * kGroupRows + rr].y);
+                        }
                         done = dense_group<MEANS>(grp, gs, glim, lane, st, acc0, acc1, win, stage, bitmap, p,
                                                   ncol, w, out, carry_head, divisor);
                     }
@@ -532,7 +546,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                 const int r = g * kGroupRows + rr;
                 const int row = row0 + rr;
                 if (!done && row < nrows)
-                    process_row<MEANS>(v[r].x, v[r].y, cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p, ncol,
+                    process_row<MEANS>(xf<OP>(v[r].x), xf<OP>(v[r].y), cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p, ncol,
                                   w, out, carry_head, divisor);
                 v[r] = __builtin_bit_cast(
                     d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, AUX));
@@ -674,7 +688,7 @@ __global__ void gen_row_indices_kernel(int32_t* __restrict__ i, const int32_t* _
 // ---------------------------------------------------------------------------
 hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t nnz,
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
-                              double divisor, bool means, hipStream_t stream) {
+                              double divisor, bool means, hipStream_t stream, int op) {
     if (ncol <= 0) return hipSuccess;
     if (nnz <= 0) {
         hipLaunchKernelGGL(colsums_zero_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_out,
@@ -709,6 +723,15 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                                stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,     \
                                carry_head, carry_tail, carry_info, divisor);                           \
     } while (0)
+#define RSP_LAUNCH_OP(OP_)                                                                             \
+    hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, OP_>), grid,   \
+                       block, 0, stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,   \
+                       carry_head, carry_tail, carry_info, divisor)
+    if (op == kOpSumSquares) {
+        RSP_LAUNCH_OP(kOpSumSquares);
+    } else if (op == kOpSumAbs) {
+        RSP_LAUNCH_OP(kOpSumAbs);
+    } else
     switch (plan.variant) {   // 0 = production; the rest are A/B builds (rsp_set_experiment)
         case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 16, kLoadAux); break;   // 16 rows in flight
         case 2: RSP_LAUNCH_W(1); break;                                     // 1 wavefront per workgroup
@@ -717,6 +740,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         default: RSP_LAUNCH_K(colsums_chunks_kernel, kBatchRows, kLoadAux); break;
     }
 #undef RSP_LAUNCH_K
+#undef RSP_LAUNCH_OP
 #undef RSP_LAUNCH_W
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -10,7 +10,7 @@
 // Rcpp's vector types and adds the three members that need R objects (clone,
 // wrap, the S4 constructor) plus a native transpose().  Pure C++/Rcpp: no HIP
 // include, so `sourceCpp` consumers build on machines without ROCm.  The GPU path
-// is behind the package's compiled, exported columnSums() (src/example.cpp).
+// is behind the package's compiled, exported columnSums() (rpkg/src/columnSums.cpp).
 //
 // Needs R + Rcpp (>= 1.0.7) to compile; neither is in the build image of this
 // repository, so this file is checked by review and by compiling the shared

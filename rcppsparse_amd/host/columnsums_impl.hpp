@@ -1,5 +1,5 @@
 // columnsums_impl.hpp -- body of the exported columnSums(), shared by the Rcpp
-// build (host/example.cpp) and the Rcpp-free test seam (host/host_seam.cpp).
+// build (host/rpkg/src/columnSums.cpp) and the Rcpp-free test seam (host/host_seam.cpp).
 //
 // Reference src/example.cpp:26-32 allocates a zero-filled NumericVector and runs
 // one InnerIterator per column.  Here the allocation stays on the caller's (R

@@ -1,7 +1,7 @@
 // host_seam.cpp -- Rcpp-free build of the host mirror, for tests.
 //
 // R and Rcpp are not in this image, so the Rcpp layer (host/RcppSparse.h,
-// host/example.cpp, host/RcppExports.cpp) cannot be compiled here.  Everything
+// host/rpkg/src/columnSums.cpp, host/rpkg/src/rcpp_glue.cpp) cannot be compiled here.  Everything
 // beneath that layer can: this file instantiates the same templates
 // (rcppsparse_core::CscMatrix, column_sums_via_hip) over plain vector types
 // that mimic the three Rcpp properties the class relies on -- copies share

@@ -316,6 +316,30 @@ def test_column_means_follow_reference_division(torch_cuda, label, ncol, mean):
     assert np.all(np.abs(means - ref) <= RTOL * scale)
 
 
+# ------------------------------------------- "next" row f3: generic column reduction (functor)
+@pytest.mark.parametrize("label,ncol,mean", REGIMES)
+@pytest.mark.parametrize("op", [capi.OP_SUM, capi.OP_SUM_SQUARES, capi.OP_SUM_ABS])
+def test_column_reduce_ops(torch_cuda, label, ncol, mean, op):
+    torch = torch_cuda
+    nnz = int(ncol * mean)
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=21, nrow=None))
+    x = synth.gen_values(nnz, seed=22, kind=0)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    if nnz == 0:
+        xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
+    got = capi.column_reduce_device(xt, pt, op).cpu().numpy()
+    ref = oracle.column_reduce(x, p, op)
+    fx = x * x if op == capi.OP_SUM_SQUARES else np.abs(x)     # 1-norm of the transformed terms
+    scale = oracle.column_abs_sums(fx if op != capi.OP_SUM else x, p)
+    assert np.all(np.abs(got - ref) <= RTOL * scale)
+    if op == capi.OP_SUM:
+        assert got.tobytes() == capi.column_sums_device(xt, pt).cpu().numpy().tobytes()
+    else:
+        assert np.all(got >= 0.0)
+    with pytest.raises(capi.RspError):
+        capi.column_reduce_device(xt, pt, 7)
+
+
 # ------------------------------------------------------------- maximum size, graph capture
 def test_maximum_nnz_int32_limit(torch_cuda):
     """nnz = 2^31 - 1, the largest matrix the reference's 32-bit p[] / iterator state can address
