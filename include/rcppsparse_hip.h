@@ -83,7 +83,9 @@ int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol,
 
 /* ---- device-resident dgCMatrix handle (upload once, sum many) ---------- */
 /* The slot layout x / i / p / Dim of reference RcppSparse.h:29-30 is the wire
- * format; i may be NULL (it is only kept for the row-wise "next" entries). */
+ * format; i may be NULL (it is only kept for the row-wise "next" entries).
+ * A handle is owned by one thread at a time (calls on the same handle must not
+ * overlap); different handles may be used from different threads. */
 typedef struct rsp_csc *rsp_csc_t;
 
 int rsp_csc_upload(const double *x, const int32_t *i, const int32_t *p,

@@ -387,15 +387,23 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
     if (!h->row_ready) {   // build the row-major form once; the scratch is released right after
         if (int rc = row_plan(h->nrow, h->nnz, &h->row_layout)) return rc;
         void* scratch = nullptr;
-        HIP_TRY(hipMalloc(&h->d_row_persist, h->row_layout.persistent_bytes));
-        HIP_TRY(hipMalloc((void**)&h->d_row_out, (size_t)h->nrow * 8));
-        hipError_t e = hipMalloc(&scratch, h->row_layout.scratch_bytes);
+        hipError_t e = hipSuccess;
+        if (!h->d_row_persist) e = hipMalloc(&h->d_row_persist, h->row_layout.persistent_bytes);
+        if (e == hipSuccess && !h->d_row_out) e = hipMalloc((void**)&h->d_row_out, (size_t)h->nrow * 8);
+        if (e == hipSuccess) e = hipMalloc(&scratch, h->row_layout.scratch_bytes);
         if (e == hipSuccess)
             e = rsp::launch_row_transpose_values(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout,
                                                  h->d_row_persist, scratch, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (scratch) (void)hipFree(scratch);
-        if (e != hipSuccess) return fail(RSP_ERR_HIP, "building the row-major form failed: %s", hipGetErrorString(e));
+        if (e != hipSuccess) {   // leave the handle usable for the column entries and for a retry
+            if (h->d_row_persist) (void)hipFree(h->d_row_persist);
+            if (h->d_row_out) (void)hipFree(h->d_row_out);
+            h->d_row_persist = nullptr;
+            h->d_row_out = nullptr;
+            (void)hipGetLastError();
+            return fail(RSP_ERR_HIP, "building the row-major form failed: %s", hipGetErrorString(e));
+        }
         h->row_ready = true;
     }
     const rsp::RowSumsLayout& L = h->row_layout;

@@ -82,3 +82,30 @@ def test_partition_zipf_never_splits_a_column():
     shard_nnz = np.diff(p[b])
     assert shard_nnz.sum() == p[-1]
     assert shard_nnz.max() <= p[-1] / 8 + counts.max()
+
+
+def test_argument_errors_do_not_need_a_device():
+    L = capi.load()
+    import ctypes
+    # negative sizes / null pointers are rejected with BAD_ARG and a message, not a crash
+    out = np.zeros(4)
+    p = np.zeros(5, dtype=np.int32)
+    rc = L.rsp_column_sums_host(None, p.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 4, -1,
+                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0)
+    assert rc == capi.RSP_ERR_BAD_ARG and b"nnz" in L.rsp_last_error()
+    rc = L.rsp_column_sums_host(None, p.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), -3, 0,
+                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0)
+    assert rc == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_set_tuning(-1) == capi.RSP_ERR_BAD_ARG and L.rsp_set_experiment(-1) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_partition_columns(None, 3, 2, None) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_csc_free(None) == capi.RSP_OK          # freeing nothing is fine
+    assert L.rsp_comm_destroy(None) == capi.RSP_OK
+    # 2^31 nonzeros cannot be addressed by the 32-bit p[] (RcppSparse.h:30)
+    rc = L.rsp_column_sums_device(None, None, 1, 2**31, None, None, 0, None)
+    assert rc == capi.RSP_ERR_BAD_ARG
+
+
+def test_workspace_size_is_a_pure_function_of_nnz():
+    a = capi.workspace_bytes(10, 10**9)
+    assert a == capi.workspace_bytes(10**6, 10**9) and a >= 24 * (10**9 // (256 * 128))
+    assert capi.workspace_bytes(5, 0) > 0
