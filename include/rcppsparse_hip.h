@@ -129,6 +129,20 @@ int rsp_column_reduce_device(const double *d_x, const int32_t *d_p, int32_t ncol
                              int64_t nnz, int op, double *d_out, void *d_workspace,
                              size_t workspace_bytes, void *stream);
 /*
+ * Row-restricted column sums ("next" row f4): what a loop over
+ * Matrix::InnerIteratorInRange (complement = 0) or InnerIteratorNotInRange
+ * (complement = 1) computes (reference RcppSparse.h:238-321; documented intent,
+ * not its out-of-bounds quirks): out[c] = sum of x[j] over the entries of column c
+ * whose row i[j] is / is not in the row set.  The set is a bitmap of nrow bits
+ * (row r = bit r % 32 of word r / 32; (nrow + 31) / 32 words in HBM).  Streams
+ * x and i (12 B/nnz); d_i must be 8-byte aligned.
+ */
+int rsp_column_sums_in_rows_device(const double *d_x, const int32_t *d_i,
+                                   const int32_t *d_p, int32_t nrow, int32_t ncol,
+                                   int64_t nnz, const uint32_t *d_row_bitmap,
+                                   int complement, double *d_out, void *d_workspace,
+                                   size_t workspace_bytes, void *stream);
+/*
  * Measurement helper: enqueue `reps` back-to-back rsp_column_sums_device calls
  * on `stream`, bracketed by hipEvents recorded on that same stream, wait for
  * the last, and return the mean milliseconds per call in *ms_per_call.

@@ -64,6 +64,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_gen_values.argtypes = [dp, u64, u64, u64, ctypes.c_int]
         L.oracle_column_reduce.argtypes = [dp, ip, i32, ctypes.c_int, dp]
         L.oracle_column_reduce.restype = None
+        L.oracle_column_sums_in_rows.argtypes = [dp, ip, ip, i32, ctypes.c_void_p, ctypes.c_int, dp]
+        L.oracle_column_sums_in_rows.restype = None
         L.oracle_gen_row_indices.argtypes = [ip, ip, i32, i32, i32, u64]
         L.oracle_gen_row_indices.restype = None
         L.oracle_gen_value.argtypes = [u64, u64, ctypes.c_int]
@@ -181,4 +183,15 @@ def column_reduce(x, p, op, ncol=None) -> np.ndarray:
     ncol = len(p) - 1 if ncol is None else int(ncol)
     out = np.empty(ncol, dtype=np.float64)
     lib().oracle_column_reduce(_dp(x), _ip(p), ncol, int(op), _dp(out))
+    return out
+
+
+def column_sums_in_rows(x, i, p, bitmap, complement=False, ncol=None) -> np.ndarray:
+    """Column sums over entries whose row is (not) in the set (restricted iterators, RcppSparse.h:238-321)."""
+    x, p, i = _prep(x, p, i)
+    bitmap = np.ascontiguousarray(bitmap, dtype=np.uint32)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty(ncol, dtype=np.float64)
+    lib().oracle_column_sums_in_rows(_dp(x), _ip(i), _ip(p), ncol, bitmap.ctypes.data, int(bool(complement)),
+                                     _dp(out))
     return out

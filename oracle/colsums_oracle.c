@@ -133,6 +133,25 @@ void oracle_column_reduce(const double *x, const int32_t *p, int32_t ncol, int o
 }
 
 /*
+ * Row-restricted column sums ("next" row f4): the column loop driven by
+ * Matrix::InnerIteratorInRange / InnerIteratorNotInRange (RcppSparse.h:238-321), restated to
+ * their documented intent -- visit the stored entries of the column whose row is / is not in
+ * the ascending set s (here a bitmap), in storage order.  The reference's constructors probe
+ * i[] and s[] out of bounds on empty inputs (:242, :299); that is not reproduced.
+ */
+void oracle_column_sums_in_rows(const double *x, const int32_t *i, const int32_t *p, int32_t ncol,
+                                const uint32_t *bitmap, int complement, double *out) {
+    for (int32_t col = 0; col < ncol; ++col) {
+        double acc = 0.0;
+        for (int32_t j = p[col]; j < p[col + 1]; ++j) {
+            const int in = (int)((bitmap[i[j] >> 5] >> (i[j] & 31)) & 1u);
+            if (in != (complement != 0)) acc += x[j];
+        }
+        out[col] = acc;
+    }
+}
+
+/*
  * Synthetic value generators shared bit-for-bit with the device generator in
  * rcppsparse_amd/csrc (integer hash -> exactly representable double), so the
  * host can rebuild any slice of a device-generated x[] without copying it.

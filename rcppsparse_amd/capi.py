@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_host", "rsp_column_sums_host_multi",
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
-    "rsp_column_sums_device_timed", "rsp_column_reduce_device",
+    "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
@@ -89,6 +89,8 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_device.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_column_means_device.argtypes = [vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_column_reduce_device.argtypes = [vp, vp, i32, i64, c.c_int, vp, vp, c.c_size_t, vp]
+    L.rsp_column_sums_in_rows_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, c.c_int, vp, vp,
+                                                 c.c_size_t, vp]
     L.rsp_column_sums_device_timed.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp, c.c_int,
                                                c.POINTER(c.c_float)]
     L.rsp_csc_row_sums.argtypes = [vp, dp]
@@ -290,6 +292,30 @@ def column_reduce_device(x_t, p_t, op: int, out_t=None, workspace=None, stream=N
     _check(load().rsp_column_reduce_device(x_t.data_ptr(), p_t.data_ptr(), ncol, nnz, int(op),
                                            out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),
                                            _stream_ptr(stream)))
+    return out_t
+
+
+def row_set_bitmap(rows, nrow: int) -> np.ndarray:
+    """Sorted row set (as the reference's restricted iterators take it) -> bitmap of nrow bits."""
+    bits = np.zeros((int(nrow) + 31) // 32, dtype=np.uint32)
+    rows = np.asarray(rows, dtype=np.int64)
+    np.bitwise_or.at(bits, rows >> 5, (np.uint32(1) << (rows & 31).astype(np.uint32)))
+    return bits
+
+
+def column_sums_in_rows_device(x_t, i_t, p_t, nrow: int, bitmap_t, complement: bool = False, out_t=None,
+                               workspace=None, stream=None):
+    """Column sums restricted to entries whose row is (not) in the set (rsp_column_sums_in_rows_device)."""
+    import torch
+    ncol, nnz = p_t.numel() - 1, x_t.numel()
+    if out_t is None:
+        out_t = torch.empty(ncol, dtype=torch.float64, device=x_t.device)
+    if workspace is None:
+        workspace = alloc_workspace(ncol, nnz, x_t.device)
+    _check(load().rsp_column_sums_in_rows_device(x_t.data_ptr(), i_t.data_ptr(), p_t.data_ptr(), int(nrow),
+                                                 ncol, nnz, bitmap_t.data_ptr(), int(bool(complement)),
+                                                 out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),
+                                                 _stream_ptr(stream)))
     return out_t
 
 

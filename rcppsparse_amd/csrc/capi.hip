@@ -117,7 +117,8 @@ int require_device(int device) {
 
 int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out,
             void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream,
-            int op = rsp::kOpSum) {
+            int op = rsp::kOpSum, const int32_t* d_i = nullptr, const uint32_t* d_bitmap = nullptr,
+            int32_t bitmap_words = 0) {
     if (int rc = check_sizes(ncol, nnz)) return rc;
     if (ncol == 0) return RSP_OK;
     if (!d_p || !d_out || (nnz > 0 && !d_x))
@@ -129,7 +130,7 @@ int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, do
     if (nnz > 0 && (!d_ws || ws_bytes < need))
         return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
     HIP_TRY(rsp::launch_column_sums(d_x, d_p, ncol, (int32_t)nnz, d_out, plan, d_ws, divisor, means,
-                                    stream, op));
+                                    stream, op, d_i, d_bitmap, bitmap_words));
     return RSP_OK;
 }
 
@@ -210,6 +211,17 @@ int rsp_column_reduce_device(const double* d_x, const int32_t* d_p, int32_t ncol
         return fail(RSP_ERR_BAD_ARG, "unknown reduction op %d", op);
     return enqueue(d_x, d_p, ncol, nnz, d_out, d_workspace, workspace_bytes, 1.0, false,
                    (hipStream_t)stream, op);
+}
+
+int rsp_column_sums_in_rows_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
+                                   int32_t ncol, int64_t nnz, const uint32_t* d_row_bitmap, int complement,
+                                   double* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
+    if (nnz > 0 && (!d_i || !d_row_bitmap)) return fail(RSP_ERR_BAD_ARG, "row indices and row bitmap are required");
+    if (((uintptr_t)d_i & 7) != 0) return fail(RSP_ERR_BAD_ARG, "d_i must be 8-byte aligned");
+    const int32_t words = (int32_t)(((int64_t)nrow + 31) / 32);
+    return enqueue(d_x, d_p, ncol, nnz, d_out, d_workspace, workspace_bytes, 1.0, false, (hipStream_t)stream,
+                   complement ? rsp::kOpMaskedOut : rsp::kOpMaskedIn, d_i, d_row_bitmap, words);
 }
 
 int rsp_column_sums_device_timed(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,

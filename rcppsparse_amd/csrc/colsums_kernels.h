@@ -24,6 +24,8 @@ constexpr int kDenseMinEnds = 8;  // groups with >= this many column ends use th
 constexpr int kOpSum = 0;
 constexpr int kOpSumSquares = 1;
 constexpr int kOpSumAbs = 2;
+constexpr int kOpMaskedIn = 3;    // only entries whose row is in a row set (bitmap)
+constexpr int kOpMaskedOut = 4;   // only entries whose row is NOT in the set
 
 // How a column-sum call is cut into chunks (one wavefront each).
 struct LaunchPlan {
@@ -40,7 +42,9 @@ inline size_t workspace_bytes_for(int32_t nchunks) {
 
 hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t nnz,
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
-                              double divisor, bool means, hipStream_t stream, int op = kOpSum);
+                              double divisor, bool means, hipStream_t stream, int op = kOpSum,
+                              const int32_t* rows_i = nullptr, const uint32_t* row_bitmap = nullptr,
+                              int32_t bitmap_words = 0);
 
 // Workspace layout of the row-wise path (rowsums.hip); offsets in bytes, 256-aligned.
 // persistent = row-major values + row offsets + carries; scratch = sort keys + rocPRIM temp.

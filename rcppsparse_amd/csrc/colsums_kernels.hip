@@ -452,8 +452,10 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
     double* __restrict__ carry_head, double* __restrict__ carry_tail,
-    int2* __restrict__ carry_info, double divisor) {
+    int2* __restrict__ carry_info, double divisor, const int32_t* __restrict__ rows_i,
+    const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words) {
     static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
+    constexpr bool MASKED = (OP == kOpMaskedIn || OP == kOpMaskedOut);
     __shared__ __attribute__((aligned(16))) double s_stage[WPG][kStageSlots];
     __shared__ __attribute__((aligned(16))) int32_t s_win[WPG][kPWin];
     __shared__ __attribute__((aligned(16))) int32_t s_hist[WPG][kHistPad];
@@ -479,10 +481,21 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)xbytes, 0x00020000);
     const int voff = lane * 16;
 
+    // masked reductions also stream the row indices of the chunk (4 B/nnz) and probe a
+    // row bitmap (L2-resident: nrow / 8 bytes) when a row of x is consumed
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(MASKED ? rows_i + cs : nullptr), 0, MASKED ? (int)((uint32_t)(ce - cs) * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)row_bitmap, 0, MASKED ? bitmap_words * 4 : 0, 0x00020000);
+
     d2 v[BATCH_ROWS];
+    int2 iv[MASKED ? BATCH_ROWS : 1];
 #pragma unroll
-    for (int r = 0; r < BATCH_ROWS; ++r)
+    for (int r = 0; r < BATCH_ROWS; ++r) {
         v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, r * 1024, AUX));
+        if (MASKED)
+            iv[r] = __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(ir, lane * 8, r * 512, AUX));
+    }
 
     int lo = 0, hi = ncol;   // invariant: p[lo] <= cs < p[hi]
     while (hi - lo > 1) {
@@ -518,6 +531,31 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
             const int row0 = b * BATCH_ROWS + g * kGroupRows;
             const int gs = cs + row0 * kRowElems;
             bool done = false;
+            // the group's four rows after the per-element transform (free for plain sums)
+            d2 t[kGroupRows];
+            if (MASKED) {
+                uint32_t m0[kGroupRows], m1[kGroupRows];
+#pragma unroll
+                for (int rr = 0; rr < kGroupRows; ++rr) {   // all eight probes in flight together
+                    const int2 ij = iv[g * kGroupRows + rr];
+                    m0[rr] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, (ij.x >> 5) * 4, 0, 0);
+                    m1[rr] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, (ij.y >> 5) * 4, 0, 0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < kGroupRows; ++rr) {
+                    const int2 ij = iv[g * kGroupRows + rr];
+                    const bool in0 = (m0[rr] >> (ij.x & 31)) & 1u, in1 = (m1[rr] >> (ij.y & 31)) & 1u;
+                    const bool want = (OP == kOpMaskedIn);
+                    t[rr].x = (in0 == want) ? v[g * kGroupRows + rr].x : 0.0;
+                    t[rr].y = (in1 == want) ? v[g * kGroupRows + rr].y : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < kGroupRows; ++rr) {
+                    t[rr].x = xf<OP>(v[g * kGroupRows + rr].x);
+                    t[rr].y = xf<OP>(v[g * kGroupRows + rr].y);
+                }
+            }
             if (row0 < nrows) {
                 // how many column ends fall inside this group of rows?
                 // (only ends up to the chunk's own end count: later ones belong to other chunks)
@@ -529,16 +567,9 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                     const int wq = load_next_ends(st, win, p, st.ccur + 1, ncol, lane, valid);
                     const uint32_t d = (uint32_t)wq - (uint32_t)gs;
                     const int n4 = __popcll(__ballot(valid && (d - 1u) < glim));
-                    if (n4 >= kDenseMinEnds) {
-                        d2 grp[kGroupRows];
-#pragma unroll
-                        for (int rr = 0; rr < kGroupRows; ++rr) {
-                            grp[rr].x = xf<OP>(v[g * kGroupRows + rr].x);
-                            grp[rr].y = xf<OP>(v[g * kGroupRows + rr].y);
-                        }
-                        done = dense_group<MEANS>(grp, gs, glim, lane, st, acc0, acc1, win, stage, bitmap, p,
+                    if (n4 >= kDenseMinEnds)
+                        done = dense_group<MEANS>(t, gs, glim, lane, st, acc0, acc1, win, stage, bitmap, p,
                                                   ncol, w, out, carry_head, divisor);
-                    }
                 }
             }
 #pragma unroll
@@ -546,10 +577,13 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                 const int r = g * kGroupRows + rr;
                 const int row = row0 + rr;
                 if (!done && row < nrows)
-                    process_row<MEANS>(xf<OP>(v[r].x), xf<OP>(v[r].y), cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p, ncol,
-                                  w, out, carry_head, divisor);
+                    process_row<MEANS>(t[rr].x, t[rr].y, cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p,
+                                       ncol, w, out, carry_head, divisor);
                 v[r] = __builtin_bit_cast(
                     d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, AUX));
+                if (MASKED)
+                    iv[r] = __builtin_bit_cast(
+                        int2, __builtin_amdgcn_raw_buffer_load_b64(ir, lane * 8, (row + BATCH_ROWS) * 512, AUX));
             }
         }
     }
@@ -688,7 +722,8 @@ __global__ void gen_row_indices_kernel(int32_t* __restrict__ i, const int32_t* _
 // ---------------------------------------------------------------------------
 hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t nnz,
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
-                              double divisor, bool means, hipStream_t stream, int op) {
+                              double divisor, bool means, hipStream_t stream, int op,
+                              const int32_t* rows_i, const uint32_t* row_bitmap, int32_t bitmap_words) {
     if (ncol <= 0) return hipSuccess;
     if (nnz <= 0) {
         hipLaunchKernelGGL(colsums_zero_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_out,
@@ -705,11 +740,11 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         if (means)                                                                                 \
             hipLaunchKernelGGL((KERNEL<BR, true, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,   \
                                nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, \
-                               carry_info, divisor);                                               \
+                               carry_info, divisor, rows_i, row_bitmap, bitmap_words);             \
         else                                                                                       \
             hipLaunchKernelGGL((KERNEL<BR, false, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,  \
                                nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, \
-                               carry_info, divisor);                                               \
+                               carry_info, divisor, rows_i, row_bitmap, bitmap_words);             \
     } while (0)
 #define RSP_LAUNCH_W(WPG_)                                                                              \
     do {                                                                                               \
@@ -717,20 +752,26 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         if (means)                                                                                     \
             hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, true, kLoadAux, WPG_>), g2, b2, 0,   \
                                stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,     \
-                               carry_head, carry_tail, carry_info, divisor);                           \
+                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap,        \
+                               bitmap_words);                                                          \
         else                                                                                           \
             hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_>), g2, b2, 0,  \
                                stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,     \
-                               carry_head, carry_tail, carry_info, divisor);                           \
+                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap,        \
+                               bitmap_words);                                                          \
     } while (0)
 #define RSP_LAUNCH_OP(OP_)                                                                             \
     hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, OP_>), grid,   \
                        block, 0, stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,   \
-                       carry_head, carry_tail, carry_info, divisor)
+                       carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words)
     if (op == kOpSumSquares) {
         RSP_LAUNCH_OP(kOpSumSquares);
     } else if (op == kOpSumAbs) {
         RSP_LAUNCH_OP(kOpSumAbs);
+    } else if (op == kOpMaskedIn) {
+        RSP_LAUNCH_OP(kOpMaskedIn);
+    } else if (op == kOpMaskedOut) {
+        RSP_LAUNCH_OP(kOpMaskedOut);
     } else
     switch (plan.variant) {   // 0 = production; the rest are A/B builds (rsp_set_experiment)
         case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 16, kLoadAux); break;   // 16 rows in flight

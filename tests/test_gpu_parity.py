@@ -340,6 +340,38 @@ def test_column_reduce_ops(torch_cuda, label, ncol, mean, op):
         capi.column_reduce_device(xt, pt, 7)
 
 
+# ------------------------------------------- "next" row f4: row-restricted column sums
+@pytest.mark.parametrize("nrow,ncol,density", [(64, 300, 0.3), (5000, 2000, 0.01), (200_000, 500, 0.02),
+                                                (1000, 40_000, 0.004)])
+@pytest.mark.parametrize("complement", [False, True])
+def test_column_sums_restricted_to_a_row_set(torch_cuda, nrow, ncol, density, complement):
+    """InnerIteratorInRange / NotInRange semantics (RcppSparse.h:238-321) as a device reduction."""
+    torch = torch_cuda
+    m = synth.rsparsematrix(nrow, ncol, density=density, seed=nrow % 97 + ncol, kind=0)
+    x, i, p = m["x"], m["i"], m["p"]
+    rng = np.random.default_rng(nrow)
+    s = np.sort(rng.choice(nrow, size=max(1, nrow // 3), replace=False))
+    bits = capi.row_set_bitmap(s, nrow)
+    got = capi.column_sums_in_rows_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(),
+                                          torch.from_numpy(p).cuda(), nrow, torch.from_numpy(bits).cuda(),
+                                          complement).cpu().numpy()
+    ref = oracle.column_sums_in_rows(x, i, p, bits, complement)
+    keep = np.isin(i, s) != complement
+    scale = oracle.column_abs_sums(np.where(keep, x, 0.0), p)
+    assert np.all(np.abs(got - ref) <= RTOL * scale)
+    # the two restrictions partition every column
+    other = capi.column_sums_in_rows_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(),
+                                            torch.from_numpy(p).cuda(), nrow, torch.from_numpy(bits).cuda(),
+                                            not complement).cpu().numpy()
+    full = oracle.column_sums(x, p)
+    assert np.all(np.abs(got + other - full) <= 4 * RTOL * oracle.column_abs_sums(x, p))
+    # empty set / full set
+    none = capi.column_sums_in_rows_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(),
+                                           torch.from_numpy(p).cuda(), nrow,
+                                           torch.zeros_like(torch.from_numpy(bits)).cuda(), False).cpu().numpy()
+    assert np.all(none == 0.0)
+
+
 # ------------------------------------------------------------- maximum size, graph capture
 def test_maximum_nnz_int32_limit(torch_cuda):
     """nnz = 2^31 - 1, the largest matrix the reference's 32-bit p[] / iterator state can address
