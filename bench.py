@@ -126,7 +126,7 @@ def cpu_baseline(p, kind, target_nnz=1_000_000_000, reps=10):
     }
 
 
-def parity_spot_check(got, p, kind, first_idx=0, ncheck=400):
+def parity_spot_check(got, p, kind, first_idx=0, ncheck=400, seed=SEED):
     """A few column ranges of the result vs the oracle (outside the timed region)."""
     import numpy as np
     import oracle
@@ -135,10 +135,10 @@ def parity_spot_check(got, p, kind, first_idx=0, ncheck=400):
     for c0 in sorted({0, ncol // 2, max(0, ncol - ncheck)}):
         c1 = min(ncol, c0 + ncheck)
         lo, hi = int(p[c0]), int(p[c1])
-        xs = oracle.gen_values(hi - lo, SEED, first_idx + lo, kind)
+        xv = oracle.gen_values(hi - lo, seed, first_idx + lo, kind)
         pl = (p[c0:c1 + 1] - lo).astype(np.int32)
-        ref = oracle.column_sums(xs, pl)
-        scale = np.maximum(oracle.column_abs_sums(xs, pl), 1e-300)
+        ref = oracle.column_sums(xv, pl)
+        scale = np.maximum(oracle.column_abs_sums(xv, pl), 1e-300)
         err = np.abs(got[c0:c1] - ref)
         worst = max(worst, float(np.max(err / scale)))
         well = np.abs(ref) >= 1e-3 * scale          # columns without heavy cancellation
@@ -215,9 +215,15 @@ def main():
     shard = sharded.make_shard(p, rank, world, balance=args.partition)
     counts, displs = sharded.gather_layout(shard.bounds)
 
-    # inputs resident in HBM before anything is timed
-    xt = torch.empty(shard.nnz, dtype=torch.float64, device=dev)
-    capi.gen_values_device(xt, SEED, shard.x0, args.kind)
+    # inputs resident in HBM before anything is timed.  A workload that would fit in the 256 MiB
+    # Infinity Cache (C2: 80 MB) is timed over a rotation of distinct copies of x (> 400 MB in
+    # total, different seeds) so that every step reads from HBM.
+    ncopies = max(1, -(-400_000_000 // max(1, 8 * shard.nnz)))
+    xs = []
+    for k in range(ncopies):
+        xk = torch.empty(shard.nnz, dtype=torch.float64, device=dev)
+        capi.gen_values_device(xk, SEED + k, shard.x0, args.kind)
+        xs.append(xk)
     pt = torch.from_numpy(shard.p_local).to(dev)
     out_local = torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=dev)[:shard.ncol]
     ws = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
@@ -256,7 +262,7 @@ def main():
     nbuf = len(outs)
     # everything the hot loop touches is created up front (host time per step must stay
     # well under the ~155 us a 1/8 shard takes on the GPU)
-    launch = [capi.prepared_column_sums(xt, pt, o, ws, stream=s_compute) for o in outs]
+    launch = [[capi.prepared_column_sums(xk, pt, o, ws, stream=s_compute) for xk in xs] for o in outs]
     if comm is None:
         gather = [None] * nbuf
     elif hasattr(comm, "prepared_gatherv"):
@@ -278,7 +284,7 @@ def main():
             s_compute.wait_event(gather_done[n - nbuf])   # this buffer's previous gather must have drained
         if ev_a is not None:
             ev_a.record(s_compute)
-        launch[k]()
+        launch[k][n % ncopies]()
         if ev_b is not None:
             ev_b.record(s_compute)
         if comm is not None:
@@ -329,7 +335,8 @@ def main():
     result = None
     if rank == 0:
         full = (recv if comm is not None else out_local).cpu().numpy()   # the last step's gathered result
-        worst, worst_rel = parity_spot_check(full, p, args.kind)
+        last_copy = (args.warmup + args.steps - 1) % ncopies      # the copy the last step summed
+        worst, worst_rel = parity_spot_check(full, p, args.kind, seed=SEED + last_copy)
         if not worst <= 1e-12:
             raise SystemExit(f"parity spot check failed: max |gpu-ref|/sum|x| = {worst:.3e}")
         # the launch rank 0 timed processed its own shard
@@ -351,6 +358,7 @@ def main():
                 "partition": args.partition,
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
+                "x_copies_rotated": ncopies,
                 "gather": (None if comm is None else getattr(comm, "name", "rsp_comm_gatherv (C ABI, RCCL)")),
             },
             "roofline": {
