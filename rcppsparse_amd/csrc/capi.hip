@@ -16,6 +16,10 @@
 #include "../../include/rcppsparse_hip.h"
 #include "colsums_kernels.h"
 
+#ifdef RSP_STAMPS
+namespace rsp { hipError_t read_stamps(unsigned long long* host, size_t n); }
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -177,6 +181,14 @@ int rsp_set_tuning(int chunk_rows) {
     g_chunk_rows_override = chunk_rows;
     return RSP_OK;
 }
+
+#ifdef RSP_STAMPS
+int rsp_debug_read_stamps(unsigned long long* host, int n) {   // diagnostic build only
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(rsp::read_stamps(host, (size_t)n));
+    return RSP_OK;
+}
+#endif
 
 int rsp_set_experiment(int variant) {
     if (variant < 0) return fail(RSP_ERR_BAD_ARG, "variant is negative");

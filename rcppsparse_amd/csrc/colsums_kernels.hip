@@ -28,6 +28,23 @@
 
 namespace rsp {
 
+// Diagnostic build only (make STAMPS=1 -> librcppsparse_hip_stamps.so, never shipped): lane 0 of
+// the first 8192 chunks records the constant 100 MHz clock at a few points of the main kernel
+// into a buffer no other code reads (tools/stamps_report.py).
+#ifdef RSP_STAMPS
+__device__ unsigned long long g_stamps[8192 * 8];
+#define RSP_STAMP(k)                                                                        \
+    do {                                                                                    \
+        if (lane == 0 && w < 8192) g_stamps[w * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+hipError_t read_stamps(unsigned long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long), 0,
+                               hipMemcpyDeviceToHost);
+}
+#else
+#define RSP_STAMP(k) do { } while (0)
+#endif
+
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------
@@ -470,6 +487,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     double* stage = s_stage[wave_in_wg];
     uint32_t* bitmap = s_bitmap[wave_in_wg];
 
+    RSP_STAMP(0);
     const int32_t cs = w * chunk_elems;
     const int64_t ce64 = (int64_t)cs + chunk_elems;
     const int32_t ce = ce64 < (int64_t)nnz ? (int32_t)ce64 : nnz;
@@ -511,6 +529,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         hi = nhi < hi ? (int)nhi : hi;
     }
     const int c0 = lo;
+    RSP_STAMP(1);
     if (w == 0)
         for (int c = lane; c < c0; c += 64) out[c] = 0.0;
 
@@ -522,12 +541,15 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     st.head_complete = __builtin_amdgcn_readfirstlane(win[0]) >= cs;
     st.has_next = c0 + 1 <= ncol;
     st.qnext = __builtin_amdgcn_readfirstlane(win[1]);
+    RSP_STAMP(2);
 
     double acc0 = 0.0, acc1 = 0.0;
     const int nbatches = (nrows + BATCH_ROWS - 1) / BATCH_ROWS;
     for (int b = 0; b < nbatches; ++b) {
 #pragma unroll
         for (int g = 0; g < BATCH_ROWS / kGroupRows; ++g) {
+            if (b == 0 && g == 1) RSP_STAMP(3);   // first group of 4 rows done
+            if (b == 1 && g == 0) RSP_STAMP(4);   // first batch of 8 rows done
             const int row0 = b * BATCH_ROWS + g * kGroupRows;
             const int gs = cs + row0 * kRowElems;
             bool done = false;
@@ -588,6 +610,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         }
     }
 
+    RSP_STAMP(5);
     const double T = wave_allreduce_sum(acc0 + acc1);
     if (lane == 0) {
         if (st.head_open) {
@@ -598,6 +621,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         }
         carry_info[w] = make_int2(c0, st.ccur - c0);
     }
+    RSP_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------

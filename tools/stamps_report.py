@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Where does a wavefront of the main kernel spend its time?  Uses the diagnostic build
+(make -C rcppsparse_amd/csrc stamps): lane 0 of the first 8192 chunks stamps the 100 MHz
+constant clock at kernel entry / after the column search / after the p-window fill / after
+the first 4 rows / after the first 8 rows / after the last row / at exit.  Prints medians in
+microseconds.  The stamped build is slower than the product; read the shares, not the total."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from bench import build_offsets, SEED
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    L = ctypes.CDLL(os.path.join(here, "rcppsparse_amd", "librcppsparse_hip_stamps.so"))
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.rsp_column_sums_workspace_bytes.argtypes = [i32, i64]
+    L.rsp_column_sums_workspace_bytes.restype = ctypes.c_size_t
+    L.rsp_column_sums_device.argtypes = [vp, vp, i32, i64, vp, vp, ctypes.c_size_t, vp]
+    L.rsp_gen_values_device.argtypes = [vp, i64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, vp]
+    L.rsp_debug_read_stamps.argtypes = [vp, ctypes.c_int]
+    nrow, ncol, nnz, shape, p = build_offsets(wl, 0)
+    pt = torch.from_numpy(p).cuda()
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    L.rsp_gen_values_device(xt.data_ptr(), nnz, SEED, 0, 0, None)
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = torch.empty(L.rsp_column_sums_workspace_bytes(ncol, nnz), dtype=torch.uint8, device="cuda")
+    for _ in range(5):
+        assert L.rsp_column_sums_device(xt.data_ptr(), pt.data_ptr(), ncol, nnz, out.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), None) == 0
+    torch.cuda.synchronize()
+    st = np.zeros(8192 * 8, dtype=np.uint64)
+    assert L.rsp_debug_read_stamps(st.ctypes.data, st.size) == 0
+    st = st.reshape(8192, 8).astype(np.int64)
+    nchunks = min(8192, (nnz + 16 * 128 - 1) // (16 * 128)) if wl in ("c2", "vignette") else 8192
+    st = st[:nchunks]
+    st = st[st[:, 6] > 0]
+    t0 = st[:, 0].min()
+    us = lambda a: float(np.median(a)) / 100.0
+    names = ["entry->search done", "search->window filled", "window->first 4 rows", "4 rows->8 rows",
+             "8 rows->last row", "last row->exit"]
+    print(f"workload {wl}: {len(st)} stamped waves; entry skew (median, max) = "
+          f"{us(st[:, 0] - t0):.2f}, {float((st[:, 0] - t0).max()) / 100:.2f} us")
+    for k, nm in enumerate(names):
+        print(f"  {nm:26s} {us(st[:, k + 1] - st[:, k]):8.2f} us   (p90 {float(np.percentile(st[:, k + 1] - st[:, k], 90)) / 100:.2f})")
+    print(f"  wave lifetime              {us(st[:, 6] - st[:, 0]):8.2f} us;  last exit - first entry = "
+          f"{float(st[:, 6].max() - t0) / 100:.2f} us")
+
+
+if __name__ == "__main__":
+    main()
