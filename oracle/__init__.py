@@ -35,10 +35,21 @@ _lib = None
 def build(force: bool = False) -> str:
     """Compile liboracle.so with the committed Makefile (gcc, no fast-math)."""
     src = os.path.join(_HERE, "colsums_oracle.c")
-    if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
-        subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True,
-                       stdout=subprocess.DEVNULL)
+
+    def stale():
+        return (force or not os.path.exists(_LIB_PATH)
+                or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src))
+    if stale():
+        import fcntl
+        fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+        try:
+            fcntl.flock(fd, fcntl.LOCK_EX)       # several processes may import at once
+            if stale():
+                subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True,
+                               stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(fd, fcntl.LOCK_UN)
+            os.close(fd)
     return _LIB_PATH
 
 

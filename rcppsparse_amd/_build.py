@@ -1,6 +1,8 @@
 """Build helper: compiles librcppsparse_hip.so for gfx950 with hipcc, in-tree."""
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -20,6 +22,24 @@ def _stale(target: str, sources) -> bool:
     return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
 
 
+@contextlib.contextmanager
+def _build_lock(name: str):
+    """Serialises builds across processes (8 bench ranks importing at once must not run
+    `make` into the same .so concurrently); the waiters re-check staleness afterwards."""
+    path = os.path.join(_HERE, f".{name}.lock")
+    try:
+        fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o644)
+    except OSError:          # read-only tree: nothing can be built anyway
+        yield
+        return
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
 def have_hipcc() -> bool:
     return shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc")
 
@@ -30,8 +50,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(LIB_PATH, srcs):
         if not have_hipcc():
             raise RuntimeError("hipcc not found: cannot build librcppsparse_hip.so")
-        cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
-        subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+        with _build_lock("build_hip"):
+            if force or _stale(LIB_PATH, srcs):      # another process may have built it meanwhile
+                cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+                subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
     return LIB_PATH
 
 
@@ -42,6 +64,8 @@ def build_host_seam(force: bool = False, verbose: bool = False) -> str:
     if not srcs:
         raise RuntimeError("host/ sources missing")
     if force or _stale(HOST_SEAM_PATH, srcs + [LIB_PATH]):
-        cmd = ["make", "-C", host] + (["-B"] if force else [])
-        subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+        with _build_lock("build_host"):
+            if force or _stale(HOST_SEAM_PATH, srcs + [LIB_PATH]):
+                cmd = ["make", "-C", host] + (["-B"] if force else [])
+                subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
     return HOST_SEAM_PATH
