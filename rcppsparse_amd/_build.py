@@ -52,7 +52,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc not found: cannot build librcppsparse_hip.so")
         with _build_lock("build_hip"):
             if force or _stale(LIB_PATH, srcs):      # another process may have built it meanwhile
-                cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+                cmd = ["make", "-j4", "-C", CSRC] + (["-B"] if force else [])
                 subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
     return LIB_PATH
 
