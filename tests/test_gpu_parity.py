@@ -123,6 +123,39 @@ def test_uniform_regimes(torch_cuda, label, ncol, mean, kind, chunk_rows):
     assert_parity(got, x, p, positive=(kind == 1))
 
 
+@pytest.mark.parametrize("pattern", ["all_ones", "ones_and_empties", "one_two", "blocks_of_eight",
+                                     "long_then_ones", "empties_every_third_of_512"])
+@pytest.mark.parametrize("chunk_rows", [0, 1, 5])
+def test_extreme_column_length_patterns(torch_cuda, pattern, chunk_rows):
+    """Every element its own column, columns of 1 separated by empty columns, exact 8-element
+    blocks (the dense path's lane granularity), a long column followed by singletons, ...:
+    the corners of the dense-group / few-ends / general slow paths and their hand-offs."""
+    n = 40_000
+    if pattern == "all_ones":
+        counts = np.ones(n, dtype=np.int64)
+    elif pattern == "ones_and_empties":
+        counts = np.tile([1, 0], n // 2).astype(np.int64)
+    elif pattern == "one_two":
+        counts = np.tile([1, 2], n // 2).astype(np.int64)
+    elif pattern == "blocks_of_eight":
+        counts = np.full(n // 8, 8, dtype=np.int64)
+    elif pattern == "long_then_ones":
+        counts = np.concatenate([[3000], np.ones(700), [1111], np.ones(300), [0, 0, 5000]]).astype(np.int64)
+    else:
+        counts = np.tile([5, 0, 0, 7, 1, 0], n // 10).astype(np.int64)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=31, kind=0)
+    capi.set_tuning(chunk_rows)
+    try:
+        got = dev_colsums(torch_cuda, x, p)
+    finally:
+        capi.set_tuning(0)
+    assert_parity(got, x, p)
+    if pattern in ("all_ones", "ones_and_empties"):      # single-element columns are exact
+        nz = counts > 0
+        assert np.array_equal(got[nz], x + 0.0)
+
+
 @pytest.mark.parametrize("order", ["shuffled", "descending"])
 @pytest.mark.parametrize("chunk_rows", [0, 2, 16])
 def test_zipf_skew(torch_cuda, order, chunk_rows):
