@@ -5,22 +5,26 @@
 //
 //     sums[c] = sum_{j = p[c]}^{p[c+1]-1} x[j]
 //
-// Design (MI355X-first, see DESIGN.md):
+// Design (MI355X-first, see DESIGN.md section 4):
 //   * The unit of work is a *chunk* of x[] (a fixed number of 128-element rows),
 //     not a set of columns, so skewed column lengths cannot unbalance the chip.
-//     One wavefront owns one chunk and streams it with 16-byte-per-lane
+//     One wavefront owns one chunk and streams it with 16-byte-per-lane `nt`
 //     buffer loads (1 KiB per wave instruction), BATCH_ROWS of them always in
-//     flight in a rolling register pipeline.  i[] is never read.
-//   * Column offsets p[] are staged per wave in an LDS window; a second small
-//     LDS histogram turns the offsets that fall inside one 128-element row into
-//     per-element column ranks (this also handles empty columns).
-//   * Rows that contain no column end take the fast path: two v_add_f64 per
-//     lane.  Rows that do contain column ends take a segmented wave scan
-//     (DPP lane exchange, no LDS) and write finished columns directly.
-//   * Columns that cross chunk edges leave a head / tail partial per chunk; a
-//     tiny second kernel adds those in ascending chunk order.  There are no
-//     floating-point atomics anywhere, so results are bit-stable run to run.
+//     flight in a rolling register pipeline.  i[] is never read by the sums.
+//   * Column offsets p[] are staged per wave in an LDS window.
+//   * A row with no column end inside takes the fast path: two v_add_f64 per lane.
+//   * A row with 1-3 column ends: one masked DPP wave reduction per end.
+//   * A group of 4 rows with many column ends (short columns): staged in LDS, every
+//     lane sums 8 consecutive elements in storage order, one integer scan and one
+//     segmented scan per group.
+//   * Anything else (e.g. runs of empty columns): per-row LDS histogram of the ends ->
+//     element ranks -> segmented DPP scan.
+//   * Columns that cross chunk edges leave a head / tail partial per chunk; a small
+//     second kernel adds those in ascending chunk order.  No floating-point atomics
+//     anywhere: results are bit-stable run to run.
 //   * No MFMA: 1 FP64 add per 8 bytes, the bound is HBM bandwidth.
+//   * The same template serves the "next" reductions: a per-element transform (sum of
+//     squares / abs) or a row-set mask (streams i[] too and probes a row bitmap).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,7 +32,7 @@
 
 namespace rsp {
 
-// Diagnostic build only (make STAMPS=1 -> librcppsparse_hip_stamps.so, never shipped): lane 0 of
+// Diagnostic build only (`make stamps` -> librcppsparse_hip_stamps.so, never shipped): lane 0 of
 // the first 8192 chunks records the constant 100 MHz clock at a few points of the main kernel
 // into a buffer no other code reads (tools/stamps_report.py).
 #ifdef RSP_STAMPS
