@@ -100,8 +100,8 @@ int rsp_csc_free(rsp_csc_t handle);
 /* ---- device-pointer path (inputs already in HBM) ----------------------- */
 /*
  * Same computation on device pointers; everything is enqueued on `stream`
- * (a hipStream_t passed as void*; NULL = the default stream) and nothing
- * synchronises.  d_x must be 16-byte aligned.  d_workspace is scratch of at
+ * (a hipStream_t passed as void*; NULL = the default stream) of the calling
+ * thread's current HIP device, and nothing synchronises.  d_x must be 16-byte aligned.  d_workspace is scratch of at
  * least rsp_column_sums_workspace_bytes(ncol, nnz) bytes, 16-byte aligned; it
  * carries no state between calls.  Graph-capture safe (no allocation, no
  * synchronisation inside).

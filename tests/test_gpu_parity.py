@@ -450,6 +450,24 @@ def test_device_entry_is_graph_capture_safe(torch_cuda):
     assert torch.equal(out, eager * 2.0)
 
 
+def test_handles_do_not_leak_device_memory(torch_cuda):
+    torch = torch_cuda
+    m = synth.rsparsematrix(20_000, 3_000, density=0.01, seed=3)
+    def cycle():
+        h = capi.DeviceCSC(m["x"], m["p"], m["Dim"], i=m["i"])
+        h.column_sums(); h.column_means(); h.row_sums()
+        h.close()
+        capi.column_sums_host(m["x"], m["p"])
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 * 2**20, (free0, free1)      # nothing accumulates across 40 cycles
+
+
 # ------------------------------------------- "next" row f2: one-shot host path over several GPUs
 @pytest.mark.parametrize("devices", [None, [0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
 def test_host_multi_shards_reassemble(torch_cuda, devices):
