@@ -13,6 +13,7 @@ constexpr int kMinChunkRows = 16; // automatic chunking never goes below this ma
 constexpr int kWavesPerWG = 4;    // independent wavefronts per workgroup
 constexpr int kPWin = 256;        // p[] entries staged in LDS per wavefront
 constexpr int kHistPad = 132;     // 129 histogram slots, padded to a 16-byte multiple
+constexpr int kStampChunks = 32768; // diagnostic build: chunks that record timestamps
 constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed once)
 constexpr int kGroupRows = 4;     // rows per dense group (512 elements, 8 per lane)
 constexpr int kGroupElems = kGroupRows * kRowElems;

@@ -33,13 +33,13 @@
 namespace rsp {
 
 // Diagnostic build only (`make stamps` -> librcppsparse_hip_stamps.so, never shipped): lane 0 of
-// the first 8192 chunks records the constant 100 MHz clock at a few points of the main kernel
+// the first kStampChunks chunks records the constant 100 MHz clock at a few points of the main kernel
 // into a buffer no other code reads (tools/stamps_report.py).
 #ifdef RSP_STAMPS
-__device__ unsigned long long g_stamps[8192 * 8];
+__device__ unsigned long long g_stamps[kStampChunks * 8];
 #define RSP_STAMP(k)                                                                        \
     do {                                                                                    \
-        if (lane == 0 && w < 8192) g_stamps[w * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (lane == 0 && w < kStampChunks) g_stamps[w * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 hipError_t read_stamps(unsigned long long* host, size_t n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long), 0,

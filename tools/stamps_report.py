@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a wavefront of the main kernel spend its time?  Uses the diagnostic build
-(make -C rcppsparse_amd/csrc stamps): lane 0 of the first 8192 chunks stamps the 100 MHz
+(make -C rcppsparse_amd/csrc stamps): lane 0 of the first 32768 chunks stamps the 100 MHz
 constant clock at kernel entry / after the column search / after the p-window fill / after
 the first 4 rows / after the first 8 rows / after the last row / at exit.  Prints medians in
 microseconds.  The stamped build is slower than the product; read the shares, not the total."""
@@ -13,6 +13,9 @@ import numpy as np
 import torch
 
 from bench import build_offsets, SEED
+
+
+NST = 32768   # kStampChunks of the diagnostic build
 
 
 def main():
@@ -35,11 +38,9 @@ def main():
         assert L.rsp_column_sums_device(xt.data_ptr(), pt.data_ptr(), ncol, nnz, out.data_ptr(), ws.data_ptr(),
                                         ws.numel(), None) == 0
     torch.cuda.synchronize()
-    st = np.zeros(8192 * 8, dtype=np.uint64)
+    st = np.zeros(NST * 8, dtype=np.uint64)
     assert L.rsp_debug_read_stamps(st.ctypes.data, st.size) == 0
-    st = st.reshape(8192, 8).astype(np.int64)
-    nchunks = min(8192, (nnz + 16 * 128 - 1) // (16 * 128)) if wl in ("c2", "vignette") else 8192
-    st = st[:nchunks]
+    st = st.reshape(NST, 8).astype(np.int64)
     st = st[st[:, 6] > 0]
     t0 = st[:, 0].min()
     us = lambda a: float(np.median(a)) / 100.0
@@ -51,6 +52,14 @@ def main():
         print(f"  {nm:26s} {us(st[:, k + 1] - st[:, k]):8.2f} us   (p90 {float(np.percentile(st[:, k + 1] - st[:, k], 90)) / 100:.2f})")
     print(f"  wave lifetime              {us(st[:, 6] - st[:, 0]):8.2f} us;  last exit - first entry = "
           f"{float(st[:, 6].max() - t0) / 100:.2f} us")
+    # resident waves over time (10 us bins): ramp-up, plateau, tail
+    span = int(st[:, 6].max() - t0)
+    edges = np.arange(0, span + 1000, 1000)
+    starts = np.histogram(st[:, 0] - t0, bins=edges)[0]
+    ends = np.histogram(st[:, 6] - t0, bins=edges)[0]
+    resident = np.cumsum(starts) - np.cumsum(ends)
+    step = max(1, len(resident) // 24)
+    print("  resident stamped waves every", step * 10, "us:", " ".join(str(int(v)) for v in resident[::step]))
 
 
 if __name__ == "__main__":
