@@ -156,6 +156,49 @@ def test_extreme_column_length_patterns(torch_cuda, pattern, chunk_rows):
         assert np.array_equal(got[nz], x + 0.0)
 
 
+def _random_structure(rng):
+    """Concatenation of random stretches: long columns, bursts of short ones, runs of empty
+    columns, singletons, exact multiples of 8 / 128 / 512 -- every path of the kernel and
+    every hand-off between paths, in random order and at random offsets."""
+    parts = []
+    for _ in range(int(rng.integers(1, 9))):
+        kind = int(rng.integers(0, 8))
+        if kind == 0:
+            parts.append(rng.integers(300, 6000, size=rng.integers(1, 6)))
+        elif kind == 1:
+            parts.append(rng.integers(0, 6, size=rng.integers(50, 3000)))
+        elif kind == 2:
+            parts.append(np.zeros(rng.integers(1, 700), dtype=np.int64))
+        elif kind == 3:
+            parts.append(np.ones(rng.integers(1, 2000), dtype=np.int64))
+        elif kind == 4:
+            parts.append(rng.choice([8, 16, 128, 256, 512, 1024], size=rng.integers(1, 12)))
+        elif kind == 5:
+            parts.append(rng.integers(20, 200, size=rng.integers(5, 300)))
+        elif kind == 6:
+            parts.append(rng.poisson(10, size=rng.integers(100, 4000)))
+        else:
+            parts.append(np.array([int(rng.integers(20_000, 120_000))]))
+    return np.concatenate(parts).astype(np.int64)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_random_structures(torch_cuda, seed):
+    rng = np.random.default_rng(1000 + seed)
+    counts = _random_structure(rng)
+    p = synth.offsets_from_counts(counts)
+    nnz = int(p[-1])
+    kind = int(rng.integers(0, 2))
+    x = synth.gen_values(nnz, seed=seed, kind=kind)
+    for chunk_rows in (0, int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31, 64]))):
+        capi.set_tuning(chunk_rows)
+        try:
+            got = dev_colsums(torch_cuda, x, p)
+        finally:
+            capi.set_tuning(0)
+        assert_parity(got, x, p, positive=(kind == 1))
+
+
 @pytest.mark.parametrize("order", ["shuffled", "descending"])
 @pytest.mark.parametrize("chunk_rows", [0, 2, 16])
 def test_zipf_skew(torch_cuda, order, chunk_rows):
