@@ -17,7 +17,8 @@ constexpr int kStampChunks = 32768; // diagnostic build: chunks that record time
 constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed once)
 constexpr int kGroupRows = 4;     // rows per dense group (512 elements, 8 per lane)
 constexpr int kGroupElems = kGroupRows * kRowElems;
-constexpr int kStageSlots = kGroupElems + kGroupElems / 8;   // LDS staging, one pad per 8 elements
+constexpr int kStageSlots = kGroupElems;   // LDS staging of one group
+constexpr int kDenseMaxLen = 64;  // longest column segment one lane may sum alone in a dense group
 constexpr int kFewEnds = 3;       // rows with <= this many column ends use the masked-reduce loop
 constexpr int kDenseMinEnds = 8;  // groups with >= this many column ends use the dense path
 

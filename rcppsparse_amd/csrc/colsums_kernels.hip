@@ -345,97 +345,72 @@ __device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int l
     refresh_next(st, win, p, st.ccur + 1, ncol, lane);
 }
 
-// Dense group: kGroupRows consecutive rows (512 elements) holding many column ends.
-// The rows are staged in LDS (padded: slot = e + e/8, conflict-free for the strided
-// reads below), every lane then owns 8 *consecutive* elements and sums them in storage
-// order, closing columns as it meets their last element; only the first column closed by
-// a lane needs data from other lanes, which one segmented wave scan per group provides.
-// A bitmap of "last element of a column" positions (ds_or) replaces the per-row
-// histogram.  Groups containing empty columns (duplicate ends) are left to the row paths.
-// Returns false (nothing consumed) when the group must be handled row by row.
+// Dense group: kGroupRows consecutive rows (512 elements) holding many column ends, i.e.
+// short columns.  The rows are staged in LDS and the work is handed out by *column*: lane j
+// takes column ccur + j, reads its bounds from the p window, and adds its elements from LDS
+// sequentially -- exactly the reference's storage order, so a column that lives inside one
+// group comes out bit-identical to the reference loop, and the open column at either end of
+// the group continues the same sequential chain through the carry.  No bitmap, no scans;
+// empty columns are just zero-length ranges.  The group goes to the row paths instead
+// (returns false, nothing consumed) if a column segment is longer than kDenseMaxLen (one lane
+// would hold the wave up) or its offsets do not fit the p window.
 template <bool MEANS>
-__device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, uint32_t glim, int lane,
-                                            WaveState& st,
-                                            double& acc0, double& acc1, int32_t* win, double* stage,
-                                            uint32_t* bitmap, const int32_t* __restrict__ p, int ncol,
-                                            int w, double* __restrict__ out,
+__device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, uint32_t glim, int n_ends,
+                                            int lane, WaveState& st, double& acc0, double& acc1,
+                                            int32_t* win, double* stage, const int32_t* __restrict__ p,
+                                            int ncol, int w, double* __restrict__ out,
                                             double* __restrict__ carry_head, double divisor) {
-    // bitmap of last-element positions; bail out on duplicate ends
-    if (lane < 16) bitmap[lane] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    int k = st.ccur + 1;
-    int prev_last = -1;
-    bool dup = false;
-    int nends = 0;
-    for (;;) {
-        bool valid;
-        const int q = load_next_ends(st, win, p, k, ncol, lane, valid);
-        const uint32_t d = (uint32_t)q - (uint32_t)gs;
-        const bool ing = valid && (d - 1u) < glim;   // glim: elements of the group this chunk owns
-        int qprev = __builtin_amdgcn_update_dpp(0, q, 0x138, 0xF, 0xF, false);   // lane - 1
-        if (lane == 0) qprev = prev_last;
-        dup = dup || (ing && q == qprev);
-        if (ing) atomicOr(&bitmap[(d - 1u) >> 5], 1u << ((d - 1u) & 31u));
-        const int n = __popcll(__ballot(ing));
-        nends += n;
-        k += n;
-        if (n < 64) break;
-        prev_last = __builtin_amdgcn_readlane(q, 63);
-    }
-    if (__ballot(dup) != 0ull) return false;
+    if (n_ends + 2 > kPWin) return false;
+    ensure_window(st, win, p, st.ccur, n_ends + 2, ncol, lane);   // p[ccur .. ccur + n_ends + 1]
+    const int woff = st.ccur - st.wbase;
+    const int ge = gs + (int)glim;   // one past the last element of the group this chunk owns
 
-    // stage the rows (lane holds elements e, e+1 of each row; e is even so both share a pad group)
-#pragma unroll
-    for (int r = 0; r < kGroupRows; ++r) {
-        const int e = r * kRowElems + 2 * lane;
-        const int slot = e + (e >> 3);
-        stage[slot] = v[r].x;
-        stage[slot + 1] = v[r].y;
+    // bounds of segment j (j = 0: the open column continuing into the group; j = n_ends: the
+    // column still open at the group's end), relative to gs; reject long segments
+    bool too_long = false;
+    for (int j = lane; j <= n_ends; j += 64) {
+        const int lo = (j == 0) ? gs : win[woff + j];
+        const int hi = (j == n_ends) ? ge : win[woff + j + 1];
+        too_long = too_long || (hi - lo > kDenseMaxLen);
     }
-    const double A = wave_allreduce_sum(acc0 + acc1);   // open column's partial from earlier rows
+    if (__ballot(too_long) != 0ull) return false;
+
+    // stage the four rows: element e of the group at stage[e]
+#pragma unroll
+    for (int r = 0; r < kGroupRows; ++r)
+        *(d2*)&stage[r * kRowElems + 2 * lane] = v[r];
+    const double A = wave_allreduce_sum(acc0 + acc1);   // sum so far of the column open at gs
     __builtin_amdgcn_wave_barrier();
 
-    // this lane's 8 flags (positions 8*lane .. 8*lane+7) and its ranks
-    const uint32_t f = (bitmap[lane >> 2] >> ((lane & 3) * 8)) & 0xFFu;
-    const int cnt = __popc(f);
-    const int rank_incl = wave_inclusive_scan_i32(cnt);
-    const int rank_excl = rank_incl - cnt;
-
-    double e8[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e8[j] = stage[9 * lane + j];
-
-    // storage-order sums; a lane's first closed column waits for the carry-in
-    double s = 0.0, head = 0.0;
-    bool seen = false;
-    int c = st.ccur + rank_excl;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        s += e8[j];
-        if ((f >> j) & 1u) {
-            if (!seen) {
-                head = s;
-                seen = true;
-            } else if (c < ncol) {
-                out[c] = finish<MEANS>(s, divisor);   // never the chunk head: a lane's 2nd+ end
-            }
-            ++c;
-            s = 0.0;
+    double carry_out = 0.0;
+    for (int j0 = 0; j0 <= n_ends; j0 += 64) {
+        const int j = j0 + lane;
+        const bool active = j <= n_ends;
+        int lo = 0, hi = 0;
+        if (active) {
+            lo = ((j == 0) ? gs : win[woff + j]) - gs;
+            hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
         }
+        double s = (j == 0) ? A : 0.0;   // the continuing column keeps adding to its running sum
+        // storage-order adds, four LDS reads in flight
+        for (int k = lo; __ballot(k < hi) != 0ull; k += 4) {
+            double e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e[u] = (k + u < hi) ? stage[k + u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + u < hi) s += e[u];
+        }
+        if (active && j < n_ends) emit_column<MEANS>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
+        if (active && j == n_ends) carry_out = s;
     }
-    if (lane == 0) {   // fold the incoming partial into the first segment of the group
-        if (seen) head += A; else s += A;
-    }
-    // s = this lane's open tail (or its whole 8-element sum if it closed nothing)
-    const double X = wave_segmented_inclusive_scan(s, rank_incl);
-    const double Xp = dpp_f64<0x138>(X);   // lane - 1 (lane 0 reads +0.0)
-    if (seen)
-        emit_column<MEANS>(st, st.ccur + rank_excl, rank_excl, head + Xp, ncol, w, out, carry_head, divisor);
-
-    acc0 = (lane == 63) ? X : 0.0;
+    // hand the open column's running sum to whatever comes next (one lane holds it)
+    const int owner = n_ends & 63;
+    const double co = readlane_f64(carry_out, owner);
+    acc0 = (lane == 0) ? co : 0.0;
     acc1 = 0.0;
-    st.ccur += nends;
-    if (nends > 0) st.head_open = false;
+    st.ccur += n_ends;
+    if (n_ends > 0) st.head_open = false;
     refresh_next(st, win, p, st.ccur + 1, ncol, lane);
     return true;
 }
@@ -480,7 +455,6 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     __shared__ __attribute__((aligned(16))) double s_stage[WPG][kStageSlots];
     __shared__ __attribute__((aligned(16))) int32_t s_win[WPG][kPWin];
     __shared__ __attribute__((aligned(16))) int32_t s_hist[WPG][kHistPad];
-    __shared__ __attribute__((aligned(16))) uint32_t s_bitmap[WPG][16];
 
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -489,7 +463,6 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     int32_t* win = s_win[wave_in_wg];
     int32_t* hist = s_hist[wave_in_wg];
     double* stage = s_stage[wave_in_wg];
-    uint32_t* bitmap = s_bitmap[wave_in_wg];
 
     RSP_STAMP(0);
     const int32_t cs = w * chunk_elems;
@@ -593,9 +566,19 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                     const int wq = load_next_ends(st, win, p, st.ccur + 1, ncol, lane, valid);
                     const uint32_t d = (uint32_t)wq - (uint32_t)gs;
                     const int n4 = __popcll(__ballot(valid && (d - 1u) < glim));
-                    if (n4 >= kDenseMinEnds)
-                        done = dense_group<MEANS>(t, gs, glim, lane, st, acc0, acc1, win, stage, bitmap, p,
-                                                  ncol, w, out, carry_head, divisor);
+                    if (n4 >= kDenseMinEnds) {
+                        // n4 saturates at 64 (one window read): count the rest of the group's ends
+                        int nall = n4, last = n4;
+                        for (int k = st.ccur + 1 + 64; last == 64 && nall < kPWin; k += 64) {
+                            bool v2;
+                            const int q2 = load_next_ends(st, win, p, k, ncol, lane, v2);
+                            const uint32_t d2_ = (uint32_t)q2 - (uint32_t)gs;
+                            last = __popcll(__ballot(v2 && (d2_ - 1u) < glim));
+                            nall += last;
+                        }
+                        done = dense_group<MEANS>(t, gs, glim, nall, lane, st, acc0, acc1, win, stage, p, ncol,
+                                                  w, out, carry_head, divisor);
+                    }
                 }
             }
 #pragma unroll

@@ -199,6 +199,24 @@ def test_fuzz_random_structures(torch_cuda, seed):
         assert_parity(got, x, p, positive=(kind == 1))
 
 
+def test_short_columns_come_out_in_reference_order_bit_exact(torch_cuda):
+    """The dense-group path hands out whole columns to lanes and adds each column's elements from
+    LDS in storage order, continuing the running sum across groups inside a chunk.  So in the
+    short-column regime (BASELINE C2: ~10 nnz per column) every column that does not straddle a
+    chunk edge must equal the reference's sequential sum bit for bit, not just within 1e-12."""
+    ncol, nnz = 200_000, 2_000_000
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=77, nrow=None))
+    x = synth.gen_values(nnz, seed=78, kind=0)
+    got = dev_colsums(torch_cuda, x, p)
+    ref = oracle.column_sums(x, p)
+    assert_parity(got, x, p)
+    chunk = 16 * 128                                   # automatic chunking at this size
+    inside = (p[:-1] // chunk) == ((np.maximum(p[1:], p[:-1] + 1) - 1) // chunk)
+    exact = got.view(np.uint64) == ref.view(np.uint64)
+    assert np.all(exact[inside]), int(np.count_nonzero(~exact[inside]))
+    assert np.count_nonzero(inside) > 0.99 * ncol
+
+
 @pytest.mark.parametrize("order", ["shuffled", "descending"])
 @pytest.mark.parametrize("chunk_rows", [0, 2, 16])
 def test_zipf_skew(torch_cuda, order, chunk_rows):
