@@ -289,7 +289,9 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
 __device__ __forceinline__ int load_next_ends(WaveState& st, int32_t* win,
                                               const int32_t* __restrict__ p, int k, int ncol, int lane,
                                               bool& valid) {
-    ensure_window(st, win, p, k, 64, ncol, lane);
+    // keep p[k - 1] (the start of the column whose end is p[k]) in the window as well, so the
+    // dense path, which needs the column starts, does not have to refill right after this
+    ensure_window(st, win, p, k - 1, 65, ncol, lane);
     const uint32_t idx = (uint32_t)k + (uint32_t)lane;
     valid = idx <= (uint32_t)ncol;
     return win[(valid ? (int)idx : k) - st.wbase];
