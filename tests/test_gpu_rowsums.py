@@ -103,3 +103,30 @@ def test_row_sums_1e8_against_oracle(torch_cuda):
     x = oracle.gen_values(nnz, 42, 0, 0)
     i = oracle.gen_row_indices(p, nrow, 42)
     check(got, x, i, p, nrow)
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_fuzz_row_entries_and_masks(torch_cuda, seed):
+    """Random shapes/densities: rowSums, rowMeans and the row-restricted column sums against the
+    oracle, including matrices with empty rows/columns and a single row or column."""
+    torch = torch_cuda
+    rng = np.random.default_rng(500 + seed)
+    nrow = int(rng.choice([1, 2, 7, 33, 500, 4096, 70_001]))
+    ncol = int(rng.choice([1, 3, 64, 900, 12_345]))
+    density = float(rng.choice([0.0005, 0.01, 0.2, 0.9]))
+    nnz = min(int(nrow * ncol * density) + int(rng.integers(0, 3)), nrow * ncol)
+    m = synth.rsparsematrix(nrow, ncol, nnz=nnz, seed=seed, kind=int(rng.integers(0, 2)))
+    x, i, p = m["x"], m["i"], m["p"]
+    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    if nnz == 0:
+        xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
+        it = torch.zeros(2, dtype=torch.int32, device="cuda")[:0]
+    check(capi.row_sums_device(xt, it, nrow).cpu().numpy(), x, i, p, nrow)
+    s = np.flatnonzero(rng.random(nrow) < 0.4)
+    bits = capi.row_set_bitmap(s, nrow)
+    for comp in (False, True):
+        got = capi.column_sums_in_rows_device(xt, it, pt, nrow, torch.from_numpy(bits).cuda(), comp).cpu().numpy()
+        ref = oracle.column_sums_in_rows(x, i, p, bits, comp)
+        keep = np.isin(i, s) != comp
+        scale = oracle.column_abs_sums(np.where(keep, x, 0.0), p)
+        assert np.all(np.abs(got - ref) <= RTOL * scale)
