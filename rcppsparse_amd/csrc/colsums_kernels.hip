@@ -355,27 +355,30 @@ __device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int l
 // the group continues the same sequential chain through the carry.  No bitmap, no scans;
 // empty columns are just zero-length ranges.  The group goes to the row paths instead
 // (returns false, nothing consumed) if a column segment is longer than kDenseMaxLen (one lane
-// would hold the wave up) or its offsets do not fit the p window.
+// would hold the wave up).
 template <bool MEANS>
 __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, uint32_t glim, int n_ends,
                                             int lane, WaveState& st, double& acc0, double& acc1,
                                             int32_t* win, double* stage, const int32_t* __restrict__ p,
                                             int ncol, int w, double* __restrict__ out,
                                             double* __restrict__ carry_head, double divisor) {
-    if (n_ends + 2 > kPWin) return false;
-    ensure_window(st, win, p, st.ccur, n_ends + 2, ncol, lane);   // p[ccur .. ccur + n_ends + 1]
-    const int woff = st.ccur - st.wbase;
     const int ge = gs + (int)glim;   // one past the last element of the group this chunk owns
 
     // bounds of segment j (j = 0: the open column continuing into the group; j = n_ends: the
-    // column still open at the group's end), relative to gs; reject long segments
-    bool too_long = false;
-    for (int j = lane; j <= n_ends; j += 64) {
-        const int lo = (j == 0) ? gs : win[woff + j];
-        const int hi = (j == n_ends) ? ge : win[woff + j + 1];
-        too_long = too_long || (hi - lo > kDenseMaxLen);
+    // column still open at the group's end).  With fewer than 64 ends a long segment is likely
+    // enough to check for (one window read); with 64 or more the average segment is at most 8
+    // elements and a rare long one only costs its own length once.
+    if (n_ends < 64) {
+        ensure_window(st, win, p, st.ccur, 66, ncol, lane);
+        const int woff = st.ccur - st.wbase;
+        bool too_long = false;
+        if (lane <= n_ends) {
+            const int lo = (lane == 0) ? gs : win[woff + lane];
+            const int hi = (lane == n_ends) ? ge : win[woff + lane + 1];
+            too_long = hi - lo > kDenseMaxLen;
+        }
+        if (__ballot(too_long) != 0ull) return false;
     }
-    if (__ballot(too_long) != 0ull) return false;
 
     // stage the four rows: element e of the group at stage[e]
 #pragma unroll
@@ -386,6 +389,8 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
 
     double carry_out = 0.0;
     for (int j0 = 0; j0 <= n_ends; j0 += 64) {
+        ensure_window(st, win, p, st.ccur + j0, 66, ncol, lane);
+        const int woff = st.ccur - st.wbase;
         const int j = j0 + lane;
         const bool active = j <= n_ends;
         int lo = 0, hi = 0;
@@ -571,15 +576,16 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                     if (n4 >= kDenseMinEnds) {
                         // n4 saturates at 64 (one window read): count the rest of the group's ends
                         int nall = n4, last = n4;
-                        for (int k = st.ccur + 1 + 64; last == 64 && nall < kPWin; k += 64) {
+                        for (int k = st.ccur + 1 + 64; last == 64 && nall < kDenseMaxEnds; k += 64) {
                             bool v2;
                             const int q2 = load_next_ends(st, win, p, k, ncol, lane, v2);
                             const uint32_t d2_ = (uint32_t)q2 - (uint32_t)gs;
                             last = __popcll(__ballot(v2 && (d2_ - 1u) < glim));
                             nall += last;
                         }
-                        done = dense_group<MEANS>(t, gs, glim, nall, lane, st, acc0, acc1, win, stage, p, ncol,
-                                                  w, out, carry_head, divisor);
+                        if (nall < kDenseMaxEnds)   // (beyond that: mostly empty columns, general path)
+                            done = dense_group<MEANS>(t, gs, glim, nall, lane, st, acc0, acc1, win, stage, p,
+                                                      ncol, w, out, carry_head, divisor);
                     }
                 }
             }
