@@ -17,7 +17,7 @@ constexpr int kStampChunks = 32768; // diagnostic build: chunks that record time
 constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed once)
 constexpr int kGroupRows = 4;     // rows per dense group (512 elements, 8 per lane)
 constexpr int kGroupElems = kGroupRows * kRowElems;
-constexpr int kStageSlots = kGroupElems;   // LDS staging of one group
+constexpr int kStageSlots = kGroupElems + 4;   // LDS staging of one group (+4: unguarded look-ahead reads)
 constexpr int kDenseMaxEnds = 2048; // more column ends than this in one group: general path
 constexpr int kDenseMaxLen = 64;  // longest column segment one lane may sum alone in a dense group
 constexpr int kFewEnds = 3;       // rows with <= this many column ends use the masked-reduce loop

@@ -399,14 +399,16 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
             hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
         }
         double s = (j == 0) ? A : 0.0;   // the continuing column keeps adding to its running sum
-        // storage-order adds, four LDS reads in flight
-        for (int k = lo; __ballot(k < hi) != 0ull; k += 4) {
-            double e[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) e[u] = (k + u < hi) ? stage[k + u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (k + u < hi) s += e[u];
+        // storage-order adds, four unguarded LDS reads in flight (the staging area is padded, so
+        // reading past a short column's end is harmless; the add is what is predicated)
+        const int n = hi - lo;
+        const double* sp = stage + lo;
+        for (int k = 0; __ballot(k < n) != 0ull; k += 4) {
+            const double e0 = sp[k], e1 = sp[k + 1], e2 = sp[k + 2], e3 = sp[k + 3];
+            if (k < n) s += e0;
+            if (k + 1 < n) s += e1;
+            if (k + 2 < n) s += e2;
+            if (k + 3 < n) s += e3;
         }
         if (active && j < n_ends) emit_column<MEANS>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
         if (active && j == n_ends) carry_out = s;
