@@ -1,21 +1,24 @@
 #include "../inst/include/RcppSparse.h"
 #include "../inst/include/columnsums_impl.hpp"
 
-//' Column sums of a sparse matrix on the GPU
+//' Sum every column of a sparse matrix on the GPU
 //'
-//' Same contract as the CPU original: takes a \code{dgCMatrix}, returns a plain
-//' numeric vector of length \code{ncol(A)}.  The per-column
-//' \code{RcppSparse::Matrix::InnerIterator} loop is replaced by one call into a
-//' HIP segmented-sum kernel (MI355X / gfx950) through the C interface declared
-//' in \code{rcppsparse_hip.h}; there is no CPU fallback, a missing GPU is an R error.
+//' Takes a \code{dgCMatrix} and returns a plain numeric vector with one sum per column,
+//' like the CPU original.  Instead of walking each column with a
+//' \code{RcppSparse::Matrix::InnerIterator}, the slots \code{x} and \code{p} are handed to a
+//' HIP segmented-sum kernel (AMD Instinct MI355X) through the C interface in
+//' \code{rcppsparse_hip.h}.  A machine without a usable GPU gets an R error, never a
+//' silently different code path.
 //'
-//' @param A an object of class \code{dgCMatrix}
+//' @param A a \code{dgCMatrix} (package Matrix)
+//' @return numeric vector of length \code{ncol(A)}
 //' @examples
-//' library(Matrix)
-//' A <- rsparsematrix(nrow = 10, ncol = 5, density = 0.5)
-//' columnSums(A)
+//' \dontrun{
+//' A <- Matrix::rsparsematrix(1e5, 1e3, density = 0.1)
+//' stopifnot(all.equal(columnSums(A), Matrix::colSums(A)))
+//' }
 //[[Rcpp::export]]
 Rcpp::NumericVector columnSums(RcppSparse::Matrix& A) {
-    // allocation of the result happens here, on the R main thread; the shim only fills it
+    // the result vector is allocated here, on the R main thread; the shim only fills it
     return rcppsparse_core::column_sums_via_hip<RcppSparse::Matrix, RcppSparse::RcppTraits>(A);
 }
