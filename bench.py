@@ -260,7 +260,11 @@ def main():
     # N > 1: the gatherv of step k runs on its own stream and overlaps the kernel of
     # step k+1 (double-buffered per-shard output); every step's gather completes
     # inside the timed region.  N = 1: one stream, no collective.
-    s_compute = torch.cuda.current_stream()
+    # both streams come from torch's pool (non-blocking streams): nothing here runs on the legacy
+    # null stream, which would implicitly synchronise with any blocking stream a library creates
+    torch.cuda.synchronize()
+    s_compute = torch.cuda.Stream()
+    torch.cuda.set_stream(s_compute)
     s_comm = torch.cuda.Stream() if comm is not None else None
     outs = ([out_local] + [torch.empty_like(out_local) for _ in range(args.gather_buffers - 1)]
             if comm is not None else [out_local])
