@@ -125,6 +125,10 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
 #define RSP_OP_SUM          0   /* f(v) = v      (== rsp_column_sums_device) */
 #define RSP_OP_SUM_SQUARES  1   /* f(v) = v * v  (squared column 2-norms)     */
 #define RSP_OP_SUM_ABS      2   /* f(v) = |v|    (column 1-norms)             */
+#define RSP_OP_MAX          3   /* largest stored entry; empty column -> -Inf; NaN entries skipped
+                                   (the loop  if (v > acc) acc = v;  from acc = -Inf)          */
+#define RSP_OP_MIN          4   /* smallest stored entry; empty column -> +Inf                 */
+#define RSP_OP_COUNT        5   /* number of stored entries (Matrix::InnerNNZs, RcppSparse.h:357-359) */
 int rsp_column_reduce_device(const double *d_x, const int32_t *d_p, int32_t ncol,
                              int64_t nnz, int op, double *d_out, void *d_workspace,
                              size_t workspace_bytes, void *stream);

@@ -117,16 +117,20 @@ void oracle_column_abs_sums(const double *x, const int32_t *p, int32_t ncol, dou
 /*
  * Generic column reduction ("next" row f3): the InnerIterator loop of example.cpp:28-30
  * with a different body, as the vignette's column loops do (Documentation.Rmd:303-312).
- * op 0: acc += v;  op 1: acc += v * v;  op 2: acc += |v|.
+ * op 0: acc += v;  op 1: acc += v * v;  op 2: acc += |v|;  op 3: if (v > acc) acc = v from -Inf;
+ * op 4: if (v < acc) acc = v from +Inf;  op 5: number of stored entries (InnerNNZs, :357-359).
  */
 void oracle_column_reduce(const double *x, const int32_t *p, int32_t ncol, int op, double *out) {
     oracle_csc A = {x, NULL, p, {0, ncol}};
     for (int32_t col = 0; col < ncol; ++col) {
-        double acc = 0.0;
+        double acc = (op == 3) ? -__builtin_huge_val() : (op == 4) ? __builtin_huge_val() : 0.0;
         oracle_inner_it it;
         for (it_begin(&it, &A, col); it_valid(&it); it_next(&it)) {
             const double v = it_value(&it);
-            acc += (op == 1) ? v * v : (op == 2) ? (v < 0 ? -v : v) : v;
+            if (op == 3) { if (v > acc) acc = v; }
+            else if (op == 4) { if (v < acc) acc = v; }
+            else if (op == 5) acc += 1.0;
+            else acc += (op == 1) ? v * v : (op == 2) ? (v < 0 ? -v : v) : v;
         }
         out[col] = acc;
     }

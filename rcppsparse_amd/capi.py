@@ -278,7 +278,7 @@ def row_sums_device(x_t, i_t, nrow: int, out_t=None, workspace=None, stream=None
     return out_t
 
 
-OP_SUM, OP_SUM_SQUARES, OP_SUM_ABS = 0, 1, 2
+OP_SUM, OP_SUM_SQUARES, OP_SUM_ABS, OP_MAX, OP_MIN, OP_COUNT = 0, 1, 2, 3, 4, 5
 
 
 def column_reduce_device(x_t, p_t, op: int, out_t=None, workspace=None, stream=None):

@@ -219,10 +219,18 @@ int rsp_column_means_device(const double* d_x, const int32_t* d_p, int32_t nrow,
 
 int rsp_column_reduce_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, int op,
                              double* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
-    if (op != RSP_OP_SUM && op != RSP_OP_SUM_SQUARES && op != RSP_OP_SUM_ABS)
-        return fail(RSP_ERR_BAD_ARG, "unknown reduction op %d", op);
+    int kop;
+    switch (op) {
+        case RSP_OP_SUM: kop = rsp::kOpSum; break;
+        case RSP_OP_SUM_SQUARES: kop = rsp::kOpSumSquares; break;
+        case RSP_OP_SUM_ABS: kop = rsp::kOpSumAbs; break;
+        case RSP_OP_MAX: kop = rsp::kOpMax; break;
+        case RSP_OP_MIN: kop = rsp::kOpMin; break;
+        case RSP_OP_COUNT: kop = rsp::kOpCount; break;
+        default: return fail(RSP_ERR_BAD_ARG, "unknown reduction op %d", op);
+    }
     return enqueue(d_x, d_p, ncol, nnz, d_out, d_workspace, workspace_bytes, 1.0, false,
-                   (hipStream_t)stream, op);
+                   (hipStream_t)stream, kop);
 }
 
 int rsp_column_sums_in_rows_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,

@@ -29,6 +29,9 @@ constexpr int kOpSumSquares = 1;
 constexpr int kOpSumAbs = 2;
 constexpr int kOpMaskedIn = 3;    // only entries whose row is in a row set (bitmap)
 constexpr int kOpMaskedOut = 4;   // only entries whose row is NOT in the set
+constexpr int kOpMax = 5;         // largest stored entry (combine = max, identity -inf)
+constexpr int kOpMin = 6;         // smallest stored entry
+constexpr int kOpCount = 7;       // number of stored entries (offsets only)
 
 // How a column-sum call is cut into chunks (one wavefront each).
 struct LaunchPlan {

@@ -78,13 +78,38 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
                             __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// Sum over all 64 lanes, returned wave-uniform.  Fixed tree: bit-stable.
-__device__ __forceinline__ double wave_allreduce_sum(double v) {
-    v += dpp_f64<0xB1>(v);    // xor 1
-    v += dpp_f64<0x4E>(v);    // xor 2
-    v += dpp_f64<0x141>(v);   // the two quads of each 8
-    v += dpp_f64<0x140>(v);   // the two halves of each row of 16: every lane holds its row's sum
-    return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
+// How a column's terms are combined.  Everything on the hot path is a sum (identity +0.0);
+// the generic column reduction also offers max / min of the stored
+// entries (identity -inf / +inf, NaN entries are skipped like a `if (v > acc) acc = v` loop).
+template <bool MEANS_, int OP_>
+struct Policy {
+    static constexpr bool kMeans = MEANS_;
+    static constexpr int kOp = OP_;
+    static constexpr bool kMax = (OP_ == kOpMax), kMin = (OP_ == kOpMin);
+    static constexpr bool kSum = !kMax && !kMin;
+    __device__ static __forceinline__ double id() {
+        return kSum ? 0.0 : (kMax ? -__builtin_huge_val() : __builtin_huge_val());
+    }
+    __device__ static __forceinline__ double comb(double a, double b) {
+        return kSum ? a + b : (kMax ? __builtin_fmax(a, b) : __builtin_fmin(a, b));
+    }
+    // value stored for a finished column
+    __device__ static __forceinline__ double finish(double v, double divisor) {
+        if (kSum) v += 0.0;   // a sum of -0.0 terms comes out +0.0 like the reference's 0.0-initialised accumulator
+        if (kMeans) v = v / divisor;   // RcppSparse.h:147-148  sums[i] / Dim[0]
+        return v;
+    }
+};
+
+// Combination over all 64 lanes, returned wave-uniform.  Fixed tree: bit-stable.
+template <class P>
+__device__ __forceinline__ double wave_allreduce(double v) {
+    v = P::comb(v, dpp_f64<0xB1>(v));    // xor 1            (every lane has a source in these four)
+    v = P::comb(v, dpp_f64<0x4E>(v));    // xor 2
+    v = P::comb(v, dpp_f64<0x141>(v));   // the two quads of each 8
+    v = P::comb(v, dpp_f64<0x140>(v));   // the two halves of each row of 16: every lane holds its row's result
+    return P::comb(P::comb(P::comb(readlane_f64(v, 0), readlane_f64(v, 16)), readlane_f64(v, 32)),
+                   readlane_f64(v, 48));
 }
 
 // Inclusive prefix sum over the 64 lanes (int): 4 in-row steps + 2 row broadcasts.
@@ -101,20 +126,21 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
 // One step of the segmented inclusive scan: add the source lane's running sum when it
 // carries the same key.  Keys are non-negative and non-decreasing across lanes; a lane
 // with no source sees key -1 (never equal).
-template <int CTRL, int ROWMASK, bool ZERO_FILL>
+template <class P, int CTRL, int ROWMASK, bool ZERO_FILL>
 __device__ __forceinline__ void seg_scan_step(double& X, int key) {
-    const double Xs = dpp_f64<CTRL, ROWMASK, ZERO_FILL>(X);
+    const double Xs = dpp_f64<CTRL, ROWMASK, ZERO_FILL>(X);   // (fill value never used: key -1 below)
     const int ks = __builtin_amdgcn_update_dpp(-1, key, CTRL, ROWMASK, 0xF, false);
-    if (ks == key) X += Xs;
+    if (ks == key) X = P::comb(X, Xs);
 }
 
+template <class P>
 __device__ __forceinline__ double wave_segmented_inclusive_scan(double X, int key) {
-    seg_scan_step<0x111, 0xF, true>(X, key);
-    seg_scan_step<0x112, 0xF, true>(X, key);
-    seg_scan_step<0x114, 0xF, true>(X, key);
-    seg_scan_step<0x118, 0xF, true>(X, key);
-    seg_scan_step<0x142, 0xA, false>(X, key);   // previous row's last lane
-    seg_scan_step<0x143, 0xC, false>(X, key);   // lane 31 into rows 2 and 3
+    seg_scan_step<P, 0x111, 0xF, true>(X, key);
+    seg_scan_step<P, 0x112, 0xF, true>(X, key);
+    seg_scan_step<P, 0x114, 0xF, true>(X, key);
+    seg_scan_step<P, 0x118, 0xF, true>(X, key);
+    seg_scan_step<P, 0x142, 0xA, false>(X, key);   // previous row's last lane
+    seg_scan_step<P, 0x143, 0xC, false>(X, key);   // lane 31 into rows 2 and 3
     return X;
 }
 
@@ -159,18 +185,15 @@ __device__ __forceinline__ void ensure_window(WaveState& st, int32_t* win,
 
 // Per-element transform of the generic column reduction: the same
 // InnerIterator-shaped loop with a different body -- sum, sum of squares, sum of |x|.
-// f(0) = 0 for all of them, so the zero-filled out-of-range lanes stay harmless.
+// f(0) = 0 for the sums, so the zero-filled out-of-range lanes stay harmless (max / min mask them).
 template <int OP>
 __device__ __forceinline__ double xf(double v) {
     if (OP == kOpSumSquares) return v * v;
     if (OP == kOpSumAbs) return __builtin_fabs(v);
-    return v;
-}
-
-template <bool MEANS>
-__device__ __forceinline__ double finish(double v, double divisor) {
-    v += 0.0;   // a sum of -0.0 terms must come out +0.0 like the reference's 0.0-initialised accumulator
-    if (MEANS) v = v / divisor;   // RcppSparse.h:147-148  sums[i] / Dim[0]
+    // max / min skip NaN entries (the loop `if (v > acc) acc = v` never takes one): turn them
+    // into the identity up front so that every path, also a one-element column, agrees
+    if (OP == kOpMax) return (v != v) ? -__builtin_huge_val() : v;
+    if (OP == kOpMin) return (v != v) ? __builtin_huge_val() : v;
     return v;
 }
 
@@ -179,15 +202,15 @@ __device__ __forceinline__ double finish(double v, double divisor) {
 // ---------------------------------------------------------------------------
 // Lane l holds elements e0 = rs + 2l (v0) and e1 = e0 + 1 (v1).  On entry
 // acc0/acc1 are the per-lane partial sums of column st.ccur from earlier rows.
-template <bool MEANS>
+template <class P>
 __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane, WaveState& st,
                                       double& acc0, double& acc1, int32_t* win, int32_t* hist,
                                       const int32_t* __restrict__ p, int ncol, int w,
                                       double* __restrict__ out, double* __restrict__ carry_head,
                                       double divisor) {
     // 1. fold the running per-lane partials into the first element of the row
-    const double A = wave_allreduce_sum(acc0 + acc1);
-    if (lane == 0) v0 += A;
+    const double A = wave_allreduce<P>(P::comb(acc0, acc1));
+    if (lane == 0) v0 = P::comb(v0, A);
 
     // 2. histogram of column ends q in (rs, rs + 128]:  hist[q - rs]++
     *(int2*)&hist[2 * lane] = make_int2(0, 0);
@@ -217,12 +240,12 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
 
     // 4. segmented inclusive scan (key kR) of each lane's open-right part
     const bool split = kL != kR;              // a column ends between e0 and e1
-    const double X = wave_segmented_inclusive_scan(split ? v1 : (v0 + v1), kR);
+    const double X = wave_segmented_inclusive_scan<P>(split ? v1 : P::comb(v0, v1), kR);
 
     // 5. finished segments
     const double Xp = dpp_f64<0x138>(X);                               // lane - 1
     const int kp = __builtin_amdgcn_update_dpp(-1, kR, 0x138, 0xF, 0xF, false);
-    const double totalL = v0 + ((kp == kL) ? Xp : 0.0);                // segment ending at e0
+    const double totalL = P::comb(v0, (kp == kL) ? Xp : P::id());      // segment ending at e0
     int kN = dpp_i32<0x130>(kL);                                       // lane + 1
     if (lane == 63) kN = tot;
     const bool endR = kN > kR;                                         // segment ending at e1
@@ -232,18 +255,18 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
         const int c = cbase + kL;
         if (st.head_open && kL == 0) {
             carry_head[w] = totalL;
-            if (st.head_complete && c < ncol) out[c] = finish<MEANS>(totalL, divisor);
+            if (st.head_complete && c < ncol) out[c] = P::finish(totalL, divisor);
         } else if (c < ncol) {
-            out[c] = finish<MEANS>(totalL, divisor);
+            out[c] = P::finish(totalL, divisor);
         }
     }
     if (endR) {
         const int c = cbase + kR;
         if (st.head_open && kR == 0) {
             carry_head[w] = X;
-            if (st.head_complete && c < ncol) out[c] = finish<MEANS>(X, divisor);
+            if (st.head_complete && c < ncol) out[c] = P::finish(X, divisor);
         } else if (c < ncol) {
-            out[c] = finish<MEANS>(X, divisor);
+            out[c] = P::finish(X, divisor);
         }
     }
 
@@ -258,7 +281,7 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
         const int start = __builtin_amdgcn_readlane(cbase + kL + 1, l);
         const int cnt = __builtin_amdgcn_readlane(gapL, l);
         for (int c = lane; c < cnt; c += 64)
-            if (start + c < ncol) out[start + c] = 0.0;
+            if (start + c < ncol) out[start + c] = P::finish(P::id(), divisor);
     }
     while (mR) {
         const int l = __builtin_ctzll(mR);
@@ -266,12 +289,12 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
         const int start = __builtin_amdgcn_readlane(cbase + kR + 1, l);
         const int cnt = __builtin_amdgcn_readlane(gapR, l);
         for (int c = lane; c < cnt; c += 64)
-            if (start + c < ncol) out[start + c] = 0.0;
+            if (start + c < ncol) out[start + c] = P::finish(P::id(), divisor);
     }
 
     // 6. carry the open tail of the row and advance the column cursor
-    acc0 = (lane == 63 && !endR) ? X : 0.0;
-    acc1 = 0.0;
+    acc0 = (lane == 63 && !endR) ? X : P::id();
+    acc1 = P::id();
     st.ccur = cbase + tot;
     st.head_open = false;
     st.has_next = (uint32_t)k <= (uint32_t)ncol;
@@ -307,22 +330,22 @@ __device__ __forceinline__ void refresh_next(WaveState& st, int32_t* win, const 
     }
 }
 
-template <bool MEANS>
+template <class P>
 __device__ __forceinline__ void emit_column(const WaveState& st, int c, int rel, double total, int ncol,
                                             int w, double* __restrict__ out,
                                             double* __restrict__ carry_head, double divisor) {
     // rel = index of this column end counted from st.ccur; the chunk's first end is the head
     if (st.head_open && rel == 0) {
         carry_head[w] = total;
-        if (st.head_complete && c < ncol) out[c] = finish<MEANS>(total, divisor);
+        if (st.head_complete && c < ncol) out[c] = P::finish(total, divisor);
     } else if (c < ncol) {
-        out[c] = finish<MEANS>(total, divisor);
+        out[c] = P::finish(total, divisor);
     }
 }
 
 // Row with n in [1, kFewEnds] column ends: one masked wave reduction per end (about 40
 // instructions each) instead of the general rank + segmented-scan machinery.
-template <bool MEANS>
+template <class P>
 __device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int lane, int n, int wq,
                                              WaveState& st, double& acc0, double& acc1, int32_t* win,
                                              const int32_t* __restrict__ p, int ncol, int w,
@@ -330,18 +353,18 @@ __device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int l
                                              double divisor) {
     const int o0 = 2 * lane;   // row-relative offsets of this lane's two elements
     int lo = 0;                // row-relative start of the segment being closed
-    double a = acc0 + acc1;
+    double a = P::comb(acc0, acc1);
     for (int j = 0; j < n; ++j) {
         const int d = __builtin_amdgcn_readlane(wq, j) - rs;   // end offset in (0, 128], uniform
-        const double t0 = (o0 >= lo && o0 < d) ? v0 : 0.0;
-        const double t1 = (o0 + 1 >= lo && o0 + 1 < d) ? v1 : 0.0;
-        const double total = wave_allreduce_sum(a + (t0 + t1));
-        if (lane == 0) emit_column<MEANS>(st, st.ccur + j, j, total, ncol, w, out, carry_head, divisor);
-        a = 0.0;
+        const double t0 = (o0 >= lo && o0 < d) ? v0 : P::id();
+        const double t1 = (o0 + 1 >= lo && o0 + 1 < d) ? v1 : P::id();
+        const double total = wave_allreduce<P>(P::comb(a, P::comb(t0, t1)));
+        if (lane == 0) emit_column<P>(st, st.ccur + j, j, total, ncol, w, out, carry_head, divisor);
+        a = P::id();
         lo = d;
     }
-    acc0 = (o0 >= lo) ? v0 : 0.0;
-    acc1 = (o0 + 1 >= lo) ? v1 : 0.0;
+    acc0 = (o0 >= lo) ? v0 : P::id();
+    acc1 = (o0 + 1 >= lo) ? v1 : P::id();
     st.ccur += n;
     st.head_open = false;
     refresh_next(st, win, p, st.ccur + 1, ncol, lane);
@@ -356,7 +379,7 @@ __device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int l
 // empty columns are just zero-length ranges.  The group goes to the row paths instead
 // (returns false, nothing consumed) if a column segment is longer than kDenseMaxLen (one lane
 // would hold the wave up).
-template <bool MEANS>
+template <class P>
 __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, uint32_t glim, int n_ends,
                                             int lane, WaveState& st, double& acc0, double& acc1,
                                             int32_t* win, double* stage, const int32_t* __restrict__ p,
@@ -384,10 +407,10 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
 #pragma unroll
     for (int r = 0; r < kGroupRows; ++r)
         *(d2*)&stage[r * kRowElems + 2 * lane] = v[r];
-    const double A = wave_allreduce_sum(acc0 + acc1);   // sum so far of the column open at gs
+    const double A = wave_allreduce<P>(P::comb(acc0, acc1));   // result so far of the column open at gs
     __builtin_amdgcn_wave_barrier();
 
-    double carry_out = 0.0;
+    double carry_out = P::id();
     for (int j0 = 0; j0 <= n_ends; j0 += 64) {
         ensure_window(st, win, p, st.ccur + j0, 66, ncol, lane);
         const int woff = st.ccur - st.wbase;
@@ -398,26 +421,26 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
             lo = ((j == 0) ? gs : win[woff + j]) - gs;
             hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
         }
-        double s = (j == 0) ? A : 0.0;   // the continuing column keeps adding to its running sum
+        double s = (j == 0) ? A : P::id();   // the continuing column keeps adding to its running result
         // storage-order adds, four unguarded LDS reads in flight (the staging area is padded, so
         // reading past a short column's end is harmless; the add is what is predicated)
         const int n = hi - lo;
         const double* sp = stage + lo;
         for (int k = 0; __ballot(k < n) != 0ull; k += 4) {
             const double e0 = sp[k], e1 = sp[k + 1], e2 = sp[k + 2], e3 = sp[k + 3];
-            if (k < n) s += e0;
-            if (k + 1 < n) s += e1;
-            if (k + 2 < n) s += e2;
-            if (k + 3 < n) s += e3;
+            if (k < n) s = P::comb(s, e0);
+            if (k + 1 < n) s = P::comb(s, e1);
+            if (k + 2 < n) s = P::comb(s, e2);
+            if (k + 3 < n) s = P::comb(s, e3);
         }
-        if (active && j < n_ends) emit_column<MEANS>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
+        if (active && j < n_ends) emit_column<P>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
         if (active && j == n_ends) carry_out = s;
     }
     // hand the open column's running sum to whatever comes next (one lane holds it)
     const int owner = n_ends & 63;
     const double co = readlane_f64(carry_out, owner);
-    acc0 = (lane == 0) ? co : 0.0;
-    acc1 = 0.0;
+    acc0 = (lane == 0) ? co : P::id();
+    acc1 = P::id();
     st.ccur += n_ends;
     if (n_ends > 0) st.head_open = false;
     refresh_next(st, win, p, st.ccur + 1, ncol, lane);
@@ -425,7 +448,7 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
 }
 
 // One row: fast path, few-ends path or the general slow path.
-template <bool MEANS>
+template <class P>
 __device__ __forceinline__ void process_row(double v0, double v1, int rs, int lane, WaveState& st,
                                        double& acc0, double& acc1, int32_t* win, int32_t* hist,
                                        const int32_t* __restrict__ p, int ncol, int w,
@@ -438,14 +461,14 @@ __device__ __forceinline__ void process_row(double v0, double v1, int rs, int la
         const uint32_t d = (uint32_t)wq - (uint32_t)rs;
         const int n = __popcll(__ballot(valid && (d - 1u) < 128u));
         if (n <= kFewEnds)
-            few_ends_row<MEANS>(v0, v1, rs, lane, n, wq, st, acc0, acc1, win, p, ncol, w, out, carry_head,
+            few_ends_row<P>(v0, v1, rs, lane, n, wq, st, acc0, acc1, win, p, ncol, w, out, carry_head,
                                 divisor);
         else
-            slow_row<MEANS>(v0, v1, rs, lane, st, acc0, acc1, win, hist, p, ncol, w, out, carry_head,
+            slow_row<P>(v0, v1, rs, lane, st, acc0, acc1, win, hist, p, ncol, w, out, carry_head,
                             divisor);
     } else {
-        acc0 += v0;
-        acc1 += v1;
+        acc0 = P::comb(acc0, v0);
+        acc1 = P::comb(acc1, v1);
     }
 }
 
@@ -460,6 +483,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     int2* __restrict__ carry_info, double divisor, const int32_t* __restrict__ rows_i,
     const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words) {
     static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
+    typedef Policy<MEANS, OP> P;
     constexpr bool MASKED = (OP == kOpMaskedIn || OP == kOpMaskedOut);
     __shared__ __attribute__((aligned(16))) double s_stage[WPG][kStageSlots];
     __shared__ __attribute__((aligned(16))) int32_t s_win[WPG][kPWin];
@@ -517,7 +541,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const int c0 = lo;
     RSP_STAMP(1);
     if (w == 0)
-        for (int c = lane; c < c0; c += 64) out[c] = 0.0;
+        for (int c = lane; c < c0; c += 64) out[c] = P::finish(P::id(), divisor);
 
     WaveState st;
     st.ccur = c0;
@@ -529,7 +553,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     st.qnext = __builtin_amdgcn_readfirstlane(win[1]);
     RSP_STAMP(2);
 
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc0 = P::id(), acc1 = P::id();
     const int nbatches = (nrows + BATCH_ROWS - 1) / BATCH_ROWS;
     for (int b = 0; b < nbatches; ++b) {
 #pragma unroll
@@ -564,6 +588,16 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                     t[rr].y = xf<OP>(v[g * kGroupRows + rr].y);
                 }
             }
+            if (!P::kSum && gs + kGroupElems > ce) {
+                // max / min: the zero-filled lanes past the end of x (only the last, partial row
+                // of the matrix has any) must not take part -- give them the identity
+#pragma unroll
+                for (int rr = 0; rr < kGroupRows; ++rr) {
+                    const int e = gs + rr * kRowElems + 2 * lane;
+                    if (e >= ce) t[rr].x = P::id();
+                    if (e + 1 >= ce) t[rr].y = P::id();
+                }
+            }
             if (row0 < nrows) {
                 // how many column ends fall inside this group of rows?
                 // (only ends up to the chunk's own end count: later ones belong to other chunks)
@@ -586,7 +620,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                             nall += last;
                         }
                         if (nall < kDenseMaxEnds)   // (beyond that: mostly empty columns, general path)
-                            done = dense_group<MEANS>(t, gs, glim, nall, lane, st, acc0, acc1, win, stage, p,
+                            done = dense_group<P>(t, gs, glim, nall, lane, st, acc0, acc1, win, stage, p,
                                                       ncol, w, out, carry_head, divisor);
                     }
                 }
@@ -596,7 +630,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                 const int r = g * kGroupRows + rr;
                 const int row = row0 + rr;
                 if (!done && row < nrows)
-                    process_row<MEANS>(t[rr].x, t[rr].y, cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p,
+                    process_row<P>(t[rr].x, t[rr].y, cs + row * kRowElems, lane, st, acc0, acc1, win, hist, p,
                                        ncol, w, out, carry_head, divisor);
                 v[r] = __builtin_bit_cast(
                     d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (row + BATCH_ROWS) * 1024, AUX));
@@ -608,11 +642,11 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     }
 
     RSP_STAMP(5);
-    const double T = wave_allreduce_sum(acc0 + acc1);
+    const double T = wave_allreduce<P>(P::comb(acc0, acc1));
     if (lane == 0) {
         if (st.head_open) {
             carry_head[w] = T;
-            carry_tail[w] = 0.0;
+            carry_tail[w] = P::id();
         } else {
             carry_tail[w] = T;
         }
@@ -632,16 +666,17 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
 // ascending order; a span longer than 64 chunks (a giant column) is summed by the
 // whole wavefront with a fixed lane-strided assignment and a fixed DPP tree, so one
 // 1e9-long column costs microseconds instead of a serial walk.  Deterministic.
-template <bool MEANS>
+template <bool MEANS, int OP = kOpSum>
 __global__ __launch_bounds__(256) void colsums_fixup_kernel(
     const int32_t* __restrict__ p, int32_t ncol, int32_t chunk_elems, int32_t nchunks,
     double* __restrict__ out, const double* __restrict__ carry_head,
     const double* __restrict__ carry_tail, const int2* __restrict__ carry_info, double divisor) {
+    typedef Policy<MEANS, OP> P;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
     int c = 0, ts = 0;
-    double first = 0.0;
+    double first = P::id();
     if (w < nchunks) {
         const int2 inf = carry_info[w];
         c = inf.x;
@@ -657,8 +692,8 @@ __global__ __launch_bounds__(256) void colsums_fixup_kernel(
     const int span = w - ts;
     if (need && span <= 64) {
         double acc = first;
-        for (int t = ts + 1; t <= w; ++t) acc += carry_head[t];
-        out[c] = finish<MEANS>(acc, divisor);
+        for (int t = ts + 1; t <= w; ++t) acc = P::comb(acc, carry_head[t]);
+        out[c] = P::finish(acc, divisor);
     }
     // giant columns: whole wave per column, one after the other
     uint64_t m = __ballot(need && span > 64);
@@ -667,27 +702,33 @@ __global__ __launch_bounds__(256) void colsums_fixup_kernel(
         m &= m - 1;
         const int wl = __builtin_amdgcn_readlane(w, l);
         const int tl = __builtin_amdgcn_readlane(ts, l);
-        double acc = 0.0;
+        double acc = P::id();
         // 8 independent loads in flight per lane; adds stay in ascending t order per lane
         for (int t0 = tl + 1 + lane; t0 <= wl; t0 += 64 * 8) {
             double h[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = t0 + 64 * u;
-                h[u] = (t <= wl) ? carry_head[t] : 0.0;
+                h[u] = (t <= wl) ? carry_head[t] : P::id();
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += h[u];
+            for (int u = 0; u < 8; ++u) acc = P::comb(acc, h[u]);
         }
-        const double total = readlane_f64(first, l) + wave_allreduce_sum(acc);
-        if (lane == l) out[c] = finish<MEANS>(total, divisor);
+        const double total = P::comb(readlane_f64(first, l), wave_allreduce<P>(acc));
+        if (lane == l) out[c] = P::finish(total, divisor);
     }
 }
 
-// nnz == 0: every column is empty
-__global__ void colsums_zero_kernel(double* __restrict__ out, int32_t ncol) {
+// nnz == 0: every column is empty (0 for sums, -inf / +inf for max / min)
+__global__ void colsums_fill_kernel(double* __restrict__ out, int32_t ncol, double value) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ncol) out[c] = 0.0;
+    if (c < ncol) out[c] = value;
+}
+
+// nnz per column as doubles (the "count" reduction: no pass over x at all)
+__global__ void colsums_count_kernel(const int32_t* __restrict__ p, double* __restrict__ out, int32_t ncol) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncol) out[c] = (double)(p[c + 1] - p[c]);
 }
 
 // ---------------------------------------------------------------------------
@@ -746,9 +787,14 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double divisor, bool means, hipStream_t stream, int op,
                               const int32_t* rows_i, const uint32_t* row_bitmap, int32_t bitmap_words) {
     if (ncol <= 0) return hipSuccess;
+    if (op == kOpCount) {   // nnz per column: offsets only, x is not read
+        hipLaunchKernelGGL(colsums_count_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_p, d_out, ncol);
+        return hipGetLastError();
+    }
     if (nnz <= 0) {
-        hipLaunchKernelGGL(colsums_zero_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_out,
-                           ncol);
+        const double empty = op == kOpMax ? -__builtin_huge_val() : (op == kOpMin ? __builtin_huge_val() : 0.0);
+        hipLaunchKernelGGL(colsums_fill_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_out, ncol,
+                           empty);
         return hipGetLastError();
     }
     char* ws = (char*)d_workspace;
@@ -793,6 +839,10 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         RSP_LAUNCH_OP(kOpMaskedIn);
     } else if (op == kOpMaskedOut) {
         RSP_LAUNCH_OP(kOpMaskedOut);
+    } else if (op == kOpMax) {
+        RSP_LAUNCH_OP(kOpMax);
+    } else if (op == kOpMin) {
+        RSP_LAUNCH_OP(kOpMin);
     } else
     switch (plan.variant) {   // 0 = production; the rest are A/B builds (rsp_set_experiment)
         case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 16, kLoadAux); break;   // 16 rows in flight
@@ -807,14 +857,18 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 fgrid((plan.nchunks + 255) / 256), fblock(256);   // one thread per chunk
-    if (means)
-        hipLaunchKernelGGL((colsums_fixup_kernel<true>), fgrid, fblock, 0, stream, d_p, ncol,
-                           plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info,
-                           divisor);
+#define RSP_FIXUP(MEANS_, OP_)                                                                        \
+    hipLaunchKernelGGL((colsums_fixup_kernel<MEANS_, OP_>), fgrid, fblock, 0, stream, d_p, ncol,       \
+                       plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info, divisor)
+    if (op == kOpMax)
+        RSP_FIXUP(false, kOpMax);
+    else if (op == kOpMin)
+        RSP_FIXUP(false, kOpMin);
+    else if (means)
+        RSP_FIXUP(true, kOpSum);
     else
-        hipLaunchKernelGGL((colsums_fixup_kernel<false>), fgrid, fblock, 0, stream, d_p, ncol,
-                           plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info,
-                           divisor);
+        RSP_FIXUP(false, kOpSum);
+#undef RSP_FIXUP
     return hipGetLastError();
 }
 

@@ -431,7 +431,37 @@ def test_column_reduce_ops(torch_cuda, label, ncol, mean, op):
     else:
         assert np.all(got >= 0.0)
     with pytest.raises(capi.RspError):
-        capi.column_reduce_device(xt, pt, 7)
+        capi.column_reduce_device(xt, pt, 99)
+
+
+@pytest.mark.parametrize("label,ncol,mean", REGIMES + [("one_column", 1, 70_001), ("singletons", 9_000, 1)])
+@pytest.mark.parametrize("chunk_rows", [0, 1, 5])
+def test_column_max_min_count(torch_cuda, label, ncol, mean, chunk_rows):
+    """max / min / count of the stored entries per column: exact (no rounding is involved).
+    Values are shifted to be all negative for max (and all positive for min) so that a stray
+    zero from a padded lane or an empty slot would show; NaN entries are skipped like the
+    `if (v > acc) acc = v` loop; an empty column is -Inf / +Inf / 0."""
+    torch = torch_cuda
+    nnz = int(ncol * mean)
+    counts = synth.uniform_counts(ncol, nnz, seed=5, nrow=None)
+    p = synth.offsets_from_counts(counts)
+    base = synth.gen_values(nnz, seed=6, kind=0)
+    capi.set_tuning(chunk_rows)
+    try:
+        for op, x in ((capi.OP_MAX, base - 7.0), (capi.OP_MIN, base + 7.0), (capi.OP_COUNT, base)):
+            x = x.copy()
+            if nnz > 10:
+                x[3] = np.nan
+                x[nnz // 2] = np.nan
+            xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+            if nnz == 0:
+                xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
+            got = capi.column_reduce_device(xt, pt, op).cpu().numpy()
+            ref = oracle.column_reduce(x, p, op)
+            assert np.array_equal(got, ref), (op, int(np.count_nonzero(got != ref)))
+    finally:
+        capi.set_tuning(0)
+    assert np.array_equal(ref, counts.astype(np.float64))
 
 
 # ------------------------------------------- "next" row f4: row-restricted column sums
