@@ -177,6 +177,18 @@ int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
                          int32_t ncol, int64_t nnz, double *d_means,
                          void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Matrix::crossprod ---------------------------------------------------- */
+/*
+ * Reference RcppSparse.h:159-194: the dense ncol x ncol matrix t(A) %*% A (column-
+ * major, ncol * ncol doubles), each entry the sparse dot product of two columns over
+ * their common rows in ascending row order.  Meant for matrices with few columns (the
+ * output is O(ncol^2)).  Same order and separate multiply / add as the reference
+ * loop: bit-identical results for finite data.  Needs the row indices.
+ */
+int rsp_csc_crossprod(rsp_csc_t handle, double *out);        /* host, ncol*ncol */
+int rsp_crossprod_device(const double *d_x, const int32_t *d_i, const int32_t *d_p,
+                         int32_t ncol, int64_t nnz, double *d_out, void *stream);
+
 /* ---- column-range partitioner (multi-GPU; pure integer, host) ---------- */
 /*
  * nnz-balanced contiguous column ranges: bounds[k] = first column c with
@@ -220,9 +232,9 @@ int rsp_comm_destroy(rsp_comm_t comm);
 int rsp_gen_values_device(double *d_x, int64_t n, uint64_t seed,
                           uint64_t first_idx, int kind, void *stream);
 
-/* d_i[p[c] + r] = floor(nrow * (r + u) / k) for the k entries of column c (u in [0,1) from
- * the same hash): ascending, distinct rows -- valid dgCMatrix row indices for synthetic
- * matrices, reproducible on the host. */
+/* The k entries of column c get one row per stratum [r*nrow/k, (r+1)*nrow/k) (integer
+ * arithmetic, position inside the stratum from the same hash): ascending, distinct rows --
+ * valid dgCMatrix row indices for synthetic matrices, reproducible on the host. */
 int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
                                int32_t ncol, uint64_t seed, void *stream);
 

@@ -77,6 +77,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_column_reduce.restype = None
         L.oracle_column_sums_in_rows.argtypes = [dp, ip, ip, i32, ctypes.c_void_p, ctypes.c_int, dp]
         L.oracle_column_sums_in_rows.restype = None
+        L.oracle_crossprod.argtypes = [dp, ip, ip, i32, dp]
+        L.oracle_crossprod.restype = None
         L.oracle_gen_row_indices.argtypes = [ip, ip, i32, i32, i32, u64]
         L.oracle_gen_row_indices.restype = None
         L.oracle_gen_value.argtypes = [u64, u64, ctypes.c_int]
@@ -205,4 +207,13 @@ def column_sums_in_rows(x, i, p, bitmap, complement=False, ncol=None) -> np.ndar
     out = np.empty(ncol, dtype=np.float64)
     lib().oracle_column_sums_in_rows(_dp(x), _ip(i), _ip(p), ncol, bitmap.ctypes.data, int(bool(complement)),
                                      _dp(out))
+    return out
+
+
+def crossprod(x, i, p, ncol=None) -> np.ndarray:
+    """RcppSparse.h:159-194: dense t(A) %*% A by pairwise sorted merges (reference order)."""
+    x, p, i = _prep(x, p, i)
+    ncol = len(p) - 1 if ncol is None else int(ncol)
+    out = np.empty((ncol, ncol), dtype=np.float64, order="F")
+    lib().oracle_crossprod(_dp(x), _ip(i), _ip(p), ncol, _dp(out))
     return out

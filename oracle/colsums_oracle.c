@@ -156,6 +156,35 @@ void oracle_column_sums_in_rows(const double *x, const int32_t *i, const int32_t
 }
 
 /*
+ * Matrix::crossprod (RcppSparse.h:159-194): dense ncol x ncol t(A) %*% A, column-major.  For
+ * every pair col1 <= col2 the two (ascending) row lists are merged and x1 * x2 is added for
+ * the common rows in ascending order; the diagonal adds x*x; res(col2, col1) mirrors
+ * res(col1, col2).  The reference's inner do/while peeks at i[] one past a column's end before
+ * testing the bound (:180-186); the bound is tested first here, the visited pairs are the same.
+ */
+void oracle_crossprod(const double *x, const int32_t *i, const int32_t *p, int32_t ncol, double *res) {
+    for (int64_t k = 0; k < (int64_t)ncol * ncol; ++k) res[k] = 0.0;
+    for (int32_t col1 = 0; col1 < ncol; ++col1) {
+        for (int32_t col2 = col1; col2 < ncol; ++col2) {
+            double acc = 0.0;
+            if (col1 == col2) {
+                for (int32_t j = p[col1]; j < p[col1 + 1]; ++j) acc += x[j] * x[j];
+            } else {
+                int32_t a = p[col1], amax = p[col1 + 1], b = p[col2], bmax = p[col2 + 1];
+                while (a < amax && b < bmax) {
+                    const int32_t r1 = i[a], r2 = i[b];
+                    if (r1 == r2) { acc += x[a] * x[b]; ++a; ++b; }
+                    else if (r1 < r2) ++a;
+                    else ++b;
+                }
+            }
+            res[(int64_t)col2 * ncol + col1] = acc;
+            res[(int64_t)col1 * ncol + col2] = acc;
+        }
+    }
+}
+
+/*
  * Synthetic value generators shared bit-for-bit with the device generator in
  * rcppsparse_amd/csrc (integer hash -> exactly representable double), so the
  * host can rebuild any slice of a device-generated x[] without copying it.
@@ -183,7 +212,7 @@ void oracle_gen_values(double *x, uint64_t n, uint64_t seed, uint64_t first_idx,
     for (uint64_t k = 0; k < n; ++k) x[k] = oracle_gen_value(seed, first_idx + k, kind);
 }
 
-/* Twin of the device generator gen_row_indices_kernel: rows of column c. */
+/* Twin of the device generator gen_row_indices_kernel (integer-only stratified rows). */
 void oracle_gen_row_indices(int32_t *i, const int32_t *p, int32_t nrow, int32_t c_first,
                             int32_t c_last, uint64_t seed) {
     /* writes i[p[c] - p[c_first] + r] for c in [c_first, c_last) */
@@ -192,13 +221,12 @@ void oracle_gen_row_indices(int32_t *i, const int32_t *p, int32_t nrow, int32_t 
         const int32_t lo = p[c], k = p[c + 1] - p[c];
         for (int32_t r = 0; r < k; ++r) {
             const uint64_t h = mix64(seed * 0xD1342543DE82EF95ull + 0x5bd1e995ull + (uint64_t)(lo + r));
-            const double u = (double)(h >> 11) * 0x1.0p-53;
-            volatile double t = (double)r + u;
-            t = t * (double)nrow;
-            t = t / (double)k;
-            int32_t row = (int32_t)t;
-            if (row >= nrow) row = nrow - 1;
-            i[lo - base + r] = row;
+            const uint64_t s0 = (uint64_t)r * (uint64_t)nrow / (uint64_t)k;
+            const uint64_t s1 = (uint64_t)(r + 1) * (uint64_t)nrow / (uint64_t)k;
+            const uint64_t width = s1 > s0 ? s1 - s0 : 1;
+            uint64_t row = s0 + (((h >> 32) * width) >> 32);
+            if (row >= (uint64_t)nrow) row = (uint64_t)nrow - 1;
+            i[lo - base + r] = (int32_t)row;
         }
     }
 }

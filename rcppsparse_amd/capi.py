@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
+    "rsp_csc_crossprod", "rsp_crossprod_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
@@ -93,6 +94,8 @@ def load(build: bool = True) -> ctypes.CDLL:
                                                  c.c_size_t, vp]
     L.rsp_column_sums_device_timed.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp, c.c_int,
                                                c.POINTER(c.c_float)]
+    L.rsp_csc_crossprod.argtypes = [vp, dp]
+    L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i64, vp, vp]
     L.rsp_csc_row_sums.argtypes = [vp, dp]
     L.rsp_csc_row_means.argtypes = [vp, dp]
     L.rsp_row_sums_workspace_bytes.argtypes = [i32, i64]
@@ -194,6 +197,12 @@ class DeviceCSC:
     def column_means(self) -> np.ndarray:
         out = np.empty(self.ncol, dtype=np.float64)
         _check(load().rsp_csc_column_means(self._h, _dp(out)))
+        return out
+
+    def crossprod(self) -> np.ndarray:
+        """Matrix::crossprod(): dense ncol x ncol t(A) %*% A."""
+        out = np.empty((self.ncol, self.ncol), dtype=np.float64, order="F")
+        _check(load().rsp_csc_crossprod(self._h, _dp(out)))
         return out
 
     def row_sums(self) -> np.ndarray:
@@ -316,6 +325,17 @@ def column_sums_in_rows_device(x_t, i_t, p_t, nrow: int, bitmap_t, complement: b
                                                  ncol, nnz, bitmap_t.data_ptr(), int(bool(complement)),
                                                  out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),
                                                  _stream_ptr(stream)))
+    return out_t
+
+
+def crossprod_device(x_t, i_t, p_t, out_t=None, stream=None):
+    """Dense t(A) %*% A on torch-owned buffers; returns an ncol x ncol tensor (symmetric)."""
+    import torch
+    ncol, nnz = p_t.numel() - 1, x_t.numel()
+    if out_t is None:
+        out_t = torch.empty((ncol, ncol), dtype=torch.float64, device=x_t.device)
+    _check(load().rsp_crossprod_device(x_t.data_ptr(), i_t.data_ptr(), p_t.data_ptr(), ncol, nnz,
+                                       out_t.data_ptr(), _stream_ptr(stream)))
     return out_t
 
 

@@ -451,6 +451,34 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
 int rsp_csc_row_sums(rsp_csc_t h, double* sums) { return csc_rows(h, sums, false); }
 int rsp_csc_row_means(rsp_csc_t h, double* means) { return csc_rows(h, means, true); }
 
+// ---- Matrix::crossprod (RcppSparse.h:159-194) -----------------------------------------------
+
+int rsp_crossprod_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t ncol,
+                         int64_t nnz, double* d_out, void* stream) {
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (ncol == 0) return RSP_OK;
+    if (!d_p || !d_out || (nnz > 0 && (!d_x || !d_i))) return fail(RSP_ERR_BAD_ARG, "null device pointer");
+    HIP_TRY(rsp::launch_crossprod(d_x, d_i, d_p, ncol, d_out, (hipStream_t)stream));
+    return RSP_OK;
+}
+
+int rsp_csc_crossprod(rsp_csc_t h, double* out) {
+    if (!h || !out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->ncol == 0) return RSP_OK;
+    if (h->nnz > 0 && !h->d_i)
+        return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: crossprod needs the row indices");
+    const size_t bytes = (size_t)h->ncol * (size_t)h->ncol * 8;
+    double* d_c = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_c, bytes));
+    hipError_t e = rsp::launch_crossprod(h->d_x, h->d_i, h->d_p, h->ncol, d_c, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_c, bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_c);
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "crossprod failed: %s", hipGetErrorString(e));
+    return RSP_OK;
+}
+
 int rsp_column_sums_host(const double* x, const int32_t* p, int32_t ncol, int64_t nnz, double* sums,
                          int device) {
     if (!sums && ncol > 0) return fail(RSP_ERR_BAD_ARG, "sums is null");

@@ -63,6 +63,10 @@ hipError_t launch_row_transpose_values(const double* d_x, const int32_t* d_i, in
                                        const RowSumsLayout& L, void* persist, void* scratch,
                                        hipStream_t stream);
 
+// Matrix::crossprod on the device (crossprod.hip): dense ncol x ncol, column-major.
+hipError_t launch_crossprod(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t ncol,
+                            double* d_out, hipStream_t stream);
+
 hipError_t launch_gen_row_indices(int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,
                                   uint64_t seed, hipStream_t stream);
 hipError_t launch_gen_values(double* d_x, int64_t n, uint64_t seed, uint64_t first_idx, int kind,

@@ -758,10 +758,10 @@ __global__ void gen_values_kernel(double* __restrict__ x, int64_t n, uint64_t se
     }
 }
 
-// Row indices for synthetic matrices: column c with k entries gets rows
-// floor(nrow * (r + u) / k), r = 0..k-1, u in [0,1) from the hash -- ascending and (for
-// k <= nrow) distinct, i.e. a valid dgCMatrix column.  One thread per column.  Mirrors
-// oracle_gen_row_indices bit for bit (plain IEEE double add / mul / div, no contraction).
+// Row indices for synthetic matrices: the k entries of a column are drawn one per stratum,
+// stratum r = [r * nrow / k, (r + 1) * nrow / k) in integer arithmetic, so rows are ascending
+// and distinct (a valid dgCMatrix column) whenever k <= nrow.  One thread per column.
+// Integer-only: oracle_gen_row_indices reproduces it bit for bit.
 __global__ void gen_row_indices_kernel(int32_t* __restrict__ i, const int32_t* __restrict__ p,
                                        int32_t nrow, int32_t ncol, uint64_t seed) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -769,13 +769,12 @@ __global__ void gen_row_indices_kernel(int32_t* __restrict__ i, const int32_t* _
     const int lo = p[c], k = p[c + 1] - p[c];
     for (int r = 0; r < k; ++r) {
         const uint64_t h = mix64(seed * 0xD1342543DE82EF95ull + 0x5bd1e995ull + (uint64_t)(lo + r));
-        const double u = (double)(h >> 11) * 0x1.0p-53;
-        double t = (double)r + u;
-        t = t * (double)nrow;
-        t = t / (double)k;
-        int row = (int)t;
-        if (row >= nrow) row = nrow - 1;
-        i[lo + r] = row;
+        const uint64_t s0 = (uint64_t)r * (uint64_t)nrow / (uint64_t)k;
+        const uint64_t s1 = (uint64_t)(r + 1) * (uint64_t)nrow / (uint64_t)k;
+        const uint64_t width = s1 > s0 ? s1 - s0 : 1;
+        uint64_t row = s0 + (((h >> 32) * width) >> 32);
+        if (row >= (uint64_t)nrow) row = (uint64_t)nrow - 1;
+        i[lo + r] = (int32_t)row;
     }
 }
 
