@@ -81,6 +81,18 @@ int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol,
                                int64_t nnz, double *sums, const int *devices,
                                int ndevices);
 
+/*
+ * Upload once, sum many, over several GPUs from one process (what an R session would
+ * hold): the columns are cut as above, every range becomes a resident shard on its
+ * device, and rsp_mcsc_column_sums runs all shards concurrently, each copying its
+ * slice straight into `sums`.  `devices` as for rsp_column_sums_host_multi.
+ */
+typedef struct rsp_mcsc *rsp_mcsc_t;
+int rsp_mcsc_upload(const double *x, const int32_t *p, int32_t nrow, int32_t ncol,
+                    int64_t nnz, const int *devices, int ndevices, rsp_mcsc_t *handle);
+int rsp_mcsc_column_sums(rsp_mcsc_t handle, double *sums);
+int rsp_mcsc_free(rsp_mcsc_t handle);
+
 /* ---- device-resident dgCMatrix handle (upload once, sum many) ---------- */
 /* The slot layout x / i / p / Dim of reference RcppSparse.h:29-30 is the wire
  * format; i may be NULL (it is only kept for the row-wise "next" entries).

@@ -30,6 +30,7 @@ UNIQUE_ID_BYTES = 128
 EXPORTED_SYMBOLS = (
     "rsp_version", "rsp_last_error", "rsp_device_count",
     "rsp_column_sums_host", "rsp_column_sums_host_multi",
+    "rsp_mcsc_upload", "rsp_mcsc_column_sums", "rsp_mcsc_free",
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
@@ -81,6 +82,9 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_device_count.argtypes = [c.POINTER(c.c_int)]
     L.rsp_column_sums_host.argtypes = [dp, ip, i32, i64, dp, c.c_int]
     L.rsp_column_sums_host_multi.argtypes = [dp, ip, i32, i64, dp, c.POINTER(c.c_int), c.c_int]
+    L.rsp_mcsc_upload.argtypes = [dp, ip, i32, i32, i64, c.POINTER(c.c_int), c.c_int, c.POINTER(vp)]
+    L.rsp_mcsc_column_sums.argtypes = [vp, dp]
+    L.rsp_mcsc_free.argtypes = [vp]
     L.rsp_csc_upload.argtypes = [dp, ip, ip, i32, i32, i64, c.c_int, c.POINTER(vp)]
     L.rsp_csc_column_sums.argtypes = [vp, dp]
     L.rsp_csc_column_means.argtypes = [vp, dp]
@@ -174,6 +178,39 @@ def column_sums_host_multi(x, p, ncol=None, devices=None) -> np.ndarray:
         arr = (ctypes.c_int * n)(*[int(d) for d in devices])
     _check(load().rsp_column_sums_host_multi(_dp(x), _ip(p), ncol, x.size, _dp(out), arr, n))
     return out
+
+
+class MultiDeviceCSC:
+    """dgCMatrix resident on several GPUs of the node (column ranges), one process."""
+
+    def __init__(self, x, p, dim, devices=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.int32)
+        self.nrow, self.ncol = int(dim[0]), int(dim[1])
+        self._h = ctypes.c_void_p()
+        if devices is None:
+            arr, n = None, 0
+        else:
+            n = len(devices)
+            arr = (ctypes.c_int * n)(*[int(d) for d in devices])
+        _check(load().rsp_mcsc_upload(_dp(x), _ip(p), self.nrow, self.ncol, x.size, arr, n,
+                                      ctypes.byref(self._h)))
+
+    def column_sums(self) -> np.ndarray:
+        out = np.empty(self.ncol, dtype=np.float64)
+        _check(load().rsp_mcsc_column_sums(self._h, _dp(out)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            load().rsp_mcsc_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceCSC:

@@ -146,6 +146,90 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
     return RSP_OK;
 }
 
+// ---- resident matrix spread over several GPUs: upload once, sum many (f2) ----------------------
+struct rsp_mcsc {
+    std::vector<rsp_csc_t> shards;
+    std::vector<int32_t> bounds;   // column range of shard k: [bounds[k], bounds[k+1])
+    int32_t ncol;
+};
+
+int rsp_mcsc_free(rsp_mcsc_t h) {
+    if (!h) return RSP_OK;
+    for (rsp_csc_t s : h->shards) rsp_csc_free(s);
+    delete h;
+    return RSP_OK;
+}
+
+int rsp_mcsc_upload(const double* x, const int32_t* p, int32_t nrow, int32_t ncol, int64_t nnz,
+                    const int* devices, int ndevices, rsp_mcsc_t* handle) {
+    if (!handle) return fail(RSP_ERR_BAD_ARG, "handle is null");
+    *handle = nullptr;
+    if (!p || (nnz > 0 && !x) || ncol < 0 || nnz < 0) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_mcsc_upload");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_NO_DEVICE, "no HIP device available");
+    }
+    std::vector<int> devs;
+    if (devices && ndevices > 0) devs.assign(devices, devices + ndevices);
+    else for (int d = 0; d < visible; ++d) devs.push_back(d);
+    for (int d : devs)
+        if (d < 0 || d >= visible) return fail(RSP_ERR_BAD_ARG, "device %d out of range [0, %d)", d, visible);
+    if (ncol > 0 && (p[0] != 0 || p[ncol] != nnz)) return fail(RSP_ERR_BAD_ARG, "p[0] must be 0 and p[ncol] must equal nnz");
+    const int G = (int)devs.size();
+    rsp_mcsc* h = new (std::nothrow) rsp_mcsc();
+    if (!h) return fail(RSP_ERR_ALLOC, "out of host memory");
+    h->ncol = ncol;
+    h->bounds.assign((size_t)G + 1, 0);
+    h->shards.assign((size_t)G, nullptr);
+    if (int rc = rsp_partition_columns(p, ncol, G, h->bounds.data())) {
+        delete h;
+        return rc;
+    }
+    // one host thread per shard: every shard goes over its own GPU's host link
+    std::vector<int> status((size_t)G, RSP_OK);
+    std::vector<std::string> message((size_t)G);
+    auto work = [&](int k) {
+        const int32_t c0 = h->bounds[k], c1 = h->bounds[k + 1];
+        std::vector<int32_t> pk((size_t)(c1 - c0) + 1);
+        for (int32_t j = 0; j <= c1 - c0; ++j) pk[j] = p[c0 + j] - p[c0];
+        const int64_t nk = (int64_t)p[c1] - p[c0];
+        status[k] = rsp_csc_upload(nk ? x + p[c0] : x, nullptr, pk.data(), nrow, c1 - c0, nk, devs[k], &h->shards[k]);
+        if (status[k] != RSP_OK) message[k] = rsp_last_error();
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < G; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (int k = 0; k < G; ++k)
+        if (status[k] != RSP_OK) {
+            const int rc = fail(status[k], "shard %d on device %d: %s", k, devs[k], message[k].c_str());
+            rsp_mcsc_free(h);
+            return rc;
+        }
+    *handle = h;
+    return RSP_OK;
+}
+
+int rsp_mcsc_column_sums(rsp_mcsc_t h, double* sums) {
+    if (!h || (h->ncol > 0 && !sums)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    const int G = (int)h->shards.size();
+    std::vector<int> status((size_t)G, RSP_OK);
+    std::vector<std::string> message((size_t)G);
+    auto work = [&](int k) {
+        if (h->bounds[k + 1] == h->bounds[k]) return;
+        status[k] = rsp_csc_column_sums(h->shards[k], sums + h->bounds[k]);   // slice lands in place
+        if (status[k] != RSP_OK) message[k] = rsp_last_error();
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < G; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (int k = 0; k < G; ++k)
+        if (status[k] != RSP_OK) return fail(status[k], "shard %d: %s", k, message[k].c_str());
+    return RSP_OK;
+}
+
 int rsp_comm_unique_id(void* id_bytes) {
     if (!id_bytes) return fail(RSP_ERR_BAD_ARG, "id_bytes is null");
     ncclUniqueId id;

@@ -580,6 +580,22 @@ def test_host_multi_shards_reassemble(torch_cuda, devices):
         capi.column_sums_host_multi(x, p, devices=[99])
 
 
+@pytest.mark.parametrize("devices", [None, [0, 0, 0], [0] * 8])
+def test_multi_device_resident_handle(torch_cuda, devices):
+    """rsp_mcsc_*: shards stay resident (here all on device 0), repeated sums run the shards
+    concurrently from host threads and write their slices in place."""
+    counts = synth.zipf_counts(20_000, 2_500_001, seed=12, nrow=400_000)
+    counts[::17] = 0
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=12, kind=0)
+    h = capi.MultiDeviceCSC(x, p, (400_000, 20_000), devices=devices)
+    a = h.column_sums()
+    b = h.column_sums()
+    h.close()
+    assert_parity(a, x, p)
+    assert a.tobytes() == b.tobytes()
+
+
 # ------------------------------------------------------------------ RCCL plumbing
 def test_rccl_single_rank_gatherv_roundtrip(torch_cuda):
     """One-rank communicator on the one GPU of this box: unique id, init, gatherv (root's own
