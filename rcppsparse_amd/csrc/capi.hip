@@ -6,6 +6,7 @@
 // a HIP device every compute entry fails with RSP_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -23,8 +24,15 @@ namespace rsp { hipError_t read_stamps(unsigned long long* host, size_t n); }
 namespace {
 
 thread_local char g_err[512] = "";
-int g_chunk_rows_override = 0;   // rsp_set_tuning / RSP_CHUNK_ROWS
-int g_variant = -1;              // rsp_set_experiment / RSP_VARIANT (-1 = read the env once)
+// tuning knobs are read by the worker threads of the multi-GPU host entries: atomics
+std::atomic<int> g_chunk_rows_override{0};   // rsp_set_tuning / RSP_CHUNK_ROWS
+std::atomic<int> g_variant{-1};              // rsp_set_experiment / RSP_VARIANT (-1 = read the env)
+
+int env_int(const char* name) {
+    const char* s = getenv(name);
+    const int v = s ? atoi(s) : 0;
+    return v < 0 ? 0 : v;
+}
 
 }  // namespace
 
@@ -51,13 +59,9 @@ using rsp::fail;
     } while (0)
 
 int chunk_rows_setting() {
-    if (g_chunk_rows_override > 0) return g_chunk_rows_override;
-    static int env = -1;
-    if (env < 0) {
-        const char* s = getenv("RSP_CHUNK_ROWS");
-        env = s ? atoi(s) : 0;
-        if (env < 0) env = 0;
-    }
+    const int o = g_chunk_rows_override.load(std::memory_order_relaxed);
+    if (o > 0) return o;
+    static const int env = env_int("RSP_CHUNK_ROWS");   // thread-safe one-time init
     return env;
 }
 
@@ -76,11 +80,12 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
         if (r > 256) r = 256;
         rows = (int)r;
     }
-    if (g_variant < 0) {
-        const char* v = getenv("RSP_VARIANT");
-        g_variant = v ? atoi(v) : 0;
+    int variant = g_variant.load(std::memory_order_relaxed);
+    if (variant < 0) {
+        static const int env = env_int("RSP_VARIANT");
+        variant = env;
     }
-    plan.variant = g_variant;
+    plan.variant = variant;
     plan.chunk_elems = rows * rsp::kRowElems;
     plan.nchunks = nnz > 0 ? (int32_t)((nnz + plan.chunk_elems - 1) / plan.chunk_elems) : 0;
     return plan;
@@ -178,7 +183,7 @@ int rsp_device_count(int* count) {
 
 int rsp_set_tuning(int chunk_rows) {
     if (chunk_rows < 0) return fail(RSP_ERR_BAD_ARG, "chunk_rows is negative");
-    g_chunk_rows_override = chunk_rows;
+    g_chunk_rows_override.store(chunk_rows, std::memory_order_relaxed);
     return RSP_OK;
 }
 
@@ -192,7 +197,7 @@ int rsp_debug_read_stamps(unsigned long long* host, int n) {   // diagnostic bui
 
 int rsp_set_experiment(int variant) {
     if (variant < 0) return fail(RSP_ERR_BAD_ARG, "variant is negative");
-    g_variant = variant;
+    g_variant.store(variant, std::memory_order_relaxed);
     return RSP_OK;
 }
 
