@@ -150,3 +150,22 @@ def test_plain_c_caller_of_the_abi(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "cabi_smoke ok" in r.stdout
+
+
+def test_host_mirror_under_address_and_ub_sanitizers(tmp_path):
+    """rcppsparse_core.hpp through the seam, 1500 random small matrices incl. empty columns, empty
+    row sets and single rows/columns, in an ASan + UBSan build (CPU entry points only)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rcppsparse_amd")
+    hostseam.load()                                   # makes sure librcppsparse_hip.so exists
+    exe = str(tmp_path / "host_selftest")
+    subprocess.run(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                    "-fno-sanitize-recover=all", os.path.join(root, "tests", "c", "host_selftest.cpp"),
+                    os.path.join(libdir, "host", "host_seam.cpp"), "-o", exe, "-L", libdir, "-lrcppsparse_hip",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    assert "host selftest ok" in r.stdout

@@ -83,3 +83,19 @@ def test_generators_agree_bitwise(kind):
         assert np.array_equal(a, np.round(a * 100) / 100.0)   # two decimals, correctly rounded
     else:
         assert a.min() >= 0.0 and a.max() < 1.0
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The oracle's C loops, KAT + 3000 random ragged matrices, built with ASan + UBSan
+    (sanitizers run on the CPU side only: the GPU pool offers none)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "selftest")
+    subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                    "-fno-sanitize-recover=all", "-fno-fast-math", "-ffp-contract=off",
+                    os.path.join(here, "oracle", "selftest.c"), os.path.join(here, "oracle", "colsums_oracle.c"),
+                    "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "oracle selftest ok" in r.stdout
