@@ -243,6 +243,29 @@ int seam_transpose(const double* x, const int* i, const int* p, const int* dim, 
     });
 }
 
+// sub-view clones and index helpers (RcppSparse.h:73-128, :198-215): `rows`/`cols` are index lists.
+// which = 0: A(row0, cols) -> ncols values; 1: A(rows, col0) -> nrows values; 2: A(rows, cols) -> nrows x ncols
+// (column-major); 3: A.col(cols) -> nrow x ncols; 4: A.row(rows) -> nrows x ncol; 5: A[index0];
+// 6: InnerIndices(col0) -> count in out[0] then the indices; 7: emptyInnerIndices(col0) likewise.
+int seam_subviews(const double* x, const int* i, const int* p, const int* dim, int nnz, int which,
+                  const int* rows, int nrows, const int* cols, int ncols, int a0, double* out) {
+    return guarded([&] {
+        Matrix A = view(x, i, p, dim, nnz);
+        IntegerVector R(const_cast<int*>(rows), (std::size_t)nrows), C(const_cast<int*>(cols), (std::size_t)ncols);
+        if (which == 0) { NumericVector v = A(a0, C); for (std::size_t k = 0; k < v.size(); ++k) out[k] = v[k]; }
+        else if (which == 1) { NumericVector v = A(R, a0); for (std::size_t k = 0; k < v.size(); ++k) out[k] = v[k]; }
+        else if (which == 2) { NumericMatrix m = A(R, C); NumericVector& d = m.data(); for (std::size_t k = 0; k < d.size(); ++k) out[k] = d[k]; }
+        else if (which == 3) { NumericMatrix m = A.col(C); NumericVector& d = m.data(); for (std::size_t k = 0; k < d.size(); ++k) out[k] = d[k]; }
+        else if (which == 4) { NumericMatrix m = A.row(R); NumericVector& d = m.data(); for (std::size_t k = 0; k < d.size(); ++k) out[k] = d[k]; }
+        else if (which == 5) { out[0] = A[a0]; }
+        else if (which == 6 || which == 7) {
+            std::vector<unsigned int> v = which == 6 ? A.InnerIndices(a0) : A.emptyInnerIndices(a0);
+            out[0] = (double)v.size();
+            for (std::size_t k = 0; k < v.size(); ++k) out[k + 1] = (double)v[k];
+        } else throw std::invalid_argument("bad selector");
+    });
+}
+
 int seam_is_appx_symmetric(const double* x, const int* i, const int* p, const int* dim, int nnz, int* out) {
     return guarded([&] {
         Matrix A = view(x, i, p, dim, nnz);

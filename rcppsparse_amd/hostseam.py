@@ -119,6 +119,36 @@ def dense(m, which, a=0, b=0) -> np.ndarray:
     return out.reshape(nc, nc).T if which == "crossprod" else out
 
 
+def subview(m, which, rows=(), cols=(), a0=0) -> np.ndarray:
+    """Sub-view clones / index helpers of the class (see seam_subviews in host_seam.cpp)."""
+    x, i, p, d = _slots(m)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    nr, nc = int(d[0]), int(d[1])
+    sel = {"row_cols": 0, "rows_col": 1, "rows_cols": 2, "cols": 3, "rows": 4, "linear": 5,
+           "InnerIndices": 6, "emptyInnerIndices": 7}[which]
+    cap = max(rows.size * max(cols.size, nc, 1), nr * max(cols.size, 1), nr + 1, 4)
+    out = np.zeros(cap + 2, dtype=np.float64)
+    vp = ctypes.c_void_p
+    _check(load().seam_subviews(*_args(x, i, p, d), ctypes.c_int(sel), rows.ctypes.data_as(vp),
+                                ctypes.c_int(rows.size), cols.ctypes.data_as(vp), ctypes.c_int(cols.size),
+                                ctypes.c_int(int(a0)), out.ctypes.data_as(vp)))
+    if sel == 0:
+        return out[:cols.size]
+    if sel == 1:
+        return out[:rows.size]
+    if sel == 2:
+        return out[:rows.size * cols.size].reshape(cols.size, rows.size).T
+    if sel == 3:
+        return out[:nr * cols.size].reshape(cols.size, nr).T
+    if sel == 4:
+        return out[:rows.size * nc].reshape(nc, rows.size).T
+    if sel == 5:
+        return out[:1]
+    n = int(out[0])
+    return out[1:1 + n].astype(np.int64)
+
+
 def transpose(m):
     x, i, p, d = _slots(m)
     tx = np.empty(max(x.size, 1), dtype=np.float64)

@@ -61,6 +61,24 @@ def test_element_and_dense_views(mat):
     assert np.allclose(hostseam.dense(mat, "crossprod"), D.T @ D, rtol=1e-13, atol=1e-13)
 
 
+def test_subview_clones_and_index_helpers(mat):
+    # RcppSparse.h:73-128 (operator() overloads, col / row of several indices, operator[]) and
+    # :198-215 (InnerIndices / emptyInnerIndices)
+    D = dense_of(mat)
+    rows, cols = [0, 7, 7, 39, 3], [29, 0, 12]
+    assert np.array_equal(hostseam.subview(mat, "row_cols", cols=cols, a0=7), D[7, cols])
+    assert np.array_equal(hostseam.subview(mat, "rows_col", rows=rows, a0=12), D[rows, 12])
+    assert np.array_equal(hostseam.subview(mat, "rows_cols", rows=rows, cols=cols), D[np.ix_(rows, cols)])
+    assert np.array_equal(hostseam.subview(mat, "cols", cols=cols), D[:, cols])
+    assert np.array_equal(hostseam.subview(mat, "rows", rows=rows), D[rows, :])
+    assert hostseam.subview(mat, "linear", a0=5)[0] == mat["x"][5]
+    for c in (0, 11, 29):
+        lo, hi = mat["p"][c], mat["p"][c + 1]
+        nz = mat["i"][lo:hi]
+        assert np.array_equal(hostseam.subview(mat, "InnerIndices", a0=c), nz)
+        assert np.array_equal(hostseam.subview(mat, "emptyInnerIndices", a0=c), np.setdiff1d(np.arange(40), nz))
+
+
 def test_restricted_iterators_implement_documented_intent(mat):
     # InnerIteratorInRange / NotInRange: column entries whose row is / is not in the sorted set
     rng = np.random.default_rng(0)
