@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
-    "rsp_csc_crossprod", "rsp_crossprod_device",
+    "rsp_csc_crossprod", "rsp_crossprod_workspace_bytes", "rsp_crossprod_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
@@ -99,7 +99,9 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_device_timed.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp, c.c_int,
                                                c.POINTER(c.c_float)]
     L.rsp_csc_crossprod.argtypes = [vp, dp]
-    L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i64, vp, vp]
+    L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
+    L.rsp_crossprod_workspace_bytes.argtypes = [i32, i64]
+    L.rsp_crossprod_workspace_bytes.restype = c.c_size_t
     L.rsp_csc_row_sums.argtypes = [vp, dp]
     L.rsp_csc_row_means.argtypes = [vp, dp]
     L.rsp_row_sums_workspace_bytes.argtypes = [i32, i64]
@@ -365,14 +367,25 @@ def column_sums_in_rows_device(x_t, i_t, p_t, nrow: int, bitmap_t, complement: b
     return out_t
 
 
-def crossprod_device(x_t, i_t, p_t, out_t=None, stream=None):
-    """Dense t(A) %*% A on torch-owned buffers; returns an ncol x ncol tensor (symmetric)."""
+def crossprod_device(x_t, i_t, p_t, nrow, out_t=None, workspace=None, stream=None, tiles=False):
+    """Dense t(A) %*% A on torch-owned buffers; returns an ncol x ncol tensor (symmetric).
+    ``tiles=True`` runs the scratch-free tile kernel (no workspace); otherwise the row-major
+    path, with a workspace of rsp_crossprod_workspace_bytes allocated here unless given."""
     import torch
+    L = load()
     ncol, nnz = p_t.numel() - 1, x_t.numel()
     if out_t is None:
         out_t = torch.empty((ncol, ncol), dtype=torch.float64, device=x_t.device)
-    _check(load().rsp_crossprod_device(x_t.data_ptr(), i_t.data_ptr(), p_t.data_ptr(), ncol, nnz,
-                                       out_t.data_ptr(), _stream_ptr(stream)))
+    ws_ptr, ws_bytes = None, 0
+    if not tiles:
+        if workspace is None:
+            nbytes = int(L.rsp_crossprod_workspace_bytes(int(nrow), int(nnz)))
+            if nbytes == 0:
+                raise RspError(RSP_ERR_HIP, L.rsp_last_error().decode())
+            workspace = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)
+        ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel()
+    _check(L.rsp_crossprod_device(x_t.data_ptr(), i_t.data_ptr(), p_t.data_ptr(), int(nrow), ncol, nnz,
+                                  out_t.data_ptr(), ws_ptr, ws_bytes, _stream_ptr(stream)))
     return out_t
 
 

@@ -458,12 +458,39 @@ int rsp_csc_row_means(rsp_csc_t h, double* means) { return csc_rows(h, means, tr
 
 // ---- Matrix::crossprod (RcppSparse.h:159-194) -----------------------------------------------
 
-int rsp_crossprod_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t ncol,
-                         int64_t nnz, double* d_out, void* stream) {
+static int xp_plan(int32_t nrow, int64_t nnz, rsp::CrossprodLayout* L) {
+    if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
+    if (int rc = check_sizes(0, nnz)) return rc;
+    hipError_t e = rsp::plan_crossprod(nrow, nnz, L);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_HIP, "planning crossprod failed: %s", hipGetErrorString(e));
+    }
+    return RSP_OK;
+}
+
+size_t rsp_crossprod_workspace_bytes(int32_t nrow, int64_t nnz) {
+    rsp::CrossprodLayout L;
+    if (xp_plan(nrow, nnz, &L) != RSP_OK) return 0;
+    return L.total_bytes;
+}
+
+int rsp_crossprod_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,
+                         int64_t nnz, double* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
     if (ncol == 0) return RSP_OK;
     if (!d_p || !d_out || (nnz > 0 && (!d_x || !d_i))) return fail(RSP_ERR_BAD_ARG, "null device pointer");
-    HIP_TRY(rsp::launch_crossprod(d_x, d_i, d_p, ncol, d_out, (hipStream_t)stream));
+    if (!d_workspace) {   // no scratch: the tile kernel
+        HIP_TRY(rsp::launch_crossprod(d_x, d_i, d_p, ncol, d_out, (hipStream_t)stream));
+        return RSP_OK;
+    }
+    rsp::CrossprodLayout L;
+    if (int rc = xp_plan(nrow, nnz, &L)) return rc;
+    if (workspace_bytes < L.total_bytes)
+        return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, L.total_bytes);
+    HIP_TRY(rsp::launch_crossprod_rows(d_x, d_i, d_p, nrow, ncol, nnz, d_out, L, d_workspace,
+                                       (hipStream_t)stream));
     return RSP_OK;
 }
 
@@ -473,14 +500,23 @@ int rsp_csc_crossprod(rsp_csc_t h, double* out) {
     if (h->ncol == 0) return RSP_OK;
     if (h->nnz > 0 && !h->d_i)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: crossprod needs the row indices");
+    rsp::CrossprodLayout L;
+    if (int rc = xp_plan(h->nrow, h->nnz, &L)) return rc;
     const size_t bytes = (size_t)h->ncol * (size_t)h->ncol * 8;
     double* d_c = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_c, bytes));
-    hipError_t e = rsp::launch_crossprod(h->d_x, h->d_i, h->d_p, h->ncol, d_c, h->stream);
+    void* d_ws = nullptr;
+    hipError_t e = hipMalloc((void**)&d_c, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_ws, L.total_bytes);
+    if (e == hipSuccess)
+        e = rsp::launch_crossprod_rows(h->d_x, h->d_i, h->d_p, h->nrow, h->ncol, h->nnz, d_c, L, d_ws, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_c, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_c);
-    if (e != hipSuccess) return fail(RSP_ERR_HIP, "crossprod failed: %s", hipGetErrorString(e));
+    if (d_ws) (void)hipFree(d_ws);
+    if (d_c) (void)hipFree(d_c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_HIP, "crossprod failed: %s", hipGetErrorString(e));
+    }
     return RSP_OK;
 }
 

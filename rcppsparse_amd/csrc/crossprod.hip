@@ -5,7 +5,18 @@
 // x1 * x2 over the common rows in ascending row order (OpenMP over c1; the package's only
 // parallel routine).  O(ncol^2) output: meant for matrices with few columns.
 //
-// Here one workgroup owns a 64 x 64 tile of the result (upper-triangular tile pairs only;
+// Two kernels, both in the reference's accumulation order (bit-identical results):
+//
+//  * crossprod_rows_kernel (used when the caller provides a workspace): the row-major form
+//    of A is built first (integer row histogram, exclusive scan, cursor fill; the order
+//    of the entries inside a row is irrelevant because a row contributes at most one
+//    product to any output).  One wavefront then owns a column c1 (or a slice of its
+//    output column): it walks c1's entries in ascending row order and, for each (k, x1),
+//    adds x1 * x2 to acc[c2] for every stored (k, c2, x2) of row k, one lane per entry of
+//    the row, the accumulators in LDS.  The work is exactly the sum over rows of
+//    nnz(row)^2 products; nothing is spent on column pairs without common rows.
+//
+//  * crossprod_tiles_kernel (no workspace needed): one workgroup owns a 64 x 64 tile of the result (upper-triangular tile pairs only;
 // the mirror image is written at the end).  It walks the rows of A in blocks of 64: the
 // 64 + 64 columns of the tile pair each keep a cursor into their (ascending) row lists,
 // the entries that fall into the current row block are scattered into two dense LDS
@@ -17,6 +28,8 @@
 // bit-identical to the reference loop for finite data.  Only entries that are stored take
 // part (presence masks), so a non-finite value never meets a structural zero.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 
 #include "colsums_kernels.h"
@@ -130,6 +143,202 @@ __global__ __launch_bounds__(256) void crossprod_tiles_kernel(
                 out[(size_t)ci * ncol + cj] = acc[qa][qb];
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-major path
+// ---------------------------------------------------------------------------------------------
+
+constexpr int kXDepth = 16;       // (row, segment) units whose loads one wave keeps in flight
+constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
+
+// (entries whose row index is outside [0, nrow) -- not a valid dgCMatrix -- are left out
+// rather than allowed to address memory out of bounds)
+__global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __restrict__ ri, int64_t nnz,
+                                                            int32_t nrow, int32_t* __restrict__ cnt) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
+        const int r = ri[e];
+        if ((unsigned)r < (unsigned)nrow) atomicAdd(&cnt[r], 1);
+    }
+}
+
+// one wavefront per column (grid-stride): entry e of column c goes to the next free slot of its row
+__global__ __launch_bounds__(256) void xp_fill_rows_kernel(const double* __restrict__ x,
+                                                           const int32_t* __restrict__ ri,
+                                                           const int32_t* __restrict__ p, int32_t nrow,
+                                                           int32_t ncol, int32_t* __restrict__ cursor, int32_t* __restrict__ rc,
+                                                           double* __restrict__ rx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int c = wave; c < ncol; c += nwaves) {
+        const int e1 = p[c + 1];
+        for (int e = p[c] + lane; e < e1; e += 64) {
+            const int r = ri[e];
+            if ((unsigned)r >= (unsigned)nrow) continue;
+            const int pos = atomicAdd(&cursor[r], 1);
+            rc[pos] = c;
+            rx[pos] = x[e];
+        }
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// acc += v as one LDS instruction (ds_add_f64, an IEEE double add performed by the LDS unit).
+// A wave's LDS instructions execute in issue order and the lanes of one instruction address
+// distinct accumulators (a row stores a column once), so every accumulator still receives its
+// products in ascending row order -- without the read / wait / add / write round trip.
+__device__ __forceinline__ void lds_add_f64(double* a, double v) {
+    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)a, v);
+}
+
+template <int kXD>
+__global__ __launch_bounds__(64) void crossprod_rows_kernel(
+    const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p,
+    const int32_t* __restrict__ rp, const int32_t* __restrict__ rc, const double* __restrict__ rx,
+    int32_t nrow, int32_t ncol, int32_t nsplit, int32_t width, double* __restrict__ out) {
+#pragma clang fp contract(off)
+    extern __shared__ double acc[];                       // out(c_lo .. c_lo+span, c1) of this wave
+    const int c1 = blockIdx.x / nsplit, c_lo = (blockIdx.x % nsplit) * width;
+    if (c1 >= ncol || c_lo >= ncol) return;               // (the launcher never creates such a slice)
+    const unsigned span = (unsigned)(min(ncol - c_lo, width));
+    const int lane = threadIdx.x;
+    for (unsigned c = lane; c < span; c += 64) acc[c] = 0.0;
+    __syncthreads();
+
+    const int e_end = p[c1 + 1];
+    for (int e0 = p[c1]; e0 < e_end; e0 += 64) {
+        // 64 entries of column c1 (ascending rows), one per lane, with the extent of their rows
+        const int n = __builtin_amdgcn_readfirstlane(min(64, e_end - e0));
+        double va = 0.0;
+        int rs = 0, len = 0;
+        if (lane < n) {
+            const int k = ri[e0 + lane];
+            va = x[e0 + lane];
+            if ((unsigned)k < (unsigned)nrow) {
+                rs = rp[k];
+                len = rp[k + 1] - rs;
+            }
+        }
+        // units of work: (entry j of the group, 64-wide segment g of its row), walked in
+        // ascending order by a scalar cursor; kXD units have their loads in flight at once
+        int j = 0, g = 0;
+        while (j < n) {
+            int cb[kXD], ju[kXD];
+            double vb[kXD];
+#pragma unroll
+            for (int u = 0; u < kXD; ++u) {
+                cb[u] = -1;
+                vb[u] = 0.0;
+                ju[u] = j < n ? j : 0;                    // (scalar) which entry unit u belongs to
+                if (j < n) {                              // uniform
+                    const int rs_j = __builtin_amdgcn_readlane(rs, j);
+                    const int len_j = __builtin_amdgcn_readlane(len, j);
+                    const int t = g * 64 + lane;
+                    if (t < len_j) {
+                        cb[u] = rc[rs_j + t];
+                        vb[u] = rx[rs_j + t];
+                    }
+                    if ((g + 1) * 64 < len_j) {
+                        ++g;
+                    } else {
+                        ++j;
+                        g = 0;
+                    }
+                }
+            }
+            // consume in the same (ascending row) order.  x1 is broadcast here, not in the issue
+            // loop: a read of `va` there makes the compiler drain the loads already in flight.
+#pragma unroll
+            for (int u = 0; u < kXD; ++u) {
+                const double x1 = readlane_f64(va, ju[u]);
+                const unsigned c = (unsigned)(cb[u] - c_lo);
+                if (cb[u] >= 0 && c < span) {
+                    const double prod = x1 * vb[u];
+                    lds_add_f64(&acc[c], prod);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* col = out + (size_t)c1 * ncol + c_lo;         // column c1 of the symmetric result
+    for (unsigned c = lane; c < span; c += 64) col[c] = acc[c];
+}
+
+// nsplit slices of `width` result rows each: width <= kXMaxWidth, every slice non-empty
+void crossprod_split(int32_t ncol, int32_t* nsplit, int32_t* width) {
+    // One wave per result column is fastest whenever there are enough columns to fill the chip
+    // (every slice of a column re-reads the same rows); slices are for the LDS limit and for
+    // matrices with very few columns.
+    int ns = (ncol + kXMaxWidth - 1) / kXMaxWidth;
+    if (ncol < 128) {
+        ns = (256 + ncol - 1) / ncol;
+        if (ns > 8) ns = 8;
+        if (ns > ncol) ns = ncol;
+    }
+    const int w = (ncol + ns - 1) / ns;
+    *width = w;
+    *nsplit = (ncol + w - 1) / w;                         // drops slices that would start beyond ncol
+}
+
+static inline size_t xp_align(size_t v) { return (v + 255) / 256 * 256; }
+
+hipError_t plan_crossprod(int32_t nrow, int64_t nnz, CrossprodLayout* L) {
+    size_t temp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0,
+                                           (size_t)nrow + 1, rocprim::plus<int32_t>(), (hipStream_t)0);
+    if (e != hipSuccess) return e;
+    size_t off = 0;
+    L->rp_off = off;     off = xp_align(off + ((size_t)nrow + 1) * 4);
+    L->cursor_off = off; off = xp_align(off + ((size_t)nrow + 1) * 4);
+    L->rc_off = off;     off = xp_align(off + (size_t)nnz * 4);
+    L->rx_off = off;     off = xp_align(off + (size_t)nnz * 8);
+    L->temp_off = off;   off = xp_align(off + temp);
+    L->temp_bytes = temp;
+    L->total_bytes = off;
+    return hipSuccess;
+}
+
+hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
+                                 int32_t ncol, int64_t nnz, double* d_out, const CrossprodLayout& L, void* ws,
+                                 hipStream_t stream) {
+    if (ncol <= 0) return hipSuccess;
+    int32_t* rp = (int32_t*)((char*)ws + L.rp_off);
+    int32_t* cursor = (int32_t*)((char*)ws + L.cursor_off);
+    int32_t* rc = (int32_t*)((char*)ws + L.rc_off);
+    double* rx = (double*)((char*)ws + L.rx_off);
+    const size_t nr1 = (size_t)nrow + 1;
+    hipError_t e = hipMemsetAsync(cursor, 0, nr1 * 4, stream);
+    if (e != hipSuccess) return e;
+    if (nnz > 0) {
+        const int64_t want = (nnz + 255) / 256;
+        hipLaunchKernelGGL(xp_count_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream,
+                           d_i, nnz, nrow, cursor);
+    }
+    size_t temp_bytes = L.temp_bytes;
+    e = rocprim::exclusive_scan((char*)ws + L.temp_off, temp_bytes, (const int32_t*)cursor, rp, 0, nr1,
+                                rocprim::plus<int32_t>(), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(cursor, rp, nr1 * 4, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+    if (nnz > 0) {
+        const int want = (ncol + 3) / 4;
+        hipLaunchKernelGGL(xp_fill_rows_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, stream,
+                           d_x, d_i, d_p, nrow, ncol, cursor, rc, rx);
+    }
+    // split a result column over several waves when there are few columns (parallelism) or many
+    // (LDS accumulators per wave)
+    int nsplit = 1, width = ncol;
+    crossprod_split(ncol, &nsplit, &width);
+    const long long grid = (long long)ncol * nsplit;
+    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(crossprod_rows_kernel<kXDepth>, dim3((unsigned)grid), dim3(64), (size_t)width * 8, stream,
+                       d_x, d_i, d_p, rp, rc, rx, nrow, ncol, nsplit, width, d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_crossprod(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t ncol,

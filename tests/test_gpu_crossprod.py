@@ -1,7 +1,8 @@
 """GPU parity of Matrix::crossprod (reference inst/include/RcppSparse.h:159-194; "next" row f3)
-against the oracle's pairwise sorted-merge loop.  The device kernel accumulates the products of
-the common rows in ascending row order with a separate multiply and add -- the reference's order
--- so finite results must be bit-identical, not merely within tolerance."""
+against the oracle's pairwise sorted-merge loop.  Both device kernels (the row-major path that
+needs a workspace, and the scratch-free tile kernel) accumulate the products of the common rows
+in ascending row order with a separate multiply and add -- the reference's order -- so finite
+results must be bit-identical, not merely within tolerance."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -24,8 +25,10 @@ def torch_cuda():
 @pytest.mark.parametrize("nrow,ncol,density", [
     (10, 10, 0.1), (5, 5, 0.5), (40, 30, 0.15), (1000, 64, 0.05), (1000, 65, 0.05), (300, 200, 0.3),
     (20_000, 130, 0.01), (64, 257, 0.9), (100_000, 8, 0.2), (3, 500, 0.6), (2_000_000, 70, 0.0003),
+    (500, 150, 1.0), (7, 1, 0.5), (1, 90, 0.7), (4000, 1100, 0.02),
 ])
-def test_crossprod_bit_exact_vs_oracle(torch_cuda, nrow, ncol, density):
+@pytest.mark.parametrize("tiles", [False, True], ids=["rows", "tiles"])
+def test_crossprod_bit_exact_vs_oracle(torch_cuda, nrow, ncol, density, tiles):
     torch = torch_cuda
     m = synth.rsparsematrix(nrow, ncol, density=density, seed=nrow % 89 + ncol, kind=0)
     x, i, p = m["x"], m["i"], m["p"]
@@ -34,20 +37,22 @@ def test_crossprod_bit_exact_vs_oracle(torch_cuda, nrow, ncol, density):
     if x.size == 0:
         xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
         it = torch.zeros(2, dtype=torch.int32, device="cuda")[:0]
-    got = capi.crossprod_device(xt, it, pt).cpu().numpy().T     # column-major buffer viewed row-major
+    got = capi.crossprod_device(xt, it, pt, nrow, tiles=tiles).cpu().numpy().T   # column-major -> row-major view
     assert got.shape == (ncol, ncol)
     assert np.array_equal(got, ref), float(np.max(np.abs(got - ref)))
     assert np.array_equal(got, got.T)                              # mirrored exactly
     A = sp.csc_matrix((x, i, p), shape=(nrow, ncol))
     dense = (A.T @ A).toarray()
     assert np.allclose(got, dense, rtol=1e-12, atol=1e-12)
-    h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
-    via_handle = h.crossprod()
-    h.close()
-    assert np.array_equal(via_handle, ref)
+    if not tiles:
+        h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
+        via_handle = h.crossprod()
+        h.close()
+        assert np.array_equal(via_handle, ref)
 
 
-def test_crossprod_nonfinite_entries_only_meet_stored_entries(torch_cuda):
+@pytest.mark.parametrize("tiles", [False, True], ids=["rows", "tiles"])
+def test_crossprod_nonfinite_entries_only_meet_stored_entries(torch_cuda, tiles):
     torch = torch_cuda
     m = synth.rsparsematrix(200, 70, density=0.1, seed=9)
     x, i, p = m["x"].copy(), m["i"], m["p"]
@@ -55,10 +60,57 @@ def test_crossprod_nonfinite_entries_only_meet_stored_entries(torch_cuda):
     x[40] = np.nan
     ref = oracle.crossprod(x, i, p)
     got = capi.crossprod_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(),
-                                torch.from_numpy(p).cuda()).cpu().numpy().T
+                                torch.from_numpy(p).cuda(), 200, tiles=tiles).cpu().numpy().T
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     ok = ~np.isnan(ref)
     assert np.array_equal(got[ok], ref[ok])
+
+
+@pytest.mark.parametrize("tiles", [False, True], ids=["rows", "tiles"])
+def test_crossprod_subnormal_and_huge_products_round_like_the_reference(torch_cuda, tiles):
+    # products and partial sums in the subnormal range, cancellation, and values near overflow:
+    # the accumulation must round exactly like the reference's `res += x1 * x2` in double
+    torch = torch_cuda
+    nrow, ncol = 400, 40
+    m = synth.rsparsematrix(nrow, ncol, density=0.4, seed=77)
+    x, i, p = m["x"].copy(), m["i"], m["p"]
+    col_scale = np.array([1e-160, 3e-158, 1e-155, 1.0, 1e150, -1e-157, 7e153, 1e-150])[np.arange(ncol) % 8]
+    x = (x + 0.37) * np.repeat(col_scale, np.diff(p))
+    with np.errstate(over="ignore", invalid="ignore"):
+        ref = oracle.crossprod(x, i, p)
+    assert np.any((np.abs(ref) > 0) & (np.abs(ref) < 2.3e-308))     # subnormal results are present
+    got = capi.crossprod_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(),
+                                torch.from_numpy(p).cuda(), nrow, tiles=tiles).cpu().numpy().T
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok], ref[ok])
+    assert np.array_equal(np.signbit(got[ok]), np.signbit(ref[ok]))
+
+
+def test_crossprod_wide_matrix_splits_result_columns(torch_cuda):
+    # more columns than one wave's LDS accumulators hold (8192): the result column is split
+    torch = torch_cuda
+    nrow, ncol = 300, 9000
+    m = synth.rsparsematrix(nrow, ncol, density=0.004, seed=5)
+    x, i, p = m["x"], m["i"], m["p"]
+    got = capi.crossprod_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(),
+                                torch.from_numpy(p).cuda(), nrow).cpu().numpy()
+    A = sp.csc_matrix((x, i, p), shape=(nrow, ncol))
+    dense = (A.T @ A).toarray()
+    assert np.array_equal(got, got.T)
+    assert np.allclose(got, dense, rtol=1e-12, atol=1e-12)
+    sub = 40
+    ref = oracle.crossprod(x[:p[sub]], i[:p[sub]], np.ascontiguousarray(p[:sub + 1]))
+    assert np.array_equal(got[:sub, :sub], ref)
+
+
+def test_crossprod_workspace_too_small_is_reported(torch_cuda):
+    torch = torch_cuda
+    m = synth.rsparsematrix(100, 20, density=0.2, seed=2)
+    xt, it, pt = (torch.from_numpy(m[k]).cuda() for k in ("x", "i", "p"))
+    ws = torch.empty(16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(capi.RspError, match="workspace too small"):
+        capi.crossprod_device(xt, it, pt, 100, workspace=ws)
 
 
 def test_crossprod_needs_row_indices(torch_cuda):
