@@ -256,6 +256,33 @@ def main():
                 comm = TorchGather(dist, rank, world)
         elif comm is None:
             raise SystemExit("--force-comm: communicator creation failed")
+        # trial gatherv with a known pattern (rank r sends r + 1): a communicator that errors or
+        # delivers wrong data is replaced by torch.distributed's before anything is timed
+        if not isinstance(comm, TorchGather):
+            ok = 1
+            try:
+                probe = torch.full((shard.ncol,), float(rank + 1), dtype=torch.float64, device=dev)
+                if recv is not None:
+                    recv.zero_()
+                comm.gatherv(probe, recv, counts, displs, 0, stream=torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                if rank == 0:
+                    want = torch.repeat_interleave(
+                        torch.arange(1, world + 1, dtype=torch.float64, device=dev),
+                        torch.as_tensor([int(c) for c in counts], device=dev))
+                    ok = int(torch.equal(recv, want))
+            except Exception as e:
+                print(f"[rank {rank}] trial gatherv failed: {e}", file=sys.stderr, flush=True)
+                ok = 0
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                if world == 1:
+                    raise SystemExit("--force-comm: trial gatherv failed")
+                comm.close()
+                comm = TorchGather(dist, rank, world)
 
     # N > 1: the gatherv of step k runs on its own stream and overlaps the kernel of
     # step k+1 (double-buffered per-shard output); every step's gather completes
