@@ -17,11 +17,14 @@ constexpr int kStampChunks = 32768; // diagnostic build: chunks that record time
 constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed once)
 constexpr int kGroupRows = 4;     // rows per dense group (512 elements, 8 per lane)
 constexpr int kGroupElems = kGroupRows * kRowElems;
-constexpr int kStageSlots = kGroupElems + 4;   // LDS staging of one group (+4: unguarded look-ahead reads)
+constexpr int kStageSlots = kGroupElems + 32;  // LDS staging of one group (+pad: unguarded look-ahead reads)
 constexpr int kDenseMaxEnds = 2048; // more column ends than this in one group: general path
-constexpr int kDenseMaxLen = 64;  // longest column segment one lane may sum alone in a dense group
+constexpr int kDenseMaxLen = 64;  // longest run of elements one lane may sum alone in a dense group
 constexpr int kFewEnds = 3;       // rows with <= this many column ends use the masked-reduce loop
-constexpr int kDenseMinEnds = 8;  // groups with >= this many column ends use the dense path
+#ifndef RSP_DENSE_MIN_ENDS
+#define RSP_DENSE_MIN_ENDS 4
+#endif
+constexpr int kDenseMinEnds = RSP_DENSE_MIN_ENDS;  // groups with >= this many column ends use the dense path
 
 // per-element transforms of the generic column reduction (values of rsp_column_reduce_device's op)
 constexpr int kOpSum = 0;

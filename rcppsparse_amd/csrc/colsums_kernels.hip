@@ -370,15 +370,20 @@ __device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int l
     refresh_next(st, win, p, st.ccur + 1, ncol, lane);
 }
 
-// Dense group: kGroupRows consecutive rows (512 elements) holding many column ends, i.e.
-// short columns.  The rows are staged in LDS and the work is handed out by *column*: lane j
-// takes column ccur + j, reads its bounds from the p window, and adds its elements from LDS
-// sequentially -- exactly the reference's storage order, so a column that lives inside one
-// group comes out bit-identical to the reference loop, and the open column at either end of
-// the group continues the same sequential chain through the carry.  No bitmap, no scans;
-// empty columns are just zero-length ranges.  The group goes to the row paths instead
-// (returns false, nothing consumed) if a column segment is longer than kDenseMaxLen (one lane
-// would hold the wave up).
+// Dense group: kGroupRows consecutive rows (512 elements) holding several column ends.  The
+// rows are staged in LDS and the work is handed out by *column*, L lanes per column with
+// L = 1 / 2 / 4 / 8 for an average segment of up to 16 / 32 / 64 / more elements:
+//   L = 1 (short columns): lane j takes column ccur + j, reads its bounds from the p window and
+//     adds its elements from LDS sequentially -- exactly the reference's storage order, so a
+//     column that lives inside one group comes out bit-identical to the reference loop, and the
+//     open column at either end of the group continues the same sequential chain through the
+//     carry.  More than 64 segments are taken 64 at a time.
+//   L > 1 (medium columns): the L lanes of a column each add every L-th element in storage
+//     order and the L partial results are combined by a fixed DPP tree (deterministic; no
+//     longer the reference's order, like every other path for columns of that length).
+// No bitmap, no scans; empty columns are just zero-length ranges.  The group goes to the row
+// paths instead (returns false, nothing consumed) if a lane would have to add more than
+// kDenseMaxLen elements alone (it would hold the wave up).
 template <class P>
 __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, uint32_t glim, int n_ends,
                                             int lane, WaveState& st, double& acc0, double& acc1,
@@ -386,19 +391,27 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
                                             int ncol, int w, double* __restrict__ out,
                                             double* __restrict__ carry_head, double divisor) {
     const int ge = gs + (int)glim;   // one past the last element of the group this chunk owns
+    // segment j = 0 is the open column continuing into the group, j = n_ends the column still
+    // open at the group's end: n_ends + 1 segments
+    // Lanes per column from the average segment length glim / nseg (uniform): up to 16 elements
+    // -> 1 lane (short columns stay in reference order, also in the partial group at the end of
+    // a chunk), up to 32 -> 2, up to 64 -> 4, longer -> 8.  glim <= 512, so each bound also
+    // limits the number of segments: nseg << shift <= 64 for shift > 0.
+    const uint32_t nseg = (uint32_t)n_ends + 1u;
+    const int shift = glim <= 16u * nseg ? 0 : (glim <= 32u * nseg ? 1 : (glim <= 64u * nseg ? 2 : 3));   // log2(L)
+    const int L = 1 << shift;
 
-    // bounds of segment j (j = 0: the open column continuing into the group; j = n_ends: the
-    // column still open at the group's end).  With fewer than 64 ends a long segment is likely
-    // enough to check for (one window read); with 64 or more the average segment is at most 8
-    // elements and a rare long one only costs its own length once.
-    if (n_ends < 64) {
+    // With 8 lanes per column no lane can exceed kDenseMaxLen (512 / 8); with 64 or more ends the
+    // average segment is at most 8 elements and a rare long one only costs its own length once.
+    // In between a long segment is likely enough to check for (one window read).
+    if (shift < 3 && n_ends < 64) {
         ensure_window(st, win, p, st.ccur, 66, ncol, lane);
         const int woff = st.ccur - st.wbase;
         bool too_long = false;
         if (lane <= n_ends) {
             const int lo = (lane == 0) ? gs : win[woff + lane];
             const int hi = (lane == n_ends) ? ge : win[woff + lane + 1];
-            too_long = hi - lo > kDenseMaxLen;
+            too_long = hi - lo > (kDenseMaxLen << shift);
         }
         if (__ballot(too_long) != 0ull) return false;
     }
@@ -411,33 +424,66 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
     __builtin_amdgcn_wave_barrier();
 
     double carry_out = P::id();
-    for (int j0 = 0; j0 <= n_ends; j0 += 64) {
-        ensure_window(st, win, p, st.ccur + j0, 66, ncol, lane);
+    int owner;   // lane holding the running result of the column still open at the group's end
+    if (shift == 0) {
+        for (int j0 = 0; j0 <= n_ends; j0 += 64) {
+            ensure_window(st, win, p, st.ccur + j0, 66, ncol, lane);
+            const int woff = st.ccur - st.wbase;
+            const int j = j0 + lane;
+            const bool active = j <= n_ends;
+            int lo = 0, hi = 0;
+            if (active) {
+                lo = ((j == 0) ? gs : win[woff + j]) - gs;
+                hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
+            }
+            double s = (j == 0) ? A : P::id();   // the continuing column keeps adding to its running result
+            // storage-order adds, four unguarded LDS reads in flight (reading past a short column's
+            // end stays inside the workgroup's LDS and is harmless; the add is what is predicated)
+            const int n = hi - lo;
+            const double* sp = stage + lo;
+            for (int k = 0; __ballot(k < n) != 0ull; k += 4) {
+                const double e0 = sp[k], e1 = sp[k + 1], e2 = sp[k + 2], e3 = sp[k + 3];
+                if (k < n) s = P::comb(s, e0);
+                if (k + 1 < n) s = P::comb(s, e1);
+                if (k + 2 < n) s = P::comb(s, e2);
+                if (k + 3 < n) s = P::comb(s, e3);
+            }
+            if (active && j < n_ends) emit_column<P>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
+            if (active && j == n_ends) carry_out = s;
+        }
+        owner = n_ends & 63;
+    } else {
+        // (n_ends + 1) * L <= 64: one pass, lanes [j * L, (j + 1) * L) share column ccur + j
+        ensure_window(st, win, p, st.ccur, 66, ncol, lane);
         const int woff = st.ccur - st.wbase;
-        const int j = j0 + lane;
+        const int j = lane >> shift, sub = lane & (L - 1);
         const bool active = j <= n_ends;
         int lo = 0, hi = 0;
         if (active) {
             lo = ((j == 0) ? gs : win[woff + j]) - gs;
             hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
         }
-        double s = (j == 0) ? A : P::id();   // the continuing column keeps adding to its running result
-        // storage-order adds, four unguarded LDS reads in flight (the staging area is padded, so
-        // reading past a short column's end is harmless; the add is what is predicated)
-        const int n = hi - lo;
-        const double* sp = stage + lo;
-        for (int k = 0; __ballot(k < n) != 0ull; k += 4) {
-            const double e0 = sp[k], e1 = sp[k + 1], e2 = sp[k + 2], e3 = sp[k + 3];
-            if (k < n) s = P::comb(s, e0);
-            if (k + 1 < n) s = P::comb(s, e1);
-            if (k + 2 < n) s = P::comb(s, e2);
-            if (k + 3 < n) s = P::comb(s, e3);
+        double s = (lane == 0) ? A : P::id();
+        const int cnt = (hi - lo - sub + L - 1) >> shift;   // this lane adds elements lo + sub + m * L, m < cnt
+        const double* sp = stage + lo + sub;
+        for (int k = 0; __ballot(k < cnt) != 0ull; k += 4) {
+            const double e0 = sp[k << shift], e1 = sp[(k + 1) << shift], e2 = sp[(k + 2) << shift],
+                         e3 = sp[(k + 3) << shift];
+            if (k < cnt) s = P::comb(s, e0);
+            if (k + 1 < cnt) s = P::comb(s, e1);
+            if (k + 2 < cnt) s = P::comb(s, e2);
+            if (k + 3 < cnt) s = P::comb(s, e3);
         }
-        if (active && j < n_ends) emit_column<P>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
-        if (active && j == n_ends) carry_out = s;
+        // the L partial results of a column: pairs, quads, the two quads of each 8
+        s = P::comb(s, dpp_f64<0xB1>(s));
+        if (shift >= 2) s = P::comb(s, dpp_f64<0x4E>(s));
+        if (shift >= 3) s = P::comb(s, dpp_f64<0x141>(s));
+        if (active && sub == 0 && j < n_ends)
+            emit_column<P>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
+        carry_out = s;
+        owner = n_ends << shift;
     }
     // hand the open column's running sum to whatever comes next (one lane holds it)
-    const int owner = n_ends & 63;
     const double co = readlane_f64(carry_out, owner);
     acc0 = (lane == 0) ? co : P::id();
     acc1 = P::id();

@@ -100,7 +100,9 @@ REGIMES = [
     # (label, ncol, mean nnz/col)
     ("short3", 20000, 3),
     ("short10", 30000, 10),       # BASELINE C2 regime
-    ("mid100", 5000, 100),
+    ("mid20", 20000, 20),         # dense path, 2 lanes per column
+    ("mid45", 9000, 45),          # 4 lanes per column
+    ("mid100", 5000, 100),        # 8 lanes per column
     ("long1000", 900, 1000),      # BASELINE C3 regime
     ("long5000", 150, 5000),
     ("sparse_cols", 50000, 0.2),  # most columns empty
