@@ -104,6 +104,22 @@ def test_crossprod_wide_matrix_splits_result_columns(torch_cuda):
     assert np.array_equal(got[:sub, :sub], ref)
 
 
+def test_crossprod_full_lds_width(torch_cuda):
+    # exactly 8192 columns: one slice per result column, 64 KB of LDS accumulators per wave
+    torch = torch_cuda
+    nrow, ncol = 60, 8192
+    m = synth.rsparsematrix(nrow, ncol, density=0.01, seed=11)
+    x, i, p = m["x"], m["i"], m["p"]
+    got = capi.crossprod_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(),
+                                torch.from_numpy(p).cuda(), nrow)
+    assert bool(torch.equal(got, got.T))
+    A = sp.csc_matrix((x, i, p), shape=(nrow, ncol))
+    for lo in (0, 4000, 8100):
+        hi = min(ncol, lo + 92)
+        want = (A.T @ A[:, lo:hi]).toarray()              # rows: all columns, cols: lo..hi
+        assert np.allclose(got[lo:hi, :].cpu().numpy().T, want, rtol=1e-12, atol=1e-12)
+
+
 def test_crossprod_workspace_too_small_is_reported(torch_cuda):
     torch = torch_cuda
     m = synth.rsparsematrix(100, 20, density=0.2, seed=2)
