@@ -21,7 +21,7 @@ constexpr int kStageSlots = kGroupElems + 32;  // LDS staging of one group (+pad
 constexpr int kDenseMaxEnds = 2048; // more column ends than this in one group: general path
 constexpr int kDenseMaxLen = 64;  // longest run of elements one lane may sum alone in a dense group
 constexpr int kFewEnds = 3;       // rows with <= this many column ends use the masked-reduce loop
-#ifndef RSP_DENSE_MIN_ENDS
+#ifndef RSP_DENSE_MIN_ENDS      // (-DRSP_DENSE_MIN_ENDS=n builds a variant for threshold sweeps, tools/ab.py)
 #define RSP_DENSE_MIN_ENDS 4
 #endif
 constexpr int kDenseMinEnds = RSP_DENSE_MIN_ENDS;  // groups with >= this many column ends use the dense path
