@@ -198,15 +198,15 @@ int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
  * loop: bit-identical results for finite data.  Needs the row indices (which must lie
  * in [0, nrow), as in any valid dgCMatrix).
  *
- * rsp_crossprod_device: with a workspace of rsp_crossprod_workspace_bytes(nrow, nnz)
- * bytes the row-major form of A is built in it and each result column is accumulated
+ * rsp_crossprod_device: with a workspace of rsp_crossprod_workspace_bytes(nrow, ncol,
+ * nnz) bytes the row-major form of A is built in it and each result column is accumulated
  * by walking the rows its column touches (work = sum over rows of nnz(row)^2 products);
  * with d_workspace == NULL a scratch-free 64 x 64 tile kernel is used instead (slower on
  * sparse data).  Both give the same bits.  rsp_crossprod_workspace_bytes needs a usable
  * device (it asks rocPRIM); 0 = error.
  */
 int rsp_csc_crossprod(rsp_csc_t handle, double *out);        /* host, ncol*ncol */
-size_t rsp_crossprod_workspace_bytes(int32_t nrow, int64_t nnz);
+size_t rsp_crossprod_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz);
 int rsp_crossprod_device(const double *d_x, const int32_t *d_i, const int32_t *d_p,
                          int32_t nrow, int32_t ncol, int64_t nnz, double *d_out,
                          void *d_workspace, size_t workspace_bytes, void *stream);

@@ -100,7 +100,7 @@ def load(build: bool = True) -> ctypes.CDLL:
                                                c.POINTER(c.c_float)]
     L.rsp_csc_crossprod.argtypes = [vp, dp]
     L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
-    L.rsp_crossprod_workspace_bytes.argtypes = [i32, i64]
+    L.rsp_crossprod_workspace_bytes.argtypes = [i32, i32, i64]
     L.rsp_crossprod_workspace_bytes.restype = c.c_size_t
     L.rsp_csc_row_sums.argtypes = [vp, dp]
     L.rsp_csc_row_means.argtypes = [vp, dp]
@@ -379,7 +379,7 @@ def crossprod_device(x_t, i_t, p_t, nrow, out_t=None, workspace=None, stream=Non
     ws_ptr, ws_bytes = None, 0
     if not tiles:
         if workspace is None:
-            nbytes = int(L.rsp_crossprod_workspace_bytes(int(nrow), int(nnz)))
+            nbytes = int(L.rsp_crossprod_workspace_bytes(int(nrow), int(ncol), int(nnz)))
             if nbytes == 0:
                 raise RspError(RSP_ERR_HIP, L.rsp_last_error().decode())
             workspace = torch.empty(nbytes, dtype=torch.uint8, device=x_t.device)

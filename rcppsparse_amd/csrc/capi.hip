@@ -458,10 +458,10 @@ int rsp_csc_row_means(rsp_csc_t h, double* means) { return csc_rows(h, means, tr
 
 // ---- Matrix::crossprod (RcppSparse.h:159-194) -----------------------------------------------
 
-static int xp_plan(int32_t nrow, int64_t nnz, rsp::CrossprodLayout* L) {
+static int xp_plan(int32_t nrow, int32_t ncol, int64_t nnz, rsp::CrossprodLayout* L) {
     if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
-    if (int rc = check_sizes(0, nnz)) return rc;
-    hipError_t e = rsp::plan_crossprod(nrow, nnz, L);
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    hipError_t e = rsp::plan_crossprod(nrow, ncol, nnz, L);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(RSP_ERR_HIP, "planning crossprod failed: %s", hipGetErrorString(e));
@@ -469,9 +469,9 @@ static int xp_plan(int32_t nrow, int64_t nnz, rsp::CrossprodLayout* L) {
     return RSP_OK;
 }
 
-size_t rsp_crossprod_workspace_bytes(int32_t nrow, int64_t nnz) {
+size_t rsp_crossprod_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz) {
     rsp::CrossprodLayout L;
-    if (xp_plan(nrow, nnz, &L) != RSP_OK) return 0;
+    if (xp_plan(nrow, ncol, nnz, &L) != RSP_OK) return 0;
     return L.total_bytes;
 }
 
@@ -486,7 +486,7 @@ int rsp_crossprod_device(const double* d_x, const int32_t* d_i, const int32_t* d
         return RSP_OK;
     }
     rsp::CrossprodLayout L;
-    if (int rc = xp_plan(nrow, nnz, &L)) return rc;
+    if (int rc = xp_plan(nrow, ncol, nnz, &L)) return rc;
     if (workspace_bytes < L.total_bytes)
         return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, L.total_bytes);
     HIP_TRY(rsp::launch_crossprod_rows(d_x, d_i, d_p, nrow, ncol, nnz, d_out, L, d_workspace,
@@ -501,7 +501,7 @@ int rsp_csc_crossprod(rsp_csc_t h, double* out) {
     if (h->nnz > 0 && !h->d_i)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: crossprod needs the row indices");
     rsp::CrossprodLayout L;
-    if (int rc = xp_plan(h->nrow, h->nnz, &L)) return rc;
+    if (int rc = xp_plan(h->nrow, h->ncol, h->nnz, &L)) return rc;
     const size_t bytes = (size_t)h->ncol * (size_t)h->ncol * 8;
     double* d_c = nullptr;
     void* d_ws = nullptr;

@@ -69,9 +69,10 @@ hipError_t launch_row_transpose_values(const double* d_x, const int32_t* d_i, in
 // Matrix::crossprod on the device (crossprod.hip): dense ncol x ncol, column-major.
 struct CrossprodLayout {   // workspace of the row-major path
     size_t rp_off, cursor_off, rc_off, rx_off, temp_off, temp_bytes, total_bytes;
+    int32_t nsplit, width;   // slices of a result column and their width (crossprod_split)
 };
-hipError_t plan_crossprod(int32_t nrow, int64_t nnz, CrossprodLayout* L);
-void crossprod_split(int32_t ncol, int32_t* nsplit, int32_t* width);
+hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, CrossprodLayout* L);
+void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, int32_t* width);
 hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
                                  int32_t ncol, int64_t nnz, double* d_out, const CrossprodLayout& L, void* ws,
                                  hipStream_t stream);

@@ -11,9 +11,9 @@
 //    of A is built first (integer row histogram, exclusive scan, cursor fill; the order
 //    of the entries inside a row is irrelevant because a row contributes at most one
 //    product to any output).  One wavefront then owns a column c1 (or a slice of its
-//    output column): it walks c1's entries in ascending row order and, for each (k, x1),
-//    adds x1 * x2 to acc[c2] for every stored (k, c2, x2) of row k, one lane per entry of
-//    the row, the accumulators in LDS.  The work is exactly the sum over rows of
+//    output column, in which case the row-major form is kept per slice): it walks c1's entries
+//    in ascending row order and, for each (k, x1), adds x1 * x2 to acc[c2] for every stored
+//    (k, c2, x2) of row k, one lane per entry of the row, the accumulators in LDS.  The work is exactly the sum over rows of
 //    nnz(row)^2 products; nothing is spent on column pairs without common rows.
 //
 //  * crossprod_tiles_kernel (no workspace needed): one workgroup owns a 64 x 64 tile of the result (upper-triangular tile pairs only;
@@ -152,30 +152,42 @@ __global__ __launch_bounds__(256) void crossprod_tiles_kernel(
 constexpr int kXDepth = 16;       // (row, segment) units whose loads one wave keeps in flight
 constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 
-// (entries whose row index is outside [0, nrow) -- not a valid dgCMatrix -- are left out
-// rather than allowed to address memory out of bounds)
-__global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __restrict__ ri, int64_t nnz,
-                                                            int32_t nrow, int32_t* __restrict__ cnt) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
-        const int r = ri[e];
-        if ((unsigned)r < (unsigned)nrow) atomicAdd(&cnt[r], 1);
+// The row-major form is kept per *slice* of result columns: "virtual row" k * nsplit + c / width
+// holds the entries (c, x) of row k whose column lies in slice c / width, so that the wave that
+// owns slice s of a result column reads exactly the entries it needs and nothing else.
+// (Entries whose row index is outside [0, nrow) -- not a valid dgCMatrix -- are left out rather
+// than allowed to address memory out of bounds.)
+// One wavefront per column (grid-stride) in both passes.
+__global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __restrict__ ri,
+                                                            const int32_t* __restrict__ p, int32_t nrow,
+                                                            int32_t ncol, int32_t nsplit, int32_t width,
+                                                            int32_t* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int c = wave; c < ncol; c += nwaves) {
+        const int e1 = p[c + 1], slice = c / width;
+        for (int e = p[c] + lane; e < e1; e += 64) {
+            const int r = ri[e];
+            if ((unsigned)r < (unsigned)nrow) atomicAdd(&cnt[(int64_t)r * nsplit + slice], 1);
+        }
     }
 }
 
-// one wavefront per column (grid-stride): entry e of column c goes to the next free slot of its row
+// entry e of column c goes to the next free slot of its virtual row
 __global__ __launch_bounds__(256) void xp_fill_rows_kernel(const double* __restrict__ x,
                                                            const int32_t* __restrict__ ri,
                                                            const int32_t* __restrict__ p, int32_t nrow,
-                                                           int32_t ncol, int32_t* __restrict__ cursor, int32_t* __restrict__ rc,
+                                                           int32_t ncol, int32_t nsplit, int32_t width,
+                                                           int32_t* __restrict__ cursor, int32_t* __restrict__ rc,
                                                            double* __restrict__ rx) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (int c = wave; c < ncol; c += nwaves) {
-        const int e1 = p[c + 1];
+        const int e1 = p[c + 1], slice = c / width;
         for (int e = p[c] + lane; e < e1; e += 64) {
             const int r = ri[e];
             if ((unsigned)r >= (unsigned)nrow) continue;
-            const int pos = atomicAdd(&cursor[r], 1);
+            const int pos = atomicAdd(&cursor[(int64_t)r * nsplit + slice], 1);
             rc[pos] = c;
             rx[pos] = x[e];
         }
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
     int32_t nrow, int32_t ncol, int32_t nsplit, int32_t width, double* __restrict__ out) {
 #pragma clang fp contract(off)
     extern __shared__ double acc[];                       // out(c_lo .. c_lo+span, c1) of this wave
-    const int c1 = blockIdx.x / nsplit, c_lo = (blockIdx.x % nsplit) * width;
+    const int c1 = blockIdx.x / nsplit, slice = blockIdx.x % nsplit, c_lo = slice * width;
     if (c1 >= ncol || c_lo >= ncol) return;               // (the launcher never creates such a slice)
     const unsigned span = (unsigned)(min(ncol - c_lo, width));
     const int lane = threadIdx.x;
@@ -220,8 +232,9 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
             const int k = ri[e0 + lane];
             va = x[e0 + lane];
             if ((unsigned)k < (unsigned)nrow) {
-                rs = rp[k];
-                len = rp[k + 1] - rs;
+                const int64_t vr = (int64_t)k * nsplit + slice;   // this slice's part of row k
+                rs = rp[vr];
+                len = rp[vr + 1] - rs;
             }
         }
         // units of work: (entry j of the group, 64-wide segment g of its row), walked in
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
 #pragma unroll
             for (int u = 0; u < kXD; ++u) {
                 const double x1 = readlane_f64(va, ju[u]);
-                const unsigned c = (unsigned)(cb[u] - c_lo);
+                const unsigned c = (unsigned)(cb[u] - c_lo);   // (every entry of the virtual row is in the slice)
                 if (cb[u] >= 0 && c < span) {
                     const double prod = x1 * vb[u];
                     lds_add_f64(&acc[c], prod);
@@ -269,16 +282,20 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
     for (unsigned c = lane; c < span; c += 64) col[c] = acc[c];
 }
 
-// nsplit slices of `width` result rows each: width <= kXMaxWidth, every slice non-empty
-void crossprod_split(int32_t ncol, int32_t* nsplit, int32_t* width) {
-    // One wave per result column is fastest whenever there are enough columns to fill the chip
-    // (every slice of a column re-reads the same rows); slices are for the LDS limit and for
-    // matrices with very few columns.
+// nsplit slices of `width` result rows each: width <= kXMaxWidth, every slice non-empty.
+// More than one slice when the LDS accumulators of a whole result column do not fit, and when
+// there are too few columns to fill the chip: then a column's work is shared by nsplit waves, as
+// long as the slices of a row keep about 32 entries on average (below that the lanes of a wave
+// run empty and nothing is gained).
+void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, int32_t* width) {
     int ns = (ncol + kXMaxWidth - 1) / kXMaxWidth;
-    if (ncol < 128) {
-        ns = (256 + ncol - 1) / ncol;
-        if (ns > 8) ns = 8;
-        if (ns > ncol) ns = ncol;
+    if (ncol < 2048 && ns == 1) {
+        const int64_t avg_row = nrow > 0 ? nnz / nrow : 0;
+        int64_t want = (2048 + ncol - 1) / ncol;
+        if (want > avg_row / 32) want = avg_row / 32;
+        if (want > 8) want = 8;
+        if (want > ncol) want = ncol;
+        if (want > 1) ns = (int)want;
     }
     const int w = (ncol + ns - 1) / ns;
     *width = w;
@@ -287,14 +304,17 @@ void crossprod_split(int32_t ncol, int32_t* nsplit, int32_t* width) {
 
 static inline size_t xp_align(size_t v) { return (v + 255) / 256 * 256; }
 
-hipError_t plan_crossprod(int32_t nrow, int64_t nnz, CrossprodLayout* L) {
+hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, CrossprodLayout* L) {
+    crossprod_split(nrow, ncol > 0 ? ncol : 1, nnz, &L->nsplit, &L->width);
+    const size_t nv1 = (size_t)nrow * (size_t)L->nsplit + 1;   // virtual rows + 1
+    if (nv1 > 0x7fffffffull) return hipErrorInvalidValue;
     size_t temp = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0,
-                                           (size_t)nrow + 1, rocprim::plus<int32_t>(), (hipStream_t)0);
+    hipError_t e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, nv1,
+                                           rocprim::plus<int32_t>(), (hipStream_t)0);
     if (e != hipSuccess) return e;
     size_t off = 0;
-    L->rp_off = off;     off = xp_align(off + ((size_t)nrow + 1) * 4);
-    L->cursor_off = off; off = xp_align(off + ((size_t)nrow + 1) * 4);
+    L->rp_off = off;     off = xp_align(off + nv1 * 4);
+    L->cursor_off = off; off = xp_align(off + nv1 * 4);
     L->rc_off = off;     off = xp_align(off + (size_t)nnz * 4);
     L->rx_off = off;     off = xp_align(off + (size_t)nnz * 8);
     L->temp_off = off;   off = xp_align(off + temp);
@@ -311,29 +331,24 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     int32_t* cursor = (int32_t*)((char*)ws + L.cursor_off);
     int32_t* rc = (int32_t*)((char*)ws + L.rc_off);
     double* rx = (double*)((char*)ws + L.rx_off);
-    const size_t nr1 = (size_t)nrow + 1;
-    hipError_t e = hipMemsetAsync(cursor, 0, nr1 * 4, stream);
+    const int nsplit = L.nsplit, width = L.width;
+    const size_t nv1 = (size_t)nrow * (size_t)nsplit + 1;
+    hipError_t e = hipMemsetAsync(cursor, 0, nv1 * 4, stream);
     if (e != hipSuccess) return e;
-    if (nnz > 0) {
-        const int64_t want = (nnz + 255) / 256;
-        hipLaunchKernelGGL(xp_count_rows_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream,
-                           d_i, nnz, nrow, cursor);
-    }
+    const int want = (ncol + 3) / 4;
+    const dim3 cgrid((unsigned)(want < 4096 ? want : 4096));
+    if (nnz > 0)
+        hipLaunchKernelGGL(xp_count_rows_kernel, cgrid, dim3(256), 0, stream, d_i, d_p, nrow, ncol, nsplit, width,
+                           cursor);
     size_t temp_bytes = L.temp_bytes;
-    e = rocprim::exclusive_scan((char*)ws + L.temp_off, temp_bytes, (const int32_t*)cursor, rp, 0, nr1,
+    e = rocprim::exclusive_scan((char*)ws + L.temp_off, temp_bytes, (const int32_t*)cursor, rp, 0, nv1,
                                 rocprim::plus<int32_t>(), stream);
     if (e != hipSuccess) return e;
-    e = hipMemcpyAsync(cursor, rp, nr1 * 4, hipMemcpyDeviceToDevice, stream);
+    e = hipMemcpyAsync(cursor, rp, nv1 * 4, hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) return e;
-    if (nnz > 0) {
-        const int want = (ncol + 3) / 4;
-        hipLaunchKernelGGL(xp_fill_rows_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, stream,
-                           d_x, d_i, d_p, nrow, ncol, cursor, rc, rx);
-    }
-    // split a result column over several waves when there are few columns (parallelism) or many
-    // (LDS accumulators per wave)
-    int nsplit = 1, width = ncol;
-    crossprod_split(ncol, &nsplit, &width);
+    if (nnz > 0)
+        hipLaunchKernelGGL(xp_fill_rows_kernel, cgrid, dim3(256), 0, stream, d_x, d_i, d_p, nrow, ncol, nsplit, width,
+                           cursor, rc, rx);
     const long long grid = (long long)ncol * nsplit;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(crossprod_rows_kernel<kXDepth>, dim3((unsigned)grid), dim3(64), (size_t)width * 8, stream,

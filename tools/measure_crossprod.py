@@ -28,7 +28,7 @@ def main():
         capi.gen_values_device(xt, 42, 0, 0)
         capi.gen_row_indices_device(it, pt, nrow, 42)
         out = torch.empty((ncol, ncol), dtype=torch.float64, device="cuda")
-        ws = torch.empty(capi.load().rsp_crossprod_workspace_bytes(nrow, nnz), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(capi.load().rsp_crossprod_workspace_bytes(nrow, ncol, nnz), dtype=torch.uint8, device="cuda")
 
         def timed(**kw):
             capi.crossprod_device(xt, it, pt, nrow, out, **kw)
