@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Long fuzz of the column-sum kernel against the oracle (a soak run, not part of the test suite):
+random concatenations of column-length stretches (the generator of tests/test_gpu_parity.py plus
+medium-length stretches), random chunk sizes, sums / max / min / sum of squares, for a given
+number of seconds.  Prints one progress line every 50 cases; exits non-zero on the first mismatch.
+
+    python tools/soak_fuzz.py --seconds 240 [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import oracle
+from rcppsparse_amd import capi, synth
+from test_gpu_parity import _random_structure, assert_parity, dev_colsums
+
+
+def structure(rng):
+    parts = [_random_structure(rng)]
+    for _ in range(int(rng.integers(0, 4))):      # extra medium-length stretches (dense path, 2-8 lanes/column)
+        mean = int(rng.choice([12, 18, 25, 40, 60, 90, 130, 200]))
+        parts.append(rng.poisson(mean, size=int(rng.integers(20, 1500))))
+        if rng.integers(0, 3) == 0:
+            parts.append(np.zeros(int(rng.integers(1, 40)), dtype=np.int64))
+    rng.shuffle(parts)
+    return np.concatenate(parts).astype(np.int64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    capi.load()
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < a.seconds:
+        rng = np.random.default_rng(a.seed * 1_000_003 + n)
+        counts = structure(rng)
+        p = synth.offsets_from_counts(counts)
+        nnz = int(p[-1])
+        kind = int(rng.integers(0, 2))
+        x = synth.gen_values(nnz, seed=n, kind=kind)
+        rows = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 13, 16, 31, 64, 200]))
+        capi.set_tuning(rows)
+        try:
+            got = dev_colsums(torch, x, p)
+            assert_parity(got, x, p, positive=(kind == 1))
+            if n % 4 == 0 and nnz > 0:               # the other combine policies on the same structure
+                xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+                for op in (capi.OP_MAX, capi.OP_MIN, capi.OP_SUM_SQUARES):
+                    g = capi.column_reduce_device(xt, pt, op).cpu().numpy()
+                    ref = oracle.column_reduce(x, p, op)
+                    if op == capi.OP_SUM_SQUARES:
+                        assert np.all(np.abs(g - ref) <= 1e-12 * np.maximum(ref, 1e-300)), (n, op)
+                    else:
+                        assert np.array_equal(g, ref), (n, op)
+        except AssertionError:
+            print(f"MISMATCH at case {n} (seed {a.seed}, chunk_rows {rows}, ncol {counts.size}, nnz {nnz})", flush=True)
+            raise
+        finally:
+            capi.set_tuning(0)
+        n += 1
+        if n % 50 == 0:
+            print(f"{n} cases ok, {time.time() - t0:.0f} s", flush=True)
+    print(f"soak ok: {n} cases in {time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
