@@ -33,12 +33,54 @@ def structure(rng):
     return np.concatenate(parts).astype(np.int64)
 
 
+def soak_next_rows(a):
+    """crossprod (both kernels, bit-exact), rowSums and row-restricted column sums on random
+    small matrices with row indices."""
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < a.seconds:
+        rng = np.random.default_rng(a.seed * 1_000_003 + n)
+        nrow = int(rng.choice([1, 2, 7, 33, 64, 65, 200, 1000, 5000]))
+        ncol = int(rng.choice([1, 2, 9, 63, 64, 65, 130, 300]))
+        density = float(rng.choice([0.0, 0.003, 0.02, 0.1, 0.4, 0.9, 1.0]))
+        m = synth.rsparsematrix(nrow, ncol, density=density, seed=n, kind=int(rng.integers(0, 2)))
+        x, i, p = m["x"], m["i"], m["p"]
+        xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+        if x.size == 0:
+            xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
+            it = torch.zeros(2, dtype=torch.int32, device="cuda")[:0]
+        what = f"case {n}: {nrow}x{ncol} density {density}"
+        ref = oracle.crossprod(x, i, p)
+        for tiles in (False, True):
+            got = capi.crossprod_device(xt, it, pt, nrow, tiles=tiles).cpu().numpy().T
+            assert np.array_equal(got, ref), (what, "crossprod", tiles)
+        if x.size:
+            got = capi.row_sums_device(xt, it, nrow).cpu().numpy()
+            ref = oracle.row_sums(x, i, p, nrow)
+            scale = oracle.row_sums(np.abs(x), i, p, nrow)
+            assert np.all(np.abs(got - ref) <= 1e-12 * scale), (what, "rowSums")
+            rows = np.flatnonzero(rng.random(nrow) < rng.random())
+            bm = capi.row_set_bitmap(rows, nrow)
+            for comp in (False, True):
+                got = capi.column_sums_in_rows_device(xt, it, pt, nrow, torch.from_numpy(bm).cuda(), comp).cpu().numpy()
+                ref = oracle.column_sums_in_rows(x, i, p, bm, comp)
+                scale = oracle.column_abs_sums(x, p)
+                assert np.all(np.abs(got - ref) <= 1e-12 * scale), (what, "in_rows", comp)
+        n += 1
+        if n % 50 == 0:
+            print(f"{n} cases ok, {time.time() - t0:.0f} s", flush=True)
+    print(f"soak ok: {n} cases in {time.time() - t0:.0f} s", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--what", default="colsums", choices=["colsums", "next"])
     a = ap.parse_args()
     capi.load()
+    if a.what == "next":
+        return soak_next_rows(a)
     t0 = time.time()
     n = 0
     while time.time() - t0 < a.seconds:
