@@ -7,26 +7,28 @@
 //
 // Two kernels, both in the reference's accumulation order (bit-identical results):
 //
-//  * crossprod_rows_kernel (used when the caller provides a workspace): the row-major form
-//    of A is built first (integer row histogram, exclusive scan, cursor fill; the order
-//    of the entries inside a row is irrelevant because a row contributes at most one
-//    product to any output).  One wavefront then owns a column c1 (or a slice of its
-//    output column, in which case the row-major form is kept per slice): it walks c1's entries
-//    in ascending row order and, for each (k, x1), adds x1 * x2 to acc[c2] for every stored
-//    (k, c2, x2) of row k, one lane per entry of the row, the accumulators in LDS.  The work is exactly the sum over rows of
+//  * crossprod_rows_kernel (used when the caller provides a workspace).  The row-major form of
+//    A is built first (integer row histogram, exclusive scan, cursor fill; the order of the
+//    entries inside a row is irrelevant because a row contributes at most one product to any
+//    output).  One wavefront then owns a result column c1 -- or a slice of it, in which case
+//    the row-major form is kept per slice: it walks c1's entries in ascending row order and,
+//    for each (k, x1), adds x1 * x2 to acc[c2] for every stored (k, c2, x2) of row k, one lane
+//    per entry of the row, the accumulators in LDS.  The work is exactly the sum over rows of
 //    nnz(row)^2 products; nothing is spent on column pairs without common rows.
 //
-//  * crossprod_tiles_kernel (no workspace needed): one workgroup owns a 64 x 64 tile of the result (upper-triangular tile pairs only;
-// the mirror image is written at the end).  It walks the rows of A in blocks of 64: the
-// 64 + 64 columns of the tile pair each keep a cursor into their (ascending) row lists,
-// the entries that fall into the current row block are scattered into two dense LDS
-// panels [row][column] with per-row presence masks, and every thread accumulates its
-// 4 x 4 sub-tile in registers over the rows that are present on both sides.  Row blocks
-// in which none of the 128 columns has an entry are skipped (the next block starts at the
-// smallest pending row).  Products are accumulated in ascending row order with a separate
-// multiply and add (no FMA contraction), i.e. in the reference's order: results are
-// bit-identical to the reference loop for finite data.  Only entries that are stored take
-// part (presence masks), so a non-finite value never meets a structural zero.
+//  * crossprod_tiles_kernel (no workspace needed).  One workgroup owns a 64 x 64 tile of the
+//    result (upper-triangular tile pairs only; the mirror image is written at the end).  It
+//    walks the rows of A in blocks of 64: the 64 + 64 columns of the tile pair each keep a
+//    cursor into their (ascending) row lists, the entries that fall into the current row block
+//    are scattered into two dense LDS panels [row][column] with per-row presence masks, and
+//    every thread accumulates its 4 x 4 sub-tile in registers over the rows that are present
+//    on both sides.  Row blocks in which none of the 128 columns has an entry are skipped (the
+//    next block starts at the smallest pending row).
+//
+// In both, products are accumulated in ascending row order with a separate multiply and add (no
+// FMA contraction), i.e. in the reference's order: results are bit-identical to the reference
+// loop.  Only entries that are stored take part, so a non-finite value never meets a structural
+// zero.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
