@@ -171,6 +171,8 @@ struct WaveState {
     bool has_next;       // ccur + 1 <= ncol
     bool head_open;      // no column end seen in this chunk yet
     bool head_complete;  // the chunk starts exactly at p[c0]
+    bool acc_in_lane0;   // the running result of the open column sits in lane 0's acc0 alone
+                         // (every other lane's acc0 and all of acc1 hold the identity)
 };
 
 // Make sure win covers p-indices [k, k + need).
@@ -295,6 +297,7 @@ __device__ __forceinline__ void slow_row(double v0, double v1, int rs, int lane,
     // 6. carry the open tail of the row and advance the column cursor
     acc0 = (lane == 63 && !endR) ? X : P::id();
     acc1 = P::id();
+    st.acc_in_lane0 = false;
     st.ccur = cbase + tot;
     st.head_open = false;
     st.has_next = (uint32_t)k <= (uint32_t)ncol;
@@ -365,6 +368,7 @@ __device__ __forceinline__ void few_ends_row(double v0, double v1, int rs, int l
     }
     acc0 = (o0 >= lo) ? v0 : P::id();
     acc1 = (o0 + 1 >= lo) ? v1 : P::id();
+    st.acc_in_lane0 = false;
     st.ccur += n;
     st.head_open = false;
     refresh_next(st, win, p, st.ccur + 1, ncol, lane);
@@ -401,27 +405,19 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
     const int shift = glim <= 16u * nseg ? 0 : (glim <= 32u * nseg ? 1 : (glim <= 64u * nseg ? 2 : 3));   // log2(L)
     const int L = 1 << shift;
 
-    // With 8 lanes per column no lane can exceed kDenseMaxLen (512 / 8); with 64 or more ends the
-    // average segment is at most 8 elements and a rare long one only costs its own length once.
-    // In between a long segment is likely enough to check for (one window read).
-    if (shift < 3 && n_ends < 64) {
-        ensure_window(st, win, p, st.ccur, 66, ncol, lane);
-        const int woff = st.ccur - st.wbase;
-        bool too_long = false;
-        if (lane <= n_ends) {
-            const int lo = (lane == 0) ? gs : win[woff + lane];
-            const int hi = (lane == n_ends) ? ge : win[woff + lane + 1];
-            too_long = hi - lo > (kDenseMaxLen << shift);
-        }
-        if (__ballot(too_long) != 0ull) return false;
-    }
-
     // stage the four rows: element e of the group at stage[e]
 #pragma unroll
     for (int r = 0; r < kGroupRows; ++r)
         *(d2*)&stage[r * kRowElems + 2 * lane] = v[r];
-    const double A = wave_allreduce<P>(P::comb(acc0, acc1));   // result so far of the column open at gs
+    // result so far of the column open at gs: after a dense group it already sits in lane 0
+    const double A = st.acc_in_lane0 ? readlane_f64(acc0, 0) : wave_allreduce<P>(P::comb(acc0, acc1));
     __builtin_amdgcn_wave_barrier();
+
+    // A lane must not add more than kDenseMaxLen elements alone.  With 8 lanes per column it cannot
+    // (512 / 8); with 64 or more ends the average segment is at most 8 elements and a rare long one
+    // only costs its own length once.  In between the bounds of the (single) pass are checked
+    // before anything is emitted.
+    const bool check_len = shift < 3 && n_ends < 64;
 
     double carry_out = P::id();
     int owner;   // lane holding the running result of the column still open at the group's end
@@ -436,6 +432,7 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
                 lo = ((j == 0) ? gs : win[woff + j]) - gs;
                 hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
             }
+            if (check_len && __ballot(hi - lo > kDenseMaxLen) != 0ull) return false;   // (single pass: nothing emitted yet)
             double s = (j == 0) ? A : P::id();   // the continuing column keeps adding to its running result
             // storage-order adds, four unguarded LDS reads in flight (reading past a short column's
             // end stays inside the workgroup's LDS and is harmless; the add is what is predicated)
@@ -443,10 +440,10 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
             const double* sp = stage + lo;
             for (int k = 0; __ballot(k < n) != 0ull; k += 4) {
                 const double e0 = sp[k], e1 = sp[k + 1], e2 = sp[k + 2], e3 = sp[k + 3];
-                if (k < n) s = P::comb(s, e0);
-                if (k + 1 < n) s = P::comb(s, e1);
-                if (k + 2 < n) s = P::comb(s, e2);
-                if (k + 3 < n) s = P::comb(s, e3);
+                s = P::comb(s, k < n ? e0 : P::id());       // (adding the identity is exact)
+                s = P::comb(s, k + 1 < n ? e1 : P::id());
+                s = P::comb(s, k + 2 < n ? e2 : P::id());
+                s = P::comb(s, k + 3 < n ? e3 : P::id());
             }
             if (active && j < n_ends) emit_column<P>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
             if (active && j == n_ends) carry_out = s;
@@ -463,16 +460,17 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
             lo = ((j == 0) ? gs : win[woff + j]) - gs;
             hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
         }
+        if (check_len && __ballot(hi - lo > (kDenseMaxLen << shift)) != 0ull) return false;
         double s = (lane == 0) ? A : P::id();
         const int cnt = (hi - lo - sub + L - 1) >> shift;   // this lane adds elements lo + sub + m * L, m < cnt
         const double* sp = stage + lo + sub;
         for (int k = 0; __ballot(k < cnt) != 0ull; k += 4) {
             const double e0 = sp[k << shift], e1 = sp[(k + 1) << shift], e2 = sp[(k + 2) << shift],
                          e3 = sp[(k + 3) << shift];
-            if (k < cnt) s = P::comb(s, e0);
-            if (k + 1 < cnt) s = P::comb(s, e1);
-            if (k + 2 < cnt) s = P::comb(s, e2);
-            if (k + 3 < cnt) s = P::comb(s, e3);
+            s = P::comb(s, k < cnt ? e0 : P::id());
+            s = P::comb(s, k + 1 < cnt ? e1 : P::id());
+            s = P::comb(s, k + 2 < cnt ? e2 : P::id());
+            s = P::comb(s, k + 3 < cnt ? e3 : P::id());
         }
         // the L partial results of a column: pairs, quads, the two quads of each 8
         s = P::comb(s, dpp_f64<0xB1>(s));
@@ -487,6 +485,7 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
     const double co = readlane_f64(carry_out, owner);
     acc0 = (lane == 0) ? co : P::id();
     acc1 = P::id();
+    st.acc_in_lane0 = true;
     st.ccur += n_ends;
     if (n_ends > 0) st.head_open = false;
     refresh_next(st, win, p, st.ccur + 1, ncol, lane);
@@ -515,6 +514,7 @@ __device__ __forceinline__ void process_row(double v0, double v1, int rs, int la
     } else {
         acc0 = P::comb(acc0, v0);
         acc1 = P::comb(acc1, v1);
+        st.acc_in_lane0 = false;
     }
 }
 
@@ -594,6 +594,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     st.wbase = c0;
     fill_window(win, p, c0, ncol, lane);
     st.head_open = true;
+    st.acc_in_lane0 = true;   // (both accumulators start as the identity in every lane)
     st.head_complete = __builtin_amdgcn_readfirstlane(win[0]) >= cs;
     st.has_next = c0 + 1 <= ncol;
     st.qnext = __builtin_amdgcn_readfirstlane(win[1]);
