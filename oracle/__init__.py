@@ -29,28 +29,35 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_THREADS_LIB_PATH = os.path.join(_HERE, "liboracle_threads.so")
 _lib = None
+_threads_lib = None
 
 
-def build(force: bool = False) -> str:
-    """Compile liboracle.so with the committed Makefile (gcc, no fast-math)."""
-    src = os.path.join(_HERE, "colsums_oracle.c")
+def _make(target: str, path: str, sources, force: bool) -> str:
+    srcs = [os.path.join(_HERE, s) for s in sources]
 
     def stale():
-        return (force or not os.path.exists(_LIB_PATH)
-                or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src))
+        return (force or not os.path.exists(path)
+                or any(os.path.getmtime(path) < os.path.getmtime(s) for s in srcs))
     if stale():
         import fcntl
         fd = os.open(os.path.join(_HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
         try:
             fcntl.flock(fd, fcntl.LOCK_EX)       # several processes may import at once
             if stale():
-                subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True,
-                               stdout=subprocess.DEVNULL)
+                subprocess.run(["make", "-C", _HERE, target], check=True, stdout=subprocess.DEVNULL)
         finally:
             fcntl.flock(fd, fcntl.LOCK_UN)
             os.close(fd)
-    return _LIB_PATH
+    return path
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so (and the threaded bench variant) with the committed Makefile
+    (gcc, no fast-math)."""
+    _make("liboracle_threads.so", _THREADS_LIB_PATH, ["colsums_threads.c", "colsums_oracle.c"], force)
+    return _make("liboracle.so", _LIB_PATH, ["colsums_oracle.c"], force)
 
 
 def lib() -> ctypes.CDLL:
@@ -114,6 +121,43 @@ def column_sums(x, p, ncol=None, i=None, nrow=0) -> np.ndarray:
     out = np.empty(ncol, dtype=np.float64)
     ii = _ip(i) if i is not None else ctypes.POINTER(ctypes.c_int32)()
     lib().oracle_column_sums(_dp(x), ii, _ip(p), int(nrow), ncol, _dp(out))
+    return out
+
+
+def threads_lib() -> ctypes.CDLL:
+    """liboracle_threads.so: the same per-column loop under an OpenMP parallel-for (bench only)."""
+    global _threads_lib
+    if _threads_lib is None:
+        try:
+            build()
+        except Exception:
+            if not os.path.exists(_THREADS_LIB_PATH):
+                raise
+        L = ctypes.CDLL(_THREADS_LIB_PATH)
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+        L.oracle_threads_column_sums.argtypes = [dp, ip, ctypes.c_int32, dp, ctypes.c_int]
+        L.oracle_threads_column_sums.restype = None
+        L.oracle_threads_gen_values.argtypes = [dp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                                ctypes.c_int, ctypes.c_int]
+        L.oracle_threads_gen_values.restype = None
+        L.oracle_threads_max.restype = ctypes.c_int
+        _threads_lib = L
+    return _threads_lib
+
+
+def column_sums_threads(x, p, nthreads: int) -> np.ndarray:
+    """example.cpp:26-32 with the column loop spread over host threads (bit-identical results)."""
+    x, p, _ = _prep(x, p)
+    out = np.empty(len(p) - 1, dtype=np.float64)
+    threads_lib().oracle_threads_column_sums(_dp(x), _ip(p), len(p) - 1, _dp(out), int(nthreads))
+    return out
+
+
+def gen_values_threads(n, seed, first_idx=0, kind=0, nthreads: int = 1) -> np.ndarray:
+    """gen_values filled by several threads (first touch spreads the pages over NUMA nodes)."""
+    out = np.empty(int(n), dtype=np.float64)
+    threads_lib().oracle_threads_gen_values(_dp(out), int(n), int(seed), int(first_idx), int(kind),
+                                            int(nthreads))
     return out
 
 

@@ -99,3 +99,13 @@ def test_oracle_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "oracle selftest ok" in r.stdout
+
+
+def test_threaded_bench_variant_is_bit_identical_to_the_serial_loop():
+    # oracle/colsums_threads.c (bench.py's optional all-cores figure): same per-column loop
+    p = synth.offsets_from_counts(synth.zipf_counts(3000, 400_000, seed=3, nrow=100_000))
+    x = oracle.gen_values(int(p[-1]), 5, 0, 0)
+    assert np.array_equal(oracle.gen_values_threads(x.size, 5, 0, 0, nthreads=4), x)
+    ref = oracle.column_sums(x, p)
+    for t in (1, 3, 8):
+        assert oracle.column_sums_threads(x, p, t).tobytes() == ref.tobytes()
