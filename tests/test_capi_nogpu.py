@@ -84,6 +84,38 @@ def test_partition_zipf_never_splits_a_column():
     assert shard_nnz.max() <= p[-1] / 8 + counts.max()
 
 
+def test_partition_properties_hypothesis():
+    """Any column-length profile, any number of parts: contiguous cover, no column split, every
+    part within one column of the ideal share, and summing the shards with the oracle gives the
+    whole-matrix result bit for bit (columns are independent)."""
+    from hypothesis import given, settings, strategies as st
+    import oracle
+
+    lengths = st.lists(st.one_of(st.integers(0, 6), st.integers(0, 400), st.just(0), st.integers(2000, 9000)),
+                       min_size=1, max_size=300)
+
+    @settings(max_examples=120, deadline=None)
+    @given(lengths, st.integers(1, 16), st.integers(0, 2**31 - 1))
+    def check(counts, nparts, seed):
+        counts = np.asarray(counts, dtype=np.int64)
+        p = synth.offsets_from_counts(counts)
+        b = capi.partition_columns(p, nparts)
+        assert b[0] == 0 and b[-1] == counts.size and np.all(np.diff(b) >= 0)
+        shard_nnz = np.diff(p[b].astype(np.int64))
+        assert shard_nnz.sum() == p[-1]
+        assert shard_nnz.max() <= -(-int(p[-1]) // nparts) + int(counts.max())
+        x = synth.gen_values(int(p[-1]), seed=seed % 1000, kind=0)
+        whole = oracle.column_sums(x, p)
+        parts = []
+        for k in range(nparts):
+            c0, c1 = int(b[k]), int(b[k + 1])
+            pl = capi.rebase_offsets(p, c0, c1)
+            parts.append(oracle.column_sums(x[p[c0]:p[c1]], pl))
+        assert np.concatenate(parts).tobytes() == whole.tobytes()
+
+    check()
+
+
 def test_argument_errors_do_not_need_a_device():
     L = capi.load()
     import ctypes
