@@ -72,6 +72,9 @@ def parse_args():
                     help="N>1: nnz-balanced column ranges (default) or the naive equal-column-count split")
     ap.add_argument("--gather-buffers", type=int, default=4,
                     help="N>1: per-shard output buffers in the kernel/gather pipeline")
+    ap.add_argument("--compute-streams", type=int, default=0,
+                    help="streams the column-sum launches alternate over (0 = automatic: 2 when there "
+                         "is a gather, i.e. N > 1, else 1)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: still create the RCCL communicator and run the 2-stream "
                          "gather pipeline (rehearsal of the N>1 code path on a 1-GPU box)")
@@ -323,7 +326,13 @@ def main():
     # both streams come from torch's pool (non-blocking streams): nothing here runs on the legacy
     # null stream, which would implicitly synchronise with any blocking stream a library creates
     torch.cuda.synchronize()
-    s_compute = torch.cuda.Stream()
+    # With a gather the launches may alternate over several streams (each with its own carries
+    # workspace; consecutive steps already write different output buffers): the next shard's
+    # kernel then fills the chip while the previous one drains and runs its fix-up.
+    ncs = (max(1, min(args.compute_streams or 2, args.gather_buffers)) if comm is not None else 1)
+    s_computes = [torch.cuda.Stream() for _ in range(ncs)]
+    wss = [ws] + [capi.alloc_workspace(shard.ncol, shard.nnz, dev) for _ in range(ncs - 1)]
+    s_compute = s_computes[0]
     torch.cuda.set_stream(s_compute)
     s_comm = torch.cuda.Stream() if comm is not None else None
     outs = ([out_local] + [torch.empty_like(out_local) for _ in range(args.gather_buffers - 1)]
@@ -331,7 +340,9 @@ def main():
     nbuf = len(outs)
     # everything the hot loop touches is created up front (host time per step must stay
     # well under the ~155 us a 1/8 shard takes on the GPU)
-    launch = [[capi.prepared_column_sums(xk, pt, o, ws, stream=s_compute) for xk in xs] for o in outs]
+    # launch[stream][buffer][copy]; step n runs on stream n % ncs (its own carries workspace)
+    launch = [[[capi.prepared_column_sums(xk, pt, o, wss[q], stream=s_computes[q]) for xk in xs] for o in outs]
+              for q in range(ncs)]
     if comm is None:
         gather = [None] * nbuf
     elif hasattr(comm, "prepared_gatherv"):
@@ -348,18 +359,19 @@ def main():
     def step(ev_a=None, ev_b=None, gpair=None):
         n = step_no[0]
         k = n % nbuf
+        sc = s_computes[n % ncs]
         step_no[0] = n + 1
         if comm is not None and n >= nbuf and not gather_done[n - nbuf].query():
-            s_compute.wait_event(gather_done[n - nbuf])   # this buffer's previous gather must have drained
+            sc.wait_event(gather_done[n - nbuf])   # this buffer's previous gather must have drained
         if ev_a is not None:
-            ev_a.record(s_compute)
-        launch[k][n % ncopies]()
+            ev_a.record(sc)
+        launch[n % ncs][k][n % ncopies]()
         if ev_b is not None:
-            ev_b.record(s_compute)
+            ev_b.record(sc)
         if comm is not None:
             done = ev_b if ev_b is not None else kernel_done[n]
             if ev_b is None:
-                done.record(s_compute)
+                done.record(sc)
             s_comm.wait_event(done)
             if gpair is not None:
                 gpair[0].record(s_comm)
@@ -373,6 +385,22 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # With overlapping launches an event pair around one launch also spans its neighbour's share
+    # of the chip, so the kernel itself is timed here, alone, before the pipeline starts.
+    iso_ms = None
+    if ncs > 1:
+        torch.cuda.synchronize()
+        iso = []
+        for r in range(7):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s_computes[0])
+            launch[0][0][r % ncopies]()
+            b.record(s_computes[0])
+            torch.cuda.synchronize()
+            iso.append(a.elapsed_time(b))
+        iso.sort()
+        iso_ms = iso[len(iso) // 2]
 
     for _ in range(args.warmup):
         step()
@@ -393,7 +421,10 @@ def main():
 
     timed = range(0, args.steps, stride)
     ktimes = sorted(ev[k][0].elapsed_time(ev[k][1]) for k in timed)
-    kernel_ms = sum(ktimes) / len(ktimes)
+    kernel_ms_in_loop = sum(ktimes) / len(ktimes)
+    kernel_ms = iso_ms if iso_ms is not None else kernel_ms_in_loop
+    if iso_ms is not None:
+        ktimes = iso          # median / min below describe the same (isolated) launches
     gather_ms = (sum(gev[k][0].elapsed_time(gev[k][1]) for k in timed) / len(ktimes)
                  if comm is not None else 0.0)
     stats = torch.tensor([elapsed, kernel_ms, gather_ms], dtype=torch.float64, device=dev)
@@ -423,7 +454,8 @@ def main():
                             f"values kind {args.kind}, seed {SEED}",
                 "parallelism": ("single GPU" if world == 1 else
                                 f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0 "
-                                "(gather of step k on a second stream, overlapping the kernel of step k+1)"),
+                                "(gather of step k on its own stream; launches alternate over "
+                                f"{ncs} compute stream(s), so step k+1 fills the chip while step k drains)"),
                 "partition": args.partition,
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
@@ -436,6 +468,9 @@ def main():
                 "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
                 "kernel": "colsums_chunks_kernel (+ colsums_fixup_kernel)",
                 "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
+                "kernel_timing": ("HIP events around each launch in the timed region" if iso_ms is None else
+                                  f"median of 7 isolated launches before the timed region; inside it {ncs} launches "
+                                  f"overlap and an event pair spans {kernel_ms_in_loop:.4f} ms"),
                 "kernel_ms_max_over_ranks": kernel_ms_max,
                 "gather_ms_on_comm_stream_max_over_ranks": gather_ms_max if comm is not None else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
