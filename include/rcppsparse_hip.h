@@ -113,10 +113,14 @@ int rsp_csc_free(rsp_csc_t handle);
 /*
  * Same computation on device pointers; everything is enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream) of the calling
- * thread's current HIP device, and nothing synchronises.  d_x must be 16-byte aligned.  d_workspace is scratch of at
- * least rsp_column_sums_workspace_bytes(ncol, nnz) bytes, 16-byte aligned; it
- * carries no state between calls.  Graph-capture safe (no allocation, no
- * synchronisation inside).
+ * thread's current HIP device, and nothing synchronises.  d_x must be 16-byte
+ * aligned.  d_workspace is scratch of at least
+ * rsp_column_sums_workspace_bytes(ncol, nnz) bytes, 16-byte aligned; it carries
+ * no state between calls, but calls that may run concurrently (different streams)
+ * need a workspace each.  Graph-capture safe (no allocation, no synchronisation
+ * inside).  Many calls on small or medium matrices: alternating them over two
+ * streams (two workspaces) lets one call fill the chip while the previous one
+ * drains (bench.py does this for the 1/8 shards of the multi-GPU runs: -15 %).
  */
 size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz);
 int rsp_column_sums_device(const double *d_x, const int32_t *d_p, int32_t ncol,
