@@ -6,7 +6,7 @@ Contract (one JSON line from rank 0):
     N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
                --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one columnSums pass over the whole matrix: the hot path of reference
+A "step" is one columnSums call over the whole matrix: the hot path of reference
 src/example.cpp:26-32, here `rsp_column_sums_device` (hand-written HIP, called
 through the C ABI of include/rcppsparse_hip.h) on inputs already resident in HBM.
 Workload (BASELINE.json configs[2], the one the metric is quoted on): 1e7 x 1e6,
@@ -15,10 +15,20 @@ With N > 1 the SAME matrix is split into N nnz-balanced contiguous column ranges
 (strong scaling: total work fixed), each rank sums its range, and the per-rank
 slices are gathered to rank 0 with an RCCL gatherv over xGMI inside every step.
 
-`value` = nnz of the whole matrix x K / wall time of the K steps (max over ranks).
+THE SAME PROTOCOL AT EVERY N (so per-N values can be divided by each other):
+`value` = nnz of the whole matrix x K / wall time of K calls issued back to back, each call
+in order on ONE stream per rank: column-sum kernels, then (N > 1) the gatherv of that call
+-- the synchronous-call semantics of the reference function; call k+1 starts when call k,
+its gather included, is done.  Max over ranks, barrier + synchronize on both sides.
+Also reported, as separate keys that never feed `value`:
+  `latency_ms_per_call`  one call at a time: host launch -> kernels -> gatherv -> the result
+                         is complete on rank 0 and the host has seen it (SURVEY.md 8d);
+  `pipelined`            calls overlapped across steps (launches alternate over two compute
+                         streams, the gather of call k runs beside the kernel of call k+1).
 `roofline.achieved` = algorithmic bytes of one launch (8 B/nnz + 12 B/column,
 SURVEY.md 8d; i[] is never read) / mean launch duration from HIP events recorded
-on the launch stream around every launch of the timed region.
+on the launch stream around the kernels of the timed region (the gather is outside them).
+`parity` = EVERY column of the gathered result against the oracle, after the timed region.
 `cpu_baseline` = the oracle (1-thread C restatement of the reference loop) timed
 on this box's host on a bounded prefix of the same matrix (rank 0, N = 1 only).
 """
@@ -55,10 +65,12 @@ WORKLOADS = {
     "m100": (10_000_000, 10_000_000, 1_000_000_000, "uniform"),
     "m300": (10_000_000, 3_300_000, 1_000_000_000, "uniform"),
     "m10": (10_000_000, 100_000_000, 1_000_000_000, "uniform"),
+    # small shapes for the -m gpu test that runs this file as a child process
+    "tiny": (200_000, 40_000, 4_000_000, "zipf"),
 }
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -71,14 +83,16 @@ def parse_args():
     ap.add_argument("--partition", default="nnz", choices=["nnz", "cols"],
                     help="N>1: nnz-balanced column ranges (default) or the naive equal-column-count split")
     ap.add_argument("--gather-buffers", type=int, default=4,
-                    help="N>1: per-shard output buffers in the kernel/gather pipeline")
-    ap.add_argument("--compute-streams", type=int, default=0,
-                    help="streams the column-sum launches alternate over (0 = automatic: 2 when there "
-                         "is a gather, i.e. N > 1, else 1)")
+                    help="pipelined figure: per-shard output buffers in the kernel/gather pipeline")
+    ap.add_argument("--compute-streams", type=int, default=2,
+                    help="pipelined figure: streams the column-sum launches alternate over")
+    ap.add_argument("--latency-calls", type=int, default=25,
+                    help="calls timed one at a time for latency_ms_per_call")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the separate pipelined figure")
     ap.add_argument("--force-comm", action="store_true",
-                    help="N=1 only: still create the RCCL communicator and run the 2-stream "
-                         "gather pipeline (rehearsal of the N>1 code path on a 1-GPU box)")
-    return ap.parse_args()
+                    help="N=1 only: still create the RCCL communicator and run the gatherv in every "
+                         "call (rehearsal of the N>1 code path on a 1-GPU box)")
+    return ap.parse_args(argv)
 
 
 def relaunch_under_torchrun(args) -> int:
@@ -167,51 +181,48 @@ def cpu_baseline(p, kind, target_nnz=1_000_000_000, reps=10):
     return out
 
 
-def parity_spot_check(got, p, kind, first_idx=0, ncheck=400, seed=SEED):
-    """A few column ranges of the result vs the oracle (outside the timed region)."""
+def parity_whole_matrix(got, p, kind, seed=SEED, first_idx=0, slab_nnz=60_000_000):
+    """EVERY column of `got` against the oracle (outside the timed region).  The matrix is walked
+    in slabs of whole columns; each slab's x is regenerated on the host by the oracle's counter-based
+    generator (bit-identical to the device generator), summed by the oracle's per-column loop
+    (the threaded variant runs the same sequential loop per column: identical bits) and compared
+    in the grading form |gpu - ref| <= 1e-12 * sum|x| per column."""
     import numpy as np
     import oracle
     ncol = len(p) - 1
-    worst, worst_rel = 0.0, 0.0
-    for c0 in sorted({0, ncol // 2, max(0, ncol - ncheck)}):
-        c1 = min(ncol, c0 + ncheck)
-        lo, hi = int(p[c0]), int(p[c1])
-        xv = oracle.gen_values(hi - lo, seed, first_idx + lo, kind)
-        pl = (p[c0:c1 + 1] - lo).astype(np.int32)
-        ref = oracle.column_sums(xv, pl)
-        scale = np.maximum(oracle.column_abs_sums(xv, pl), 1e-300)
-        err = np.abs(got[c0:c1] - ref)
-        worst = max(worst, float(np.max(err / scale)))
-        well = np.abs(ref) >= 1e-3 * scale          # columns without heavy cancellation
+    p64 = np.asarray(p, dtype=np.int64)
+    nthreads = max(1, usable_cores())
+    worst, worst_rel, nbad, empties_exact = 0.0, 0.0, 0, True
+    c0 = 0
+    while c0 < ncol:
+        c1 = int(np.searchsorted(p64, p64[c0] + slab_nnz, side="right")) - 1
+        c1 = min(ncol, max(c1, c0 + 1))
+        lo, hi = int(p64[c0]), int(p64[c1])
+        pl = (p64[c0:c1 + 1] - lo).astype(np.int32)
+        if hi > lo:
+            xv = oracle.gen_values_threads(hi - lo, seed, first_idx + lo, kind, nthreads)
+            ref = oracle.column_sums_threads(xv, pl, nthreads)
+            scale = oracle.column_abs_sums(xv, pl)
+        else:
+            ref = np.zeros(c1 - c0)
+            scale = np.zeros(c1 - c0)
+        g = got[c0:c1]
+        err = np.abs(g - ref)
+        nbad += int(np.count_nonzero(~(err <= 1e-12 * scale)))
+        nz = scale > 0
+        if nz.any():
+            worst = max(worst, float(np.max(err[nz] / scale[nz])))
+        well = nz & (np.abs(ref) >= 1e-3 * scale)          # columns without heavy cancellation
         if well.any():
             worst_rel = max(worst_rel, float(np.max(err[well] / np.abs(ref[well]))))
-    return worst, worst_rel
-
-
-class TorchGather:
-    """Same gatherv (grouped RCCL send/recv) issued through torch.distributed's own
-    communicator; used only if the C-ABI communicator cannot be created."""
-    name = "torch.distributed batch_isend_irecv (RCCL)"
-
-    def __init__(self, dist, rank, world):
-        self.dist, self.rank, self.world = dist, rank, world
-
-    def gatherv(self, send_t, recv_t, counts, displs, root=0, stream=None):
-        import torch
-        dist = self.dist
-        with torch.cuda.stream(stream):
-            if self.rank == root:
-                ops = [dist.P2POp(dist.irecv, recv_t[int(displs[r]):int(displs[r] + counts[r])], r)
-                       for r in range(self.world) if r != root and counts[r] > 0]
-                recv_t[int(displs[root]):int(displs[root] + counts[root])].copy_(send_t, non_blocking=True)
-            else:
-                ops = [dist.P2POp(dist.isend, send_t, root)] if send_t.numel() > 0 else []
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-
-    def close(self):
-        pass
+        empty = pl[1:] == pl[:-1]
+        if empty.any():
+            empties_exact = empties_exact and bool(np.all(g[empty] == 0.0) and not np.any(np.signbit(g[empty])))
+        c0 = c1
+    return {"max_abs_err_over_l1": worst, "tolerance": 1e-12,
+            "max_rel_err_where_ref_ge_1e-3_l1": worst_rel,
+            "columns_checked": "all", "ncol": ncol, "columns_out_of_tolerance": nbad,
+            "empty_columns_exactly_plus_zero": empties_exact}
 
 
 def traffic_from_profiles(workload):
@@ -228,8 +239,58 @@ def traffic_from_profiles(workload):
     return best
 
 
-def main():
-    args = parse_args()
+def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev, shard, counts, displs,
+                      recv):
+    """The C-ABI communicator (rsp_comm_*), checked with a trial gatherv of a known pattern.  If it
+    cannot be created or delivers wrong data on any rank, EVERY rank switches to the same gatherv
+    through torch.distributed (plumbing only, never a compute fallback); config.gather says which."""
+    uid = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(uid, 0)
+
+    def all_ok(ok):
+        if world == 1:
+            return bool(ok)
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    comm = None
+    try:
+        comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+        ok = True
+    except Exception as e:
+        print(f"[rank {rank}] rsp_comm_init failed: {e}", file=sys.stderr, flush=True)
+        ok = False
+    if all_ok(ok):
+        ok = True
+        try:   # rank r sends r + 1 everywhere in its slice
+            probe = torch.full((shard.ncol,), float(rank + 1), dtype=torch.float64, device=dev)
+            if recv is not None:
+                recv.zero_()
+            comm.gatherv(probe, recv, counts, displs, 0, stream=torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            if rank == 0:
+                want = torch.repeat_interleave(
+                    torch.arange(1, world + 1, dtype=torch.float64, device=dev),
+                    torch.as_tensor([int(c) for c in counts], device=dev))
+                ok = bool(torch.equal(recv, want))
+        except Exception as e:
+            print(f"[rank {rank}] trial gatherv failed: {e}", file=sys.stderr, flush=True)
+            ok = False
+        if all_ok(ok):
+            return comm, False
+    if comm is not None:
+        comm.close()
+    if world == 1:
+        raise SystemExit("--force-comm: the C-ABI communicator failed (see stderr)")
+    return None, True
+
+
+def main(argv=None):
+    args = parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
@@ -266,119 +327,22 @@ def main():
         capi.gen_values_device(xk, SEED + k, shard.x0, args.kind)
         xs.append(xk)
     pt = torch.from_numpy(shard.p_local).to(dev)
-    out_local = torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=dev)[:shard.ncol]
-    ws = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
     use_comm = world > 1 or args.force_comm
     recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (use_comm and rank == 0) else None
-    comm = None
+    comm, fell_back = (None, False)
     if use_comm:
-        uid = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-        if world > 1:
-            dist.broadcast(uid, 0)
-        try:
-            comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
-            ok = 1
-        except Exception as e:   # plumbing failure of the C-ABI communicator (never a compute fallback)
-            print(f"[rank {rank}] rsp_comm_init failed: {e}", file=sys.stderr, flush=True)
-            comm, ok = None, 0
-        if world > 1:   # every rank must take the same gather path
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                if comm is not None:
-                    comm.close()
-                comm = TorchGather(dist, rank, world)
-        elif comm is None:
-            raise SystemExit("--force-comm: communicator creation failed")
-        # trial gatherv with a known pattern (rank r sends r + 1): a communicator that errors or
-        # delivers wrong data is replaced by torch.distributed's before anything is timed
-        if not isinstance(comm, TorchGather):
-            ok = 1
-            try:
-                probe = torch.full((shard.ncol,), float(rank + 1), dtype=torch.float64, device=dev)
-                if recv is not None:
-                    recv.zero_()
-                comm.gatherv(probe, recv, counts, displs, 0, stream=torch.cuda.current_stream())
-                torch.cuda.synchronize()
-                if rank == 0:
-                    want = torch.repeat_interleave(
-                        torch.arange(1, world + 1, dtype=torch.float64, device=dev),
-                        torch.as_tensor([int(c) for c in counts], device=dev))
-                    ok = int(torch.equal(recv, want))
-            except Exception as e:
-                print(f"[rank {rank}] trial gatherv failed: {e}", file=sys.stderr, flush=True)
-                ok = 0
-            if world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok:
-                if world == 1:
-                    raise SystemExit("--force-comm: trial gatherv failed")
-                comm.close()
-                comm = TorchGather(dist, rank, world)
+        comm, fell_back = make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev,
+                                            shard, counts, displs, recv)
 
-    # N > 1: the gatherv of step k runs on its own stream and overlaps the kernel of
-    # step k+1 (double-buffered per-shard output); every step's gather completes
-    # inside the timed region.  N = 1: one stream, no collective.
-    # both streams come from torch's pool (non-blocking streams): nothing here runs on the legacy
-    # null stream, which would implicitly synchronise with any blocking stream a library creates
-    torch.cuda.synchronize()
-    # With a gather the launches may alternate over several streams (each with its own carries
-    # workspace; consecutive steps already write different output buffers): the next shard's
-    # kernel then fills the chip while the previous one drains and runs its fix-up.
-    ncs = (max(1, min(args.compute_streams or 2, args.gather_buffers)) if comm is not None else 1)
-    s_computes = [torch.cuda.Stream() for _ in range(ncs)]
-    wss = [ws] + [capi.alloc_workspace(shard.ncol, shard.nnz, dev) for _ in range(ncs - 1)]
-    s_compute = s_computes[0]
-    torch.cuda.set_stream(s_compute)
-    s_comm = torch.cuda.Stream() if comm is not None else None
-    outs = ([out_local] + [torch.empty_like(out_local) for _ in range(args.gather_buffers - 1)]
-            if comm is not None else [out_local])
-    nbuf = len(outs)
-    # everything the hot loop touches is created up front (host time per step must stay
-    # well under the ~155 us a 1/8 shard takes on the GPU)
-    # launch[stream][buffer][copy]; step n runs on stream n % ncs (its own carries workspace)
-    launch = [[[capi.prepared_column_sums(xk, pt, o, wss[q], stream=s_computes[q]) for xk in xs] for o in outs]
-              for q in range(ncs)]
-    if comm is None:
-        gather = [None] * nbuf
-    elif hasattr(comm, "prepared_gatherv"):
-        gather = [comm.prepared_gatherv(o, recv, counts, displs, 0, stream=s_comm) for o in outs]
-    else:
-        gather = [(lambda o=o: comm.gatherv(o, recv, counts, displs, 0, stream=s_comm)) for o in outs]
-    total_steps = args.warmup + args.steps
-    kernel_done = [torch.cuda.Event() for _ in range(total_steps)]
-    gather_done = [torch.cuda.Event() for _ in range(total_steps)]
-    gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)] if comm is not None else []
-    step_no = [0]
+    def new_out():
+        return torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=dev)[:shard.ncol]
 
-    def step(ev_a=None, ev_b=None, gpair=None):
-        n = step_no[0]
-        k = n % nbuf
-        sc = s_computes[n % ncs]
-        step_no[0] = n + 1
-        if comm is not None and n >= nbuf and not gather_done[n - nbuf].query():
-            sc.wait_event(gather_done[n - nbuf])   # this buffer's previous gather must have drained
-        if ev_a is not None:
-            ev_a.record(sc)
-        launch[n % ncs][k][n % ncopies]()
-        if ev_b is not None:
-            ev_b.record(sc)
+    def new_gather(stream):
+        if not use_comm:
+            return None
         if comm is not None:
-            done = ev_b if ev_b is not None else kernel_done[n]
-            if ev_b is None:
-                done.record(sc)
-            s_comm.wait_event(done)
-            if gpair is not None:
-                gpair[0].record(s_comm)
-            gather[k]()
-            if gpair is not None:
-                gpair[1].record(s_comm)
-            gather_done[n].record(s_comm)
+            return sharded.RcclGather(comm, counts, displs, 0, stream=stream)
+        return sharded.TorchGather(dist, rank, world, counts, displs, 0, stream=stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -386,63 +350,117 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # With overlapping launches an event pair around one launch also spans its neighbour's share
-    # of the chip, so the kernel itself is timed here, alone, before the pipeline starts.
-    iso_ms = None
-    if ncs > 1:
-        torch.cuda.synchronize()
-        iso = []
-        for r in range(7):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(s_computes[0])
-            launch[0][0][r % ncopies]()
-            b.record(s_computes[0])
-            torch.cuda.synchronize()
-            iso.append(a.elapsed_time(b))
-        iso.sort()
-        iso_ms = iso[len(iso) // 2]
+    # Streams come from torch's pool (non-blocking): nothing here runs on the legacy null stream,
+    # which would implicitly synchronise with any blocking stream a library creates.
+    torch.cuda.synchronize()
+    s_main = torch.cuda.Stream()
+    torch.cuda.set_stream(s_main)
 
+    # ------------------------------------------------------------------ the timed protocol
+    # one call = kernels, then this call's gather, in order on s_main (rcppsparse_amd/sharded.py)
+    out_main = new_out()
+    ws_main = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
+    launch_main = [capi.prepared_column_sums(xk, pt, out_main, ws_main, stream=s_main) for xk in xs]
+    calls = [0]
+
+    def compute(_shard):
+        launch_main[calls[0] % ncopies]()
+        calls[0] += 1
+        return out_main
+
+    driver = sharded.ShardedColumnSums(shard, compute, new_gather(s_main))
     for _ in range(args.warmup):
-        step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+        driver.step(recv)
+    # a shard's kernel is ~0.15 ms at N = 8, so with a gather the timing events (one queue packet
+    # each) sit on every 4th step only; N = 1 times every launch
+    stride = 4 if use_comm else 1
+    timed = list(range(0, args.steps, stride))
+    mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    ev = {k: (mk(), mk(), mk()) for k in timed}
     fence()
     t0 = time.perf_counter()
-    # N > 1: a shard's kernel is ~0.15 ms, so the timing events themselves (one queue packet
-    # each) are only placed on every 4th step; N = 1 times every launch
-    stride = 4 if comm is not None else 1
     for k in range(args.steps):
-        if k % stride == 0:
-            step(ev[k][0], ev[k][1], gev[k] if gev else None)
+        e = ev.get(k)
+        if e is None:
+            driver.step(recv)
         else:
-            step()
+            e[0].record(s_main)
+            driver.step(recv, on_computed=lambda e=e: e[1].record(s_main))
+            e[2].record(s_main)
     fence()
     elapsed = time.perf_counter() - t0
 
-    timed = range(0, args.steps, stride)
     ktimes = sorted(ev[k][0].elapsed_time(ev[k][1]) for k in timed)
-    kernel_ms_in_loop = sum(ktimes) / len(ktimes)
-    kernel_ms = iso_ms if iso_ms is not None else kernel_ms_in_loop
-    if iso_ms is not None:
-        ktimes = iso          # median / min below describe the same (isolated) launches
-    gather_ms = (sum(gev[k][0].elapsed_time(gev[k][1]) for k in timed) / len(ktimes)
-                 if comm is not None else 0.0)
-    stats = torch.tensor([elapsed, kernel_ms, gather_ms], dtype=torch.float64, device=dev)
+    kernel_ms = sum(ktimes) / len(ktimes)
+    gtimes = sorted(ev[k][1].elapsed_time(ev[k][2]) for k in timed) if use_comm else [0.0]
+    gather_ms = sum(gtimes) / len(gtimes)
+
+    # ------------------------------------------------------------------ latency of one call
+    lat = []
+    for _ in range(max(1, args.latency_calls)):
+        fence()
+        t1 = time.perf_counter()
+        driver.step(recv)
+        s_main.synchronize()          # rank 0: every slice has arrived; other ranks: their send is done
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat.sort()
+    lat_med, lat_min = lat[len(lat) // 2], lat[0]
+
+    # ------------------------------------------------------------------ pipelined figure (separate key)
+    pipe = None
+    if not args.no_pipelined:
+        ncs = max(1, args.compute_streams)
+        nbuf = max(ncs, args.gather_buffers - args.gather_buffers % ncs)
+        s_computes = [torch.cuda.Stream() for _ in range(ncs)]
+        s_comm = torch.cuda.Stream() if use_comm else None
+        wss = [capi.alloc_workspace(shard.ncol, shard.nnz, dev) for _ in range(ncs)]
+        outs = [new_out() for _ in range(nbuf)]
+        prepared = [[[capi.prepared_column_sums(xk, pt, o, wss[q], stream=s_computes[q]) for xk in xs]
+                     for o in outs] for q in range(ncs)]
+        launches = [[(lambda n, f=prepared[q][k]: f[n % ncopies]()) for k in range(nbuf)] for q in range(ncs)]
+        g = new_gather(s_comm)
+        gathers = [(None if g is None else (lambda o=o: g(o, recv))) for o in outs]
+        pl = sharded.PipelinedColumnSums(torch, launches, gathers, s_computes, s_comm, nbuf)
+        for _ in range(args.warmup):
+            pl.step()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            pl.step()
+        fence()
+        pipe_elapsed = time.perf_counter() - t2
+        pstats = torch.tensor([pipe_elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(pstats, op=dist.ReduceOp.MAX)
+        pipe_elapsed = float(pstats[0])
+        pipe = {"value": nnz * args.steps / pipe_elapsed, "unit": "nnz/s",
+                "ms_per_step": pipe_elapsed / args.steps * 1e3, "compute_streams": ncs, "output_buffers": nbuf,
+                "protocol": "calls overlapped across steps: launches alternate over the compute streams, the "
+                            "gather of call k runs on its own stream beside the kernel of call k+1; "
+                            "NOT the protocol of `value`"}
+        del prepared, launches, outs, wss
+
+    stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms_max, gather_ms_max = float(stats[0]), float(stats[1]), float(stats[2])
+    elapsed, kernel_ms_max, gather_ms_max, lat_med_max = (float(v) for v in stats)
 
+    # ------------------------------------------------------------------ parity: every column
+    # one more call on copy 0 of x (seed SEED), outside every timed region
+    calls[0] = 0
+    driver.step(recv)
+    fence()
     result = None
     if rank == 0:
-        full = (recv if comm is not None else out_local).cpu().numpy()   # the last step's gathered result
-        last_copy = (args.warmup + args.steps - 1) % ncopies      # the copy the last step summed
-        worst, worst_rel = parity_spot_check(full, p, args.kind, seed=SEED + last_copy)
-        if not worst <= 1e-12:
-            raise SystemExit(f"parity spot check failed: max |gpu-ref|/sum|x| = {worst:.3e}")
+        full = (recv if use_comm else out_main).cpu().numpy()
+        parity = parity_whole_matrix(full, p, args.kind)
+        if parity["columns_out_of_tolerance"] or not parity["empty_columns_exactly_plus_zero"]:
+            raise SystemExit(f"parity check failed: {json.dumps(parity)}")
         # the launch rank 0 timed processed its own shard
         algo_bytes = 8 * shard.nnz + 4 * (shard.ncol + 1) + 8 * shard.ncol
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         value = nnz * args.steps / elapsed
+        gname = None if not use_comm else (sharded.TorchGather.name if fell_back else sharded.RcclGather.name)
         result = {
             "metric": "columnSums nnz/s + achieved HBM GB/s vs roofline, 1e9-nnz CSC at 1/2/4/8 GPUs",
             "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps,
@@ -453,31 +471,37 @@ def main():
                 "workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, "
                             f"values kind {args.kind}, seed {SEED}",
                 "parallelism": ("single GPU" if world == 1 else
-                                f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0 "
-                                "(gather of step k on its own stream; launches alternate over "
-                                f"{ncs} compute stream(s), so step k+1 fills the chip while step k drains)"),
+                                f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0"),
+                "protocol": "K calls back to back; each call in order on one stream per rank: kernels, then "
+                            "that call's gatherv (N > 1); identical at every N",
                 "partition": args.partition,
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
                 "x_copies_rotated": ncopies,
-                "gather": (None if comm is None else getattr(comm, "name", "rsp_comm_gatherv (C ABI, RCCL)")),
+                "gather": gname,
+                "gather_fell_back_to_torch_distributed": bool(fell_back),
             },
+            "latency_ms_per_call": lat_med,
+            "latency": {"ms_median": lat_med, "ms_min": lat_min, "ms_median_max_over_ranks": lat_med_max,
+                        "calls": len(lat),
+                        "protocol": "one call at a time: barrier, then host launch -> kernels -> gatherv -> stream "
+                                    "synchronize on rank 0 (the gathered result is complete and the host has seen it)"},
+            "pipelined": pipe,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
                 "kernel": "colsums_chunks_kernel (+ colsums_fixup_kernel)",
                 "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
-                "kernel_timing": ("HIP events around each launch in the timed region" if iso_ms is None else
-                                  f"median of 7 isolated launches before the timed region; inside it {ncs} launches "
-                                  f"overlap and an event pair spans {kernel_ms_in_loop:.4f} ms"),
+                "kernel_timing": f"HIP events on the launch stream around the kernels of {len(timed)} of the "
+                                 f"{args.steps} timed calls (the gather is outside the pair)",
                 "kernel_ms_max_over_ranks": kernel_ms_max,
-                "gather_ms_on_comm_stream_max_over_ranks": gather_ms_max if comm is not None else None,
+                "gather_ms": gather_ms if use_comm else None,
+                "gather_ms_min_max": [gtimes[0], gtimes[-1]] if use_comm else None,
+                "gather_ms_max_over_ranks": gather_ms_max if use_comm else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
-            "parity": {"max_abs_err_over_l1": worst, "tolerance": 1e-12,
-                       "max_rel_err_where_ref_ge_1e-3_l1": worst_rel,
-                       "columns_checked": "3 ranges of 400 columns vs the oracle"},
+            "parity": parity,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(p, args.kind)

@@ -265,8 +265,14 @@ int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
                                int32_t ncol, uint64_t seed, void *stream);
 
 /* ---- tuning knobs (experiments; defaults are chosen per problem size) --- */
-/* chunk_rows: 128-element rows of x owned by one wavefront (0 = automatic). */
+/* chunk_rows: 128-element rows of x owned by one wavefront (0 = automatic; any value is
+ * clamped so that one chunk never exceeds 1 GiB of x). */
 int rsp_set_tuning(int chunk_rows);
+/* Taper of the automatic chunking: the last tail_permille / 1000 of x is cut into chunks of
+ * tail_chunk_rows rows, which are dispatched last and fill the chip while the long chunks of
+ * the final round finish at different times.  (0, 0) = no taper, (-1, -1) = built-in default.
+ * Results stay within the documented tolerance for every setting. */
+int rsp_set_taper(int tail_permille, int tail_chunk_rows);
 /* Selects an alternative build of the main kernel for A/B measurements
  * (0 = production; 1 = 16 rows in flight; 2 / 3 = 1 / 2 wavefronts per workgroup;
  * 4 = default cache policy instead of nt loads).  Not for production use; results

@@ -26,7 +26,7 @@ RSP_ERR_RCCL = 5
 RSP_ERR_ALLOC = 6
 UNIQUE_ID_BYTES = 128
 
-# every symbol include/rcppsparse_hip.h declares (checked by tests/test_capi_symbols.py)
+# every symbol include/rcppsparse_hip.h declares (checked by tests/test_capi_nogpu.py)
 EXPORTED_SYMBOLS = (
     "rsp_version", "rsp_last_error", "rsp_device_count",
     "rsp_column_sums_host", "rsp_column_sums_host_multi",
@@ -39,7 +39,8 @@ EXPORTED_SYMBOLS = (
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
-    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_experiment",
+    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper",
+    "rsp_set_experiment",
 )
 
 
@@ -118,6 +119,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_gen_row_indices_device.argtypes = [vp, vp, i32, i32, u64, vp]
     L.rsp_set_tuning.argtypes = [c.c_int]
     L.rsp_set_experiment.argtypes = [c.c_int]
+    L.rsp_set_taper.argtypes = [c.c_int, c.c_int]
     _lib = L
     return L
 
@@ -149,6 +151,11 @@ def device_count() -> int:
 
 def set_tuning(chunk_rows: int = 0) -> None:
     _check(load().rsp_set_tuning(int(chunk_rows)))
+
+
+def set_taper(tail_permille: int = -1, tail_chunk_rows: int = -1) -> None:
+    """(0, 0) = no taper, (-1, -1) = the library's default."""
+    _check(load().rsp_set_taper(int(tail_permille), int(tail_chunk_rows)))
 
 
 def set_experiment(variant: int = 0) -> None:

@@ -27,6 +27,8 @@ thread_local char g_err[512] = "";
 // tuning knobs are read by the worker threads of the multi-GPU host entries: atomics
 std::atomic<int> g_chunk_rows_override{0};   // rsp_set_tuning / RSP_CHUNK_ROWS
 std::atomic<int> g_variant{-1};              // rsp_set_experiment / RSP_VARIANT (-1 = read the env)
+std::atomic<int> g_taper_permille{-1};       // rsp_set_taper / RSP_TAPER (-1 = env, else the default)
+std::atomic<int> g_taper_rows{-1};
 
 int env_int(const char* name) {
     const char* s = getenv(name);
@@ -65,21 +67,50 @@ int chunk_rows_setting() {
     return env;
 }
 
+// Taper of the automatic chunking: the last `permille` thousandths of x are cut into chunks of
+// `rows` rows (rsp_set_taper / RSP_TAPER="permille,rows"; -1 = built-in default).
+void taper_setting(int* permille, int* rows) {
+    static const int env_pm = [] {
+        const char* s = getenv("RSP_TAPER");
+        return s ? atoi(s) : -1;
+    }();
+    static const int env_rows = [] {
+        const char* s = getenv("RSP_TAPER");
+        const char* c = s ? strchr(s, ',') : nullptr;
+        return c ? atoi(c + 1) : -1;
+    }();
+    int pm = g_taper_permille.load(std::memory_order_relaxed);
+    int r = g_taper_rows.load(std::memory_order_relaxed);
+    if (pm < 0) pm = env_pm;
+    if (r < 0) r = env_rows;
+    if (pm < 0) pm = rsp::kTaperPermille;
+    if (r <= 0) r = rsp::kTaperRows;
+    *permille = pm > 1000 ? 1000 : pm;
+    *rows = r;
+}
+
 // Chunking policy: enough chunks to keep every CU busy with several waves and
 // to let the hardware dispatcher balance the tail, but chunks long enough to
 // amortise the per-chunk column search.  Always a whole number of 128-element
-// rows so every chunk starts 1 KiB-aligned.
+// rows so every chunk starts 1 KiB-aligned.  When the call runs for several rounds
+// of resident waves, the end of x is cut into shorter chunks (the taper): they are
+// dispatched last and fill the chip while the long chunks of the last round finish
+// at different times.
 rsp::LaunchPlan make_plan(int64_t nnz) {
     rsp::LaunchPlan plan;
+    const int64_t total_rows = (nnz + rsp::kRowElems - 1) / rsp::kRowElems;
     int rows = chunk_rows_setting();
-    if (rows <= 0) {
-        const int64_t total_rows = (nnz + rsp::kRowElems - 1) / rsp::kRowElems;
+    const bool automatic = rows <= 0;
+    if (automatic) {
         const int64_t target_chunks = 256 * 32;   // 256 CUs x 32 waves
         int64_t r = (total_rows + target_chunks - 1) / target_chunks;
         if (r < rsp::kMinChunkRows) r = rsp::kMinChunkRows;
         if (r > 256) r = 256;
         rows = (int)r;
     }
+    // byte counts and offsets inside one chunk are 32-bit in the kernel (buffer descriptor size,
+    // soffset): a chunk never exceeds 1 GiB of x, whatever the knob says
+    if (rows > rsp::kMaxChunkRows) rows = rsp::kMaxChunkRows;
     int variant = g_variant.load(std::memory_order_relaxed);
     if (variant < 0) {
         static const int env = env_int("RSP_VARIANT");
@@ -87,9 +118,44 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
     }
     plan.variant = variant;
     plan.chunk_elems = rows * rsp::kRowElems;
-    plan.nchunks = nnz > 0 ? (int32_t)((nnz + plan.chunk_elems - 1) / plan.chunk_elems) : 0;
+    plan.tail_elems = plan.chunk_elems;
+    int64_t nbody = nnz > 0 ? (total_rows + rows - 1) / rows : 0, ntail = 0;
+    int pm, trows;
+    taper_setting(&pm, &trows);
+    if (automatic && pm > 0 && trows < rows && nbody > rsp::kTaperMinChunks) {
+        const int64_t body_rows = (total_rows * (1000 - pm) / 1000) / rows * rows;
+        nbody = body_rows / rows;
+        ntail = (total_rows - body_rows + trows - 1) / trows;
+        plan.tail_elems = trows * rsp::kRowElems;
+    }
+    plan.nbody = (int32_t)nbody;
+    plan.nchunks = (int32_t)(nbody + ntail);
     return plan;
 }
+
+// The handle entries run on the handle's device: switch to it for the duration of the call and
+// put the calling thread's current device back on every exit path (a torch-hosting process
+// would otherwise find its later allocations on another GPU).
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev_) != hipSuccess) {
+            (void)hipGetLastError();
+            prev_ = -1;
+        }
+        err_ = (prev_ == device) ? hipSuccess : hipSetDevice(device);
+        if (prev_ == device) prev_ = -1;   // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev_ >= 0) (void)hipSetDevice(prev_);
+    }
+    hipError_t error() const { return err_; }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+private:
+    int prev_ = -1;
+    hipError_t err_ = hipSuccess;
+};
 
 int check_sizes(int32_t ncol, int64_t nnz) {
     if (ncol < 0) return fail(RSP_ERR_BAD_ARG, "ncol is negative (%d)", ncol);
@@ -183,7 +249,14 @@ int rsp_device_count(int* count) {
 
 int rsp_set_tuning(int chunk_rows) {
     if (chunk_rows < 0) return fail(RSP_ERR_BAD_ARG, "chunk_rows is negative");
-    g_chunk_rows_override.store(chunk_rows, std::memory_order_relaxed);
+    g_chunk_rows_override.store(chunk_rows, std::memory_order_relaxed);   // (make_plan clamps it to kMaxChunkRows)
+    return RSP_OK;
+}
+
+int rsp_set_taper(int tail_permille, int tail_chunk_rows) {
+    if (tail_permille > 1000) return fail(RSP_ERR_BAD_ARG, "tail_permille is above 1000");
+    g_taper_permille.store(tail_permille < 0 ? -1 : tail_permille, std::memory_order_relaxed);
+    g_taper_rows.store(tail_chunk_rows <= 0 ? -1 : tail_chunk_rows, std::memory_order_relaxed);
     return RSP_OK;
 }
 
@@ -292,7 +365,7 @@ int rsp_gen_row_indices_device(int32_t* d_i, const int32_t* d_p, int32_t nrow, i
 
 int rsp_csc_free(rsp_csc_t h) {
     if (!h) return RSP_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard on(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_i) (void)hipFree(h->d_i);
@@ -315,7 +388,8 @@ int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t 
     if (!p || (nnz > 0 && !x)) return fail(RSP_ERR_BAD_ARG, "x or p is null");
     if (int rc = check_offsets_host(p, ncol, nnz)) return rc;
     if (int rc = require_device(device)) return rc;
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard on(device);
+    HIP_TRY(on.error());
 
     rsp_csc* h = new (std::nothrow) rsp_csc();
     if (!h) return fail(RSP_ERR_ALLOC, "out of host memory");
@@ -350,7 +424,8 @@ int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t 
 
 static int csc_run(rsp_csc_t h, double* host_out, bool means) {
     if (!h || !host_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard on(h->device);
+    HIP_TRY(on.error());
     if (h->ncol == 0) return RSP_OK;
     if (int rc = enqueue(h->d_x, h->d_p, h->ncol, h->nnz, h->d_out, h->d_ws, h->ws_bytes,
                          means ? (double)h->nrow : 1.0, means, h->stream))
@@ -417,7 +492,8 @@ int rsp_row_means_device(const double* d_x, const int32_t* d_i, int32_t nrow, in
 
 static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
     if (!h || !host_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard on(h->device);
+    HIP_TRY(on.error());
     if (h->nrow == 0) return RSP_OK;
     if (h->nnz > 0 && !h->d_i)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: rowSums needs the row indices");
@@ -496,7 +572,8 @@ int rsp_crossprod_device(const double* d_x, const int32_t* d_i, const int32_t* d
 
 int rsp_csc_crossprod(rsp_csc_t h, double* out) {
     if (!h || !out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard on(h->device);
+    HIP_TRY(on.error());
     if (h->ncol == 0) return RSP_OK;
     if (h->nnz > 0 && !h->d_i)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: crossprod needs the row indices");

@@ -36,16 +36,39 @@ constexpr int kOpMax = 5;         // largest stored entry (combine = max, identi
 constexpr int kOpMin = 6;         // smallest stored entry
 constexpr int kOpCount = 7;       // number of stored entries (offsets only)
 
-// How a column-sum call is cut into chunks (one wavefront each).
+// How a column-sum call is cut into chunks (one wavefront each).  The first `nbody` chunks have
+// `chunk_elems` elements; the rest of x (the tapered tail) is cut into shorter chunks of
+// `tail_elems` elements, which the dispatcher hands out last: they fill the chip while the long
+// chunks of the final round finish at different times.  Without a taper
+// tail_elems == chunk_elems.  Chunk starts are multiples of kRowElems (1 KiB of x).
 struct LaunchPlan {
-    int32_t chunk_elems;   // multiple of kRowElems
-    int32_t nchunks;       // ceil(nnz / chunk_elems), >= 1 when nnz > 0
+    int32_t chunk_elems;   // elements per body chunk, multiple of kRowElems
+    int32_t nbody;         // number of body chunks
+    int32_t tail_elems;    // elements per tail chunk, multiple of kRowElems
+    int32_t nchunks;       // nbody + tail chunks; >= 1 when nnz > 0
     int variant;           // 0 = production kernel; >0 = experiment variants (env RSP_VARIANT)
+};
+constexpr int kTaperPermille = 150;  // default taper: the last 15 % of x ...
+constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
+constexpr int kTaperMinChunks = 12288; // only calls of more than two rounds of resident waves (2 x 6144) are tapered
+constexpr int kMaxChunkRows = 1 << 20;   // 1 GiB of x per chunk: byte counts and offsets inside a chunk stay < 2^31
+
+// chunk index <-> first element, shared by host code and both kernels
+struct ChunkMap {
+    int32_t body, nbody, tail;
+    __host__ __device__ int64_t start(int32_t w) const {
+        return w < nbody ? (int64_t)w * body : (int64_t)nbody * body + (int64_t)(w - nbody) * tail;
+    }
+    __host__ __device__ int32_t elems(int32_t w) const { return w < nbody ? body : tail; }
+    __host__ __device__ int32_t chunk_of(int64_t e) const {
+        const int64_t edge = (int64_t)nbody * body;
+        return e < edge ? (int32_t)(e / body) : nbody + (int32_t)((e - edge) / tail);
+    }
 };
 
 inline size_t workspace_bytes_for(int32_t nchunks) {
-    // carry_head[nchunks] + carry_tail[nchunks] (double) + carry_info[nchunks] (int2)
-    size_t b = (size_t)nchunks * (8 + 8 + 8);
+    // carry_head[nchunks] + carry_tail[nchunks] (double) + carry_info[nchunks] (int4)
+    size_t b = (size_t)nchunks * (8 + 8 + 16);
     return (b + 255) & ~(size_t)255;
 }
 

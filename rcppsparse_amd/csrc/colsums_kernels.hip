@@ -524,9 +524,9 @@ __device__ __forceinline__ void process_row(double v0, double v1, int rs, int la
 template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG, int OP = kOpSum>
 __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
-    int32_t chunk_elems, int32_t nchunks, double* __restrict__ out,
+    ChunkMap cmap, int32_t nchunks, double* __restrict__ out,
     double* __restrict__ carry_head, double* __restrict__ carry_tail,
-    int2* __restrict__ carry_info, double divisor, const int32_t* __restrict__ rows_i,
+    int4* __restrict__ carry_info, double divisor, const int32_t* __restrict__ rows_i,
     const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words) {
     static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
     typedef Policy<MEANS, OP> P;
@@ -544,8 +544,8 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     double* stage = s_stage[wave_in_wg];
 
     RSP_STAMP(0);
-    const int32_t cs = w * chunk_elems;
-    const int64_t ce64 = (int64_t)cs + chunk_elems;
+    const int32_t cs = (int32_t)cmap.start(w);          // (< nnz <= 2^31 - 1)
+    const int64_t ce64 = (int64_t)cs + cmap.elems(w);
     const int32_t ce = ce64 < (int64_t)nnz ? (int32_t)ce64 : nnz;
     const int32_t nrows = (int32_t)(((int64_t)ce - cs + 127) >> 7);
 
@@ -595,7 +595,8 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     fill_window(win, p, c0, ncol, lane);
     st.head_open = true;
     st.acc_in_lane0 = true;   // (both accumulators start as the identity in every lane)
-    st.head_complete = __builtin_amdgcn_readfirstlane(win[0]) >= cs;
+    const int32_t p_c0 = __builtin_amdgcn_readfirstlane(win[0]);   // first element of column c0
+    st.head_complete = p_c0 >= cs;
     st.has_next = c0 + 1 <= ncol;
     st.qnext = __builtin_amdgcn_readfirstlane(win[1]);
     RSP_STAMP(2);
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                     t[rr].y = xf<OP>(v[g * kGroupRows + rr].y);
                 }
             }
-            if (!P::kSum && gs + kGroupElems > ce) {
+            if (!P::kSum && ce - gs < kGroupElems) {   // (gs <= ce; written so that nothing overflows near 2^31)
                 // max / min: the zero-filled lanes past the end of x (only the last, partial row
                 // of the matrix has any) must not take part -- give them the identity
 #pragma unroll
@@ -697,7 +698,11 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         } else {
             carry_tail[w] = T;
         }
-        carry_info[w] = make_int2(c0, st.ccur - c0);
+        // everything the fix-up needs about this chunk in one 16-byte record: its first column, the
+        // number of column ends inside, the chunk holding that column's first element and whether the
+        // column starts exactly on that chunk's edge (then its first part is that chunk's head)
+        const int32_t ts = cmap.chunk_of(p_c0);
+        carry_info[w] = make_int4(c0, st.ccur - c0, ts, (int64_t)p_c0 == cmap.start(ts) ? 1 : 0);
     }
     RSP_STAMP(6);
 }
@@ -708,39 +713,38 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
 // One thread per chunk w.  If a column that started in an earlier chunk ends in
 // chunk w, its sum is   first + head[ts+1] + ... + head[w]   where ts is the chunk
 // holding the column's first element and `first` is that chunk's tail (or its head
-// when the column starts exactly on the chunk edge).  Short spans (the common case:
-// a column spilling over one or two chunk edges) are added by the owning thread in
-// ascending order; a span longer than 64 chunks (a giant column) is summed by the
-// whole wavefront with a fixed lane-strided assignment and a fixed DPP tree, so one
-// 1e9-long column costs microseconds instead of a serial walk.  Deterministic.
+// when the column starts exactly on the chunk edge).  ts and the edge flag come from the
+// main kernel's record, and the two partials of the usual case (a column spilling over
+// ONE chunk edge) are loaded together with that record, so the launch is one memory
+// round trip deep.  Short spans are added by the owning thread in ascending order; a span
+// longer than 64 chunks (a giant column) is summed by the whole wavefront with a fixed
+// lane-strided assignment and a fixed DPP tree, so one 1e9-long column costs
+// microseconds instead of a serial walk.  Deterministic.
 template <bool MEANS, int OP = kOpSum>
 __global__ __launch_bounds__(256) void colsums_fixup_kernel(
-    const int32_t* __restrict__ p, int32_t ncol, int32_t chunk_elems, int32_t nchunks,
-    double* __restrict__ out, const double* __restrict__ carry_head,
-    const double* __restrict__ carry_tail, const int2* __restrict__ carry_info, double divisor) {
+    int32_t ncol, int32_t nchunks, double* __restrict__ out, const double* __restrict__ carry_head,
+    const double* __restrict__ carry_tail, const int4* __restrict__ carry_info, double divisor) {
     typedef Policy<MEANS, OP> P;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
     int c = 0, ts = 0;
-    double first = P::id();
+    double first = P::id(), head_w = P::id();
     if (w < nchunks) {
-        const int2 inf = carry_info[w];
+        const int4 inf = carry_info[w];                       // three independent loads
+        head_w = carry_head[w];
+        const double tail_prev = w > 0 ? carry_tail[w - 1] : P::id();
         c = inf.x;
-        if (inf.y != 0 && c < ncol) {          // a column ends in chunk w ...
-            const int pc = p[c];
-            if (pc < w * chunk_elems) {        // ... and it started in an earlier chunk
-                need = true;
-                ts = pc / chunk_elems;         // chunk holding the column's first element
-                first = (pc == ts * chunk_elems) ? carry_head[ts] : carry_tail[ts];
-            }
-        }
+        ts = inf.z;
+        // a column ends in chunk w and it started in an earlier chunk
+        need = inf.y != 0 && c < ncol && ts < w;
+        if (need) first = inf.w ? carry_head[ts] : (ts == w - 1 ? tail_prev : carry_tail[ts]);
     }
     const int span = w - ts;
     if (need && span <= 64) {
         double acc = first;
-        for (int t = ts + 1; t <= w; ++t) acc = P::comb(acc, carry_head[t]);
-        out[c] = P::finish(acc, divisor);
+        for (int t = ts + 1; t < w; ++t) acc = P::comb(acc, carry_head[t]);
+        out[c] = P::finish(P::comb(acc, head_w), divisor);
     }
     // giant columns: whole wave per column, one after the other
     uint64_t m = __ballot(need && span > 64);
@@ -846,17 +850,18 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     char* ws = (char*)d_workspace;
     double* carry_head = (double*)ws;
     double* carry_tail = carry_head + plan.nchunks;
-    int2* carry_info = (int2*)(carry_tail + plan.nchunks);
+    int4* carry_info = (int4*)(carry_tail + plan.nchunks);   // (16-byte aligned: the workspace is, and 16 * nchunks bytes precede it)
+    const ChunkMap cmap{plan.chunk_elems, plan.nbody, plan.tail_elems};
     const dim3 grid((plan.nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
 #define RSP_LAUNCH_K(KERNEL, BR, AUX_)                                                              \
     do {                                                                                           \
         if (means)                                                                                 \
             hipLaunchKernelGGL((KERNEL<BR, true, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,   \
-                               nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, \
+                               nnz, cmap, plan.nchunks, d_out, carry_head, carry_tail, \
                                carry_info, divisor, rows_i, row_bitmap, bitmap_words);             \
         else                                                                                       \
             hipLaunchKernelGGL((KERNEL<BR, false, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,  \
-                               nnz, plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, \
+                               nnz, cmap, plan.nchunks, d_out, carry_head, carry_tail, \
                                carry_info, divisor, rows_i, row_bitmap, bitmap_words);             \
     } while (0)
 #define RSP_LAUNCH_W(WPG_)                                                                              \
@@ -864,18 +869,18 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         const dim3 g2((plan.nchunks + (WPG_) - 1) / (WPG_)), b2((WPG_) * 64);                          \
         if (means)                                                                                     \
             hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, true, kLoadAux, WPG_>), g2, b2, 0,   \
-                               stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,     \
+                               stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,     \
                                carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap,        \
                                bitmap_words);                                                          \
         else                                                                                           \
             hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_>), g2, b2, 0,  \
-                               stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,     \
+                               stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,     \
                                carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap,        \
                                bitmap_words);                                                          \
     } while (0)
 #define RSP_LAUNCH_OP(OP_)                                                                             \
     hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, OP_>), grid,   \
-                       block, 0, stream, d_x, d_p, ncol, nnz, plan.chunk_elems, plan.nchunks, d_out,   \
+                       block, 0, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,   \
                        carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words)
     if (op == kOpSumSquares) {
         RSP_LAUNCH_OP(kOpSumSquares);
@@ -904,8 +909,8 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     if (e != hipSuccess) return e;
     const dim3 fgrid((plan.nchunks + 255) / 256), fblock(256);   // one thread per chunk
 #define RSP_FIXUP(MEANS_, OP_)                                                                        \
-    hipLaunchKernelGGL((colsums_fixup_kernel<MEANS_, OP_>), fgrid, fblock, 0, stream, d_p, ncol,       \
-                       plan.chunk_elems, plan.nchunks, d_out, carry_head, carry_tail, carry_info, divisor)
+    hipLaunchKernelGGL((colsums_fixup_kernel<MEANS_, OP_>), fgrid, fblock, 0, stream, ncol,            \
+                       plan.nchunks, d_out, carry_head, carry_tail, carry_info, divisor)
     if (op == kOpMax)
         RSP_FIXUP(false, kOpMax);
     else if (op == kOpMin)

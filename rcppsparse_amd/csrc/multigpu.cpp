@@ -23,6 +23,40 @@ int fail(int code, const char* fmt, ...);   // capi.hip: sets rsp_last_error() t
 }
 using rsp::fail;
 
+namespace {
+
+// Runs work(0..G-1) with one host thread per shard (shard 0 on the calling thread, whose current
+// HIP device is put back afterwards).  Started threads are always joined, also when creating a
+// later one throws; nothing escapes: std::bad_alloc / std::system_error become `false`.
+template <class Work>
+bool run_shards(int G, Work&& work) noexcept {
+    struct Joiner {
+        std::vector<std::thread> threads;
+        ~Joiner() {
+            for (auto& t : threads)
+                if (t.joinable()) t.join();
+        }
+    };
+    bool ok = true;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    try {
+        Joiner j;
+        j.threads.reserve(G > 1 ? (size_t)G - 1 : 0);
+        for (int k = 1; k < G; ++k) j.threads.emplace_back([&work, k] { work(k); });
+        work(0);
+    } catch (...) {   // (the Joiner has joined whatever was started)
+        ok = false;
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return ok;
+}
+
+}  // namespace
+
 struct rsp_comm {
     ncclComm_t comm;
     int nranks, rank, device;
@@ -64,7 +98,7 @@ int rsp_rebase_offsets(const int32_t* p, int32_t c0, int32_t c1, int32_t* p_loca
 // and copies its slice of the sums straight into sums + c0.  No collective is needed: the
 // result lives in host memory.  `devices` may repeat an ordinal (several shards on one GPU).
 int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, int64_t nnz, double* sums,
-                               const int* devices, int ndevices) {
+                               const int* devices, int ndevices) try {
     if (!p || (nnz > 0 && !x) || (ncol > 0 && !sums) || ncol < 0 || nnz < 0)
         return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_column_sums_host_multi");
     int visible = 0;
@@ -93,57 +127,62 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
 
     std::vector<int> status((size_t)G, RSP_OK);
     std::vector<std::string> message((size_t)G);
-    auto work = [&](int k) {
+    auto work = [&](int k) noexcept {
         const int32_t c0 = bounds[k], c1 = bounds[k + 1];
         const int32_t nc = c1 - c0;
         if (nc == 0) return;
         const int64_t n0 = p[c0], nk = (int64_t)p[c1] - p[c0];
-        double *d_x = nullptr, *d_out = nullptr;
+        double *d_x = nullptr, *d_out = nullptr;   // released on every path below
         int32_t* d_p = nullptr;
         void* d_ws = nullptr;
         hipStream_t st = nullptr;
-        std::vector<int32_t> pk((size_t)nc + 1);
-        for (int32_t j = 0; j <= nc; ++j) pk[j] = p[c0 + j] - (int32_t)n0;
-        auto check = [&](hipError_t e, const char* what) {
-            if (e != hipSuccess && status[k] == RSP_OK) {
-                status[k] = RSP_ERR_HIP;
-                message[k] = std::string(what) + ": " + hipGetErrorString(e);
+        try {
+            std::vector<int32_t> pk((size_t)nc + 1);
+            for (int32_t j = 0; j <= nc; ++j) pk[j] = p[c0 + j] - (int32_t)n0;
+            auto check = [&](hipError_t e, const char* what) {
+                if (e != hipSuccess && status[k] == RSP_OK) {
+                    status[k] = RSP_ERR_HIP;
+                    message[k] = std::string(what) + ": " + hipGetErrorString(e);
+                }
+                return e == hipSuccess;
+            };
+            const size_t xbytes = (((size_t)nk * 8 + 15) & ~(size_t)15) + 16;
+            bool ok = check(hipSetDevice(devs[k]), "hipSetDevice");
+            const size_t wsb = rsp_column_sums_workspace_bytes(nc, nk);
+            ok = ok && check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+            ok = ok && check(hipMalloc((void**)&d_x, xbytes), "hipMalloc x");
+            ok = ok && check(hipMalloc((void**)&d_p, ((size_t)nc + 1) * 4), "hipMalloc p");
+            ok = ok && check(hipMalloc((void**)&d_out, (size_t)nc * 8), "hipMalloc out");
+            ok = ok && check(hipMalloc(&d_ws, wsb), "hipMalloc workspace");
+            if (ok && nk > 0)
+                ok = check(hipMemcpyAsync(d_x, x + n0, (size_t)nk * 8, hipMemcpyHostToDevice, st), "H2D x");
+            ok = ok && check(hipMemcpyAsync(d_p, pk.data(), ((size_t)nc + 1) * 4, hipMemcpyHostToDevice, st), "H2D p");
+            if (ok) {
+                const int rc = rsp_column_sums_device(d_x, d_p, nc, nk, d_out, d_ws, wsb, st);
+                if (rc != RSP_OK) {
+                    status[k] = rc;
+                    message[k] = rsp_last_error();   // this thread's message
+                    ok = false;
+                }
             }
-            return e == hipSuccess;
-        };
-        const size_t xbytes = (((size_t)nk * 8 + 15) & ~(size_t)15) + 16;
-        bool ok = check(hipSetDevice(devs[k]), "hipSetDevice");
-        const size_t wsb = rsp_column_sums_workspace_bytes(nc, nk);
-        ok = ok && check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
-        ok = ok && check(hipMalloc((void**)&d_x, xbytes), "hipMalloc x");
-        ok = ok && check(hipMalloc((void**)&d_p, ((size_t)nc + 1) * 4), "hipMalloc p");
-        ok = ok && check(hipMalloc((void**)&d_out, (size_t)nc * 8), "hipMalloc out");
-        ok = ok && check(hipMalloc(&d_ws, wsb), "hipMalloc workspace");
-        if (ok && nk > 0) ok = check(hipMemcpyAsync(d_x, x + n0, (size_t)nk * 8, hipMemcpyHostToDevice, st), "H2D x");
-        ok = ok && check(hipMemcpyAsync(d_p, pk.data(), ((size_t)nc + 1) * 4, hipMemcpyHostToDevice, st), "H2D p");
-        if (ok) {
-            const int rc = rsp_column_sums_device(d_x, d_p, nc, nk, d_out, d_ws, wsb, st);
-            if (rc != RSP_OK) {
-                status[k] = rc;
-                message[k] = rsp_last_error();   // this thread's message
-                ok = false;
-            }
+            ok = ok && check(hipMemcpyAsync(sums + c0, d_out, (size_t)nc * 8, hipMemcpyDeviceToHost, st), "D2H sums");
+            if (st) check(hipStreamSynchronize(st), "hipStreamSynchronize");   // (pk is still alive here)
+        } catch (...) {   // a host allocation of this shard failed (its offsets or an error text)
+            if (st) (void)hipStreamSynchronize(st);
+            status[k] = RSP_ERR_ALLOC;
         }
-        ok = ok && check(hipMemcpyAsync(sums + c0, d_out, (size_t)nc * 8, hipMemcpyDeviceToHost, st), "D2H sums");
-        if (st) check(hipStreamSynchronize(st), "hipStreamSynchronize");
         if (d_x) (void)hipFree(d_x);
         if (d_p) (void)hipFree(d_p);
         if (d_out) (void)hipFree(d_out);
         if (d_ws) (void)hipFree(d_ws);
         if (st) (void)hipStreamDestroy(st);
     };
-    std::vector<std::thread> threads;
-    for (int k = 1; k < G; ++k) threads.emplace_back(work, k);
-    work(0);
-    for (auto& t : threads) t.join();
+    if (!run_shards(G, work)) return fail(RSP_ERR_ALLOC, "out of host memory or threads while running the shards");
     for (int k = 0; k < G; ++k)
         if (status[k] != RSP_OK) return fail(status[k], "shard %d on device %d: %s", k, devs[k], message[k].c_str());
     return RSP_OK;
+} catch (...) {   // std::bad_alloc from the bookkeeping vectors: nothing was started yet
+    return fail(RSP_ERR_ALLOC, "out of host memory in rsp_column_sums_host_multi");
 }
 
 // ---- resident matrix spread over several GPUs: upload once, sum many (f2) ----------------------
@@ -170,64 +209,79 @@ int rsp_mcsc_upload(const double* x, const int32_t* p, int32_t nrow, int32_t nco
         (void)hipGetLastError();
         return fail(RSP_ERR_NO_DEVICE, "no HIP device available");
     }
-    std::vector<int> devs;
-    if (devices && ndevices > 0) devs.assign(devices, devices + ndevices);
-    else for (int d = 0; d < visible; ++d) devs.push_back(d);
-    for (int d : devs)
-        if (d < 0 || d >= visible) return fail(RSP_ERR_BAD_ARG, "device %d out of range [0, %d)", d, visible);
-    if (ncol > 0 && (p[0] != 0 || p[ncol] != nnz)) return fail(RSP_ERR_BAD_ARG, "p[0] must be 0 and p[ncol] must equal nnz");
-    const int G = (int)devs.size();
-    rsp_mcsc* h = new (std::nothrow) rsp_mcsc();
-    if (!h) return fail(RSP_ERR_ALLOC, "out of host memory");
-    h->ncol = ncol;
-    h->bounds.assign((size_t)G + 1, 0);
-    h->shards.assign((size_t)G, nullptr);
-    if (int rc = rsp_partition_columns(p, ncol, G, h->bounds.data())) {
-        delete h;
-        return rc;
-    }
-    // one host thread per shard: every shard goes over its own GPU's host link
-    std::vector<int> status((size_t)G, RSP_OK);
-    std::vector<std::string> message((size_t)G);
-    auto work = [&](int k) {
-        const int32_t c0 = h->bounds[k], c1 = h->bounds[k + 1];
-        std::vector<int32_t> pk((size_t)(c1 - c0) + 1);
-        for (int32_t j = 0; j <= c1 - c0; ++j) pk[j] = p[c0 + j] - p[c0];
-        const int64_t nk = (int64_t)p[c1] - p[c0];
-        status[k] = rsp_csc_upload(nk ? x + p[c0] : x, nullptr, pk.data(), nrow, c1 - c0, nk, devs[k], &h->shards[k]);
-        if (status[k] != RSP_OK) message[k] = rsp_last_error();
-    };
-    std::vector<std::thread> threads;
-    for (int k = 1; k < G; ++k) threads.emplace_back(work, k);
-    work(0);
-    for (auto& t : threads) t.join();
-    for (int k = 0; k < G; ++k)
-        if (status[k] != RSP_OK) {
-            const int rc = fail(status[k], "shard %d on device %d: %s", k, devs[k], message[k].c_str());
-            rsp_mcsc_free(h);
+    rsp_mcsc* h = nullptr;
+    try {
+        std::vector<int> devs;
+        if (devices && ndevices > 0) devs.assign(devices, devices + ndevices);
+        else for (int d = 0; d < visible; ++d) devs.push_back(d);
+        for (int d : devs)
+            if (d < 0 || d >= visible) return fail(RSP_ERR_BAD_ARG, "device %d out of range [0, %d)", d, visible);
+        if (ncol > 0 && (p[0] != 0 || p[ncol] != nnz))
+            return fail(RSP_ERR_BAD_ARG, "p[0] must be 0 and p[ncol] must equal nnz");
+        const int G = (int)devs.size();
+        h = new rsp_mcsc();
+        h->ncol = ncol;
+        h->bounds.assign((size_t)G + 1, 0);
+        h->shards.assign((size_t)G, nullptr);
+        if (int rc = rsp_partition_columns(p, ncol, G, h->bounds.data())) {
+            delete h;
             return rc;
         }
+        // one host thread per shard: every shard goes over its own GPU's host link
+        std::vector<int> status((size_t)G, RSP_OK);
+        std::vector<std::string> message((size_t)G);
+        auto work = [&](int k) noexcept {
+            try {
+                const int32_t c0 = h->bounds[k], c1 = h->bounds[k + 1];
+                std::vector<int32_t> pk((size_t)(c1 - c0) + 1);
+                for (int32_t j = 0; j <= c1 - c0; ++j) pk[j] = p[c0 + j] - p[c0];
+                const int64_t nk = (int64_t)p[c1] - p[c0];
+                status[k] = rsp_csc_upload(nk ? x + p[c0] : x, nullptr, pk.data(), nrow, c1 - c0, nk, devs[k],
+                                           &h->shards[k]);
+                if (status[k] != RSP_OK) message[k] = rsp_last_error();
+            } catch (...) {   // (a shard that was uploaded stays in h->shards and is freed below)
+                status[k] = RSP_ERR_ALLOC;
+            }
+        };
+        if (!run_shards(G, work)) {
+            rsp_mcsc_free(h);
+            return fail(RSP_ERR_ALLOC, "out of host memory or threads while uploading the shards");
+        }
+        for (int k = 0; k < G; ++k)
+            if (status[k] != RSP_OK) {
+                const int rc = fail(status[k], "shard %d on device %d: %s", k, devs[k], message[k].c_str());
+                rsp_mcsc_free(h);
+                return rc;
+            }
+    } catch (...) {
+        if (h) rsp_mcsc_free(h);
+        return fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_upload");
+    }
     *handle = h;
     return RSP_OK;
 }
 
-int rsp_mcsc_column_sums(rsp_mcsc_t h, double* sums) {
+int rsp_mcsc_column_sums(rsp_mcsc_t h, double* sums) try {
     if (!h || (h->ncol > 0 && !sums)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
     const int G = (int)h->shards.size();
     std::vector<int> status((size_t)G, RSP_OK);
     std::vector<std::string> message((size_t)G);
-    auto work = [&](int k) {
+    auto work = [&](int k) noexcept {
         if (h->bounds[k + 1] == h->bounds[k]) return;
         status[k] = rsp_csc_column_sums(h->shards[k], sums + h->bounds[k]);   // slice lands in place
-        if (status[k] != RSP_OK) message[k] = rsp_last_error();
+        if (status[k] != RSP_OK) {
+            try {
+                message[k] = rsp_last_error();
+            } catch (...) {
+            }
+        }
     };
-    std::vector<std::thread> threads;
-    for (int k = 1; k < G; ++k) threads.emplace_back(work, k);
-    work(0);
-    for (auto& t : threads) t.join();
+    if (!run_shards(G, work)) return fail(RSP_ERR_ALLOC, "out of host memory or threads while summing the shards");
     for (int k = 0; k < G; ++k)
         if (status[k] != RSP_OK) return fail(status[k], "shard %d: %s", k, message[k].c_str());
     return RSP_OK;
+} catch (...) {
+    return fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_column_sums");
 }
 
 int rsp_comm_unique_id(void* id_bytes) {
@@ -299,8 +353,11 @@ int rsp_comm_gatherv(rsp_comm_t c, const double* d_send, int64_t send_count, dou
 
 int rsp_comm_destroy(rsp_comm_t c) {
     if (!c) return RSP_OK;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     (void)hipSetDevice(c->device);
     ncclResult_t r = ncclCommDestroy(c->comm);
+    if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
     delete c;
     if (r != ncclSuccess) return fail(RSP_ERR_RCCL, "ncclCommDestroy: %s", ncclGetErrorString(r));
     return RSP_OK;

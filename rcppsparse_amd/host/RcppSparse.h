@@ -82,8 +82,10 @@ public:
         return out;
     }
 
-    // t(A) as a new Matrix (reference :375-385 calls back into R's Matrix::t;
-    // here a native counting transpose, no R evaluation, safe off the main thread)
+    // t(A) as a new Matrix (reference :375-385 calls back into R's Matrix::t; here a native
+    // counting transpose with no R evaluation).  Like the reference's, this method allocates Rcpp
+    // vectors and so belongs on the R main thread; only transpose_into() (plain std::vector
+    // output, no R API) is safe off it.
     Matrix transpose() {
         std::vector<double> tx;
         std::vector<int> ti, tp;

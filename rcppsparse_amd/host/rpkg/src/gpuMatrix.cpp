@@ -1,0 +1,78 @@
+#include "../inst/include/RcppSparse.h"
+#include "../inst/include/rcppsparse_hip.h"
+
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+// GPU-resident dgCMatrix behind an R external pointer ("next" row f2 of SURVEY.md section 8).
+//
+// The slots x / i / p / Dim (reference inst/include/RcppSparse.h:29-41, the layout wrap() writes
+// back at :387-394) are the wire format: gpuMatrix(A) uploads them once and hands R an external
+// pointer that owns the DEVICE copy only; columnSums() on that handle runs the same kernels on
+// the resident copy and pays no PCIe transfer of x.  The handle is explicit on purpose: caching
+// device copies by SEXP address would be wrong, because R objects are mutable in place through
+// this very class (reference vignettes/Documentation.Rmd:335-347) and addresses are reused after
+// a garbage collection.  A later change of A is therefore NOT seen by an existing handle.
+//
+// Lifetime: the external pointer carries a C finalizer that calls rsp_csc_free when R collects
+// it (or at gpuFree(), whichever comes first; a released handle raises an R error afterwards).
+
+namespace {
+
+void release_gpu_matrix(rsp_csc* h) { rsp_csc_free(h); }   // rsp_csc_free(NULL) is fine
+
+typedef Rcpp::XPtr<rsp_csc, Rcpp::PreserveStorage, release_gpu_matrix, true> GpuMatrixPtr;
+
+rsp_csc* resident(SEXP handle) {
+    GpuMatrixPtr ptr(handle);
+    rsp_csc* h = ptr.get();
+    if (!h) throw std::invalid_argument("this gpuMatrix handle has been released");
+    return h;
+}
+
+}  // namespace
+
+//' Keep a sparse matrix in GPU memory
+//'
+//' Uploads the slots of a \code{dgCMatrix} to one GPU and returns a handle (an external
+//' pointer of class \code{"gpuMatrix"}).  \code{columnSums()} on the handle does not transfer
+//' the matrix again.  The handle holds a copy: later changes of \code{A} are not seen.
+//'
+//' @param A a \code{dgCMatrix}
+//' @param device GPU ordinal (default: environment variable \code{RCPPSPARSE_DEVICE}, else 0)
+//' @return external pointer of class \code{"gpuMatrix"} with attribute \code{Dim}
+//[[Rcpp::export]]
+SEXP gpuMatrix(RcppSparse::Matrix& A, int device) {
+    const long long nnz = (long long)A.n_nonzero();
+    rsp_csc_t h = 0;
+    const int rc = rsp_csc_upload(nnz ? &A.x[0] : (const double*)0, nnz ? &A.i[0] : (const int*)0, &A.p[0],
+                                  (int)A.rows(), (int)A.cols(), nnz, device, &h);
+    if (rc != RSP_OK) throw std::runtime_error(std::string("RcppSparse gpuMatrix (HIP): ") + rsp_last_error());
+    GpuMatrixPtr ptr(h, true);                       // R now owns the device copy
+    ptr.attr("class") = "gpuMatrix";
+    ptr.attr("Dim") = Rcpp::IntegerVector::create((int)A.rows(), (int)A.cols());
+    return ptr;
+}
+
+//' Column sums of a GPU-resident matrix
+//' @param handle a \code{"gpuMatrix"}
+//' @return numeric vector of length \code{ncol}
+//[[Rcpp::export]]
+Rcpp::NumericVector gpuColumnSums(SEXP handle) {
+    rsp_csc* h = resident(handle);
+    Rcpp::IntegerVector dim = GpuMatrixPtr(handle).attr("Dim");
+    Rcpp::NumericVector sums(dim[1]);                // allocated by R, on the R main thread
+    if (dim[1] == 0) return sums;
+    if (rsp_csc_column_sums(h, &sums[0]) != RSP_OK)
+        throw std::runtime_error(std::string("RcppSparse columnSums (HIP): ") + rsp_last_error());
+    return sums;
+}
+
+//' Release the GPU copy now instead of at garbage collection
+//' @param handle a \code{"gpuMatrix"}
+//[[Rcpp::export]]
+void gpuFree(SEXP handle) {
+    GpuMatrixPtr ptr(handle);
+    ptr.release();                                   // runs the finalizer once and clears the pointer
+}

@@ -1,33 +1,76 @@
-// rcpp_glue.cpp -- hand-written R <-> C++ registration for the package's single routine.
+// rcpp_glue.cpp -- hand-written R <-> C++ registration of the package's native routines.
 //
-// R reaches native code through two C symbols of the package's shared object: the routine
-// itself and the init hook R runs right after dlopen().  A drop-in for the reference package
-// has to export them under the reference's names (reference src/RcppExports.cpp:16 and :31)
-// and register the routine with arity 1 and dynamic symbol lookup switched off, because the
-// R wrapper calls it by its registered name (`.Call(`_RcppSparse_columnSums`, A)`).
+// R reaches native code through C symbols of the package's shared object: the routines
+// themselves and the init hook R runs right after dlopen().  A drop-in for the reference package
+// has to export the reference's two symbols under the reference's names (reference
+// src/RcppExports.cpp:16 and :31) and register `_RcppSparse_columnSums` with arity 1 and dynamic
+// symbol lookup switched off, because the R wrapper calls it by its registered name
+// (`.Call(`_RcppSparse_columnSums`, A)`).  The three gpuMatrix routines after it are additions
+// of this package.
 //
 // Rcpp::compileAttributes() can regenerate an equivalent file from the [[Rcpp::export]]
-// attribute in columnSums.cpp; delete this one if you do.  Nothing here touches HIP: loading
-// the package must stay cheap and must succeed on a machine without a GPU (the device is
-// first touched inside columnSums()).
+// attributes in columnSums.cpp / gpuMatrix.cpp; delete this one if you do.  Nothing here touches
+// HIP: loading the package must stay cheap and must succeed on a machine without a GPU (the
+// device is first touched inside columnSums() / gpuMatrix()).
 #include "../inst/include/RcppSparse.h"
 #include <Rcpp.h>
 
-// the exported C++ function, defined in columnSums.cpp
+// A package built with -DRCPP_USE_GLOBAL_ROSTREAM must define the two stream objects itself
+// (reference src/RcppExports.cpp:9-12); without these lines such a build fails to link.
+#ifdef RCPP_USE_GLOBAL_ROSTREAM
+Rcpp::Rostream<true>& Rcpp::Rcout = Rcpp::Rcpp_cout_get();
+Rcpp::Rostream<false>& Rcpp::Rcerr = Rcpp::Rcpp_cerr_get();
+#endif
+
+// the exported C++ functions (columnSums.cpp, gpuMatrix.cpp)
 Rcpp::NumericVector columnSums(RcppSparse::Matrix& A);
+SEXP gpuMatrix(RcppSparse::Matrix& A, int device);
+Rcpp::NumericVector gpuColumnSums(SEXP handle);
+void gpuFree(SEXP handle);
 
 namespace {
 
-// One .Call entry point: SEXP in (an S4 dgCMatrix), SEXP out (a numeric vector).
+// Every .Call entry point has the shape of reference src/RcppExports.cpp:16-24:
 // BEGIN_RCPP / END_RCPP turn any C++ exception -- a missing dgCMatrix slot, a HIP failure
-// reported by the shim -- into an R condition instead of unwinding through R's C stack.
+// reported by the shim -- into an R condition instead of unwinding through R's C stack; the
+// RNGScope keeps R's random-number state consistent around the call exactly like the
+// generated glue does (:19; nothing here draws random numbers).
 SEXP call_columnSums(SEXP dgCMatrix) {
     BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
     // Exporter<RcppSparse::Matrix> wraps the four slots by reference; `A` keeps them alive
     // (protected from the garbage collector) until the end of this call
     Rcpp::traits::input_parameter<RcppSparse::Matrix&>::type A(dgCMatrix);
-    Rcpp::NumericVector sums = columnSums(A);
-    return Rcpp::wrap(sums);
+    result = Rcpp::wrap(columnSums(A));
+    return result;
+    END_RCPP
+}
+
+SEXP call_gpuMatrix(SEXP dgCMatrix, SEXP device) {
+    BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
+    Rcpp::traits::input_parameter<RcppSparse::Matrix&>::type A(dgCMatrix);
+    result = gpuMatrix(A, Rcpp::as<int>(device));
+    return result;
+    END_RCPP
+}
+
+SEXP call_gpuColumnSums(SEXP handle) {
+    BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
+    result = Rcpp::wrap(gpuColumnSums(handle));
+    return result;
+    END_RCPP
+}
+
+SEXP call_gpuFree(SEXP handle) {
+    BEGIN_RCPP
+    Rcpp::RNGScope rng_state;
+    gpuFree(handle);
+    return R_NilValue;
     END_RCPP
 }
 
@@ -36,10 +79,16 @@ SEXP call_columnSums(SEXP dgCMatrix) {
 extern "C" {
 
 SEXP _RcppSparse_columnSums(SEXP A) { return call_columnSums(A); }
+SEXP _RcppSparse_gpuMatrix(SEXP A, SEXP device) { return call_gpuMatrix(A, device); }
+SEXP _RcppSparse_gpuColumnSums(SEXP handle) { return call_gpuColumnSums(handle); }
+SEXP _RcppSparse_gpuFree(SEXP handle) { return call_gpuFree(handle); }
 
 void R_init_RcppSparse(DllInfo* dll) {
     static const R_CallMethodDef routines[] = {
-        {"_RcppSparse_columnSums", reinterpret_cast<DL_FUNC>(&_RcppSparse_columnSums), 1},
+        {"_RcppSparse_columnSums", reinterpret_cast<DL_FUNC>(&_RcppSparse_columnSums), 1},   // the reference's
+        {"_RcppSparse_gpuMatrix", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuMatrix), 2},
+        {"_RcppSparse_gpuColumnSums", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuColumnSums), 1},
+        {"_RcppSparse_gpuFree", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuFree), 1},
         {NULL, NULL, 0}};
     R_registerRoutines(dll, /*.C*/ NULL, /*.Call*/ routines, /*.Fortran*/ NULL, /*.External*/ NULL);
     R_useDynamicSymbols(dll, FALSE);   // only registered names resolve

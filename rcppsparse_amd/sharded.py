@@ -9,9 +9,19 @@ reduction between ranks and the result is independent of the rank count up to
 the per-shard chunking (each shard is summed by the same single-GPU kernel).
 
 The compute step and the gather are injected, so the same driver runs
-  * on GPUs:  compute = C-ABI ``rsp_column_sums_device``, gather = RCCL;
+  * on GPUs (``bench.py``):  compute = C-ABI ``rsp_column_sums_device``,
+    gather = ``RcclGather`` (or ``TorchGather`` if the C-ABI communicator
+    cannot be created);
   * in the world_size-2 ``gloo`` CPU tests: compute = whatever the test passes
-    in, gather = ``torch.distributed.gather`` over gloo.
+    in, gather = ``GlooGather``.
+
+Two drivers:
+  * ``ShardedColumnSums``  -- one call = compute, then gather, in order on one
+    stream: the synchronous-call semantics of reference src/example.cpp:26-32.
+    This is the protocol ``bench.py`` reports as ``value`` at every N.
+  * ``PipelinedColumnSums`` -- GPU only: launches alternate over several compute
+    streams and the gather of call k runs on its own stream beside the kernel of
+    call k+1.  Reported by ``bench.py`` as a separate, labelled figure.
 """
 from __future__ import annotations
 
@@ -70,8 +80,10 @@ def imbalance(p: np.ndarray, bounds: np.ndarray) -> float:
     return float(per.max() / max(per.mean(), 1e-300))
 
 
+# ------------------------------------------------------------------ gather backends
 class GlooGather:
     """Host-side stand-in for the RCCL gatherv (CPU tests): torch.distributed.gather."""
+    name = "torch.distributed.gather (gloo, CPU tests)"
 
     def __init__(self, counts, root: int = 0):
         import torch.distributed as dist
@@ -94,27 +106,111 @@ class GlooGather:
 
 
 class RcclGather:
-    """RCCL gatherv through the C ABI (rsp_comm_gatherv) on the current torch stream."""
+    """RCCL gatherv through the C ABI (rsp_comm_gatherv), enqueued on `stream` (None = the
+    current torch stream at call time).  The ctypes arguments are converted once per send
+    buffer, so a call in a hot loop is a single foreign call."""
+    name = "rsp_comm_gatherv (C ABI, RCCL)"
 
-    def __init__(self, comm: capi.Comm, counts, displs, root: int = 0):
-        self.comm, self.counts, self.displs, self.root = comm, counts, displs, root
+    def __init__(self, comm: capi.Comm, counts, displs, root: int = 0, stream=None):
+        self.comm, self.counts, self.displs, self.root, self.stream = comm, counts, displs, root, stream
+        self._prepared = {}
 
     def __call__(self, send, recv):
-        self.comm.gatherv(send, recv, self.counts, self.displs, self.root)
+        if self.stream is None:
+            self.comm.gatherv(send, recv, self.counts, self.displs, self.root)
+            return
+        key = (send.data_ptr(), 0 if recv is None else recv.data_ptr())
+        run = self._prepared.get(key)
+        if run is None:
+            run = self.comm.prepared_gatherv(send, recv, self.counts, self.displs, self.root, stream=self.stream)
+            self._prepared[key] = run
+        run()
 
 
+class TorchGather:
+    """The same gatherv (grouped RCCL send/recv) issued through torch.distributed's own
+    communicator; bench.py uses it only if the C-ABI communicator cannot be created, and says
+    so in ``config.gather``.  Works over gloo too (CPU test of the layout)."""
+    name = "torch.distributed batch_isend_irecv (fallback: the C-ABI communicator failed)"
+
+    def __init__(self, dist, rank, world, counts, displs, root: int = 0, stream=None):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.counts, self.displs, self.root, self.stream = counts, displs, root, stream
+
+    def __call__(self, send, recv):
+        import contextlib
+        import torch
+        dist, root, counts, displs = self.dist, self.root, self.counts, self.displs
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        with ctx:
+            if self.rank == root:
+                ops = [dist.P2POp(dist.irecv, recv[int(displs[r]):int(displs[r] + counts[r])], r)
+                       for r in range(self.world) if r != root and counts[r] > 0]
+                recv[int(displs[root]):int(displs[root] + counts[root])].copy_(send, non_blocking=True)
+            else:
+                ops = [dist.P2POp(dist.isend, send, root)] if send.numel() > 0 else []
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+
+
+# ------------------------------------------------------------------------- drivers
 class ShardedColumnSums:
-    """columnSums of one shard + gather of all shards' slices to rank 0.
+    """columnSums of one shard, then the gather of all shards' slices to rank 0, in order.
 
     compute(shard) -> per-shard sums (tensor of shard.ncol doubles)
-    gather(send, recv) -> fills recv (rank 0 only) from every rank's send
+    gather(send, recv) -> fills recv (rank 0 only) from every rank's send; None = no
+                          exchange step (a single shard that is not asked to rehearse it)
     """
 
     def __init__(self, shard: Shard, compute, gather):
         self.shard, self.compute, self.gather = shard, compute, gather
 
-    def step(self, recv):
+    def step(self, recv, on_computed=None):
         local = self.compute(self.shard)
-        if self.shard.world > 1:
+        if on_computed is not None:
+            on_computed()
+        if self.gather is not None:
             self.gather(local, recv)
         return local
+
+
+class PipelinedColumnSums:
+    """GPU only.  Call n runs its kernel on compute stream n % S into output buffer n % B and its
+    gather on the communication stream, so the gather of call n overlaps the kernel of call n+1
+    and, with S > 1, call n+1 fills the chip while call n drains.  Every stream needs its own
+    carries workspace (include/rcppsparse_hip.h); a buffer is reused only after its previous
+    gather has drained.
+
+    launches[q][k]() enqueues the column sums on compute stream q into outs[k];
+    gathers[k]() enqueues the gather of outs[k] on comm_stream (None entries = no exchange).
+    """
+
+    def __init__(self, torch, launches, gathers, compute_streams, comm_stream, nbuf: int):
+        self.launches, self.gathers = launches, gathers
+        self.compute_streams, self.comm_stream, self.nbuf = compute_streams, comm_stream, nbuf
+        self.n = 0
+        # events are created up front: the hot loop only records and waits
+        self.kernel_done = [torch.cuda.Event() for _ in range(nbuf)]
+        self.buffer_free = [torch.cuda.Event() for _ in range(nbuf)]
+        self.freed_on = [None] * nbuf      # stream that recorded buffer_free[k] (None = never used)
+
+    def step(self):
+        n = self.n
+        k, q = n % self.nbuf, n % len(self.compute_streams)
+        sc = self.compute_streams[q]
+        self.n = n + 1
+        # outs[k] may be overwritten once whatever read it last (its gather, or with no exchange the
+        # kernel that wrote it, if that ran on another stream) has finished
+        if self.freed_on[k] is not None and self.freed_on[k] is not sc and not self.buffer_free[k].query():
+            sc.wait_event(self.buffer_free[k])
+        self.launches[q][k](n)
+        if self.gathers[k] is not None:
+            self.kernel_done[k].record(sc)
+            self.comm_stream.wait_event(self.kernel_done[k])
+            self.gathers[k]()
+            self.buffer_free[k].record(self.comm_stream)
+            self.freed_on[k] = self.comm_stream
+        else:
+            self.buffer_free[k].record(sc)
+            self.freed_on[k] = sc

@@ -17,11 +17,26 @@ struct SEXPREC {
     std::map<std::string, SEXP> slots;
     std::string klass, error;
     bool is_s4 = false;
+    // external pointers (Rcpp::XPtr): address, C finalizer, attributes; character scalars
+    bool is_extptr = false;
+    void* extptr = 0;
+    void (*finalizer)(SEXP) = 0;
+    std::map<std::string, SEXP> attrs;
+    std::string str;
 };
 
 namespace Rcpp {
 
 inline SEXP mock_new() { return new SEXPREC(); }   // the test process is short-lived: no GC
+inline SEXP mock_nil() { static SEXPREC nil; return &nil; }
+// what R's garbage collector does to an unreachable external pointer: run its finalizer once
+inline void mock_collect(SEXP s) {
+    if (s && s->is_extptr && s->finalizer) {
+        void (*f)(SEXP) = s->finalizer;
+        s->finalizer = 0;
+        f(s);
+    }
+}
 
 template <class T>
 class MockVector {
@@ -110,6 +125,71 @@ private:
     SEXP s_;
 };
 
+inline SEXP wrap(const char* text) { SEXP s = mock_new(); s->str = text; return s; }
+inline SEXP wrap(SEXP s) { return s; }
+
+template <class T>
+T as(SEXP s);
+template <>
+inline int as<int>(SEXP s) {
+    if (!s || !s->integer || s->integer->empty()) throw std::invalid_argument("Expecting a single integer value");
+    return (*s->integer)[0];
+}
+
+// GetRNGstate() / PutRNGstate() bracket of the generated glue: counted so a test can see it ran
+struct RNGScope {
+    static int& live() { static int n = 0; return n; }
+    static int& entered() { static int n = 0; return n; }
+    RNGScope() { ++live(); ++entered(); }
+    ~RNGScope() { --live(); }
+};
+
+template <class T>
+class PreserveStorage {};
+template <class T>
+void standard_delete_finalizer(T* p) { delete p; }
+
+// Rcpp::XPtr: an R external pointer owning a C object, released by a C finalizer when R
+// collects it (or by release()).  Same template signature as Rcpp's.
+template <class T, template <class> class StoragePolicy = PreserveStorage,
+          void Finalizer(T*) = standard_delete_finalizer<T>, bool finalizeOnExit = false>
+class XPtr {
+public:
+    class AttrProxy {
+    public:
+        AttrProxy(SEXP owner, const std::string& name) : owner_(owner), name_(name) {}
+        AttrProxy& operator=(const char* text) { owner_->attrs[name_] = wrap(text); return *this; }
+        AttrProxy& operator=(const IntegerVector& v) { owner_->attrs[name_] = wrap(v); return *this; }
+        operator IntegerVector() const { return IntegerVector(owner_->attrs.at(name_)); }
+
+    private:
+        SEXP owner_;
+        std::string name_;
+    };
+    explicit XPtr(SEXP s) : s_(s) {
+        if (!s || !s->is_extptr) throw std::invalid_argument("Expecting an external pointer");
+    }
+    explicit XPtr(T* p, bool set_delete_finalizer = true) : s_(mock_new()) {
+        s_->is_extptr = true;
+        s_->extptr = p;
+        if (set_delete_finalizer) s_->finalizer = &finalize;
+    }
+    T* get() const { return static_cast<T*>(s_->extptr); }
+    void release() { finalize(s_); }                 // finalizer now, pointer cleared
+    AttrProxy attr(const std::string& name) const { return AttrProxy(s_, name); }
+    operator SEXP() const { return s_; }
+
+private:
+    static void finalize(SEXP s) {
+        T* p = static_cast<T*>(s->extptr);
+        if (p) {
+            s->extptr = 0;                           // R_ClearExternalPtr
+            Finalizer(p);
+        }
+    }
+    SEXP s_;
+};
+
 class RObject {
 public:
     RObject() : s_(0) {}
@@ -159,6 +239,7 @@ inline int R_registerRoutines(DllInfo* dll, const void*, const R_CallMethodDef* 
     return 1;
 }
 inline int R_useDynamicSymbols(DllInfo* dll, Rboolean v) { dll->dynamic_symbols = (v != FALSE); return 1; }
+#define R_NilValue (Rcpp::mock_nil())
 #ifndef NULL
 #define NULL 0
 #endif

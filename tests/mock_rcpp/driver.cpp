@@ -4,6 +4,8 @@
 //   driver registered          -> prints the registered routine name and arity
 //   driver missing_slot        -> S4 without `p`: the glue must turn the exception into an R error
 //   driver kat                 -> Documentation.Rmd:213-216 matrix through .Call (needs a GPU)
+//   driver handle              -> gpuMatrix(A) external pointer: resident sums, copy semantics, finalizer (GPU)
+//   driver handle_nogpu        -> gpuMatrix(A) on a machine without a GPU must be an R error
 #include "../../rcppsparse_amd/host/RcppSparse.h"
 
 #include <cstdio>
@@ -29,11 +31,56 @@ int main(int argc, char** argv) {
     R_init_RcppSparse(&dll);
     if (!dll.registered || dll.dynamic_symbols) return 10;
     if (mode == "registered") {
-        std::printf("%s %d\n", dll.registered[0].name, dll.registered[0].numArgs);
-        return (dll.registered[1].name == 0) ? 0 : 11;
+        for (int k = 0; dll.registered[k].name; ++k)
+            std::printf("%s %d\n", dll.registered[k].name, dll.registered[k].numArgs);
+        return 0;
     }
     typedef SEXP (*call1)(SEXP);
+    typedef SEXP (*call2)(SEXP, SEXP);
     call1 fn = (call1)dll.registered[0].fun;          // what .Call(`_RcppSparse_columnSums`, A) resolves to
+    if (mode == "handle" || mode == "handle_nogpu") {
+        call2 gpu_matrix = 0;
+        call1 gpu_sums = 0, gpu_free = 0;
+        for (int k = 0; dll.registered[k].name; ++k) {
+            const std::string nm = dll.registered[k].name;
+            if (nm == "_RcppSparse_gpuMatrix") gpu_matrix = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuColumnSums") gpu_sums = (call1)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuFree") gpu_free = (call1)dll.registered[k].fun;
+        }
+        if (!gpu_matrix || !gpu_sums || !gpu_free) return 20;
+        SEXP A = dgc(true);
+        SEXP dev = Rcpp::wrap(Rcpp::IntegerVector::create(0, 0));
+        SEXP h = gpu_matrix(A, dev);
+        if (mode == "handle_nogpu") {
+            std::printf("%s\n", h->error.c_str());
+            return h->error.empty() ? 21 : 0;
+        }
+        if (!h->error.empty()) { std::printf("R error: %s\n", h->error.c_str()); return 22; }
+        if (!h->is_extptr || !h->extptr || h->attrs.at("class")->str != "gpuMatrix") return 23;
+        const double want[5] = {0.0, 0.41, 0.35, 0.84 + 0.37, 0.26};
+        SEXP r = gpu_sums(h);
+        if (!r->error.empty() || r->num->size() != 5 || std::memcmp(&(*r->num)[0], want, sizeof want) != 0) return 24;
+        // the handle is a COPY: changing the R object in place (Documentation.Rmd:335-347) is not seen
+        (*A->slots.at("x")->num)[0] = 99.0;
+        r = gpu_sums(h);
+        if (std::memcmp(&(*r->num)[0], want, sizeof want) != 0) return 25;
+        SEXP fresh = fn(A);                             // ... while the one-shot path sees the new value
+        if ((*fresh->num)[1] != 99.0) return 26;
+        // a second handle, dropped without gpuFree: R's collector runs the finalizer exactly once
+        SEXP h2 = gpu_matrix(A, dev);
+        if (!h2->error.empty()) return 27;
+        Rcpp::mock_collect(h2);
+        if (h2->extptr != 0) return 28;
+        Rcpp::mock_collect(h2);                         // (already cleared: nothing happens)
+        // explicit release, then use: an R error, not a crash
+        if (!gpu_free(h)->error.empty() || h->extptr != 0) return 29;
+        r = gpu_sums(h);
+        if (r->error.find("released") == std::string::npos) return 30;
+        if (!gpu_free(h)->error.empty()) return 31;     // releasing twice is harmless
+        if (Rcpp::RNGScope::live() != 0 || Rcpp::RNGScope::entered() < 6) return 32;
+        std::printf("gpuMatrix handle ok\n");
+        return 0;
+    }
     if (mode == "missing_slot") {
         SEXP r = fn(dgc(false));
         std::printf("%s\n", r->error.c_str());

@@ -1,0 +1,150 @@
+"""-m gpu tests of the N > 1 path on the ONE GPU this box has:
+
+  * bench.py itself, run as a child process with --force-comm, so the communicator created
+    through the C ABI, the in-order kernel -> gatherv call, the latency loop and the pipelined
+    figure are under the driver's own test run;
+  * BASELINE configs 4 and 5 at FULL size: the 8 nnz-balanced column-range shards of the
+    1e9-nnz uniform and Zipf matrices, generated in HBM at their offsets exactly as bench.py
+    does, summed one after the other through rsp_column_sums_device and reassembled.
+
+The 8-rank RCCL exchange itself needs 8 GPUs (the driver's node); its layout and driver are
+covered by tests/test_sharded_gloo.py, and a one-rank communicator runs here.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from rcppsparse_amd import capi, sharded, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked tests need a GPU: the HIP path has no CPU fallback")
+    capi.load()
+    yield torch
+    capi.set_tuning(0)
+
+
+def _run_bench(*flags, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # the contract: ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_child_process_runs_the_comm_path_at_shard_size(torch_cuda):
+    """`bench.py --gpus 1 --force-comm --workload c4shard`: one C4 shard (1.25e8 nnz), the
+    communicator of the C ABI, the gatherv inside every call."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--gpus", "1", "--force-comm", "--workload", "c4shard", "--steps", "8", "--warmup", "2",
+                   "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["unit"] == "nnz/s"
+    assert d["config"]["gather"] == "rsp_comm_gatherv (C ABI, RCCL)"
+    assert d["config"]["gather_fell_back_to_torch_distributed"] is False
+    par = d["parity"]
+    assert par["columns_checked"] == "all" and par["ncol"] == 125_000
+    assert par["columns_out_of_tolerance"] == 0 and par["max_abs_err_over_l1"] <= RTOL
+    assert par["empty_columns_exactly_plus_zero"] is True
+    # both protocols are reported, and the like-for-like one is the metric
+    assert d["latency_ms_per_call"] > 0 and d["latency"]["calls"] >= 1
+    assert d["pipelined"]["value"] > 0 and "NOT the protocol" in d["pipelined"]["protocol"]
+    assert d["value"] == pytest.approx(125_000_000 * 8 / (d["ms_per_step"] * 8e-3), rel=1e-9)
+    # a call cannot be faster than its kernels; a single call pays the host round trip on top
+    roof = d["roofline"]
+    assert roof["kernel_ms"] <= d["ms_per_step"] * 1.02
+    assert d["latency_ms_per_call"] >= roof["kernel_ms_min"]
+    # the mean gather time lies between the individual gather timings
+    lo, hi = roof["gather_ms_min_max"]
+    assert lo <= roof["gather_ms"] <= hi
+    assert 0.3 < roof["frac"] < 1.0
+
+
+def test_bench_child_process_default_protocol_small(torch_cuda):
+    """The N = 1 protocol of the bench line (no communicator), on a small Zipf matrix, with the
+    CPU baseline leg: every key of the contract is there and parity covers every column."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--workload", "tiny", "--steps", "6", "--warmup", "2")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline",
+                "latency_ms_per_call", "pipelined", "parity"):
+        assert key in d, key
+    assert d["config"]["gather"] is None and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["parity"]["columns_checked"] == "all" and d["parity"]["columns_out_of_tolerance"] == 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.parametrize("shape", ["uniform", "zipf"])
+def test_c4_c5_eight_shards_at_full_size_on_one_gpu(torch_cuda, shape):
+    """BASELINE configs 4 (uniform) and 5 (Zipf): 1e7 x 1e6, nnz 1e9, cut into 8 nnz-balanced
+    column ranges.  Each shard's x is generated in HBM at shard.x0 (as every rank of bench.py
+    does), summed through rsp_column_sums_device with its rebased offsets, and the slices are
+    reassembled at the gather layout's displacements.  Checks: the oracle on both edges of every
+    shard, identical bits on a second pass, the imbalance figure, and the reassembled result
+    against ONE launch over the whole matrix (different chunking, same tolerance)."""
+    torch = torch_cuda
+    nrow, ncol, nnz, G = 10_000_000, 1_000_000, 1_000_000_000, 8
+    if torch.cuda.get_device_properties(0).total_memory < 24 * 2**30:
+        pytest.skip("needs >= 24 GB of HBM")
+    torch.cuda.empty_cache()
+    counts_col = (synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow) if shape == "uniform"
+                  else synth.zipf_counts(ncol, nnz, seed=42, nrow=nrow))
+    p = synth.offsets_from_counts(counts_col)
+    shards = [sharded.make_shard(p, r, G) for r in range(G)]
+    counts, displs = sharded.gather_layout(shards[0].bounds)
+    assert int(counts.sum()) == ncol and shards[0].x0 == 0 and shards[-1].x1 == nnz
+    imb = sharded.imbalance(p, shards[0].bounds)
+    assert imb < (1.0001 if shape == "uniform" else 1.02), imb
+    # no column is split, and the shards tile x exactly
+    for a, b in zip(shards, shards[1:]):
+        assert a.c1 == b.c0 and a.x1 == b.x0
+
+    full = torch.empty(ncol, dtype=torch.float64, device="cuda")       # what rank 0 would receive
+    for sh in shards:
+        xt = torch.empty(sh.nnz, dtype=torch.float64, device="cuda")
+        capi.gen_values_device(xt, seed=42, first_idx=sh.x0, kind=0)
+        pt = torch.from_numpy(sh.p_local).cuda()
+        ws = capi.alloc_workspace(sh.ncol, sh.nnz)
+        out = torch.empty(sh.ncol, dtype=torch.float64, device="cuda")
+        capi.column_sums_device(xt, pt, out, ws)
+        again = torch.empty_like(out)
+        capi.column_sums_device(xt, pt, again, ws)
+        assert torch.equal(out, again), sh.rank                           # run-to-run bits
+        d0 = int(displs[sh.rank])
+        full[d0:d0 + sh.ncol].copy_(out)
+        got = out.cpu().numpy()
+        # the oracle on both edges of the shard (the columns next to the cuts)
+        for a, b in ((0, min(300, sh.ncol)), (max(0, sh.ncol - 300), sh.ncol)):
+            lo, hi = int(sh.p_local[a]), int(sh.p_local[b])
+            xs = oracle.gen_values(hi - lo, 42, sh.x0 + lo, 0)
+            pl = (sh.p_local[a:b + 1] - lo).astype(np.int32)
+            ref = oracle.column_sums(xs, pl)
+            scale = oracle.column_abs_sums(xs, pl)
+            assert np.all(np.abs(got[a:b] - ref) <= RTOL * scale), (shape, sh.rank, a)
+        empty = np.diff(sh.p_local) == 0
+        assert np.all(got[empty] == 0.0) and not np.any(np.signbit(got[empty]))
+        del xt, out, again, ws, pt
+
+    # one launch over the whole matrix: every column of the reassembled result agrees with it
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    capi.gen_values_device(xt, seed=42, kind=0)
+    pt = torch.from_numpy(p).cuda()
+    whole = capi.column_sums_device(xt, pt)
+    l1 = capi.column_reduce_device(xt, pt, capi.OP_SUM_ABS)
+    assert bool(torch.all((whole - full).abs() <= 2 * RTOL * l1))
+    assert [int(d) for d in displs] == [sh.c0 for sh in shards]     # slices land at their columns

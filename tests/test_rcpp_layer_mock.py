@@ -25,6 +25,7 @@ def driver(tmp_path_factory):
     mock = os.path.join(ROOT, "tests", "mock_rcpp")
     subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-I", mock, "-o", exe,
                     os.path.join(mock, "driver.cpp"), os.path.join(rpkg, "src", "columnSums.cpp"),
+                    os.path.join(rpkg, "src", "gpuMatrix.cpp"),
                     os.path.join(rpkg, "src", "rcpp_glue.cpp"), "-L", libdir, "-lrcppsparse_hip",
                     f"-Wl,-rpath,{libdir}"], check=True)
     return exe
@@ -34,9 +35,34 @@ def run(exe, mode):
     return subprocess.run([exe, mode], capture_output=True, text=True, timeout=120)
 
 
-def test_package_registers_exactly_the_reference_routine(driver):
+def test_package_registers_the_reference_routine_first(driver):
+    """Entry 0 is the reference's one routine (src/RcppExports.cpp:26-29), name and arity; the
+    gpuMatrix handle routines follow it."""
     r = run(driver, "registered")
-    assert r.returncode == 0 and r.stdout.split() == ["_RcppSparse_columnSums", "1"]
+    assert r.returncode == 0
+    rows = [ln.split() for ln in r.stdout.splitlines()]
+    assert rows[0] == ["_RcppSparse_columnSums", "1"]
+    assert rows[1:] == [["_RcppSparse_gpuMatrix", "2"], ["_RcppSparse_gpuColumnSums", "1"],
+                        ["_RcppSparse_gpuFree", "1"]]
+
+
+def test_glue_also_builds_with_global_rostream(tmp_path):
+    """reference src/RcppExports.cpp:9-12: a build with -DRCPP_USE_GLOBAL_ROSTREAM has to define
+    Rcpp::Rcout / Rcpp::Rcerr in the package; the glue carries those definitions (they are
+    compiled here against stand-in declarations, since real Rcpp is not in this image)."""
+    rpkg = os.path.join(ROOT, "rcppsparse_amd", "host", "rpkg")
+    subprocess.run(["bash", os.path.join(rpkg, "assemble.sh")], check=True, stdout=subprocess.DEVNULL)
+    shim = tmp_path / "rostream_decl.h"
+    shim.write_text("namespace Rcpp { template <bool B> struct Rostream {}; "
+                    "extern Rostream<true>& Rcout; extern Rostream<false>& Rcerr; "
+                    "inline Rostream<true>& Rcpp_cout_get() { static Rostream<true> s; return s; } "
+                    "inline Rostream<false>& Rcpp_cerr_get() { static Rostream<false> s; return s; } }\n")
+    obj = tmp_path / "glue.o"
+    subprocess.run(["g++", "-std=c++14", "-c", "-DRCPP_USE_GLOBAL_ROSTREAM", "-include", str(shim),
+                    "-I", os.path.join(ROOT, "tests", "mock_rcpp"), "-o", str(obj),
+                    os.path.join(rpkg, "src", "rcpp_glue.cpp")], check=True)
+    syms = subprocess.run(["nm", "-C", str(obj)], capture_output=True, text=True, check=True).stdout
+    assert "Rcpp::Rcout" in syms and "Rcpp::Rcerr" in syms
 
 
 def test_missing_slot_becomes_an_r_error_with_the_reference_message(driver):
@@ -51,6 +77,24 @@ def test_without_a_gpu_columnSums_is_an_r_error_not_a_cpu_answer(driver):
         pytest.skip("a GPU is present")
     r = run(driver, "kat")
     assert r.returncode == 16 and "no HIP device" in r.stdout
+
+
+def test_without_a_gpu_gpuMatrix_is_an_r_error(driver):
+    from rcppsparse_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = run(driver, "handle_nogpu")
+    assert r.returncode == 0 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_matrix_external_pointer_handle(driver):
+    """gpuMatrix(A) -> external pointer (finalizer = rsp_csc_free); columnSums on it runs on the
+    resident copy, does not see later in-place changes of A, survives neither gpuFree nor the
+    collector, and a released handle is an R error."""
+    r = run(driver, "handle")
+    assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
+    assert "gpuMatrix handle ok" in r.stdout
 
 
 @pytest.mark.gpu

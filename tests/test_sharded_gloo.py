@@ -91,12 +91,15 @@ def _torch_gather_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import bench
         counts = [5, 0, 7][:world] if world == 3 else [4, 9]
         displs = np.cumsum([0] + counts[:-1])
         send = torch.full((counts[rank],), float(rank + 1), dtype=torch.float64)
         recv = torch.zeros(sum(counts), dtype=torch.float64) if rank == 0 else None
-        bench.TorchGather(dist, rank, world).gatherv(send, recv, counts, displs, 0, stream=None)
+        # the same driver bench.py runs, with the fallback gather as its exchange step
+        seen = []
+        driver = sharded.ShardedColumnSums(None, lambda _shard: send,
+                                           sharded.TorchGather(dist, rank, world, counts, displs, 0))
+        assert driver.step(recv, on_computed=lambda: seen.append(1)) is send and seen == [1]
         if rank == 0:
             want = np.concatenate([np.full(c, r + 1.0) for r, c in enumerate(counts)])
             q.put(bool(np.array_equal(recv.numpy(), want)))
@@ -106,8 +109,8 @@ def _torch_gather_worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_fallback_gatherv_layout(world):
-    """bench.py's torch.distributed gatherv (used only if the C-ABI communicator cannot be
-    created) fills the same counts/displacements layout, including an empty slice."""
+    """sharded.TorchGather (bench.py uses it only if the C-ABI communicator cannot be created)
+    fills the same counts/displacements layout, including an empty slice."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     mp.spawn(_torch_gather_worker, args=(world, _free_port(), q), nprocs=world, join=True)
