@@ -371,9 +371,10 @@ def main(argv=None):
     driver = sharded.ShardedColumnSums(shard, compute, new_gather(s_main))
     for _ in range(args.warmup):
         driver.step(recv)
-    # a shard's kernel is ~0.15 ms at N = 8, so with a gather the timing events (one queue packet
-    # each) sit on every 4th step only; N = 1 times every launch
-    stride = 4 if use_comm else 1
+    # a shard's kernel is ~0.15 ms at N = 8 and a C2-sized call ~25 us, so with a gather or a small
+    # matrix the timing events (one queue packet each, plus their host cost) sit on every 4th step
+    # only; the large single-GPU workloads time every launch
+    stride = 4 if (use_comm or shard.nnz < 200_000_000) else 1
     timed = list(range(0, args.steps, stride))
     mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
     ev = {k: (mk(), mk(), mk()) for k in timed}

@@ -13,7 +13,7 @@ constexpr int kMinChunkRows = 16; // automatic chunking never goes below this ma
 constexpr int kWavesPerWG = 4;    // independent wavefronts per workgroup
 constexpr int kPWin = 256;        // p[] entries staged in LDS per wavefront
 constexpr int kHistPad = 132;     // 129 histogram slots, padded to a 16-byte multiple
-constexpr int kStampChunks = 32768; // diagnostic build: chunks that record timestamps
+constexpr int kStampChunks = 65536; // diagnostic build: chunks that record timestamps
 constexpr int kLoadAux = 2;       // buffer_load cache policy: 2 = nt (streamed once)
 constexpr int kGroupRows = 4;     // rows per dense group (512 elements, 8 per lane)
 constexpr int kGroupElems = kGroupRows * kRowElems;
@@ -46,11 +46,17 @@ struct LaunchPlan {
     int32_t nbody;         // number of body chunks
     int32_t tail_elems;    // elements per tail chunk, multiple of kRowElems
     int32_t nchunks;       // nbody + tail chunks; >= 1 when nnz > 0
+    uint32_t extra_lds_bytes;  // unused dynamic LDS per workgroup: caps the resident wavefronts per CU (long calls)
     int variant;           // 0 = production kernel; >0 = experiment variants (env RSP_VARIANT)
 };
-constexpr int kTaperPermille = 150;  // default taper: the last 15 % of x ...
+// Calls of at least this many chunks (four rounds of the 6144 wave slots) run with 2 workgroups
+// = 8 wavefronts per CU instead of 6 = 24: +1.0-1.3 % on the 1e9-nnz workloads in interleaved A/B
+// (profiles/r02_chunking.md); shorter calls want every slot (C2 loses 30 % at 8 per CU).
+constexpr int kLowOccupancyMinChunks = 4 * 6144;
+constexpr uint32_t kLowOccupancyExtraLds = 32 * 1024;
+constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
-constexpr int kTaperMinChunks = 12288; // only calls of more than two rounds of resident waves (2 x 6144) are tapered
+constexpr int kTaperMinChunks = 6144;  // only calls of more than one round of resident waves (256 CUs x 24) are tapered
 constexpr int kMaxChunkRows = 1 << 20;   // 1 GiB of x per chunk: byte counts and offsets inside a chunk stay < 2^31
 
 // chunk index <-> first element, shared by host code and both kernels

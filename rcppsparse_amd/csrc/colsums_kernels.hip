@@ -431,6 +431,10 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
             if (active) {
                 lo = ((j == 0) ? gs : win[woff + j]) - gs;
                 hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
+                // a valid p[] gives 0 <= lo <= hi <= glim; an invalid one (device entries do not check it)
+                // must not turn into a long loop or a read outside the staged group
+                lo = lo < 0 ? 0 : (lo > (int)glim ? (int)glim : lo);
+                hi = hi < lo ? lo : (hi > (int)glim ? (int)glim : hi);
             }
             if (check_len && __ballot(hi - lo > kDenseMaxLen) != 0ull) return false;   // (single pass: nothing emitted yet)
             double s = (j == 0) ? A : P::id();   // the continuing column keeps adding to its running result
@@ -459,6 +463,8 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
         if (active) {
             lo = ((j == 0) ? gs : win[woff + j]) - gs;
             hi = ((j == n_ends) ? ge : win[woff + j + 1]) - gs;
+            lo = lo < 0 ? 0 : (lo > (int)glim ? (int)glim : lo);   // (see above: only an invalid p[] is clamped)
+            hi = hi < lo ? lo : (hi > (int)glim ? (int)glim : hi);
         }
         if (check_len && __ballot(hi - lo > (kDenseMaxLen << shift)) != 0ull) return false;
         double s = (lane == 0) ? A : P::id();
@@ -701,7 +707,10 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         // everything the fix-up needs about this chunk in one 16-byte record: its first column, the
         // number of column ends inside, the chunk holding that column's first element and whether the
         // column starts exactly on that chunk's edge (then its first part is that chunk's head)
-        const int32_t ts = cmap.chunk_of(p_c0);
+        // (0 <= ts <= w for a valid p[]; clamped so that an invalid one cannot send the fix-up outside
+        // the carries)
+        int32_t ts = cmap.chunk_of(p_c0 < 0 ? 0 : p_c0);
+        ts = ts > w ? w : ts;
         carry_info[w] = make_int4(c0, st.ccur - c0, ts, (int64_t)p_c0 == cmap.start(ts) ? 1 : 0);
     }
     RSP_STAMP(6);
@@ -853,14 +862,17 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     int4* carry_info = (int4*)(carry_tail + plan.nchunks);   // (16-byte aligned: the workspace is, and 16 * nchunks bytes precede it)
     const ChunkMap cmap{plan.chunk_elems, plan.nbody, plan.tail_elems};
     const dim3 grid((plan.nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
+    // experiment ids >= 16: (id - 16) KiB of unused dynamic LDS per workgroup, which lowers the number of
+    // resident waves per CU (occupancy sweeps, tools/taper_sweep.py)
+    const unsigned extra_lds = plan.variant >= 16 ? (unsigned)(plan.variant - 16) * 1024u : plan.extra_lds_bytes;
 #define RSP_LAUNCH_K(KERNEL, BR, AUX_)                                                              \
     do {                                                                                           \
         if (means)                                                                                 \
-            hipLaunchKernelGGL((KERNEL<BR, true, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,   \
+            hipLaunchKernelGGL((KERNEL<BR, true, AUX_>), grid, block, extra_lds, stream, d_x, d_p, ncol,   \
                                nnz, cmap, plan.nchunks, d_out, carry_head, carry_tail, \
                                carry_info, divisor, rows_i, row_bitmap, bitmap_words);             \
         else                                                                                       \
-            hipLaunchKernelGGL((KERNEL<BR, false, AUX_>), grid, block, 0, stream, d_x, d_p, ncol,  \
+            hipLaunchKernelGGL((KERNEL<BR, false, AUX_>), grid, block, extra_lds, stream, d_x, d_p, ncol,  \
                                nnz, cmap, plan.nchunks, d_out, carry_head, carry_tail, \
                                carry_info, divisor, rows_i, row_bitmap, bitmap_words);             \
     } while (0)

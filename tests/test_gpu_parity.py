@@ -615,3 +615,126 @@ def test_rccl_single_rank_gatherv_roundtrip(torch_cuda):
     torch.cuda.synchronize()
     assert torch.equal(recv[250:1250], send) and recv[:250].abs().sum() == 0 and recv[1250:].abs().sum() == 0
     comm.close()
+
+
+# ------------------------------------------------------------------ robustness
+def test_chunk_rows_knob_is_clamped(torch_cuda):
+    """rsp_set_tuning accepts any chunk_rows, but one chunk never exceeds 1 GiB of x (byte counts
+    and offsets inside a chunk are 32-bit in the kernel): 2^22 and 2^30 rows per chunk give the
+    same, correct sums as the automatic chunking on a matrix spanning several such chunks."""
+    torch = torch_cuda
+    nnz, ncol = 300_000_000, 3_000
+    if torch.cuda.get_device_properties(0).total_memory < 12 * 2**30:
+        pytest.skip("needs >= 12 GB of HBM")
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=9, nrow=None))
+    pt = torch.from_numpy(p).cuda()
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    capi.gen_values_device(xt, seed=9, kind=0)
+    capi.set_tuning(0)
+    base = capi.column_sums_device(xt, pt)
+    l1 = capi.column_reduce_device(xt, pt, capi.OP_SUM_ABS)
+    try:
+        for rows in (2**20, 2**22, 2**30):
+            capi.set_tuning(rows)
+            assert capi.workspace_bytes(ncol, nnz) >= 32 * 3          # >= 3 chunks of <= 2^27 elements
+            got = capi.column_sums_device(xt, pt)
+            torch.cuda.synchronize()
+            assert bool(torch.all((got - base).abs() <= 2 * RTOL * l1)), rows
+    finally:
+        capi.set_tuning(0)
+
+
+@pytest.mark.parametrize("taper", [(0, 0), (150, 64), (500, 16), (1000, 32), (999, 1)])
+def test_tapered_chunking_keeps_parity_and_bits(torch_cuda, taper):
+    """rsp_set_taper: the last part of x in shorter chunks.  Every setting stays within tolerance
+    of the oracle, bit-stable, on a matrix with > 12288 chunks (so that the taper applies), with a
+    giant column crossing the body/tail edge and short columns on both sides of it."""
+    torch = torch_cuda
+    counts = np.concatenate([synth.uniform_counts(40_000, 12_000_000, seed=4, nrow=None), [9_000_000],
+                             synth.uniform_counts(300_000, 3_000_000, seed=5, nrow=None)]).astype(np.int64)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=6, kind=0)
+    try:
+        capi.set_taper(*taper)
+        got = dev_colsums(torch, x, p)
+        again = dev_colsums(torch, x, p)
+    finally:
+        capi.set_taper(-1, -1)
+    assert_parity(got, x, p)
+    assert got.tobytes() == again.tobytes()
+
+
+BAD_P = {
+    "descending": lambda n, nnz, rng: np.linspace(nnz, 0, n + 1).astype(np.int32),
+    "random": lambda n, nnz, rng: rng.integers(0, nnz + 1, size=n + 1).astype(np.int32),
+    "negative_and_huge": lambda n, nnz, rng: rng.choice(
+        np.array([-2**31, -1, 0, nnz // 2, nnz, nnz + 1, 2**31 - 1], dtype=np.int64), size=n + 1).astype(np.int32),
+    "all_past_the_end": lambda n, nnz, rng: np.full(n + 1, 2**31 - 1, dtype=np.int32),
+    "nonzero_start": lambda n, nnz, rng: np.sort(rng.integers(nnz // 3, nnz + 1, size=n + 1)).astype(np.int32),
+    "sawtooth": lambda n, nnz, rng: ((np.arange(n + 1) * 37) % 4096 * (nnz // 4096)).astype(np.int32),
+}
+
+
+@pytest.mark.parametrize("pattern", sorted(BAD_P))
+@pytest.mark.parametrize("ncol,nnz", [(50_000, 600_000), (300, 5_000_000)])
+def test_invalid_offsets_on_a_device_entry_stay_in_bounds(torch_cuda, pattern, ncol, nnz):
+    """include/rcppsparse_hip.h: the device entries trust p[] ("their reads and writes stay in
+    bounds for any p, but the sums are then unspecified").  Offsets that no dgCMatrix can have
+    must neither fault, nor hang, nor write outside the output and the workspace."""
+    torch = torch_cuda
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(pattern.encode()))
+    p = BAD_P[pattern](ncol, nnz, rng)
+    pad = 4096
+    out = torch.full((ncol + 2 * pad,), -7.0, dtype=torch.float64, device="cuda")
+    wsb = capi.workspace_bytes(ncol, nnz)
+    ws = torch.full((wsb + 2 * pad,), 0x5A, dtype=torch.uint8, device="cuda")
+    xt = torch.ones(nnz, dtype=torch.float64, device="cuda")
+    pt = torch.from_numpy(p).cuda()
+    for op in (None, capi.OP_MAX):
+        if op is None:
+            capi.column_sums_device(xt, pt, out[pad:pad + ncol], ws[pad:pad + wsb])
+        else:
+            capi.column_reduce_device(xt, pt, op, out[pad:pad + ncol], ws[pad:pad + wsb])
+        torch.cuda.synchronize()                       # a fault would surface here
+        assert bool(torch.all(out[:pad] == -7.0)) and bool(torch.all(out[pad + ncol:] == -7.0))
+        assert bool(torch.all(ws[:pad] == 0x5A)) and bool(torch.all(ws[pad + wsb:] == 0x5A))
+    # the device is still healthy: a valid call right after gives the right answer
+    good = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=1, nrow=None))
+    got = capi.column_sums_device(xt, torch.from_numpy(good).cuda()).cpu().numpy()
+    assert np.array_equal(got, np.diff(good).astype(np.float64))
+
+
+def test_max_min_at_the_int32_limit(torch_cuda):
+    """the guard that gives the zero-filled lanes past the end of x the identity must
+    not overflow when nnz is within one group of 2^31 - 1: max of all-negative and min of
+    all-positive data in the last column."""
+    torch = torch_cuda
+    nnz = 2**31 - 1
+    if torch.cuda.get_device_properties(0).total_memory < 40 * 2**30:
+        pytest.skip("needs >= 40 GB of HBM")
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    capi.gen_values_device(xt, seed=5, kind=1)         # U(0, 1): all positive
+    cuts = [0, 5, nnz - 300, nnz - 1, nnz]
+    p = torch.tensor(cuts, dtype=torch.int32, device="cuda")
+    mins = capi.column_reduce_device(xt, p, capi.OP_MIN).cpu().numpy()
+    want_min = [float(torch.min(xt[a:b]).item()) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(mins, want_min) and np.all(mins > 0.0)
+    xt.neg_()                                          # all negative
+    maxs = capi.column_reduce_device(xt, p, capi.OP_MAX).cpu().numpy()
+    assert np.array_equal(maxs, [-v for v in want_min]) and np.all(maxs < 0.0)
+
+
+def test_handle_calls_leave_the_current_device_alone(torch_cuda):
+    """the handle entries switch to the handle's device for the call and put the calling
+    thread's device back (on this 1-GPU box: the current device and torch's view of it do not move)."""
+    torch = torch_cuda
+    m = synth.rsparsematrix(500, 80, density=0.05, seed=2)
+    before = torch.cuda.current_device()
+    h = capi.DeviceCSC(m["x"], m["p"], m["Dim"], i=m["i"])
+    h.column_sums(); h.row_sums(); h.crossprod()
+    h.close()
+    capi.column_sums_host_multi(m["x"], m["p"], devices=[0, 0, 0])
+    assert torch.cuda.current_device() == before
+    t = torch.ones(4, device="cuda")
+    assert t.device.index == before

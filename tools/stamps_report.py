@@ -15,11 +15,12 @@ import torch
 from bench import build_offsets, SEED
 
 
-NST = 32768   # kStampChunks of the diagnostic build
+NST = 65536   # kStampChunks of the diagnostic build
 
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    taper = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None   # "permille,rows[,chunk_rows]"
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     L = ctypes.CDLL(os.path.join(here, "rcppsparse_amd", "librcppsparse_hip_stamps.so"))
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
@@ -28,6 +29,13 @@ def main():
     L.rsp_column_sums_device.argtypes = [vp, vp, i32, i64, vp, vp, ctypes.c_size_t, vp]
     L.rsp_gen_values_device.argtypes = [vp, i64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, vp]
     L.rsp_debug_read_stamps.argtypes = [vp, ctypes.c_int]
+    stream = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None   # "waves,rows"
+    if taper:
+        L.rsp_set_taper(taper[0], taper[1])
+        if len(taper) > 2:
+            L.rsp_set_tuning(taper[2])
+    if stream and len(stream) > 2:
+        L.rsp_set_experiment(stream[2])     # third field of an (otherwise unused) "a,b,experiment" argument
     nrow, ncol, nnz, shape, p = build_offsets(wl, 0)
     pt = torch.from_numpy(p).cuda()
     xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
@@ -41,7 +49,8 @@ def main():
     st = np.zeros(NST * 8, dtype=np.uint64)
     assert L.rsp_debug_read_stamps(st.ctypes.data, st.size) == 0
     st = st.reshape(NST, 8).astype(np.int64)
-    st = st[st[:, 6] > 0]
+    widx = np.nonzero(st[:, 6] > 0)[0]
+    st = st[widx]
     t0 = st[:, 0].min()
     us = lambda a: float(np.median(a)) / 100.0
     names = ["entry->search done", "search->window filled", "window->first 4 rows", "4 rows->8 rows",
@@ -60,6 +69,28 @@ def main():
     resident = np.cumsum(starts) - np.cumsum(ends)
     step = max(1, len(resident) // 24)
     print("  resident stamped waves every", step * 10, "us:", " ".join(str(int(v)) for v in resident[::step]))
+    # delivered bandwidth over time: a wave consumes its first 8 rows between stamps 2 and 4 and the
+    # rest of its chunk, at a steady pace, between stamps 4 and 5 (rows of 1 KiB)
+    nbins = 40
+    width = span / nbins
+    rows = np.zeros(nbins)
+    total_rows = (nnz + 127) // 128
+    per_wave = np.full(len(st), float(total_rows) / max(1, len(st)))      # (mean chunk length)
+    if taper and taper[0] > 0 and (len(taper) < 3 or taper[2] == 0):          # the automatic plan of capi.hip make_plan
+        r = int(min(256, max(16, -(-total_rows // 8192))))
+        body_rows = (total_rows * (1000 - taper[0]) // 1000) // r * r
+        if taper[1] < r and -(-total_rows // r) > 6144:
+            per_wave = np.where(widx < body_rows // r, float(r), float(taper[1]))
+    for a, b, share in ((2, 4, None), (4, 5, None)):
+        ta, tb = (st[:, a] - t0).astype(np.float64), (st[:, b] - t0).astype(np.float64)
+        r = np.minimum(8.0, per_wave) if a == 2 else np.maximum(per_wave - 8.0, 0.0)
+        dur = np.maximum(tb - ta, 1.0)
+        for k in range(nbins):
+            lo, hi = k * width, (k + 1) * width
+            ov = np.clip(np.minimum(tb, hi) - np.maximum(ta, lo), 0.0, None)
+            rows[k] += float(np.sum(r * ov / dur))
+    gbps = rows * 1024.0 / (width / 100.0 * 1e-6) / 1e9
+    print(f"  consumed GB/s per {width / 100:.1f} us bin:", " ".join(f"{v:.0f}" for v in gbps))
 
 
 if __name__ == "__main__":
