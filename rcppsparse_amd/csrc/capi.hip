@@ -441,11 +441,11 @@ int rsp_csc_column_means(rsp_csc_t h, double* means) { return csc_run(h, means, 
 
 // ---- row-wise "next" entries (Matrix::rowSums / rowMeans, RcppSparse.h:138-156) ----------
 
-static int row_plan(int32_t nrow, int64_t nnz, rsp::RowSumsLayout* L) {
+static int row_plan(int32_t nrow, int64_t nnz, bool keep_row_form, rsp::RowSumsLayout* L) {
     if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
     if (int rc = check_sizes(0, nnz)) return rc;
     const size_t cs = rsp::workspace_bytes_for(make_plan(nnz).nchunks);
-    hipError_t e = rsp::plan_row_sums(nrow, nnz, cs, L);
+    hipError_t e = rsp::plan_row_sums(nrow, nnz, cs, keep_row_form, L);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(RSP_ERR_HIP, "planning the row-wise path failed: %s", hipGetErrorString(e));
@@ -455,7 +455,7 @@ static int row_plan(int32_t nrow, int64_t nnz, rsp::RowSumsLayout* L) {
 
 size_t rsp_row_sums_workspace_bytes(int32_t nrow, int64_t nnz) {
     rsp::RowSumsLayout L;
-    if (row_plan(nrow, nnz, &L) != RSP_OK) return 0;
+    if (row_plan(nrow, nnz, false, &L) != RSP_OK) return 0;
     return L.persistent_bytes + L.scratch_bytes;
 }
 
@@ -464,18 +464,14 @@ static int row_enqueue(const double* d_x, const int32_t* d_i, int32_t nrow, int6
     if (nrow == 0) return RSP_OK;
     if (!d_out || (nnz > 0 && (!d_x || !d_i))) return fail(RSP_ERR_BAD_ARG, "null device pointer");
     rsp::RowSumsLayout L;
-    if (int rc = row_plan(nrow, nnz, &L)) return rc;
+    if (int rc = row_plan(nrow, nnz, false, &L)) return rc;
     if (!ws || ws_bytes < L.persistent_bytes + L.scratch_bytes)
         return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes,
                     L.persistent_bytes + L.scratch_bytes);
     char* persist = (char*)ws;
     char* scratch = persist + L.persistent_bytes;
-    HIP_TRY(rsp::launch_row_transpose_values(d_x, d_i, nrow, nnz, L, persist, scratch, stream));
-    // rowSums(A) = columnSums(t(A)): same kernels, row offsets in place of p
-    const rsp::LaunchPlan plan = make_plan(nnz);
-    HIP_TRY(rsp::launch_column_sums((const double*)(persist + L.vals_off), (const int32_t*)(persist + L.prow_off),
-                                    nrow, (int32_t)nnz, d_out, plan, persist + L.colsums_off, divisor, means,
-                                    stream));
+    HIP_TRY(rsp::launch_row_build(d_x, d_i, nrow, nnz, L, persist, scratch, stream));
+    HIP_TRY(rsp::launch_row_reduce(nrow, nnz, L, persist, d_out, divisor, means, make_plan(nnz), stream));
     return RSP_OK;
 }
 
@@ -499,15 +495,15 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
     if (h->nnz > 0 && !h->d_i)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: rowSums needs the row indices");
     if (!h->row_ready) {   // build the row-major form once; the scratch is released right after
-        if (int rc = row_plan(h->nrow, h->nnz, &h->row_layout)) return rc;
+        if (int rc = row_plan(h->nrow, h->nnz, true, &h->row_layout)) return rc;
         void* scratch = nullptr;
         hipError_t e = hipSuccess;
         if (!h->d_row_persist) e = hipMalloc(&h->d_row_persist, h->row_layout.persistent_bytes);
         if (e == hipSuccess && !h->d_row_out) e = hipMalloc((void**)&h->d_row_out, (size_t)h->nrow * 8);
         if (e == hipSuccess) e = hipMalloc(&scratch, h->row_layout.scratch_bytes);
         if (e == hipSuccess)
-            e = rsp::launch_row_transpose_values(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout,
-                                                 h->d_row_persist, scratch, h->stream);
+            e = rsp::launch_row_build(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout, h->d_row_persist, scratch,
+                                      h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (scratch) (void)hipFree(scratch);
         if (e != hipSuccess) {   // leave the handle usable for the column entries and for a retry
@@ -520,11 +516,8 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
         }
         h->row_ready = true;
     }
-    const rsp::RowSumsLayout& L = h->row_layout;
-    char* persist = (char*)h->d_row_persist;
-    HIP_TRY(rsp::launch_column_sums((const double*)(persist + L.vals_off), (const int32_t*)(persist + L.prow_off),
-                                    h->nrow, (int32_t)h->nnz, h->d_row_out, make_plan(h->nnz),
-                                    persist + L.colsums_off, means ? (double)h->ncol : 1.0, means, h->stream));
+    HIP_TRY(rsp::launch_row_reduce(h->nrow, h->nnz, h->row_layout, h->d_row_persist, h->d_row_out,
+                                   means ? (double)h->ncol : 1.0, means, make_plan(h->nnz), h->stream));
     HIP_TRY(hipMemcpyAsync(host_out, h->d_row_out, (size_t)h->nrow * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return RSP_OK;

@@ -57,6 +57,8 @@ constexpr uint32_t kLowOccupancyExtraLds = 32 * 1024;
 constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
 constexpr int kTaperMinChunks = 6144;  // only calls of more than one round of resident waves (256 CUs x 24) are tapered
+constexpr size_t kLdsBitmapMinBytes = 16 * 1024;   // row-restricted sums: smaller bitmaps stay in L1 ...
+constexpr size_t kLdsBitmapMaxBytes = 128 * 1024;  // ... bigger ones do not fit beside the kernel's 21.5 KB of LDS
 constexpr int kMaxChunkRows = 1 << 20;   // 1 GiB of x per chunk: byte counts and offsets inside a chunk stay < 2^31
 
 // chunk index <-> first element, shared by host code and both kernels
@@ -85,15 +87,21 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               int32_t bitmap_words = 0);
 
 // Workspace layout of the row-wise path (rowsums.hip); offsets in bytes, 256-aligned.
-// persistent = row-major values + row offsets + carries; scratch = sort keys + rocPRIM temp.
+// mode 0 (block form, one-shot calls): persistent = the entries grouped by row block (values, row indices)
+// and the first entry of every block; scratch = rocPRIM temp.
+// mode 1 (row form, kept by the handle): persistent = row-major values + row offsets + the column-sum
+// carries; scratch = sort keys + rocPRIM temp.
 struct RowSumsLayout {
-    size_t vals_off, prow_off, colsums_off, persistent_bytes;
+    int mode;
+    size_t vals_off, rows_off, boff_off, prow_off, colsums_off, persistent_bytes;
     size_t keys_off, temp_off, temp_bytes, scratch_bytes;
+    int32_t shift, nblocks;
 };
-hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, RowSumsLayout* L);
-hipError_t launch_row_transpose_values(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
-                                       const RowSumsLayout& L, void* persist, void* scratch,
-                                       hipStream_t stream);
+hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form, RowSumsLayout* L);
+hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
+                            const RowSumsLayout& L, void* persist, void* scratch, hipStream_t stream);
+hipError_t launch_row_reduce(int32_t nrow, int64_t nnz, const RowSumsLayout& L, void* persist, double* d_out,
+                             double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream);
 
 // Matrix::crossprod on the device (crossprod.hip): dense ncol x ncol, column-major.
 struct CrossprodLayout {   // workspace of the row-major path

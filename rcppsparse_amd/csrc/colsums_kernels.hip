@@ -527,7 +527,11 @@ __device__ __forceinline__ void process_row(double v0, double v1, int rs, int la
 // ---------------------------------------------------------------------------
 // main kernel: one wavefront per chunk
 // ---------------------------------------------------------------------------
-template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG, int OP = kOpSum>
+// LDSMAP (row-restricted sums only): the row bitmap is copied into (dynamic) LDS once per workgroup and
+// probed there.  With ~1e6 rows the bitmap (125 KB) is too big for the 32 KB L1, and 64 random 4-byte
+// probes per wave instruction into L2 cost more than the 12 B/nnz stream itself; in LDS they are a
+// couple of cycles.  One workgroup (WPG wavefronts) per CU then.
+template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG, int OP = kOpSum, bool LDSMAP = false>
 __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     ChunkMap cmap, int32_t nchunks, double* __restrict__ out,
@@ -539,15 +543,23 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     constexpr bool MASKED = (OP == kOpMaskedIn || OP == kOpMaskedOut);
     __shared__ __attribute__((aligned(16))) double s_stage[WPG][kStageSlots];
     __shared__ __attribute__((aligned(16))) int32_t s_win[WPG][kPWin];
-    __shared__ __attribute__((aligned(16))) int32_t s_hist[WPG][kHistPad];
+    static_assert(kHistPad * sizeof(int32_t) <= kStageSlots * sizeof(double), "the histogram lives in the staging area");
 
+    extern __shared__ uint32_t s_bitmap[];   // LDSMAP only: bitmap_words words
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int w = blockIdx.x * WPG + wave_in_wg;
+    if (LDSMAP) {   // (every wavefront of the workgroup takes part, also one without a chunk)
+        for (int k = threadIdx.x; k < bitmap_words; k += WPG * 64) s_bitmap[k] = row_bitmap[k];
+        __syncthreads();
+    }
     if (w >= nchunks) return;
     int32_t* win = s_win[wave_in_wg];
-    int32_t* hist = s_hist[wave_in_wg];
     double* stage = s_stage[wave_in_wg];
+    // the general row path's histogram shares the staging area of the dense path: a wave is in one
+    // of the two at any time, and a dense group that gives up has no further use for what it staged.
+    // 21.5 KB of LDS per workgroup = 7 workgroups (28 wavefronts) per CU.
+    int32_t* hist = reinterpret_cast<int32_t*>(stage);
 
     RSP_STAMP(0);
     const int32_t cs = (int32_t)cmap.start(w);          // (< nnz <= 2^31 - 1)
@@ -624,8 +636,14 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
 #pragma unroll
                 for (int rr = 0; rr < kGroupRows; ++rr) {   // all eight probes in flight together
                     const int2 ij = iv[g * kGroupRows + rr];
-                    m0[rr] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, (ij.x >> 5) * 4, 0, 0);
-                    m1[rr] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, (ij.y >> 5) * 4, 0, 0);
+                    if (LDSMAP) {   // (a row index outside the bitmap -- not a valid dgCMatrix -- reads word 0)
+                        const uint32_t w0 = (uint32_t)ij.x >> 5, w1 = (uint32_t)ij.y >> 5;
+                        m0[rr] = s_bitmap[w0 < (uint32_t)bitmap_words ? w0 : 0u];
+                        m1[rr] = s_bitmap[w1 < (uint32_t)bitmap_words ? w1 : 0u];
+                    } else {
+                        m0[rr] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, (ij.x >> 5) * 4, 0, 0);
+                        m1[rr] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, (ij.y >> 5) * 4, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int rr = 0; rr < kGroupRows; ++rr) {
@@ -894,7 +912,31 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, OP_>), grid,   \
                        block, 0, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,   \
                        carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words)
-    if (op == kOpSumSquares) {
+    // row-restricted sums with a bitmap of 16-128 KB (about 1e5-1e6 rows): bitmap in LDS
+    const size_t bitmap_bytes = (size_t)bitmap_words * 4;
+    if ((op == kOpMaskedIn || op == kOpMaskedOut) && bitmap_bytes > kLdsBitmapMinBytes &&
+        bitmap_bytes <= kLdsBitmapMaxBytes) {
+        static bool raised = false;   // (benign if two threads both do it)
+        if (!raised) {
+            hipError_t ea = hipFuncSetAttribute(
+                (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedIn, true>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBitmapMaxBytes);
+            if (ea == hipSuccess)
+                ea = hipFuncSetAttribute(
+                    (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedOut, true>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBitmapMaxBytes);
+            if (ea != hipSuccess) return ea;
+            raised = true;
+        }
+        if (op == kOpMaskedIn)
+            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedIn, true>),
+                               grid, block, bitmap_bytes, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,
+                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words);
+        else
+            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedOut, true>),
+                               grid, block, bitmap_bytes, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,
+                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words);
+    } else if (op == kOpSumSquares) {
         RSP_LAUNCH_OP(kOpSumSquares);
     } else if (op == kOpSumAbs) {
         RSP_LAUNCH_OP(kOpSumAbs);

@@ -49,15 +49,17 @@ def main():
         row = {"workload": wl, "nnz": nnz, "nrow": nrow, "workspace_GB": nbytes / 1e9,
                "row_sums_device_ms": med, "row_sums_device_nnz_per_s": nnz / med * 1e3,
                "algorithmic_GBps": B / med / 1e6}
-        # cached form: same data re-reduced by the column-sum kernels (prow sits in ws)
-        import ctypes
-        vals = ws[:8 * nnz].view(torch.float64)
-        off = (8 * nnz + 255) // 256 * 256
-        prow = ws[off:off + 4 * (nrow + 1)].view(torch.int32)
-        ws2 = capi.alloc_workspace(nrow, nnz)
-        med2, _ = ev_time(lambda: capi.column_sums_device(vals, prow, out, ws2), 10)
-        row["cached_row_major_ms"] = med2
-        row["cached_nnz_per_s"] = nnz / med2 * 1e3
+        # repeated sums on a resident matrix: the row-wise form is already in the workspace, only the
+        # last kernel runs.  Timed here as "second call with the same workspace minus the build": the C ABI
+        # keeps that form behind the handle (rsp_csc_row_sums), whose call also copies nrow doubles back.
+        if nnz <= 200_000_000:
+            h = capi.DeviceCSC(xt.cpu().numpy(), p, (nrow, ncol), i=it.cpu().numpy())
+            h.row_sums()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                h.row_sums()
+            row["handle_repeat_ms_incl_D2H"] = (time.perf_counter() - t0) / 5 * 1e3
+            h.close()
         # CPU: oracle rowSums on the first columns holding ~5e7 nnz
         ncs = max(1, int(np.searchsorted(p, 50_000_000, side="right")) - 1)
         nz = int(p[ncs])
@@ -69,7 +71,7 @@ def main():
         ref = oracle.row_sums(xs, is_, ps, nrow)
         row["cpu_oracle_nnz_per_s"] = nz / (time.perf_counter() - t0)
         print(json.dumps(row), flush=True)
-        del xt, it, ws, vals, prow
+        del xt, it, ws
         torch.cuda.empty_cache()
 
 
