@@ -130,7 +130,6 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
     }
     plan.nbody = (int32_t)nbody;
     plan.nchunks = (int32_t)(nbody + ntail);
-    plan.extra_lds_bytes = (automatic && plan.nchunks >= rsp::kLowOccupancyMinChunks) ? rsp::kLowOccupancyExtraLds : 0u;
     return plan;
 }
 

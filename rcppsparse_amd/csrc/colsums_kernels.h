@@ -46,14 +46,8 @@ struct LaunchPlan {
     int32_t nbody;         // number of body chunks
     int32_t tail_elems;    // elements per tail chunk, multiple of kRowElems
     int32_t nchunks;       // nbody + tail chunks; >= 1 when nnz > 0
-    uint32_t extra_lds_bytes;  // unused dynamic LDS per workgroup: caps the resident wavefronts per CU (long calls)
     int variant;           // 0 = production kernel; >0 = experiment variants (env RSP_VARIANT)
 };
-// Calls of at least this many chunks (four rounds of the 6144 wave slots) run with 2 workgroups
-// = 8 wavefronts per CU instead of 6 = 24: +1.0-1.3 % on the 1e9-nnz workloads in interleaved A/B
-// (profiles/r02_chunking.md); shorter calls want every slot (C2 loses 30 % at 8 per CU).
-constexpr int kLowOccupancyMinChunks = 4 * 6144;
-constexpr uint32_t kLowOccupancyExtraLds = 32 * 1024;
 constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
 constexpr int kTaperMinChunks = 6144;  // only calls of more than one round of resident waves (256 CUs x 24) are tapered

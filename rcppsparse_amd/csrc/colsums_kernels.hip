@@ -882,7 +882,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     const dim3 grid((plan.nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
     // experiment ids >= 16: (id - 16) KiB of unused dynamic LDS per workgroup, which lowers the number of
     // resident waves per CU (occupancy sweeps, tools/taper_sweep.py)
-    const unsigned extra_lds = plan.variant >= 16 ? (unsigned)(plan.variant - 16) * 1024u : plan.extra_lds_bytes;
+    const unsigned extra_lds = plan.variant >= 16 ? (unsigned)(plan.variant - 16) * 1024u : 0u;
 #define RSP_LAUNCH_K(KERNEL, BR, AUX_)                                                              \
     do {                                                                                           \
         if (means)                                                                                 \
