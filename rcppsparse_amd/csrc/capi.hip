@@ -107,7 +107,9 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
         if (r < rsp::kMinChunkRows) r = rsp::kMinChunkRows;
         if (r > 256) r = 256;
         rows = (int)r;
+        if (total_rows <= rsp::kShortCallRows && rows < rsp::kShortCallChunkRows) rows = rsp::kShortCallChunkRows;
     }
+    plan.short_pipeline = automatic && total_rows <= rsp::kShortCallRows;
     // byte counts and offsets inside one chunk are 32-bit in the kernel (buffer descriptor size,
     // soffset): a chunk never exceeds 1 GiB of x, whatever the knob says
     if (rows > rsp::kMaxChunkRows) rows = rsp::kMaxChunkRows;

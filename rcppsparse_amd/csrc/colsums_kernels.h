@@ -46,8 +46,15 @@ struct LaunchPlan {
     int32_t nbody;         // number of body chunks
     int32_t tail_elems;    // elements per tail chunk, multiple of kRowElems
     int32_t nchunks;       // nbody + tail chunks; >= 1 when nnz > 0
+    bool short_pipeline;   // 4 rows in flight per wavefront instead of 8 (calls that fit one round of waves)
     int variant;           // 0 = production kernel; >0 = experiment variants (env RSP_VARIANT)
 };
+// Calls of at most this many 128-element rows (C2: 78 125) are one round of resident wavefronts that all
+// start together: half of x is requested in the first microsecond and nothing is consumed before it
+// has arrived.  With 4 rows in flight (and 20-row chunks) the first rows are there sooner and the
+// column work starts earlier: C2 26.6 -> 24.6 us (profiles/r02_c2.md); longer calls keep 8.
+constexpr int kShortCallRows = 131072;
+constexpr int kShortCallChunkRows = 20;
 constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
 constexpr int kTaperMinChunks = 6144;  // only calls of more than one round of resident waves (256 CUs x 24) are tapered

@@ -954,7 +954,13 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         case 2: RSP_LAUNCH_W(1); break;                                     // 1 wavefront per workgroup
         case 3: RSP_LAUNCH_W(2); break;                                     // 2 wavefronts per workgroup
         case 4: RSP_LAUNCH_K(colsums_chunks_kernel, kBatchRows, 0); break;  // default cache policy
-        default: RSP_LAUNCH_K(colsums_chunks_kernel, kBatchRows, kLoadAux); break;
+        case 5: RSP_LAUNCH_K(colsums_chunks_kernel, 4, kLoadAux); break;    // 4 rows in flight
+        default:
+            if (plan.short_pipeline)
+                RSP_LAUNCH_K(colsums_chunks_kernel, 4, kLoadAux);
+            else
+                RSP_LAUNCH_K(colsums_chunks_kernel, kBatchRows, kLoadAux);
+            break;
     }
 #undef RSP_LAUNCH_K
 #undef RSP_LAUNCH_OP
