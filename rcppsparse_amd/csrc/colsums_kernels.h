@@ -57,7 +57,7 @@ constexpr int kShortCallRows = 131072;
 constexpr int kShortCallChunkRows = 20;
 constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
-constexpr int kTaperMinChunks = 6144;  // only calls of more than one round of resident waves (256 CUs x 24) are tapered
+constexpr int kTaperMinChunks = 12288; // only calls of more than two rounds of resident waves are tapered (a 1.25e8-nnz shard loses 1 % with it)
 constexpr size_t kLdsBitmapMinBytes = 16 * 1024;   // row-restricted sums: smaller bitmaps stay in L1 ...
 constexpr size_t kLdsBitmapMaxBytes = 128 * 1024;  // ... bigger ones do not fit beside the kernel's 21.5 KB of LDS
 constexpr int kMaxChunkRows = 1 << 20;   // 1 GiB of x per chunk: byte counts and offsets inside a chunk stay < 2^31
