@@ -69,7 +69,9 @@ int chunk_rows_setting() {
 
 // Taper of the automatic chunking: the last `permille` thousandths of x are cut into chunks of
 // `rows` rows (rsp_set_taper / RSP_TAPER="permille,rows"; -1 = built-in default).
-void taper_setting(int* permille, int* rows) {
+// *chosen: the caller picked the taper (setter or environment), so the "long calls only" rule of the
+// automatic choice does not apply.
+void taper_setting(int* permille, int* rows, bool* chosen) {
     static const int env_pm = [] {
         const char* s = getenv("RSP_TAPER");
         return s ? atoi(s) : -1;
@@ -83,6 +85,7 @@ void taper_setting(int* permille, int* rows) {
     int r = g_taper_rows.load(std::memory_order_relaxed);
     if (pm < 0) pm = env_pm;
     if (r < 0) r = env_rows;
+    *chosen = pm >= 0;
     if (pm < 0) pm = rsp::kTaperPermille;
     if (r <= 0) r = rsp::kTaperRows;
     *permille = pm > 1000 ? 1000 : pm;
@@ -123,8 +126,9 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
     plan.tail_elems = plan.chunk_elems;
     int64_t nbody = nnz > 0 ? (total_rows + rows - 1) / rows : 0, ntail = 0;
     int pm, trows;
-    taper_setting(&pm, &trows);
-    if (automatic && pm > 0 && trows < rows && nbody > rsp::kTaperMinChunks) {
+    bool chosen;
+    taper_setting(&pm, &trows, &chosen);
+    if (automatic && pm > 0 && trows < rows && (chosen || nbody > rsp::kTaperMinChunks)) {
         const int64_t body_rows = (total_rows * (1000 - pm) / 1000) / rows * rows;
         nbody = body_rows / rows;
         ntail = (total_rows - body_rows + trows - 1) / trows;

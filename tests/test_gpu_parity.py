@@ -647,15 +647,20 @@ def test_chunk_rows_knob_is_clamped(torch_cuda):
 @pytest.mark.parametrize("taper", [(0, 0), (150, 64), (500, 16), (1000, 32), (999, 1)])
 def test_tapered_chunking_keeps_parity_and_bits(torch_cuda, taper):
     """rsp_set_taper: the last part of x in shorter chunks.  Every setting stays within tolerance
-    of the oracle, bit-stable, on a matrix with > 12288 chunks (so that the taper applies), with a
-    giant column crossing the body/tail edge and short columns on both sides of it."""
+    of the oracle, bit-stable (an explicit setting applies to a call of any length), with a giant
+    column crossing the body/tail edge and short columns on both sides of it; the tapered plan really
+    has more chunks than the plain one."""
     torch = torch_cuda
     counts = np.concatenate([synth.uniform_counts(40_000, 12_000_000, seed=4, nrow=None), [9_000_000],
                              synth.uniform_counts(300_000, 3_000_000, seed=5, nrow=None)]).astype(np.int64)
     p = synth.offsets_from_counts(counts)
     x = synth.gen_values(int(p[-1]), seed=6, kind=0)
     try:
+        capi.set_taper(0, 0)
+        plain_ws = capi.workspace_bytes(len(p) - 1, len(x))
         capi.set_taper(*taper)
+        if taper[0] > 0 and taper[1] < 23:       # (the automatic body chunks are 23 rows at this size)
+            assert capi.workspace_bytes(len(p) - 1, len(x)) > plain_ws     # more, shorter chunks
         got = dev_colsums(torch, x, p)
         again = dev_colsums(torch, x, p)
     finally:
