@@ -438,16 +438,25 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
             }
             if (check_len && __ballot(hi - lo > kDenseMaxLen) != 0ull) return false;   // (single pass: nothing emitted yet)
             double s = (j == 0) ? A : P::id();   // the continuing column keeps adding to its running result
-            // storage-order adds, four unguarded LDS reads in flight (reading past a short column's
-            // end stays inside the workgroup's LDS and is harmless; the add is what is predicated)
+            // Storage-order adds.  Whole quads first: four unguarded LDS reads, four adds and ONE select
+            // per lane and step (a lane whose column has no whole quad left keeps its sum; what it read
+            // past its column's end stays inside the workgroup's LDS and is thrown away); then the last
+            // 0-3 elements of every column.  Same order of adds as element by element, at less than half
+            // the vector instructions.
             const int n = hi - lo;
             const double* sp = stage + lo;
-            for (int k = 0; __ballot(k < n) != 0ull; k += 4) {
-                const double e0 = sp[k], e1 = sp[k + 1], e2 = sp[k + 2], e3 = sp[k + 3];
-                s = P::comb(s, k < n ? e0 : P::id());       // (adding the identity is exact)
-                s = P::comb(s, k + 1 < n ? e1 : P::id());
-                s = P::comb(s, k + 2 < n ? e2 : P::id());
-                s = P::comb(s, k + 3 < n ? e3 : P::id());
+            const int nquads = n >> 2;
+            for (int q = 0; __ballot(q < nquads) != 0ull; ++q) {
+                const double e0 = sp[4 * q], e1 = sp[4 * q + 1], e2 = sp[4 * q + 2], e3 = sp[4 * q + 3];
+                const double t = P::comb(P::comb(P::comb(P::comb(s, e0), e1), e2), e3);
+                s = q < nquads ? t : s;
+            }
+            {
+                const double* tp = sp + 4 * nquads;
+                const int rem = n & 3;
+                const double e0 = tp[0], e1 = tp[1], e2 = tp[2];
+                const double t0 = P::comb(s, e0), t1 = P::comb(t0, e1), t2 = P::comb(t1, e2);
+                s = rem == 0 ? s : (rem == 1 ? t0 : (rem == 2 ? t1 : t2));
             }
             if (active && j < n_ends) emit_column<P>(st, st.ccur + j, j, s, ncol, w, out, carry_head, divisor);
             if (active && j == n_ends) carry_out = s;
@@ -470,13 +479,19 @@ __device__ __forceinline__ bool dense_group(const d2 (&v)[kGroupRows], int gs, u
         double s = (lane == 0) ? A : P::id();
         const int cnt = (hi - lo - sub + L - 1) >> shift;   // this lane adds elements lo + sub + m * L, m < cnt
         const double* sp = stage + lo + sub;
-        for (int k = 0; __ballot(k < cnt) != 0ull; k += 4) {
+        const int nquads = cnt >> 2;                        // whole quads first, then the last 0-3 (see above)
+        for (int q = 0; __ballot(q < nquads) != 0ull; ++q) {
+            const int k = 4 * q;
             const double e0 = sp[k << shift], e1 = sp[(k + 1) << shift], e2 = sp[(k + 2) << shift],
                          e3 = sp[(k + 3) << shift];
-            s = P::comb(s, k < cnt ? e0 : P::id());
-            s = P::comb(s, k + 1 < cnt ? e1 : P::id());
-            s = P::comb(s, k + 2 < cnt ? e2 : P::id());
-            s = P::comb(s, k + 3 < cnt ? e3 : P::id());
+            const double t = P::comb(P::comb(P::comb(P::comb(s, e0), e1), e2), e3);
+            s = q < nquads ? t : s;
+        }
+        {
+            const int k = 4 * nquads, rem = cnt & 3;
+            const double e0 = sp[k << shift], e1 = sp[(k + 1) << shift], e2 = sp[(k + 2) << shift];
+            const double t0 = P::comb(s, e0), t1 = P::comb(t0, e1), t2 = P::comb(t1, e2);
+            s = rem <= 0 ? s : (rem == 1 ? t0 : (rem == 2 ? t1 : t2));
         }
         // the L partial results of a column: pairs, quads, the two quads of each 8
         s = P::comb(s, dpp_f64<0xB1>(s));

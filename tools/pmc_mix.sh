@@ -6,10 +6,10 @@ set -e -o pipefail
 WL=$1
 cd /tmp && export TMPDIR=/tmp
 O=/root/repo/gpurun_out
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM"; do
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR" "SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --output-format csv -d $O/pmc_${WL}_$tag -- \
-    python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $WL > $O/pmc_${WL}_$tag.log 2>&1
+    python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --latency-calls 1 --workload $WL > $O/pmc_${WL}_$tag.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -11,7 +11,11 @@ import numpy as np
 import torch
 
 from bench import build_offsets, SEED
-from rcppsparse_amd import capi
+from rcppsparse_amd import capi, _build
+
+if os.environ.get("RSP_AB_LIB"):        # time another build of the library (e.g. a saved baseline .so)
+    _build.LIB_PATH = os.path.abspath(os.environ["RSP_AB_LIB"])
+    _build.build_library = lambda *a, **k: _build.LIB_PATH
 
 
 def main():
