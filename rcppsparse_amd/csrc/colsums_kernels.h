@@ -55,6 +55,7 @@ struct LaunchPlan {
 // column work starts earlier: C2 26.6 -> 24.6 us (profiles/r02_c2.md); longer calls keep 8.
 constexpr int kShortCallRows = 131072;
 constexpr int kShortCallChunkRows = 20;
+constexpr int kGuessWindow = 1024;   // offsets read around the guessed first column of a chunk (short calls)
 constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
 constexpr int kTaperMinChunks = 12288; // only calls of more than two rounds of resident waves are tapered (a 1.25e8-nnz shard loses 1 % with it)
