@@ -27,7 +27,8 @@
  * without checking): p[0] == 0, p non-decreasing, p[ncol] == nnz.  The host
  * entry points verify this and return RSP_ERR_BAD_ARG otherwise; the device
  * entry points trust the caller (their reads and writes stay in bounds for
- * any p, but the sums are then unspecified).
+ * any p -- tests/test_gpu_parity.py::test_invalid_offsets_on_a_device_entry_stay_in_bounds --
+ * but the sums are then unspecified).
  */
 #ifndef RCPPSPARSE_HIP_H
 #define RCPPSPARSE_HIP_H
@@ -97,7 +98,9 @@ int rsp_mcsc_free(rsp_mcsc_t handle);
 /* The slot layout x / i / p / Dim of reference RcppSparse.h:29-30 is the wire
  * format; i may be NULL (it is only kept for the row-wise "next" entries).
  * A handle is owned by one thread at a time (calls on the same handle must not
- * overlap); different handles may be used from different threads. */
+ * overlap); different handles may be used from different threads.  The handle
+ * entries (and the multi-GPU host entries) run on the handle's device and put the
+ * calling thread's current HIP device back before they return. */
 typedef struct rsp_csc *rsp_csc_t;
 
 int rsp_csc_upload(const double *x, const int32_t *i, const int32_t *p,
@@ -230,7 +233,8 @@ int rsp_rebase_offsets(const int32_t *p, int32_t c0, int32_t c1, int32_t *p_loca
 /* ---- RCCL gatherv of per-shard sums over xGMI -------------------------- */
 /* One communicator per process (one process per GPU).  The 128-byte unique id
  * is created on rank 0 and distributed by the caller (e.g. a torch.distributed
- * broadcast or a file), then every rank calls rsp_comm_init. */
+ * broadcast or a file), then every rank calls rsp_comm_init, which makes `device`
+ * the calling thread's current HIP device (as a process-per-GPU program wants). */
 #define RSP_UNIQUE_ID_BYTES 128
 typedef struct rsp_comm *rsp_comm_t;
 
