@@ -93,11 +93,14 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 // and the first entry of every block; scratch = rocPRIM temp.
 // mode 1 (row form, kept by the handle): persistent = row-major values + row offsets + the column-sum
 // carries; scratch = sort keys + rocPRIM temp.
+// mode 2 (tile partition, one-shot calls up to 1.6e7 rows): persistent as mode 0; scratch = the
+// (block, supertile) count table + rocPRIM scan temp.
 struct RowSumsLayout {
     int mode;
     size_t vals_off, rows_off, boff_off, prow_off, colsums_off, persistent_bytes;
-    size_t keys_off, temp_off, temp_bytes, scratch_bytes;
-    int32_t shift, nblocks;
+    size_t table_off, keys_off, temp_off, temp_bytes, scratch_bytes;
+    int32_t shift, nblocks, nsuper;
+    int64_t super_elems;
 };
 hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form, RowSumsLayout* L);
 hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
