@@ -109,6 +109,39 @@ def test_row_sums_1e8_against_oracle(torch_cuda):
     check(got, x, i, p, nrow)
 
 
+@pytest.mark.parametrize("nrow,nnz", [(13_700_000, 3_000_000), (40_000_000, 5_000_000), (16_384, 2_000_000),
+                                      (16_385, 400_000)])
+def test_row_sums_forms_by_row_count(torch_cuda, nrow, nnz):
+    """The one-shot entry regroups by 16384-row blocks with the hand-written tile partition up to 832
+    blocks (1.36e7 rows) and sorts by 4096-row block above that; a matrix of exactly one block and
+    one of two blocks sit on the other edge.  Same oracle, same tolerance, bit-stable."""
+    torch = torch_cuda
+    ncol = 2_000
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=nrow % 1000, nrow=nrow))
+    pt = torch.from_numpy(p).cuda()
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    it = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    capi.gen_values_device(xt, 7, 0, 0)
+    capi.gen_row_indices_device(it, pt, nrow, 7)
+    got = capi.row_sums_device(xt, it, nrow).cpu().numpy()
+    again = capi.row_sums_device(xt, it, nrow).cpu().numpy()
+    assert got.tobytes() == again.tobytes()
+    x = oracle.gen_values(nnz, 7, 0, 0)
+    i = oracle.gen_row_indices(p, nrow, 7)
+    check(got, x, i, p, nrow)
+    # entries whose row index is not in [0, nrow) -- not a valid dgCMatrix -- are left out, not added elsewhere
+    it2 = it.clone()
+    it2[::1000] = nrow + 5
+    it2[1::1000] = -3
+    got2 = capi.row_sums_device(xt, it2, nrow).cpu().numpy()
+    keep = np.ones(nnz, dtype=bool)
+    keep[::1000] = False
+    keep[1::1000] = False
+    ref2 = np.bincount(i[keep], weights=x[keep], minlength=nrow)
+    scale2 = np.bincount(i[keep], weights=np.abs(x[keep]), minlength=nrow)
+    assert np.all(np.abs(got2 - ref2) <= 1e-11 * np.maximum(scale2, 1e-300) + 1e-300)
+
+
 @pytest.mark.parametrize("seed", range(25))
 def test_fuzz_row_entries_and_masks(torch_cuda, seed):
     """Random shapes/densities: rowSums, rowMeans and the row-restricted column sums against the
