@@ -277,6 +277,11 @@ int rsp_set_tuning(int chunk_rows);
  * the final round finish at different times.  (0, 0) = no taper, (-1, -1) = built-in default.
  * Results stay within the documented tolerance for every setting. */
 int rsp_set_taper(int tail_permille, int tail_chunk_rows);
+/* How a call over nnz entries is cut into chunks (one wavefront each) under the settings in force:
+ * plan4 = { elements per body chunk, number of body chunks, elements per tail chunk, total chunks }.
+ * Chunk w starts at w * body for w < nbody and at nbody * body + (w - nbody) * tail after that; all
+ * sizes are multiples of 128 elements.  Pure host arithmetic, no device needed (tools, tests). */
+int rsp_plan_describe(int64_t nnz, int32_t *plan4);
 /* Selects an alternative build of the main kernel for A/B measurements
  * (0 = production; 1 = 16 rows in flight; 2 / 3 = 1 / 2 wavefronts per workgroup;
  * 4 = default cache policy instead of nt loads).  Not for production use; results

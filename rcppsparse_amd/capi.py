@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
-    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper",
+    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe",
     "rsp_set_experiment",
 )
 
@@ -120,6 +120,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_set_tuning.argtypes = [c.c_int]
     L.rsp_set_experiment.argtypes = [c.c_int]
     L.rsp_set_taper.argtypes = [c.c_int, c.c_int]
+    L.rsp_plan_describe.argtypes = [i64, ip]
     _lib = L
     return L
 
@@ -156,6 +157,13 @@ def set_tuning(chunk_rows: int = 0) -> None:
 def set_taper(tail_permille: int = -1, tail_chunk_rows: int = -1) -> None:
     """(0, 0) = no taper, (-1, -1) = the library's default."""
     _check(load().rsp_set_taper(int(tail_permille), int(tail_chunk_rows)))
+
+
+def plan_describe(nnz: int) -> dict:
+    """How a call over nnz entries would be chunked now (rsp_plan_describe)."""
+    out = np.zeros(4, dtype=np.int32)
+    _check(load().rsp_plan_describe(int(nnz), _ip(out)))
+    return {"body_elems": int(out[0]), "nbody": int(out[1]), "tail_elems": int(out[2]), "nchunks": int(out[3])}
 
 
 def set_experiment(variant: int = 0) -> None:

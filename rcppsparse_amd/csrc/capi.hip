@@ -259,6 +259,17 @@ int rsp_set_tuning(int chunk_rows) {
     return RSP_OK;
 }
 
+int rsp_plan_describe(int64_t nnz, int32_t* plan4) {
+    if (!plan4) return fail(RSP_ERR_BAD_ARG, "plan4 is null");
+    if (int rc = check_sizes(0, nnz)) return rc;
+    const rsp::LaunchPlan plan = make_plan(nnz);
+    plan4[0] = plan.chunk_elems;
+    plan4[1] = plan.nbody;
+    plan4[2] = plan.tail_elems;
+    plan4[3] = plan.nchunks;
+    return RSP_OK;
+}
+
 int rsp_set_taper(int tail_permille, int tail_chunk_rows) {
     if (tail_permille > 1000) return fail(RSP_ERR_BAD_ARG, "tail_permille is above 1000");
     g_taper_permille.store(tail_permille < 0 ? -1 : tail_permille, std::memory_order_relaxed);

@@ -141,3 +141,56 @@ def test_workspace_size_is_a_pure_function_of_nnz():
     a = capi.workspace_bytes(10, 10**9)
     assert a == capi.workspace_bytes(10**6, 10**9) and a >= 24 * (10**9 // (256 * 128))
     assert capi.workspace_bytes(5, 0) > 0
+
+
+def _chunk_starts(plan, nnz):
+    w = np.arange(plan["nchunks"], dtype=np.int64)
+    edge = plan["nbody"] * plan["body_elems"]
+    return np.where(w < plan["nbody"], w * plan["body_elems"], edge + (w - plan["nbody"]) * plan["tail_elems"])
+
+
+@pytest.mark.parametrize("nnz", [1, 127, 128, 129, 2048, 10**5, 10**7, 125_000_000, 10**9, 2**31 - 1])
+def test_chunk_plan_tiles_x_exactly(nnz):
+    """rsp_plan_describe: whatever the knobs say, the chunks are whole 128-element rows, start where the
+    previous one ends, cover [0, nnz) with no empty chunk, never exceed 1 GiB of x, and the workspace is
+    32 bytes per chunk."""
+    try:
+        for tuning, taper in [(0, (-1, -1)), (0, (0, 0)), (0, (300, 16)), (0, (1000, 8)), (1, (-1, -1)),
+                              (37, (-1, -1)), (2**22, (-1, -1)), (2**30, (500, 1))]:
+            capi.set_tuning(tuning)
+            capi.set_taper(*taper)
+            plan = capi.plan_describe(nnz)
+            assert plan["body_elems"] % 128 == 0 and plan["tail_elems"] % 128 == 0
+            assert 128 <= plan["tail_elems"] <= plan["body_elems"] <= 2**27
+            assert 0 <= plan["nbody"] <= plan["nchunks"] and plan["nchunks"] >= 1
+            starts = _chunk_starts(plan, nnz)
+            assert starts[0] == 0 and np.all(np.diff(starts) > 0) and starts[-1] < nnz
+            last_len = plan["body_elems"] if plan["nchunks"] == plan["nbody"] else plan["tail_elems"]
+            assert starts[-1] + last_len >= nnz                       # the last chunk reaches the end ...
+            if plan["nchunks"] > plan["nbody"] > 0:                   # ... and the tail begins where the body ends
+                assert starts[plan["nbody"]] == plan["nbody"] * plan["body_elems"]
+            assert capi.workspace_bytes(10, nnz) == -(-32 * plan["nchunks"] // 256) * 256
+    finally:
+        capi.set_tuning(0)
+        capi.set_taper(-1, -1)
+
+
+def test_automatic_chunk_plan_policy():
+    """The automatic policy: short calls (one round of wavefronts) get 20-row chunks and no taper; calls of
+    more than two rounds get 256-row chunks with the last tenth of x in 64-row chunks; an explicit
+    rsp_set_tuning switches the taper off."""
+    c2 = capi.plan_describe(10**7)
+    assert c2["body_elems"] == 20 * 128 and c2["nchunks"] == c2["nbody"] == -(-78125 // 20)
+    shard = capi.plan_describe(125_000_000)
+    assert shard["nchunks"] == shard["nbody"] and 6144 < shard["nchunks"] <= 12288
+    c3 = capi.plan_describe(10**9)
+    assert c3["body_elems"] == 256 * 128 and c3["tail_elems"] == 64 * 128
+    tail_rows = (c3["nchunks"] - c3["nbody"]) * 64
+    total_rows = -(-10**9 // 128)
+    assert 0.09 * total_rows < tail_rows < 0.11 * total_rows
+    try:
+        capi.set_tuning(256)
+        fixed = capi.plan_describe(10**9)
+        assert fixed["nchunks"] == fixed["nbody"] == -(-total_rows // 256)
+    finally:
+        capi.set_tuning(0)

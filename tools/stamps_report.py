@@ -75,12 +75,10 @@ def main():
     width = span / nbins
     rows = np.zeros(nbins)
     total_rows = (nnz + 127) // 128
-    per_wave = np.full(len(st), float(total_rows) / max(1, len(st)))      # (mean chunk length)
-    if taper and taper[0] > 0 and (len(taper) < 3 or taper[2] == 0):          # the automatic plan of capi.hip make_plan
-        r = int(min(256, max(16, -(-total_rows // 8192))))
-        body_rows = (total_rows * (1000 - taper[0]) // 1000) // r * r
-        if taper[1] < r and -(-total_rows // r) > 6144:
-            per_wave = np.where(widx < body_rows // r, float(r), float(taper[1]))
+    plan = (ctypes.c_int32 * 4)()
+    L.rsp_plan_describe.argtypes = [i64, ctypes.POINTER(ctypes.c_int32)]
+    assert L.rsp_plan_describe(nnz, plan) == 0       # the chunking in force: body chunks, then the tapered tail
+    per_wave = np.where(widx < plan[1], plan[0] / 128.0, plan[2] / 128.0)
     for a, b, share in ((2, 4, None), (4, 5, None)):
         ta, tb = (st[:, a] - t0).astype(np.float64), (st[:, b] - t0).astype(np.float64)
         r = np.minimum(8.0, per_wave) if a == 2 else np.maximum(per_wave - 8.0, 0.0)
