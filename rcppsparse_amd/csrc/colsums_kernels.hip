@@ -14,17 +14,20 @@
 //   * Column offsets p[] are staged per wave in an LDS window.
 //   * A row with no column end inside takes the fast path: two v_add_f64 per lane.
 //   * A row with 1-3 column ends: one masked DPP wave reduction per end.
-//   * A group of 4 rows with many column ends (short columns): staged in LDS, every
-//     lane sums 8 consecutive elements in storage order, one integer scan and one
-//     segmented scan per group.
+//   * A group of 4 rows with many column ends (short and medium columns): staged in LDS and
+//     handed out by column, 1 / 2 / 4 / 8 lanes per column; a lane adds its column's elements
+//     in storage order (whole quads, then the last 0-3).
 //   * Anything else (e.g. runs of empty columns): per-row LDS histogram of the ends ->
 //     element ranks -> segmented DPP scan.
-//   * Columns that cross chunk edges leave a head / tail partial per chunk; a small
-//     second kernel adds those in ascending chunk order.  No floating-point atomics
+//   * Columns that cross chunk edges leave a head / tail partial and a 16-byte record per chunk;
+//     a small second kernel adds those in ascending chunk order.  No floating-point atomics
 //     anywhere: results are bit-stable run to run.
+//   * Chunks: 256 rows for long calls with the last tenth of x in 64-row chunks (ChunkMap), 20
+//     rows and 4 loads in flight for calls that fit one round of wavefronts (capi.hip make_plan).
 //   * No MFMA: 1 FP64 add per 8 bytes, the bound is HBM bandwidth.
 //   * The same template serves the "next" reductions: a per-element transform (sum of
-//     squares / abs) or a row-set mask (streams i[] too and probes a row bitmap).
+//     squares / abs), max / min, or a row-set mask (streams i[] too and probes a row bitmap
+//     in L1, in LDS or in L2 depending on its size).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
