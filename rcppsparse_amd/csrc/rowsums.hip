@@ -365,25 +365,27 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     const int rows_here = 1 << shift, mask = rows_here - 1;
     for (int r = tid; r < rows_here; r += kAccThreads) sums[r] = 0.0;
     const int32_t s0 = boff[b], s1 = boff[b + 1];
-    // entries of the next step travel in registers while the current step is added
-    int32_t r0, r1;
-    double v0, v1;
-    auto fetch = [&](int32_t t) {
-        const int32_t j0 = t + tid, j1 = t + kAccThreads + tid;
-        r0 = j0 < s1 ? pr[j0] : -1;
-        v0 = j0 < s1 ? px[j0] : 0.0;
-        r1 = j1 < s1 ? pr[j1] : -1;
-        v1 = j1 < s1 ? px[j1] : 0.0;
+    // the entries of the next TWO steps travel in registers (two sets, refilled right after they have been
+    // staged) while the current step is added: 48 KB of loads in flight per CU
+    struct Regs {
+        int32_t r0, r1;
+        double v0, v1;
     };
-    fetch(s0);
-    for (int32_t t = s0; t < s1; t += kAccStage) {
+    auto fetch = [&](Regs& g, int32_t t) {
+        const int32_t j0 = t + tid, j1 = t + kAccThreads + tid;
+        g.r0 = j0 < s1 ? pr[j0] : -1;
+        g.v0 = j0 < s1 ? px[j0] : 0.0;
+        g.r1 = j1 < s1 ? pr[j1] : -1;
+        g.v1 = j1 < s1 ? px[j1] : 0.0;
+    };
+    auto step = [&](Regs& g, int32_t refill_from) {
         __syncthreads();   // the previous step has been added (first pass: the sums are zeroed)
-        st_r[tid] = r0;
-        st_x[tid] = v0;
-        st_r[tid + kAccThreads] = r1;
-        st_x[tid + kAccThreads] = v1;
+        st_r[tid] = g.r0;
+        st_x[tid] = g.v0;
+        st_r[tid + kAccThreads] = g.r1;
+        st_x[tid + kAccThreads] = g.v1;
         __syncthreads();
-        fetch(t + kAccStage);
+        fetch(g, refill_from);
         if (wave == 0) {   // (slots past the end of the block hold row -1)
 #pragma unroll
             for (int q0 = 0; q0 < kAccStage; q0 += 8 * 64) {
@@ -398,6 +400,13 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
                     if (rr[u] >= 0) lds_add_f64(&sums[rr[u] & mask], xv[u]);
             }
         }
+    };
+    Regs ga, gb;
+    fetch(ga, s0);
+    fetch(gb, s0 + kAccStage);
+    for (int32_t t = s0; t < s1; t += 2 * kAccStage) {
+        step(ga, t + 2 * kAccStage);
+        if (t + kAccStage < s1) step(gb, t + 3 * kAccStage);   // (uniform: every thread takes the same path)
     }
     __syncthreads();
     const int64_t row0 = (int64_t)b << shift;
