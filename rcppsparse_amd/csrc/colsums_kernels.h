@@ -97,9 +97,9 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 // (block, supertile) count table + rocPRIM scan temp.
 struct RowSumsLayout {
     int mode;
-    size_t vals_off, rows_off, boff_off, prow_off, colsums_off, persistent_bytes;
+    size_t vals_off, rows_off, boff_off, prow_off, colsums_off, partial_off, persistent_bytes;
     size_t table_off, keys_off, temp_off, temp_bytes, scratch_bytes;
-    int32_t shift, nblocks, nsuper;
+    int32_t shift, nblocks, nsuper, nsplit;   // nsplit: accumulate workgroups per row block (mode 2)
     int64_t super_elems;
 };
 hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form, RowSumsLayout* L);

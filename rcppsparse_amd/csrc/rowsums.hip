@@ -48,15 +48,18 @@ constexpr int kRowBlockShift = 12;   // block sort: 4096 rows per block, 32 KB o
 
 // tile partition
 constexpr int kPartShift = 14;            // 16384 rows per block: 128 KB of LDS sums per workgroup
-constexpr int kPartMaxBlocks = 832;       // LDS counters / cursors of the partition kernel (with the tile: < 160 KB)
+constexpr int kPartMaxBlocks = 832;       // LDS counters / cursors of the partition kernel (with the stage: < 160 KB)
 constexpr int kPartThreads = 1024;        // partition workgroup: 16 wavefronts
 constexpr int kPartWaves = kPartThreads / 64;
-constexpr int kPartPerThread = 8;
-constexpr int kTileElems = kPartThreads * kPartPerThread;   // 8192 entries sorted in LDS at a time
-constexpr int kTilesPerSuper = 20;        // a workgroup's supertile: 163 840 entries
+constexpr int kPartPerThread = 24;        // entries a thread holds in registers while its tile is ranked
+constexpr int kTileElems = kPartThreads * kPartPerThread;   // 24576 entries ranked together ...
+constexpr int kStageElems = 8192;         // ... and sorted through LDS 8192 positions at a time
+constexpr int kTilesPerSuper = 7;         // a workgroup's supertile: at most 172 032 entries
 constexpr size_t kCountTableMaxBytes = 64u << 20;
-constexpr int kAccThreads = 1024;         // accumulate workgroup: 16 wavefronts stage the entries, ONE adds them
-constexpr int kAccStage = 2048;           // entries staged per step
+constexpr int kAccThreads = 1024;         // accumulate workgroup: 15 wavefronts stage the entries, ONE adds them
+constexpr int kAccStagers = kAccThreads - 64;
+constexpr int kAccDepth = 8;              // steps of entries a staging thread has in flight (8 x 11.5 KB per CU)
+constexpr int kAccMaxSplit = 8;           // workgroups that may share one row block
 
 static unsigned key_bits(int32_t nrow) {
     unsigned b = 1;
@@ -79,6 +82,38 @@ struct RowBlockOf {
 // ---------------------------------------------------------------------------------------------
 // planning
 // ---------------------------------------------------------------------------------------------
+// Workgroups per row block in the accumulate pass.  One per block leaves the last round of a grid of
+// 611 blocks on 256 CUs 61 % empty (and a 62-block matrix on a quarter of the chip); the blocks'
+// entries are split into equal parts instead, each part summed by its own workgroup and the parts
+// added up in a fixed order afterwards.  Cost model: rounds x bytes a workgroup moves (its entries,
+// plus its block of sums written and read back).
+static int accumulate_split(int32_t nblocks, int64_t nnz, int64_t rows_per_block) {
+    static int ncu = 0;   // (benign if two threads both fill it in)
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            ncu = n;
+        else {
+            (void)hipGetLastError();
+            return 1;   // no device to plan for (workspace queries on a host without one)
+        }
+    }
+    int best = 1;
+    double best_cost = 0;
+    for (int ns = 1; ns <= kAccMaxSplit; ++ns) {
+        const int64_t units = (int64_t)nblocks * ns;
+        const int64_t rounds = (units + ncu - 1) / ncu;
+        const double unit_bytes = 12.0 * (double)nnz / (double)units + (ns > 1 ? 24.0 : 8.0) * (double)rows_per_block;
+        const double cost = (double)rounds * unit_bytes;
+        if (ns == 1 || cost < best_cost * 0.97) {   // (a split has to pay for itself)
+            best = ns;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form,
                          RowSumsLayout* L) {
     memset(L, 0, sizeof(*L));
@@ -89,10 +124,15 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
         L->mode = 2;
         L->shift = kPartShift;
         L->nblocks = (int32_t)(part_blocks > 0 ? part_blocks : 1);
-        int64_t super = (int64_t)kTileElems * kTilesPerSuper;   // grow until the count table fits its budget
+        // supertile: whole tiles, small enough for ~1000 workgroups when the matrix allows, large enough
+        // for the count table to fit its budget
+        int64_t tiles = nnz / ((int64_t)1024 * kTileElems);
+        tiles = tiles < 1 ? 1 : tiles > kTilesPerSuper ? kTilesPerSuper : tiles;
+        int64_t super = (int64_t)kTileElems * tiles;
         while (((nnz + super - 1) / super) * L->nblocks * 4 > (int64_t)kCountTableMaxBytes) super *= 2;
         L->super_elems = super;
         L->nsuper = (int32_t)((nnz + super - 1) / super);
+        L->nsplit = accumulate_split(L->nblocks, nnz, (int64_t)1 << kPartShift);
         const size_t table_entries = (size_t)L->nsuper * (size_t)L->nblocks + 1;   // + the total
         size_t temp = 0;
         e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, table_entries,
@@ -101,6 +141,8 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
         L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);                // x grouped by row block
         L->rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);                // their row indices
         L->boff_off = off;  off = align_up(off + ((size_t)L->nblocks + 1) * 4, 256);   // first slot of every block
+        L->partial_off = off;                                                          // sums per (part, row)
+        if (L->nsplit > 1) off = align_up(off + (size_t)L->nsplit * (size_t)(nrow > 0 ? nrow : 0) * 8, 256);
         L->persistent_bytes = off;
         off = 0;
         L->table_off = off; off = align_up(off + table_entries * 4, 256);
@@ -207,6 +249,16 @@ __global__ __launch_bounds__(64) void rows_block_accumulate_kernel(
 // ---------------------------------------------------------------------------------------------
 // tile partition: histogram, partition, accumulate
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also waits for every outstanding global
+// load and store of the wave (s_waitcnt vmcnt(0)); in the two kernels below that would expose the
+// latency of the loads just issued for the NEXT step and of the stores of the step just written out,
+// once per step (measured on the partition pass: 14 of 18 us per tile).  Loaded registers are still
+// waited for where they are used (the compiler counts those), and a store has read its registers
+// when it has issued, so neither needs the full drain.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 1. entries per (row block, supertile).  The table is [block][supertile], so that ONE flat exclusive
 //    scan yields for every pair the number of entries in earlier blocks plus those of the same block
 //    in earlier supertiles: its first output slot.  (Row indices outside [0, nrow) -- not a valid
@@ -236,17 +288,21 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
     for (int b = tid; b < nblocks; b += kPartThreads) table[(size_t)b * nsuper + s] = s_hist[b];
 }
 
-// 3. the partition pass.  LDS: the tile sorted by block (values, row indices), one cursor per block
-//    (next output slot of this supertile), the tile's first position per block, and one counter per
-//    (wavefront, block).
+// 3. the partition pass.  A tile of 24576 entries (24 per thread, in registers) is ranked at once, so a
+//    block's run in it is ~40 entries at 600 blocks; the sorted order then passes through an LDS stage
+//    of 8192 positions at a time ("rounds"), each written out with consecutive lanes on consecutive slots.
+//    Long runs matter because a run's first and last 64 bytes reach memory as partial (32-byte) writes:
+//    PMC at 13-entry runs showed 1.74x the write requests of a coalesced copy and twice its time.
+//    LDS: the stage (values, row indices), one cursor per block (next output slot of this supertile),
+//    the tile's first sorted position per block, and one counter per (wavefront, block).
 __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift,
     int32_t nblocks, int64_t super_elems, int32_t nsuper, const int32_t* __restrict__ first_slot,
     double* __restrict__ px, int32_t* __restrict__ pr) {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
-    double* stage_x = (double*)s_raw;                                   // kTileElems
-    int32_t* stage_r = (int32_t*)(stage_x + kTileElems);                // kTileElems
-    int32_t* cursor = stage_r + kTileElems;                             // nblocks
+    double* stage_x = (double*)s_raw;                                   // kStageElems
+    int32_t* stage_r = (int32_t*)(stage_x + kStageElems);               // kStageElems
+    int32_t* cursor = stage_r + kStageElems;                            // nblocks
     int32_t* tstart = cursor + nblocks;                                 // nblocks + 1
     int32_t* cnt = tstart + nblocks + 1;                                // kPartWaves x nblocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -255,29 +311,34 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
     const int64_t e0 = (int64_t)s * super_elems;
     const int64_t e1 = e0 + super_elems < nnz ? e0 + super_elems : nnz;
     int32_t* mycnt = cnt + (size_t)wave * nblocks;
-    // this thread's entries of the current tile (coalesced across the workgroup); the next tile's are
-    // fetched as soon as the current ones sit in LDS, so their latency hides behind the write-out
-    int32_t r[kPartPerThread], rank[kPartPerThread];
-    double v[kPartPerThread];
-    auto fetch = [&](int64_t tile) {
+    // the supertile as two buffer resources: a load is then one VGPR offset (the thread) plus a scalar
+    // offset (tile, k) -- no address registers, of which 48 loads would need 96 -- and reads past the
+    // end return zero instead of faulting
+    const int32_t len = (int32_t)(e1 - e0);
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc((void*)(ri + e0), 0, len * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + e0), 0, len * 8, 0x00020000);
+    for (int32_t tile = 0; tile < len; tile += kTileElems) {
+        // this thread's entries (coalesced across the workgroup): the row indices first, they are needed
+        // first; the values arrive while the tile is ranked
+        int32_t r[kPartPerThread], pos[kPartPerThread];
+        double v[kPartPerThread];
 #pragma unroll
         for (int k = 0; k < kPartPerThread; ++k) {
-            const int64_t j = tile + k * kPartThreads + tid;
-            const bool in = j < e1;
-            r[k] = in ? ri[j] : -1;
-            v[k] = in ? x[j] : 0.0;
+            const int32_t t = __builtin_amdgcn_raw_buffer_load_b32(res_r, tid * 4, (tile + k * kPartThreads) * 4, 2);
+            r[k] = tile + k * kPartThreads + tid < len ? t : -1;
         }
-    };
-    fetch(e0);
-    for (int64_t tile = e0; tile < e1; tile += kTileElems) {
+#pragma unroll
+        for (int k = 0; k < kPartPerThread; ++k)   // (aux 2 = nt: read once)
+            v[k] = __builtin_bit_cast(
+                double, __builtin_amdgcn_raw_buffer_load_b64(res_x, tid * 8, (tile + k * kPartThreads) * 8, 2));
         for (int k = tid; k < kPartWaves * nblocks; k += kPartThreads) cnt[k] = 0;
-        __syncthreads();   // (also: cursors initialised / updated, previous tile written out)
+        lds_barrier();   // (also: cursors initialised / updated, previous tile's last round read out of the stage)
         // rank of every entry among the entries of the same block handled by the same wavefront:
         // program order inside the wavefront, hardware order inside one LDS instruction -- both fixed
 #pragma unroll
         for (int k = 0; k < kPartPerThread; ++k)
-            rank[k] = (uint32_t)r[k] < (uint32_t)nrow ? atomicAdd(&mycnt[(uint32_t)r[k] >> shift], 1) : -1;
-        __syncthreads();
+            pos[k] = (uint32_t)r[k] < (uint32_t)nrow ? atomicAdd(&mycnt[(uint32_t)r[k] >> shift], 1) : -1;
+        lds_barrier();
         // per block: counts of the wavefronts -> exclusive prefix over the wavefronts, total into tstart
         for (int b = tid; b < nblocks; b += kPartThreads) {
             int run = 0;
@@ -289,7 +350,7 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
             }
             tstart[b] = run;
         }
-        __syncthreads();
+        lds_barrier();
         // exclusive scan of the totals over the blocks (one wavefront; nblocks <= 64 lanes x 13)
         if (wave == 0) {
             const int per = (nblocks + 63) >> 6;
@@ -312,28 +373,35 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
                 }
             if (lane == 63) tstart[nblocks] = incl;
         }
-        __syncthreads();
-        // the tile, sorted by block, into LDS
+        lds_barrier();
+        // position of every entry in the tile's order by block
 #pragma unroll
         for (int k = 0; k < kPartPerThread; ++k)
-            if (rank[k] >= 0) {
+            if (pos[k] >= 0) {
                 const int b = (uint32_t)r[k] >> shift;
-                const int pos = tstart[b] + mycnt[b] + rank[k];
-                stage_x[pos] = v[k];
-                stage_r[pos] = r[k];
+                pos[k] += tstart[b] + mycnt[b];
             }
-        fetch(tile + kTileElems);   // (past the supertile: nothing is loaded)
-        __syncthreads();
-        // ... and out: consecutive threads, consecutive positions, consecutive slots inside a block's run
         const int total = tstart[nblocks];
-        for (int j = tid; j < total; j += kPartThreads) {
-            const int32_t rr = stage_r[j];
-            const int b = (uint32_t)rr >> shift;
-            const int32_t dest = cursor[b] + (j - tstart[b]);
-            px[dest] = stage_x[j];
-            pr[dest] = rr;
+        for (int base = 0; base < total; base += kStageElems) {   // (uniform: every thread sees the same total)
+            // this round's positions into the stage ...
+#pragma unroll
+            for (int k = 0; k < kPartPerThread; ++k)
+                if ((uint32_t)(pos[k] - base) < (uint32_t)kStageElems) {
+                    stage_x[pos[k] - base] = v[k];
+                    stage_r[pos[k] - base] = r[k];
+                }
+            lds_barrier();
+            // ... and out: consecutive threads, consecutive positions, consecutive slots inside a block's run
+            const int n = total - base < kStageElems ? total - base : kStageElems;
+            for (int j = tid; j < n; j += kPartThreads) {
+                const int32_t rr = stage_r[j];
+                const int b = (uint32_t)rr >> shift;
+                const int32_t dest = cursor[b] + (base + j - tstart[b]);
+                px[dest] = stage_x[j];
+                pr[dest] = rr;
+            }
+            lds_barrier();
         }
-        __syncthreads();
         for (int b = tid; b < nblocks; b += kPartThreads) cursor[b] += tstart[b + 1] - tstart[b];
     }
 }
@@ -347,77 +415,112 @@ __global__ void rows_tile_offsets_kernel(const int32_t* __restrict__ first_slot,
     if (b == nblocks) boff[b] = first_slot[(size_t)nblocks * nsuper];
 }
 
-// 4. one 16-wave workgroup per row block.  All wavefronts stage the block's entries (coalesced loads,
-//    the next step's already in flight); ONE wavefront adds them, 64 per LDS instruction, in slot order.
-//    (An LDS double add costs the same ~16 cycles whether 4 or 64 of its lanes are active, so letting
-//    every wavefront pick "its" rows out of each step is 16 times the LDS work: 9.5 ms instead of 2.)
+// 4. `nsplit` 16-wave workgroups per row block, each over an equal part of the block's entries.  Fifteen
+//    wavefronts stage entries into one of two LDS buffers (coalesced loads, eight steps of them in
+//    flight per thread); the sixteenth adds the buffer staged in the previous step, 64 entries per LDS
+//    instruction, in slot order.  (An LDS double add costs the same whether 4 or 64 of its lanes are
+//    active, so letting every wavefront pick "its" rows out of each step is 16 times the LDS work:
+//    9.5 ms instead of 2.  Adding while the others stage keeps the LDS unit's ~0.7 ns per entry off
+//    the critical path; with one buffer the two alternated and the loads in flight could not cover it.)
+//    nsplit == 1: sums (or means) straight to `out`.  Otherwise each part's sums go to part_out + part * nrow
+//    and rows_combine_parts_kernel adds the parts up.
 template <bool MEANS>
 __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     const double* __restrict__ px, const int32_t* __restrict__ pr, const int32_t* __restrict__ boff,
-    int32_t nrow, int32_t shift, double* __restrict__ out, double divisor) {
+    int32_t nrow, int32_t shift, int32_t nsplit, double* __restrict__ out, double* __restrict__ part_out,
+    double divisor) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double* sums = (double*)s_raw;                          // 1 << shift
-    double* st_x = sums + ((size_t)1 << shift);             // kAccStage
-    int32_t* st_r = (int32_t*)(st_x + kAccStage);           // kAccStage
+    double* st_x = sums + ((size_t)1 << shift);             // 2 x kAccStagers
+    int32_t* st_r = (int32_t*)(st_x + 2 * kAccStagers);     // 2 x kAccStagers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit;
     const int rows_here = 1 << shift, mask = rows_here - 1;
     for (int r = tid; r < rows_here; r += kAccThreads) sums[r] = 0.0;
+    // this workgroup's part of the block: whole steps, the same for every run
     const int32_t s0 = boff[b], s1 = boff[b + 1];
-    // the entries of the next TWO steps travel in registers (two sets, refilled right after they have been
-    // staged) while the current step is added: 48 KB of loads in flight per CU
-    struct Regs {
-        int32_t r0, r1;
-        double v0, v1;
-    };
-    auto fetch = [&](Regs& g, int32_t t) {
-        const int32_t j0 = t + tid, j1 = t + kAccThreads + tid;
-        g.r0 = j0 < s1 ? pr[j0] : -1;
-        g.v0 = j0 < s1 ? px[j0] : 0.0;
-        g.r1 = j1 < s1 ? pr[j1] : -1;
-        g.v1 = j1 < s1 ? px[j1] : 0.0;
-    };
-    auto step = [&](Regs& g, int32_t refill_from) {
-        __syncthreads();   // the previous step has been added (first pass: the sums are zeroed)
-        st_r[tid] = g.r0;
-        st_x[tid] = g.v0;
-        st_r[tid + kAccThreads] = g.r1;
-        st_x[tid + kAccThreads] = g.v1;
-        __syncthreads();
-        fetch(g, refill_from);
-        if (wave == 0) {   // (slots past the end of the block hold row -1)
+    const int32_t steps_all = (s1 - s0 + kAccStagers - 1) / kAccStagers;
+    const int32_t steps_per = (steps_all + nsplit - 1) / nsplit;
+    const int64_t u0_ = (int64_t)s0 + (int64_t)part * steps_per * kAccStagers;
+    const int64_t u1_ = u0_ + (int64_t)steps_per * kAccStagers;
+    const int32_t u0 = (int32_t)(u0_ < s1 ? u0_ : s1), u1 = (int32_t)(u1_ < s1 ? u1_ : s1);
+    const int32_t nsteps = (u1 - u0 + kAccStagers - 1) / kAccStagers;
+    // steps are taken kAccDepth at a time (static register rotation); the ones past the end stage row -1
+    const int32_t nrounds = (nsteps + kAccDepth - 1) / kAccDepth;
+    // Barrier k closes step k's staging.  The adder adds step k between barriers k and k + 1, the stagers
+    // refill that buffer (step k + 2) after barrier k + 1: both sides execute nrounds * kAccDepth barriers.
+    if (__builtin_amdgcn_readfirstlane(wave) != 0) {
+        const int stid = tid - 64;   // staging thread (wavefronts 1..15)
+        const int64_t last = (int64_t)u1 - 1;   // (nrounds > 0 implies u1 > u0)
+        int32_t gr[kAccDepth];
+        double gv[kAccDepth];
+        auto fetch = [&](int d, int32_t step) {   // unconditional loads from clamped addresses: exact wait counts
+            const int64_t j = (int64_t)u0 + (int64_t)step * kAccStagers + stid;
+            const int32_t t = __builtin_nontemporal_load(pr + (j <= last ? j : last));
+            gv[d] = __builtin_nontemporal_load(px + (j <= last ? j : last));
+            gr[d] = j <= last ? t : -1;
+        };
+        if (nrounds > 0) {
 #pragma unroll
-            for (int q0 = 0; q0 < kAccStage; q0 += 8 * 64) {
-                int32_t rr[8];
+            for (int d = 0; d < kAccDepth; ++d) fetch(d, d);
+        }
+        for (int32_t q = 0; q < nrounds; ++q) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) rr[u] = st_r[q0 + u * 64 + lane];
-                double xv[8];
+            for (int d = 0; d < kAccDepth; ++d) {
+                st_r[(d & 1) * kAccStagers + stid] = gr[d];
+                st_x[(d & 1) * kAccStagers + stid] = gv[d];
+                fetch(d, (q + 1) * kAccDepth + d);
+                lds_barrier();
+            }
+        }
+    } else {
+        for (int32_t q = 0; q < nrounds; ++q) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xv[u] = st_x[q0 + u * 64 + lane];
+            for (int d = 0; d < kAccDepth; ++d) {
+                lds_barrier();
+                const int32_t* br = st_r + (d & 1) * kAccStagers;
+                const double* bx = st_x + (d & 1) * kAccStagers;
+                int32_t rr[kAccStagers / 64];
+                double xv[kAccStagers / 64];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < kAccStagers / 64; ++u) rr[u] = br[u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < kAccStagers / 64; ++u) xv[u] = bx[u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < kAccStagers / 64; ++u)   // (slots past the end of the part hold row -1)
                     if (rr[u] >= 0) lds_add_f64(&sums[rr[u] & mask], xv[u]);
             }
         }
-    };
-    Regs ga, gb;
-    fetch(ga, s0);
-    fetch(gb, s0 + kAccStage);
-    for (int32_t t = s0; t < s1; t += 2 * kAccStage) {
-        step(ga, t + 2 * kAccStage);
-        if (t + kAccStage < s1) step(gb, t + 3 * kAccStage);   // (uniform: every thread takes the same path)
     }
     __syncthreads();
     const int64_t row0 = (int64_t)b << shift;
     for (int r = tid; r < rows_here; r += kAccThreads) {
         const int64_t row = row0 + r;
         if (row < nrow) {
-            double t = sums[r] + 0.0;     // a sum of -0.0 terms comes out +0.0, like the reference's accumulator
-            if (MEANS) t = t / divisor;   // RcppSparse.h:153-154
-            out[row] = t;
+            if (nsplit > 1) {
+                part_out[(size_t)part * (size_t)nrow + (size_t)row] = sums[r];
+            } else {
+                double t = sums[r] + 0.0;     // a sum of -0.0 terms comes out +0.0, like the reference's accumulator
+                if (MEANS) t = t / divisor;   // RcppSparse.h:153-154
+                out[row] = t;
+            }
         }
     }
+}
+
+// 5. (nsplit > 1) a row's sum = its parts, added in part order.
+template <bool MEANS>
+__global__ void rows_combine_parts_kernel(const double* __restrict__ part_out, int32_t nrow, int32_t nsplit,
+                                          double* __restrict__ out, double divisor) {
+#pragma clang fp contract(off)
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nrow) return;
+    double t = part_out[row];
+    for (int q = 1; q < nsplit; ++q) t += part_out[(size_t)q * (size_t)nrow + (size_t)row];
+    t = t + 0.0;
+    if (MEANS) t = t / divisor;   // RcppSparse.h:153-154
+    out[row] = t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -451,11 +554,11 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
         const size_t table_entries = (size_t)L.nsuper * (size_t)L.nblocks + 1;
         e = hipMemsetAsync(table + (table_entries - 1), 0, 4, stream);   // the slot that receives the total
         if (e != hipSuccess) return e;
-        const size_t part_lds = (size_t)kTileElems * 12 + ((size_t)L.nblocks * (2 + kPartWaves) + 1) * 4;
+        const size_t part_lds = (size_t)kStageElems * 12 + ((size_t)L.nblocks * (2 + kPartWaves) + 1) * 4;
         static bool raised = false;   // (benign if two threads both do it)
         if (!raised) {
             e = hipFuncSetAttribute((const void*)rows_tile_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((size_t)kTileElems * 12 + ((size_t)kPartMaxBlocks * (2 + kPartWaves) + 1) * 4));
+                                    (int)((size_t)kStageElems * 12 + ((size_t)kPartMaxBlocks * (2 + kPartWaves) + 1) * 4));
             if (e != hipSuccess) return e;
             raised = true;
         }
@@ -513,7 +616,7 @@ hipError_t launch_row_reduce(int32_t nrow, int64_t nnz, const RowSumsLayout& L, 
     const int32_t* pr = (const int32_t*)((char*)persist + L.rows_off);
     const int32_t* boff = (const int32_t*)((char*)persist + L.boff_off);
     if (L.mode == 2) {
-        const size_t acc_lds = ((size_t)8 << L.shift) + (size_t)kAccStage * 12;
+        const size_t acc_lds = ((size_t)8 << L.shift) + (size_t)2 * kAccStagers * 12;
         static bool raised2 = false;
         if (!raised2) {
             hipError_t e = hipFuncSetAttribute((const void*)rows_tile_accumulate_kernel<true>,
@@ -524,12 +627,23 @@ hipError_t launch_row_reduce(int32_t nrow, int64_t nnz, const RowSumsLayout& L, 
             if (e != hipSuccess) return e;
             raised2 = true;
         }
+        double* parts = (double*)((char*)persist + L.partial_off);
+        const dim3 grid((unsigned)L.nblocks * (unsigned)L.nsplit);
         if (means)
-            hipLaunchKernelGGL(rows_tile_accumulate_kernel<true>, dim3(L.nblocks), dim3(kAccThreads), acc_lds, stream,
-                               px, pr, boff, nrow, L.shift, d_out, divisor);
+            hipLaunchKernelGGL(rows_tile_accumulate_kernel<true>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
+                               boff, nrow, L.shift, L.nsplit, d_out, parts, divisor);
         else
-            hipLaunchKernelGGL(rows_tile_accumulate_kernel<false>, dim3(L.nblocks), dim3(kAccThreads), acc_lds, stream,
-                               px, pr, boff, nrow, L.shift, d_out, divisor);
+            hipLaunchKernelGGL(rows_tile_accumulate_kernel<false>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
+                               boff, nrow, L.shift, L.nsplit, d_out, parts, divisor);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || L.nsplit <= 1) return e;
+        const dim3 cgrid((unsigned)(((int64_t)nrow + 255) / 256));
+        if (means)
+            hipLaunchKernelGGL(rows_combine_parts_kernel<true>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
+                               d_out, divisor);
+        else
+            hipLaunchKernelGGL(rows_combine_parts_kernel<false>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
+                               d_out, divisor);
         return hipGetLastError();
     }
     const size_t lds = (size_t)8 << L.shift;
