@@ -9,14 +9,16 @@
 //     pass, then added up block by block.
 //       1. rows_tile_histogram_kernel   entries per (block, supertile)              reads  4 B/nnz
 //       2. one exclusive scan over that table (rocPRIM; a few MB) = first output slot of every pair
-//       3. rows_tile_partition_kernel   a workgroup walks its supertile in tiles of 8192 entries:
-//          ranks them per block with wave-private LDS counters, SORTS THE TILE BY BLOCK IN LDS, and
-//          writes every block's run to its cursor -- consecutive lanes store consecutive slots, so
-//          the ~600 output streams leave as runs of ~13 entries instead of single 8-byte stores
-//                                                                reads 12 B/nnz, writes 12 B/nnz
-//       4. rows_tile_accumulate_kernel  one 16-wave workgroup per block: the block's sums live in
-//          128 KB of LDS, tiles of entries are staged once and every wave adds the rows it owns
-//          (row mod 16) with ds_add_f64, in slot order              reads 12 B/nnz, writes 8 B/row
+//       3. rows_tile_partition_kernel   a workgroup walks its supertile in tiles of 22528 entries (22
+//          per thread, in registers): ranks them per block with wave-private LDS counters, SORTS THE
+//          TILE BY BLOCK THROUGH LDS (8192 positions per round), and writes every block's run to its
+//          cursor -- consecutive lanes store consecutive slots, so the ~600 output streams leave as
+//          runs of ~37 entries instead of single 8-byte stores     reads 12 B/nnz, writes 12 B/nnz
+//       4. rows_tile_accumulate_kernel  16-wave workgroups, `nsplit` per block: the block's sums live
+//          in 128 KB of LDS; fifteen wavefronts stage entries, the sixteenth adds the previous step's
+//          with ds_add_f64, in slot order (the LDS unit's ~1.6 cycles per double add is the bound)
+//                                                                   reads 12 B/nnz, writes 8 B/row
+//       5. rows_combine_parts_kernel    (nsplit > 1) adds the parts of every row in part order
 //     About 40 B/nnz of traffic and a workspace of 12 B/nnz + the count table.  An entry's slot is a
 //     function of the data alone (no global atomics, wave-private counters combined in a fixed
 //     order), and a row's terms are added by one wavefront in slot order: bit-stable run to run.
@@ -51,10 +53,10 @@ constexpr int kPartShift = 14;            // 16384 rows per block: 128 KB of LDS
 constexpr int kPartMaxBlocks = 832;       // LDS counters / cursors of the partition kernel (with the stage: < 160 KB)
 constexpr int kPartThreads = 1024;        // partition workgroup: 16 wavefronts
 constexpr int kPartWaves = kPartThreads / 64;
-constexpr int kPartPerThread = 24;        // entries a thread holds in registers while its tile is ranked
-constexpr int kTileElems = kPartThreads * kPartPerThread;   // 24576 entries ranked together ...
+constexpr int kPartPerThread = 22;        // entries a thread holds in registers while its tile is ranked (24 spills)
+constexpr int kTileElems = kPartThreads * kPartPerThread;   // 22528 entries ranked together ...
 constexpr int kStageElems = 8192;         // ... and sorted through LDS 8192 positions at a time
-constexpr int kTilesPerSuper = 7;         // a workgroup's supertile: at most 172 032 entries
+constexpr int kTilesPerSuper = 7;         // a workgroup's supertile: at most 157 696 entries
 constexpr size_t kCountTableMaxBytes = 64u << 20;
 constexpr int kAccThreads = 1024;         // accumulate workgroup: 15 wavefronts stage the entries, ONE adds them
 constexpr int kAccStagers = kAccThreads - 64;
@@ -259,6 +261,14 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// A wave-uniform pointer, moved to scalar registers.
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (void*)(((uint64_t)hi << 32) | lo);
+}
+
 // 1. entries per (row block, supertile).  The table is [block][supertile], so that ONE flat exclusive
 //    scan yields for every pair the number of entries in earlier blocks plus those of the same block
 //    in earlier supertiles: its first output slot.  (Row indices outside [0, nrow) -- not a valid
@@ -288,11 +298,13 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
     for (int b = tid; b < nblocks; b += kPartThreads) table[(size_t)b * nsuper + s] = s_hist[b];
 }
 
-// 3. the partition pass.  A tile of 24576 entries (24 per thread, in registers) is ranked at once, so a
-//    block's run in it is ~40 entries at 600 blocks; the sorted order then passes through an LDS stage
+// 3. the partition pass.  A tile of 22528 entries (22 per thread, in registers) is ranked at once, so a
+//    block's run in it is ~37 entries at 600 blocks; the sorted order then passes through an LDS stage
 //    of 8192 positions at a time ("rounds"), each written out with consecutive lanes on consecutive slots.
-//    Long runs matter because a run's first and last 64 bytes reach memory as partial (32-byte) writes:
-//    PMC at 13-entry runs showed 1.74x the write requests of a coalesced copy and twice its time.
+//    Run length is what the write side pays for: at 13-entry runs (8192-entry tiles) the pass took 8.4 ms
+//    and PMC showed 1.74x the write requests of a coalesced copy, almost half of them 32-byte partials;
+//    27-entry runs 6.8 ms, 54-entry runs 5.9 ms (profiles/r02_rowsums.md).  Per tile the kernel is
+//    otherwise bound by its scattered LDS accesses (rank, place, stage: ~55 % of its cycles).
 //    LDS: the stage (values, row indices), one cursor per block (next output slot of this supertile),
 //    the tile's first sorted position per block, and one counter per (wavefront, block).
 __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
@@ -314,30 +326,37 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
     // the supertile as two buffer resources: a load is then one VGPR offset (the thread) plus a scalar
     // offset (tile, k) -- no address registers, of which 48 loads would need 96 -- and reads past the
     // end return zero instead of faulting
-    const int32_t len = (int32_t)(e1 - e0);
-    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc((void*)(ri + e0), 0, len * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t res_x = __builtin_amdgcn_make_buffer_rsrc((void*)(x + e0), 0, len * 8, 0x00020000);
-    for (int32_t tile = 0; tile < len; tile += kTileElems) {
-        // this thread's entries (coalesced across the workgroup): the row indices first, they are needed
-        // first; the values arrive while the tile is ranked
-        int32_t r[kPartPerThread], pos[kPartPerThread];
-        double v[kPartPerThread];
+    // (e0 is a 64-bit product, which the compiler computes in vector registers; a descriptor left there
+    // costs a readfirstlane loop around every load)
+    const int32_t len = __builtin_amdgcn_readfirstlane((int32_t)(e1 - e0));
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ri + e0), 0, len * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_x = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + e0), 0, len * 8, 0x00020000);
+    // this thread's entries of the current tile (coalesced across the workgroup; the row indices first,
+    // they are needed first).  The NEXT tile's are requested into the same registers as soon as the
+    // current ones have all gone to the stage, so they travel during the last round's write-out.
+    int32_t r[kPartPerThread], pos[kPartPerThread];
+    double v[kPartPerThread];
+    auto fetch = [&](int32_t tile) {
 #pragma unroll
         for (int k = 0; k < kPartPerThread; ++k) {
-            const int32_t t = __builtin_amdgcn_raw_buffer_load_b32(res_r, tid * 4, (tile + k * kPartThreads) * 4, 2);
-            r[k] = tile + k * kPartThreads + tid < len ? t : -1;
-        }
+            r[k] = __builtin_amdgcn_raw_buffer_load_b32(res_r, tid * 4, (tile + k * kPartThreads) * 4, 2);
+        }   // (nothing but loads here: whatever touched a loaded register would wait for it on the spot)
 #pragma unroll
         for (int k = 0; k < kPartPerThread; ++k)   // (aux 2 = nt: read once)
             v[k] = __builtin_bit_cast(
                 double, __builtin_amdgcn_raw_buffer_load_b64(res_x, tid * 8, (tile + k * kPartThreads) * 8, 2));
+    };
+    fetch(0);
+    for (int32_t tile = 0; tile < len; tile += kTileElems) {
         for (int k = tid; k < kPartWaves * nblocks; k += kPartThreads) cnt[k] = 0;
         lds_barrier();   // (also: cursors initialised / updated, previous tile's last round read out of the stage)
         // rank of every entry among the entries of the same block handled by the same wavefront:
         // program order inside the wavefront, hardware order inside one LDS instruction -- both fixed
 #pragma unroll
-        for (int k = 0; k < kPartPerThread; ++k)
+        for (int k = 0; k < kPartPerThread; ++k) {
+            if (tile + k * kPartThreads + tid >= len) r[k] = -1;   // (a load past the end returned 0)
             pos[k] = (uint32_t)r[k] < (uint32_t)nrow ? atomicAdd(&mycnt[(uint32_t)r[k] >> shift], 1) : -1;
+        }
         lds_barrier();
         // per block: counts of the wavefronts -> exclusive prefix over the wavefronts, total into tstart
         for (int b = tid; b < nblocks; b += kPartThreads) {
@@ -381,8 +400,8 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
                 const int b = (uint32_t)r[k] >> shift;
                 pos[k] += tstart[b] + mycnt[b];
             }
-        const int total = tstart[nblocks];
-        for (int base = 0; base < total; base += kStageElems) {   // (uniform: every thread sees the same total)
+        const int total = __builtin_amdgcn_readfirstlane(tstart[nblocks]);   // (uniform, and the compiler knows)
+        auto round = [&](int base, bool last) {
             // this round's positions into the stage ...
 #pragma unroll
             for (int k = 0; k < kPartPerThread; ++k)
@@ -390,6 +409,7 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
                     stage_x[pos[k] - base] = v[k];
                     stage_r[pos[k] - base] = r[k];
                 }
+            if (last) fetch(tile + kTileElems);   // (past the supertile: zeros, unused)
             lds_barrier();
             // ... and out: consecutive threads, consecutive positions, consecutive slots inside a block's run
             const int n = total - base < kStageElems ? total - base : kStageElems;
@@ -401,7 +421,13 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
                 pr[dest] = rr;
             }
             lds_barrier();
-        }
+        };
+        // (the last round is a separate copy of the code: with the fetch inside the loop the compiler has
+        // every round wait for "its" loads, and on the in-order counter that means for the previous round's
+        // stores as well -- 8.3 ms instead of 6.9)
+        int base = 0;
+        for (; base + kStageElems < total; base += kStageElems) round(base, false);
+        round(base, true);
         for (int b = tid; b < nblocks; b += kPartThreads) cursor[b] += tstart[b + 1] - tstart[b];
     }
 }

@@ -142,6 +142,41 @@ def test_row_sums_forms_by_row_count(torch_cuda, nrow, nnz):
     assert np.all(np.abs(got2 - ref2) <= 1e-11 * np.maximum(scale2, 1e-300) + 1e-300)
 
 
+@pytest.mark.parametrize("pattern", ["one_row", "first_tiles_invalid", "edge_blocks", "one_block_dense", "all_invalid"])
+def test_row_sums_skewed_tiles(torch_cuda, pattern):
+    """Shapes of a partition tile the uniform generator never makes: every entry of a tile in ONE block
+    (the sorted tile then takes three passes through the LDS stage and its runs are whole rounds), tiles
+    without a single valid entry (which still have to fetch the next tile), entries only in the first and
+    last block.  nrow gives 62 blocks, so the accumulate pass splits blocks among workgroups; means go
+    through the parts' combine step as well."""
+    torch = torch_cuda
+    nrow, ncol, nnz = 1_000_000, 1_000, 300_000
+    rng = np.random.default_rng(len(pattern))
+    x = rng.standard_normal(nnz)
+    if pattern == "one_row":
+        i = np.full(nnz, 5, dtype=np.int32)
+    elif pattern == "first_tiles_invalid":
+        i = rng.integers(0, nrow, nnz).astype(np.int32)
+        i[:50_000] = nrow + 7          # more than two tiles of 22528
+    elif pattern == "edge_blocks":
+        i = np.where(rng.random(nnz) < 0.5, rng.integers(0, 100, nnz), rng.integers(nrow - 100, nrow, nnz)).astype(np.int32)
+    elif pattern == "one_block_dense":
+        i = rng.integers(3 * 16384, 4 * 16384, nnz).astype(np.int32)
+    else:
+        i = np.full(nnz, -1, dtype=np.int32)
+    xt, it = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda()
+    got = capi.row_sums_device(xt, it, nrow).cpu().numpy()
+    again = capi.row_sums_device(xt, it, nrow).cpu().numpy()
+    assert got.tobytes() == again.tobytes()
+    keep = (i >= 0) & (i < nrow)
+    ref = np.bincount(i[keep], weights=x[keep], minlength=nrow)
+    scale = np.bincount(i[keep], weights=np.abs(x[keep]), minlength=nrow)
+    assert np.all(np.abs(got - ref) <= RTOL * scale), float(np.max(np.abs(got - ref)))
+    assert not np.any(np.signbit(got[scale == 0]))
+    means = capi.row_sums_device(xt, it, nrow, ncol_for_means=ncol).cpu().numpy()
+    assert means.tobytes() == (got / ncol).tobytes()
+
+
 @pytest.mark.parametrize("seed", range(25))
 def test_fuzz_row_entries_and_masks(torch_cuda, seed):
     """Random shapes/densities: rowSums, rowMeans and the row-restricted column sums against the
