@@ -178,12 +178,18 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
 /* ---- row-wise "next" entries: Matrix::rowSums / rowMeans ----------------- */
 /*
  * Reference RcppSparse.h:138-144 / :151-156: sums[i[j]] += x[j] over all stored
- * entries (rowMeans divides by Dim[1]).  Computed as columnSums(t(A)): a stable
- * device radix sort of (i, x) by row keeps every row's values in ascending
- * storage order, then the column-sum kernels reduce them.  Deterministic, no
- * float atomics.  The handle variants build the row-major form on first use and
- * keep it (the handle must have been uploaded with i[]); the device variants
- * rebuild it in the caller's workspace on every call.
+ * entries (rowMeans divides by Dim[1]).  Deterministic, no float atomics in
+ * global memory, bit-stable run to run, within 1e-12 * sum|x| of the reference's
+ * order.  The handle variants (the handle must have been uploaded with i[])
+ * build the row-major form on first use -- a stable device radix sort of (i, x)
+ * by row, i.e. columnSums(t(A)) -- and keep it: repeated calls only reduce.
+ * The device variants regroup the entries by block of 16384 rows in the caller's
+ * workspace on every call (one hand-written partition pass, sums accumulated in
+ * LDS; matrices of more than 1.36e7 rows sort by 4096-row block instead); the
+ * workspace is 12 B/nnz + up to 64 B/row + a count table of at most 64 MB.
+ * Entries whose row index is outside [0, nrow) are left out, not added elsewhere.
+ * Ask for the workspace size with the device current that will run the call
+ * (the plan looks at its CU count).
  * rsp_row_sums_workspace_bytes needs a usable device (it asks rocPRIM); 0 = error.
  */
 int rsp_csc_row_sums(rsp_csc_t handle, double *sums);     /* nrow doubles, host */
