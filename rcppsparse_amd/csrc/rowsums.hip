@@ -63,17 +63,25 @@ constexpr int kAccStagers = kAccThreads - 64;
 constexpr int kAccDepth = 8;              // steps of entries a staging thread has in flight (8 x 11.5 KB per CU)
 constexpr int kAccMaxSplit = 8;           // workgroups that may share one row block
 
-static unsigned key_bits(int32_t nrow) {
+// bits needed to hold every value up to and including v
+static unsigned bits_to_hold(uint32_t v) {
     unsigned b = 1;
-    while (b < 31 && (1u << b) < (unsigned)nrow) ++b;
+    while (b < 32 && (v >> b) != 0) ++b;
     return b;
 }
 
-// first bit the block sort looks at (all bits of a matrix with a single block: nothing to sort by)
-static unsigned block_begin_bit(int32_t nrow) {
-    const unsigned hi = key_bits(nrow);
-    return hi > (unsigned)kRowBlockShift ? (unsigned)kRowBlockShift : hi;
-}
+// Sort key of an entry: its row index, or ONE value past every valid key when the index is not in
+// [0, nrow) -- not a valid dgCMatrix.  Such entries then sort behind all others, outside every row's
+// (or row block's) range; left as they are their upper bits would scatter them among the valid entries
+// and the offsets searched below would be those of an unsorted array.
+struct RowKey {
+    uint32_t nrow, past;
+    __host__ __device__ uint32_t operator()(uint32_t row) const { return row < nrow ? row : past; }
+};
+using RowKeyIterator = rocprim::transform_iterator<const uint32_t*, RowKey, uint32_t>;
+
+// block sort: the key past the valid ones is the first row of the block after the last
+static uint32_t block_sort_past(int32_t nblocks) { return (uint32_t)nblocks << kRowBlockShift; }
 
 // block id of an entry, as the offsets search sees the sorted row indices
 struct RowBlockOf {
@@ -158,10 +166,11 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
         L->shift = kRowBlockShift;
         L->nblocks = (int32_t)(((int64_t)nrow + (1 << kRowBlockShift) - 1) >> kRowBlockShift);
         if (L->nblocks < 1) L->nblocks = 1;
-        if (block_begin_bit(nrow) < key_bits(nrow)) {   // (a matrix of one block is copied, not sorted)
-            e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                          (const double*)nullptr, (double*)nullptr, (size_t)nnz,
-                                          block_begin_bit(nrow), key_bits(nrow), (hipStream_t)0);
+        {
+            const RowKey key{(uint32_t)nrow, block_sort_past(L->nblocks)};
+            e = rocprim::radix_sort_pairs(nullptr, sort_bytes, RowKeyIterator((const uint32_t*)nullptr, key),
+                                          (uint32_t*)nullptr, (const double*)nullptr, (double*)nullptr, (size_t)nnz,
+                                          (unsigned)kRowBlockShift, bits_to_hold(key.past), (hipStream_t)0);
             if (e != hipSuccess) return e;
         }
         auto ids = rocprim::make_transform_iterator((const uint32_t*)nullptr, RowBlockOf{kRowBlockShift});
@@ -176,9 +185,10 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
         off = 0;
     } else {
         L->mode = 1;
-        e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                      (const double*)nullptr, (double*)nullptr, (size_t)nnz, 0u, key_bits(nrow),
-                                      (hipStream_t)0);
+        const RowKey key{(uint32_t)nrow, (uint32_t)nrow};
+        e = rocprim::radix_sort_pairs(nullptr, sort_bytes, RowKeyIterator((const uint32_t*)nullptr, key),
+                                      (uint32_t*)nullptr, (const double*)nullptr, (double*)nullptr, (size_t)nnz, 0u,
+                                      bits_to_hold(key.past), (hipStream_t)0);
         if (e != hipSuccess) return e;
         e = rocprim::lower_bound(nullptr, search_bytes, (const uint32_t*)nullptr,
                                  rocprim::counting_iterator<uint32_t>(0), (int32_t*)nullptr, (size_t)nnz,
@@ -549,6 +559,19 @@ __global__ void rows_combine_parts_kernel(const double* __restrict__ part_out, i
     out[row] = t;
 }
 
+// row form: the values of entries whose row index was not in [0, nrow) (sorted behind all rows) become +0.0
+__global__ void rows_clear_invalid_tail_kernel(double* __restrict__ vals, const int32_t* __restrict__ prow,
+                                               int32_t nrow, int64_t nnz) {
+    const int64_t first = prow[nrow];
+    for (int64_t j = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz;
+         j += (int64_t)gridDim.x * blockDim.x)
+        vals[j] = 0.0;
+}
+
+__global__ void rows_close_offsets_kernel(int32_t* __restrict__ prow, int32_t nrow, int64_t nnz) {
+    prow[nrow] = (int32_t)nnz;
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -563,14 +586,22 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
         int32_t* prow = (int32_t*)((char*)persist + L.prow_off);
         uint32_t* keys = (uint32_t*)((char*)scratch + L.keys_off);
         if (nnz > 0) {
-            e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)d_i, keys, d_x, vals, (size_t)nnz, 0u,
-                                          key_bits(nrow), stream);
+            const RowKey key{(uint32_t)nrow, (uint32_t)nrow};   // (entries outside [0, nrow) sort behind row nrow - 1)
+            e = rocprim::radix_sort_pairs(temp, temp_bytes, RowKeyIterator((const uint32_t*)d_i, key), keys, d_x, vals,
+                                          (size_t)nnz, 0u, bits_to_hold(key.past), stream);
             if (e != hipSuccess) return e;
         }
         temp_bytes = L.temp_bytes;
-        // prow[r] = first position whose row index is >= r  (r = 0..nrow; prow[nrow] = nnz)
-        return rocprim::lower_bound(temp, temp_bytes, (const uint32_t*)keys, rocprim::counting_iterator<uint32_t>(0),
-                                    prow, (size_t)nnz, (size_t)nrow + 1, rocprim::less<uint32_t>(), stream);
+        // prow[r] = first position whose key is >= r  (r = 0..nrow; prow[nrow] = number of valid entries)
+        e = rocprim::lower_bound(temp, temp_bytes, (const uint32_t*)keys, rocprim::counting_iterator<uint32_t>(0),
+                                 prow, (size_t)nnz, (size_t)nrow + 1, rocprim::less<uint32_t>(), stream);
+        if (e != hipSuccess || nnz == 0) return e;
+        // What lies behind prow[nrow] belongs to no row.  Those values become +0.0 and the last row takes them
+        // in (prow[nrow] = nnz), so that the column-sum kernels see offsets that end at nnz, like a valid p[]:
+        // adding +0.0 changes no sum (the accumulator starts at +0.0, so no partial sum is -0.0).
+        hipLaunchKernelGGL(rows_clear_invalid_tail_kernel, dim3(256), dim3(256), 0, stream, vals, prow, nrow, nnz);
+        hipLaunchKernelGGL(rows_close_offsets_kernel, dim3(1), dim3(1), 0, stream, prow, nrow, nnz);
+        return hipGetLastError();
     }
     if (L.mode == 2) {
         double* px = (double*)((char*)persist + L.vals_off);
@@ -612,19 +643,16 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
     double* px = (double*)((char*)persist + L.vals_off);
     uint32_t* pr = (uint32_t*)((char*)persist + L.rows_off);
     int32_t* boff = (int32_t*)((char*)persist + L.boff_off);
-    if (nnz > 0 && block_begin_bit(nrow) < key_bits(nrow)) {
-        // stable, on the block bits only: the entries of a block keep their storage order
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)d_i, pr, d_x, px, (size_t)nnz,
-                                      block_begin_bit(nrow), key_bits(nrow), stream);
-        if (e != hipSuccess) return e;
-    } else if (nnz > 0) {   // a single block: the entries are already together
-        e = hipMemcpyAsync(px, d_x, (size_t)nnz * 8, hipMemcpyDeviceToDevice, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(pr, d_i, (size_t)nnz * 4, hipMemcpyDeviceToDevice, stream);
+    if (nnz > 0) {
+        // stable, on the block bits only: the entries of a block keep their storage order; entries that are
+        // not in [0, nrow) get the key past the last block and end up behind boff[nblocks]
+        const RowKey key{(uint32_t)nrow, block_sort_past(L.nblocks)};
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, RowKeyIterator((const uint32_t*)d_i, key), pr, d_x, px,
+                                      (size_t)nnz, (unsigned)kRowBlockShift, bits_to_hold(key.past), stream);
         if (e != hipSuccess) return e;
     }
     temp_bytes = L.temp_bytes;
-    // boff[b] = first position whose block id is >= b  (b = 0..nblocks).  Entries whose row index is not
-    // in [0, nrow) -- not a valid dgCMatrix -- may sit anywhere; the accumulate kernel leaves them out.
+    // boff[b] = first position whose block id is >= b  (b = 0..nblocks)
     auto ids = rocprim::make_transform_iterator((const uint32_t*)pr, RowBlockOf{L.shift});
     return rocprim::lower_bound(temp, temp_bytes, ids, rocprim::counting_iterator<uint32_t>(0), boff, (size_t)nnz,
                                 (size_t)L.nblocks + 1, rocprim::less<uint32_t>(), stream);

@@ -130,16 +130,41 @@ def test_row_sums_forms_by_row_count(torch_cuda, nrow, nnz):
     i = oracle.gen_row_indices(p, nrow, 7)
     check(got, x, i, p, nrow)
     # entries whose row index is not in [0, nrow) -- not a valid dgCMatrix -- are left out, not added elsewhere
+    # (in every flavour: just past the end, negative, and with upper bits that would sort them among the valid ones)
     it2 = it.clone()
     it2[::1000] = nrow + 5
     it2[1::1000] = -3
+    it2[2::1000] = torch.arange(0, nnz, 1000, device="cuda", dtype=torch.int64)[: it2[2::1000].numel()].to(torch.int32) * 37 + 2 * nrow
+    it2[3::1000] = -(torch.arange(0, nnz, 1000, device="cuda", dtype=torch.int64)[: it2[3::1000].numel()].to(torch.int32) * 53) - 1
     got2 = capi.row_sums_device(xt, it2, nrow).cpu().numpy()
     keep = np.ones(nnz, dtype=bool)
-    keep[::1000] = False
-    keep[1::1000] = False
+    for k in range(4):
+        keep[k::1000] = False
     ref2 = np.bincount(i[keep], weights=x[keep], minlength=nrow)
     scale2 = np.bincount(i[keep], weights=np.abs(x[keep]), minlength=nrow)
     assert np.all(np.abs(got2 - ref2) <= 1e-11 * np.maximum(scale2, 1e-300) + 1e-300)
+
+
+def test_handle_row_sums_leave_out_invalid_row_indices(torch_cuda):
+    """The handle's row-major form sorts by row; entries whose row index is not in [0, nrow) must end up
+    behind every row's range whatever their upper bits are (they get the key nrow), not among the rows."""
+    rng = np.random.default_rng(77)
+    nrow, ncol, nnz = 70_001, 300, 150_000
+    x = rng.standard_normal(nnz)
+    i = rng.integers(0, nrow, nnz).astype(np.int32)
+    bad = rng.random(nnz) < 0.1
+    i[bad] = rng.choice([nrow, nrow + 1, 2 * nrow + 3, 2**30 + 17, -1, -nrow, -2**31], size=int(bad.sum())).astype(np.int32)
+    p = np.concatenate(([0], np.sort(rng.integers(0, nnz + 1, ncol - 1)), [nnz])).astype(np.int32)
+    h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
+    hs, hs2 = h.row_sums(), h.row_sums()
+    hm = h.row_means()
+    cs = h.column_sums()
+    h.close()
+    ref = np.bincount(i[~bad], weights=x[~bad], minlength=nrow)
+    scale = np.bincount(i[~bad], weights=np.abs(x[~bad]), minlength=nrow)
+    assert hs.tobytes() == hs2.tobytes() and hm.tobytes() == (hs / ncol).tobytes()
+    assert np.all(np.abs(hs - ref) <= RTOL * scale), float(np.max(np.abs(hs - ref)))
+    assert np.allclose(cs, oracle.column_sums(x, p), rtol=0, atol=1e-9)    # column sums do not look at i[]
 
 
 @pytest.mark.parametrize("pattern", ["one_row", "first_tiles_invalid", "edge_blocks", "one_block_dense", "all_invalid"])
