@@ -23,6 +23,7 @@
  *
  * Index types follow the reference: p[] and i[] are 32-bit int
  * (RcppSparse.h:30, :232), so nnz <= 2^31-1; byte offsets are 64-bit inside.
+ * ncol may be up to 2^31 - 65537 (more is RSP_ERR_BAD_ARG).
  * Contract on p (what Matrix::dgCMatrix guarantees and the reference assumes
  * without checking): p[0] == 0, p non-decreasing, p[ncol] == nnz.  The host
  * entry points verify this and return RSP_ERR_BAD_ARG otherwise; the device
@@ -183,10 +184,12 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
  * order.  The handle variants (the handle must have been uploaded with i[])
  * build the row-major form on first use -- a stable device radix sort of (i, x)
  * by row, i.e. columnSums(t(A)) -- and keep it: repeated calls only reduce.
- * The device variants regroup the entries by block of 16384 rows in the caller's
- * workspace on every call (one hand-written partition pass, sums accumulated in
- * LDS; matrices of more than 1.36e7 rows sort by 4096-row block instead); the
- * workspace is 12 B/nnz + up to 64 B/row + a count table of at most 64 MB.
+ * The device variants accumulate in LDS, 16384 rows per workgroup: matrices of
+ * up to 49152 rows are summed straight from x / i (workspace: the workgroups'
+ * partial sums, at most a few hundred MB); larger ones are first regrouped by
+ * block of 16384 rows in the caller's workspace on every call (one hand-written
+ * partition pass; more than 1.36e7 rows: a sort by 4096-row block instead), with
+ * a workspace of 12 B/nnz + up to 64 B/row + a count table of at most 64 MB.
  * Entries whose row index is outside [0, nrow) are left out, not added elsewhere.
  * Ask for the workspace size with the device current that will run the call
  * (the plan looks at its CU count).

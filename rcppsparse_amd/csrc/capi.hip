@@ -165,6 +165,8 @@ private:
 
 int check_sizes(int32_t ncol, int64_t nnz) {
     if (ncol < 0) return fail(RSP_ERR_BAD_ARG, "ncol is negative (%d)", ncol);
+    if (ncol > INT32_MAX - 65536)   // column cursors run a few windows past the current column in 32 bits
+        return fail(RSP_ERR_BAD_ARG, "ncol = %d is above the supported 2^31 - 65537", ncol);
     if (nnz < 0 || nnz > INT32_MAX)
         return fail(RSP_ERR_BAD_ARG,
                     "nnz = %lld is outside [0, 2^31-1] (p[] is 32-bit, RcppSparse.h:30)",
@@ -487,7 +489,7 @@ static int row_enqueue(const double* d_x, const int32_t* d_i, int32_t nrow, int6
     char* persist = (char*)ws;
     char* scratch = persist + L.persistent_bytes;
     HIP_TRY(rsp::launch_row_build(d_x, d_i, nrow, nnz, L, persist, scratch, stream));
-    HIP_TRY(rsp::launch_row_reduce(nrow, nnz, L, persist, d_out, divisor, means, make_plan(nnz), stream));
+    HIP_TRY(rsp::launch_row_reduce(d_x, d_i, nrow, nnz, L, persist, d_out, divisor, means, make_plan(nnz), stream));
     return RSP_OK;
 }
 
@@ -532,7 +534,7 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
         }
         h->row_ready = true;
     }
-    HIP_TRY(rsp::launch_row_reduce(h->nrow, h->nnz, h->row_layout, h->d_row_persist, h->d_row_out,
+    HIP_TRY(rsp::launch_row_reduce(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout, h->d_row_persist, h->d_row_out,
                                    means ? (double)h->ncol : 1.0, means, make_plan(h->nnz), h->stream));
     HIP_TRY(hipMemcpyAsync(host_out, h->d_row_out, (size_t)h->nrow * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

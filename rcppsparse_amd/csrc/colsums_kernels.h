@@ -100,12 +100,14 @@ struct RowSumsLayout {
     size_t vals_off, rows_off, boff_off, prow_off, colsums_off, partial_off, persistent_bytes;
     size_t table_off, keys_off, temp_off, temp_bytes, scratch_bytes;
     int32_t shift, nblocks, nsuper, nsplit;   // nsplit: accumulate workgroups per row block (mode 2)
+    bool direct;   // mode 2, one row block: no regrouping, the accumulate pass reads the caller's x / i
     int64_t super_elems;
 };
 hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form, RowSumsLayout* L);
 hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
                             const RowSumsLayout& L, void* persist, void* scratch, hipStream_t stream);
-hipError_t launch_row_reduce(int32_t nrow, int64_t nnz, const RowSumsLayout& L, void* persist, double* d_out,
+hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
+                             const RowSumsLayout& L, void* persist, double* d_out,
                              double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream);
 
 // Matrix::crossprod on the device (crossprod.hip): dense ncol x ncol, column-major.

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __res
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (int c = wave; c < ncol; c += nwaves) {
         const int e1 = p[c + 1], slice = c / width;
-        for (int e = p[c] + lane; e < e1; e += 64) {
+        for (int64_t e = (int64_t)p[c] + lane; e < e1; e += 64) {   // (64-bit: e1 may be 2^31 - 1)
             const int r = ri[e];
             if ((unsigned)r < (unsigned)nrow) atomicAdd(&cnt[(int64_t)r * nsplit + slice], 1);
         }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void xp_fill_rows_kernel(const double* __restr
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (int c = wave; c < ncol; c += nwaves) {
         const int e1 = p[c + 1], slice = c / width;
-        for (int e = p[c] + lane; e < e1; e += 64) {
+        for (int64_t e = (int64_t)p[c] + lane; e < e1; e += 64) {   // (64-bit: e1 may be 2^31 - 1)
             const int r = ri[e];
             if ((unsigned)r >= (unsigned)nrow) continue;
             const int pos = atomicAdd(&cursor[(int64_t)r * nsplit + slice], 1);
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
     __syncthreads();
 
     const int e_end = p[c1 + 1];
-    for (int e0 = p[c1]; e0 < e_end; e0 += 64) {
+    for (int64_t e0 = p[c1]; e0 < e_end; e0 += 64) {   // (64-bit: e_end may be 2^31 - 1)
         // 64 entries of column c1 (ascending rows), one per lane, with the extent of their rows
-        const int n = __builtin_amdgcn_readfirstlane(min(64, e_end - e0));
+        const int n = __builtin_amdgcn_readfirstlane((int)min((int64_t)64, e_end - e0));
         double va = 0.0;
         int rs = 0, len = 0;
         if (lane < n) {

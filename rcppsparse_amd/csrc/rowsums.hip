@@ -2,7 +2,12 @@
 //
 // Reference inst/include/RcppSparse.h:138-144 scatters sums(i[j]) += x[j] while walking the
 // columns.  On the device that is a reduction by key with 1e7 keys and no locality in the key.
-// Three forms, chosen in plan_row_sums:
+// Four forms, chosen in plan_row_sums:
+//
+//   direct (one-shot calls on matrices of up to 3 row blocks, 49152 rows): nothing is regrouped.  Steps 4
+//     and 5 below run on the caller's x / i, every block's workgroups scanning all entries and adding
+//     those of their block: 12 B/nnz per block, no workspace beyond the parts' sums
+//     (5e8 nnz: 1.45 / 2.7 / 4.0 ms for 1 / 2 / 3 blocks; regrouping first costs 4.5-5.4 ms there).
 //
 //   tile partition (one-shot calls, rsp_row_sums_device, up to 1.36e7 rows) -- all hand-written:
 //     the entries are regrouped by ROW BLOCK (16384 rows: what one CU's LDS holds as sums) in ONE
@@ -61,7 +66,8 @@ constexpr size_t kCountTableMaxBytes = 64u << 20;
 constexpr int kAccThreads = 1024;         // accumulate workgroup: 15 wavefronts stage the entries, ONE adds them
 constexpr int kAccStagers = kAccThreads - 64;
 constexpr int kAccDepth = 8;              // steps of entries a staging thread has in flight (8 x 11.5 KB per CU)
-constexpr int kAccMaxSplit = 8;           // workgroups that may share one row block
+constexpr int kAccMaxSplit = 1024;        // workgroups that may share one row block
+constexpr int kDirectMaxBlocks = 3;       // up to here the accumulate pass scans the caller's x / i once per block instead
 
 // bits needed to hold every value up to and including v
 static unsigned bits_to_hold(uint32_t v) {
@@ -95,9 +101,9 @@ struct RowBlockOf {
 // Workgroups per row block in the accumulate pass.  One per block leaves the last round of a grid of
 // 611 blocks on 256 CUs 61 % empty (and a 62-block matrix on a quarter of the chip); the blocks'
 // entries are split into equal parts instead, each part summed by its own workgroup and the parts
-// added up in a fixed order afterwards.  Cost model: rounds x bytes a workgroup moves (its entries,
-// plus its block of sums written and read back).
-static int accumulate_split(int32_t nblocks, int64_t nnz, int64_t rows_per_block) {
+// added up in a fixed order afterwards.  Cost model: rounds x bytes a workgroup moves (its share of the
+// `stream_entries` entries a block's workgroups scan between them, plus its block of sums written and read back).
+static int accumulate_split(int32_t nblocks, int64_t stream_entries, int64_t rows_per_block) {
     static int ncu = 0;   // (benign if two threads both fill it in)
     if (ncu == 0) {
         int dev = 0, n = 0;
@@ -109,12 +115,14 @@ static int accumulate_split(int32_t nblocks, int64_t nnz, int64_t rows_per_block
             return 1;   // no device to plan for (workspace queries on a host without one)
         }
     }
+    static const int candidates[] = {1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024};
     int best = 1;
     double best_cost = 0;
-    for (int ns = 1; ns <= kAccMaxSplit; ++ns) {
+    for (int ns : candidates) {
+        if (ns > kAccMaxSplit) break;
         const int64_t units = (int64_t)nblocks * ns;
         const int64_t rounds = (units + ncu - 1) / ncu;
-        const double unit_bytes = 12.0 * (double)nnz / (double)units + (ns > 1 ? 24.0 : 8.0) * (double)rows_per_block;
+        const double unit_bytes = 12.0 * (double)stream_entries / (double)ns + (ns > 1 ? 24.0 : 8.0) * (double)rows_per_block;
         const double cost = (double)rounds * unit_bytes;
         if (ns == 1 || cost < best_cost * 0.97) {   // (a split has to pay for itself)
             best = ns;
@@ -142,14 +150,21 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
         while (((nnz + super - 1) / super) * L->nblocks * 4 > (int64_t)kCountTableMaxBytes) super *= 2;
         L->super_elems = super;
         L->nsuper = (int32_t)((nnz + super - 1) / super);
-        L->nsplit = accumulate_split(L->nblocks, nnz, (int64_t)1 << kPartShift);
+        const int64_t rows_here = nrow < (1 << kPartShift) ? (nrow > 0 ? nrow : 1) : (1 << kPartShift);
+        // Few blocks: no regrouping at all.  A block's workgroups scan the caller's x / i as they are and add
+        // the entries of their block (12 B/nnz per block instead of ~40 B/nnz and the partition pass's LDS work;
+        // 5e8 nnz: 1.45 ms for one block, 2.7 ms for two; the partition form takes 4.5-5.4 ms at 2-61 blocks).
+        L->direct = L->nblocks <= kDirectMaxBlocks;
+        L->nsplit = accumulate_split(L->nblocks, L->direct ? nnz : nnz / L->nblocks, rows_here);
         const size_t table_entries = (size_t)L->nsuper * (size_t)L->nblocks + 1;   // + the total
         size_t temp = 0;
         e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, table_entries,
                                     rocprim::plus<int32_t>(), (hipStream_t)0);
         if (e != hipSuccess) return e;
-        L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);                // x grouped by row block
-        L->rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);                // their row indices
+        if (!L->direct) {
+            L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);            // x grouped by row block
+            L->rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);            // their row indices
+        }
         L->boff_off = off;  off = align_up(off + ((size_t)L->nblocks + 1) * 4, 256);   // first slot of every block
         L->partial_off = off;                                                          // sums per (part, row)
         if (L->nsplit > 1) off = align_up(off + (size_t)L->nsplit * (size_t)(nrow > 0 ? nrow : 0) * 8, 256);
@@ -232,12 +247,12 @@ __global__ __launch_bounds__(64) void rows_block_accumulate_kernel(
     __builtin_amdgcn_wave_barrier();
     const int32_t s0 = boff[b], s1 = boff[b + 1];
     // 16 steps of 64 entries in flight (12 KB per wavefront, 5 wavefronts per CU)
-    for (int32_t s = s0; s < s1; s += 16 * 64) {
+    for (int64_t s = s0; s < s1; s += 16 * 64) {   // (64-bit: s1 may be 2^31 - 1)
         int32_t r[16];
         double v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int32_t j = s + k * 64 + lane;
+            const int64_t j = s + k * 64 + lane;
             const bool in = j < s1;
             r[k] = in ? pr[j] : -1;
             v[k] = in ? px[j] : 0.0;
@@ -463,8 +478,8 @@ __global__ void rows_tile_offsets_kernel(const int32_t* __restrict__ first_slot,
 template <bool MEANS>
 __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     const double* __restrict__ px, const int32_t* __restrict__ pr, const int32_t* __restrict__ boff,
-    int32_t nrow, int32_t shift, int32_t nsplit, double* __restrict__ out, double* __restrict__ part_out,
-    double divisor) {
+    int64_t direct_nnz, int32_t nrow, int32_t shift, int32_t nsplit, double* __restrict__ out,
+    double* __restrict__ part_out, double divisor) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double* sums = (double*)s_raw;                          // 1 << shift
@@ -475,13 +490,14 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     const int rows_here = 1 << shift, mask = rows_here - 1;
     for (int r = tid; r < rows_here; r += kAccThreads) sums[r] = 0.0;
     // this workgroup's part of the block: whole steps, the same for every run
-    const int32_t s0 = boff[b], s1 = boff[b + 1];
-    const int32_t steps_all = (s1 - s0 + kAccStagers - 1) / kAccStagers;
+    // (direct form: every block scans all of x / i, which are then the caller's arrays)
+    const int32_t s0 = direct_nnz >= 0 ? 0 : boff[b], s1 = direct_nnz >= 0 ? (int32_t)direct_nnz : boff[b + 1];
+    const int32_t steps_all = (int32_t)(((int64_t)s1 - s0 + kAccStagers - 1) / kAccStagers);
     const int32_t steps_per = (steps_all + nsplit - 1) / nsplit;
     const int64_t u0_ = (int64_t)s0 + (int64_t)part * steps_per * kAccStagers;
     const int64_t u1_ = u0_ + (int64_t)steps_per * kAccStagers;
     const int32_t u0 = (int32_t)(u0_ < s1 ? u0_ : s1), u1 = (int32_t)(u1_ < s1 ? u1_ : s1);
-    const int32_t nsteps = (u1 - u0 + kAccStagers - 1) / kAccStagers;
+    const int32_t nsteps = (int32_t)(((int64_t)u1 - u0 + kAccStagers - 1) / kAccStagers);
     // steps are taken kAccDepth at a time (static register rotation); the ones past the end stage row -1
     const int32_t nrounds = (nsteps + kAccDepth - 1) / kAccDepth;
     // Barrier k closes step k's staging.  The adder adds step k between barriers k and k + 1, the stagers
@@ -524,8 +540,9 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
 #pragma unroll
                 for (int u = 0; u < kAccStagers / 64; ++u) xv[u] = bx[u * 64 + lane];
 #pragma unroll
-                for (int u = 0; u < kAccStagers / 64; ++u)   // (slots past the end of the part hold row -1)
-                    if (rr[u] >= 0) lds_add_f64(&sums[rr[u] & mask], xv[u]);
+                for (int u = 0; u < kAccStagers / 64; ++u)   // (slots past the end of the part hold row -1; the direct
+                    // form also meets other blocks' entries and whatever else the caller's i[] holds)
+                    if ((uint32_t)rr[u] < (uint32_t)nrow && (rr[u] >> shift) == b) lds_add_f64(&sums[rr[u] & mask], xv[u]);
             }
         }
     }
@@ -603,6 +620,7 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
         hipLaunchKernelGGL(rows_close_offsets_kernel, dim3(1), dim3(1), 0, stream, prow, nrow, nnz);
         return hipGetLastError();
     }
+    if (L.mode == 2 && L.direct) return hipSuccess;   // nothing to regroup
     if (L.mode == 2) {
         double* px = (double*)((char*)persist + L.vals_off);
         int32_t* pr = (int32_t*)((char*)persist + L.rows_off);
@@ -659,15 +677,17 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
 }
 
 // Row sums / means from the row-wise form in `persist`.
-hipError_t launch_row_reduce(int32_t nrow, int64_t nnz, const RowSumsLayout& L, void* persist, double* d_out,
+hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
+                             const RowSumsLayout& L, void* persist, double* d_out,
                              double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream) {
     if (nrow <= 0) return hipSuccess;
     if (L.mode == 1)   // rowSums(A) = columnSums(t(A)): same kernels, row offsets in place of p
         return launch_column_sums((const double*)((char*)persist + L.vals_off),
                                   (const int32_t*)((char*)persist + L.prow_off), nrow, (int32_t)nnz, d_out,
                                   colsums_plan, (char*)persist + L.colsums_off, divisor, means, stream);
-    const double* px = (const double*)((char*)persist + L.vals_off);
-    const int32_t* pr = (const int32_t*)((char*)persist + L.rows_off);
+    const bool direct = L.mode == 2 && L.direct;
+    const double* px = direct ? d_x : (const double*)((char*)persist + L.vals_off);
+    const int32_t* pr = direct ? d_i : (const int32_t*)((char*)persist + L.rows_off);
     const int32_t* boff = (const int32_t*)((char*)persist + L.boff_off);
     if (L.mode == 2) {
         const size_t acc_lds = ((size_t)8 << L.shift) + (size_t)2 * kAccStagers * 12;
@@ -685,10 +705,10 @@ hipError_t launch_row_reduce(int32_t nrow, int64_t nnz, const RowSumsLayout& L, 
         const dim3 grid((unsigned)L.nblocks * (unsigned)L.nsplit);
         if (means)
             hipLaunchKernelGGL(rows_tile_accumulate_kernel<true>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
-                               boff, nrow, L.shift, L.nsplit, d_out, parts, divisor);
+                               boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.nsplit, d_out, parts, divisor);
         else
             hipLaunchKernelGGL(rows_tile_accumulate_kernel<false>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
-                               boff, nrow, L.shift, L.nsplit, d_out, parts, divisor);
+                               boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.nsplit, d_out, parts, divisor);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || L.nsplit <= 1) return e;
         const dim3 cgrid((unsigned)(((int64_t)nrow + 255) / 256));
