@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
-    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe",
+    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe", "rsp_set_crossprod_exact",
     "rsp_set_experiment",
 )
 
@@ -120,6 +120,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_set_tuning.argtypes = [c.c_int]
     L.rsp_set_experiment.argtypes = [c.c_int]
     L.rsp_set_taper.argtypes = [c.c_int, c.c_int]
+    L.rsp_set_crossprod_exact.argtypes = [c.c_int]
     L.rsp_plan_describe.argtypes = [i64, ip]
     _lib = L
     return L
@@ -152,6 +153,12 @@ def device_count() -> int:
 
 def set_tuning(chunk_rows: int = 0) -> None:
     _check(load().rsp_set_tuning(int(chunk_rows)))
+
+
+def set_crossprod_exact(exact: bool) -> None:
+    """True: crossprod keeps the reference's accumulation order (bit-identical) on every shape; False (default):
+    tall matrices (ncol <= 128, long columns) go to the matrix-core form (rsp_set_crossprod_exact)."""
+    _check(load().rsp_set_crossprod_exact(int(bool(exact))))
 
 
 def set_taper(tail_permille: int = -1, tail_chunk_rows: int = -1) -> None:

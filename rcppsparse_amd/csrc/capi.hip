@@ -27,6 +27,7 @@ thread_local char g_err[512] = "";
 // tuning knobs are read by the worker threads of the multi-GPU host entries: atomics
 std::atomic<int> g_chunk_rows_override{0};   // rsp_set_tuning / RSP_CHUNK_ROWS
 std::atomic<int> g_variant{-1};              // rsp_set_experiment / RSP_VARIANT (-1 = read the env)
+std::atomic<int> g_crossprod_exact{-1};      // rsp_set_crossprod_exact / RSP_CROSSPROD_EXACT (-1 = read the env)
 std::atomic<int> g_taper_permille{-1};       // rsp_set_taper / RSP_TAPER (-1 = env, else the default)
 std::atomic<int> g_taper_rows{-1};
 
@@ -546,10 +547,25 @@ int rsp_csc_row_means(rsp_csc_t h, double* means) { return csc_rows(h, means, tr
 
 // ---- Matrix::crossprod (RcppSparse.h:159-194) -----------------------------------------------
 
+static bool crossprod_exact() {
+    int v = g_crossprod_exact.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* env = getenv("RSP_CROSSPROD_EXACT");
+        v = (env && env[0] && env[0] != '0') ? 1 : 0;
+        g_crossprod_exact.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
+int rsp_set_crossprod_exact(int exact) {
+    g_crossprod_exact.store(exact ? 1 : 0, std::memory_order_relaxed);
+    return RSP_OK;
+}
+
 static int xp_plan(int32_t nrow, int32_t ncol, int64_t nnz, rsp::CrossprodLayout* L) {
     if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
     if (int rc = check_sizes(ncol, nnz)) return rc;
-    hipError_t e = rsp::plan_crossprod(nrow, ncol, nnz, L);
+    hipError_t e = rsp::plan_crossprod(nrow, ncol, nnz, crossprod_exact(), L);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(RSP_ERR_HIP, "planning crossprod failed: %s", hipGetErrorString(e));

@@ -114,8 +114,13 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
 struct CrossprodLayout {   // workspace of the row-major path
     size_t rp_off, cursor_off, rc_off, rx_off, temp_off, temp_bytes, total_bytes;
     int32_t nsplit, width;   // slices of a result column and their width (crossprod_split)
+    // tall form (few long columns; matrix cores, not bit-identical): workgroups, row panels per workgroup,
+    // column tiles; their results and the "x holds a non-finite value" flag in the workspace
+    bool tall;
+    int32_t ngroups, panels_per_group, ntiles;
+    size_t partial_off, flag_off;
 };
-hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, CrossprodLayout* L);
+hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, CrossprodLayout* L);
 void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, int32_t* width);
 hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
                                  int32_t ncol, int64_t nnz, double* d_out, const CrossprodLayout& L, void* ws,

@@ -5,7 +5,9 @@
 // x1 * x2 over the common rows in ascending row order (OpenMP over c1; the package's only
 // parallel routine).  O(ncol^2) output: meant for matrices with few columns.
 //
-// Two kernels, both in the reference's accumulation order (bit-identical results):
+// Two kernels in the reference's accumulation order (bit-identical results), and a third for the tall
+// matrices the routine is meant for, where that order is a serial walk of every column (see "tall form"
+// below: dense rank-k updates on the matrix cores, results within the floating-point tolerance):
 //
 //  * crossprod_rows_kernel (used when the caller provides a workspace).  The row-major form of
 //    A is built first (integer row histogram, exclusive scan, cursor fill; the order of the
@@ -25,7 +27,7 @@
 //    on both sides.  Row blocks in which none of the 128 columns has an entry are skipped (the
 //    next block starts at the smallest pending row).
 //
-// In both, products are accumulated in ascending row order with a separate multiply and add (no
+// In these two, products are accumulated in ascending row order with a separate multiply and add (no
 // FMA contraction), i.e. in the reference's order: results are bit-identical to the reference
 // loop.  Only entries that are stored take part, so a non-finite value never meets a structural
 // zero.
@@ -154,6 +156,12 @@ __global__ __launch_bounds__(256) void crossprod_tiles_kernel(
 constexpr int kXDepth = 16;       // (row, segment) units whose loads one wave keeps in flight
 constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 
+// tall form (few columns, long columns)
+constexpr int kTallMaxCols = 128;        // 8 column tiles of 16: 36 tile pairs, 9 per wavefront
+constexpr int kTallRows = 64;            // rows of A densified in LDS at a time (a "panel")
+constexpr int kTallMaxGroups = 1024;     // workgroups = partial results to add up
+constexpr int64_t kTallMinColumnLength = 32768;   // below this the exact form's serial walk is short enough
+
 // The row-major form is kept per *slice* of result columns: "virtual row" k * nsplit + c / width
 // holds the entries (c, x) of row k whose column lies in slice c / width, so that the wave that
 // owns slice s of a result column reads exactly the entries it needs and nothing else.
@@ -163,7 +171,9 @@ constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 __global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __restrict__ ri,
                                                             const int32_t* __restrict__ p, int32_t nrow,
                                                             int32_t ncol, int32_t nsplit, int32_t width,
-                                                            int32_t* __restrict__ cnt) {
+                                                            int32_t* __restrict__ cnt,
+                                                            const int32_t* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;   // (tall form: the row-major form is only needed if x is not all finite)
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (int c = wave; c < ncol; c += nwaves) {
@@ -181,7 +191,9 @@ __global__ __launch_bounds__(256) void xp_fill_rows_kernel(const double* __restr
                                                            const int32_t* __restrict__ p, int32_t nrow,
                                                            int32_t ncol, int32_t nsplit, int32_t width,
                                                            int32_t* __restrict__ cursor, int32_t* __restrict__ rc,
-                                                           double* __restrict__ rx) {
+                                                           double* __restrict__ rx,
+                                                           const int32_t* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (int c = wave; c < ncol; c += nwaves) {
@@ -214,9 +226,11 @@ template <int kXD>
 __global__ __launch_bounds__(64) void crossprod_rows_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p,
     const int32_t* __restrict__ rp, const int32_t* __restrict__ rc, const double* __restrict__ rx,
-    int32_t nrow, int32_t ncol, int32_t nsplit, int32_t width, double* __restrict__ out) {
+    int32_t nrow, int32_t ncol, int32_t nsplit, int32_t width, double* __restrict__ out,
+    const int32_t* __restrict__ run_if) {
 #pragma clang fp contract(off)
     extern __shared__ double acc[];                       // out(c_lo .. c_lo+span, c1) of this wave
+    if (run_if && *run_if == 0) return;                   // (stands by for the tall form, which then has run)
     const int c1 = blockIdx.x / nsplit, slice = blockIdx.x % nsplit, c_lo = slice * width;
     if (c1 >= ncol || c_lo >= ncol) return;               // (the launcher never creates such a slice)
     const unsigned span = (unsigned)(min(ncol - c_lo, width));
@@ -284,6 +298,179 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
     for (unsigned c = lane; c < span; c += 64) col[c] = acc[c];
 }
 
+// ---------------------------------------------------------------------------------------------
+// tall form: t(A) %*% A as a dense rank-k update on the matrix cores
+// ---------------------------------------------------------------------------------------------
+// The forms above give every output its products one after the other in ascending row order, which is
+// what makes them bit-identical to the reference -- and what makes them slow on the shape crossprod is
+// meant for: few columns, many rows.  48 columns of 4.5e7 rows are 48 serial walks of 4.5e7 steps:
+// 24.8 s (round 2, 2^31 - 1 entries), the work itself being 1e11 multiply-adds.  For ncol <= 128 and
+// columns of >= 32768 entries on average the library therefore sums in a different order: the rows of
+// A are densified 64 at a time into an LDS panel P[64][ncol] (zero where nothing is stored) and
+// C += t(P) P runs as v_mfma_f64_16x16x4_f64 over the 16 x 16 tile pairs I <= J, every workgroup over
+// its own range of rows; the workgroups' results are added up in workgroup order.  Deterministic, within
+// 1e-12 * sum |x1 x2| of the reference's order (tests/test_gpu_crossprod.py), not bit-identical.
+// The same 48 x 4.5e7 matrix: 16.9 ms (3 ms of it the scan of x below, 13.4 ms the kernel, which reads
+// the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms.
+// A product of a structural zero with a non-finite value would be NaN where the reference has nothing:
+// xp_nonfinite_kernel looks at x first, and if anything is not finite the tall kernels exit at once and
+// the exact row-major path (whose kernels otherwise exit at once) does the work.
+__global__ __launch_bounds__(256) void xp_nonfinite_kernel(const double* __restrict__ x, int64_t nnz,
+                                                           int32_t* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t u = (uint64_t)__double_as_longlong(x[j]);
+        bad |= ((u >> 52) & 0x7ff) == 0x7ff;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+typedef double xp_v4f64 __attribute__((ext_vector_type(4)));
+
+// tile pair number q of the upper triangle (I <= J) of an NT x NT grid of tiles, row by row
+__device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
+    I = 0;
+    while (q >= nt - I) {
+        q -= nt - I;
+        ++I;
+    }
+    J = I + q;
+}
+
+// One workgroup (4 wavefronts) per range of row panels, straight from the CSC arrays: a column's entries are
+// in ascending row order, so the part of it that falls into the workgroup's rows is one contiguous piece
+// (two binary searches per column at the start) and every panel takes the next few entries of each piece.
+// NT = column tiles.  Wavefront w loads columns w * CPW .. w * CPW + CPW - 1 (64 entries of each per panel,
+// all loads issued before the first is used) and owns the tile pairs q = w, w + 4, ... (at most MAXP), whose
+// 16 x 16 accumulators stay in registers.  Panels without entries are skipped: the next panel starts at the
+// smallest row any column has pending.
+template <int NT>
+__global__ __launch_bounds__(256) void crossprod_tall_kernel(
+    const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p, int32_t nrow,
+    int32_t ncol, int64_t nnz, int32_t panels_per_group, const int32_t* __restrict__ nonfinite,
+    double* __restrict__ partial) {
+    constexpr int W = NT * 16, NP = NT * (NT + 1) / 2, MAXP = (NP + 3) / 4, CPW = W / 4;
+    __shared__ double panel[kTallRows][W];
+    __shared__ int32_t s_cur[W], s_end[W], s_next[4];
+    if (*nonfinite) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ti[MAXP], tj[MAXP];
+    xp_v4f64 acc[MAXP];
+#pragma unroll
+    for (int s = 0; s < MAXP; ++s) {
+        tall_pair(s * 4 + wave < NP ? s * 4 + wave : 0, NT, ti[s], tj[s]);
+        acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
+    }
+    const int64_t R0 = (int64_t)blockIdx.x * panels_per_group * kTallRows;
+    const int64_t R1 = R0 + (int64_t)panels_per_group * kTallRows < nrow ? R0 + (int64_t)panels_per_group * kTallRows : nrow;
+    // this workgroup's piece of every column: [first entry with row >= R0, first entry with row >= R1)
+    if (tid < W) {
+        int32_t lo = 0, hi = 0;
+        if (tid < ncol) {
+            int64_t a = p[tid], b = p[tid + 1];
+            a = a < 0 ? 0 : (a > nnz ? nnz : a);   // (an invalid p[] must not lead outside x / i)
+            b = b < a ? a : (b > nnz ? nnz : b);
+            int64_t l = a, h = b;
+            while (l < h) {
+                const int64_t m = (l + h) >> 1;
+                if (ri[m] < R0) l = m + 1; else h = m;
+            }
+            lo = (int32_t)l;
+            h = b;
+            while (l < h) {
+                const int64_t m = (l + h) >> 1;
+                if (ri[m] < R1) l = m + 1; else h = m;
+            }
+            hi = (int32_t)l;
+        }
+        s_cur[tid] = lo;
+        s_end[tid] = hi;
+    }
+    __syncthreads();
+    int64_t r0 = R0;
+    while (r0 < R1) {
+        for (int k = tid; k < kTallRows * W; k += 256) (&panel[0][0])[k] = 0.0;
+        __syncthreads();
+        // 64 entries of each of this wavefront's columns; those below r0 + 64 go into the panel
+        int32_t row[CPW];
+        double val[CPW];
+        int32_t cur[CPW], end[CPW];
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            cur[k] = s_cur[wave * CPW + k];
+            end[k] = s_end[wave * CPW + k];
+            const int64_t e = (int64_t)cur[k] + lane;
+            const bool in = e < end[k];
+            row[k] = in ? ri[e] : 0x7fffffff;
+            val[k] = in ? x[e] : 0.0;
+        }
+        int32_t pending = 0x7fffffff;   // smallest row this wavefront's columns still have to deliver
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const bool below = (int64_t)row[k] < r0 + kTallRows;   // (lanes past the end hold INT_MAX)
+            const uint32_t local = (uint32_t)((int64_t)row[k] - r0);
+            if (below && local < (uint32_t)kTallRows) panel[local][wave * CPW + k] = val[k];
+            const int n = __popcll(__ballot(below));   // (also steps over rows below r0: an unsorted, invalid column)
+            if (lane == 0) s_cur[wave * CPW + k] = cur[k] + n;
+            // next row of this column: its first entry not taken, or unknown (then: the next panel) if all 64 were
+            int32_t nx = below ? 0x7fffffff : row[k];
+            if (n == 64 && (int64_t)cur[k] + 64 < end[k]) nx = (int32_t)(r0 + kTallRows < 0x7fffffff ? r0 + kTallRows : 0x7fffffff);
+            pending = nx < pending ? nx : pending;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int32_t o = __shfl_xor(pending, d, 64);
+            pending = o < pending ? o : pending;
+        }
+        if (lane == 0) s_next[wave] = pending;
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < kTallRows / 4; ++ks) {
+            const double* prow = &panel[4 * ks + (lane >> 4)][lane & 15];
+#pragma unroll
+            for (int s = 0; s < MAXP; ++s)
+                if (s * 4 + wave < NP)   // (uniform per wavefront)
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(prow[16 * ti[s]], prow[16 * tj[s]], acc[s], 0, 0, 0);
+        }
+        int32_t nxt = s_next[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) nxt = s_next[w] < nxt ? s_next[w] : nxt;
+        __syncthreads();   // (panel and s_next are rewritten next)
+        const int64_t step = r0 + kTallRows;
+        const int64_t jump = R0 + (((int64_t)nxt - R0) / kTallRows) * kTallRows;   // the panel that holds row nxt
+        r0 = nxt == 0x7fffffff ? R1 : (jump > step ? jump : step);
+    }
+    // tile (I, J), element (row, col) = C(16 I + row, 16 J + col); lane: col = lane & 15, row = (lane >> 4) + 4 r
+    double* mine = partial + (size_t)blockIdx.x * NP * 256;
+#pragma unroll
+    for (int s = 0; s < MAXP; ++s)
+        if (s * 4 + wave < NP) {
+            double* t = mine + (size_t)(s * 4 + wave) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[s][r];
+        }
+}
+
+// out(c1, c2) = the workgroups' results for that element, added in workgroup order (both triangles)
+__global__ __launch_bounds__(256) void crossprod_tall_combine_kernel(const double* __restrict__ partial,
+                                                                     int32_t ngroups, int32_t nt, int32_t ncol,
+                                                                     const int32_t* __restrict__ nonfinite,
+                                                                     double* __restrict__ out) {
+#pragma clang fp contract(off)
+    if (*nonfinite) return;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (int64_t)ncol * ncol) return;
+    const int c1 = (int)(k / ncol), c2 = (int)(k % ncol);
+    const int a = c1 < c2 ? c1 : c2, b = c1 < c2 ? c2 : c1;   // a <= b: tile pair (a / 16, b / 16)
+    const int I = a >> 4, J = b >> 4;
+    const int q = I * nt - I * (I - 1) / 2 + (J - I);
+    const int np = nt * (nt + 1) / 2;
+    const double* t = partial + (size_t)q * 256 + (size_t)(a & 15) * 16 + (b & 15);
+    double sum = 0.0;
+    for (int g = 0; g < ngroups; ++g) sum += t[(size_t)g * np * 256];
+    out[k] = sum;
+}
+
 // nsplit slices of `width` result rows each: width <= kXMaxWidth, every slice non-empty.
 // More than one slice when the LDS accumulators of a whole result column do not fit, and when
 // there are too few columns to fill the chip: then a column's work is shared by nsplit waves, as
@@ -306,8 +493,26 @@ void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, i
 
 static inline size_t xp_align(size_t v) { return (v + 255) / 256 * 256; }
 
-hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, CrossprodLayout* L) {
+static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiated for: 1, 2, 3, 4, 6 or 8
+    const int nt = (ncol + 15) / 16;
+    return nt <= 4 ? (nt < 1 ? 1 : nt) : (nt <= 6 ? 6 : 8);
+}
+
+hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, CrossprodLayout* L) {
+    memset(L, 0, sizeof(*L));
     crossprod_split(nrow, ncol > 0 ? ncol : 1, nnz, &L->nsplit, &L->width);
+    L->tall = !exact && ncol >= 1 && ncol <= kTallMaxCols && nnz / ncol >= kTallMinColumnLength;
+    if (L->tall) {   // one row-major form, unsliced, shared with the exact kernel that stands by
+        L->nsplit = 1;
+        L->width = ncol;
+        L->ntiles = tall_tiles(ncol);
+        const int64_t npanels = ((int64_t)nrow + kTallRows - 1) / kTallRows;
+        int64_t per = (npanels + kTallMaxGroups - 1) / kTallMaxGroups;
+        if (per < 1) per = 1;
+        L->panels_per_group = (int32_t)per;
+        L->ngroups = (int32_t)((npanels + per - 1) / per);
+        if (L->ngroups < 1) L->ngroups = 1;
+    }
     const size_t nv1 = (size_t)nrow * (size_t)L->nsplit + 1;   // virtual rows + 1
     if (nv1 > 0x7fffffffull) return hipErrorInvalidValue;
     size_t temp = 0;
@@ -321,8 +526,21 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, CrossprodLayo
     L->rx_off = off;     off = xp_align(off + (size_t)nnz * 8);
     L->temp_off = off;   off = xp_align(off + temp);
     L->temp_bytes = temp;
+    if (L->tall) {
+        const size_t np = (size_t)L->ntiles * (L->ntiles + 1) / 2;
+        L->partial_off = off; off = xp_align(off + (size_t)L->ngroups * np * 256 * 8);
+        L->flag_off = off;    off = xp_align(off + 4);
+    }
     L->total_bytes = off;
     return hipSuccess;
+}
+
+template <int NT>
+static void launch_tall(const CrossprodLayout& L, const double* d_x, const int32_t* d_i, const int32_t* d_p,
+                        int32_t nrow, int32_t ncol, int64_t nnz, const int32_t* flag, double* partial,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(crossprod_tall_kernel<NT>, dim3((unsigned)L.ngroups), dim3(256), 0, stream, d_x, d_i, d_p, nrow,
+                       ncol, nnz, L.panels_per_group, flag, partial);
 }
 
 hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
@@ -335,13 +553,36 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     double* rx = (double*)((char*)ws + L.rx_off);
     const int nsplit = L.nsplit, width = L.width;
     const size_t nv1 = (size_t)nrow * (size_t)nsplit + 1;
-    hipError_t e = hipMemsetAsync(cursor, 0, nv1 * 4, stream);
+    hipError_t e = hipSuccess;
+    const int32_t* run_if = nullptr;
+    if (L.tall) {
+        int32_t* flag = (int32_t*)((char*)ws + L.flag_off);
+        double* partial = (double*)((char*)ws + L.partial_off);
+        e = hipMemsetAsync(flag, 0, 4, stream);
+        if (e != hipSuccess) return e;
+        if (nnz > 0) hipLaunchKernelGGL(xp_nonfinite_kernel, dim3(2048), dim3(256), 0, stream, d_x, nnz, flag);
+        switch (L.ntiles) {
+            case 1: launch_tall<1>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 2: launch_tall<2>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 3: launch_tall<3>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 4: launch_tall<4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 6: launch_tall<6>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            default: launch_tall<8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+        }
+        const int64_t outs = (int64_t)ncol * ncol;
+        hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream,
+                           partial, L.ngroups, L.ntiles, ncol, flag, d_out);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        run_if = flag;   // everything below only works if x holds a non-finite value
+    }
+    e = hipMemsetAsync(cursor, 0, nv1 * 4, stream);
     if (e != hipSuccess) return e;
     const int want = (ncol + 3) / 4;
     const dim3 cgrid((unsigned)(want < 4096 ? want : 4096));
     if (nnz > 0)
         hipLaunchKernelGGL(xp_count_rows_kernel, cgrid, dim3(256), 0, stream, d_i, d_p, nrow, ncol, nsplit, width,
-                           cursor);
+                           cursor, run_if);
     size_t temp_bytes = L.temp_bytes;
     e = rocprim::exclusive_scan((char*)ws + L.temp_off, temp_bytes, (const int32_t*)cursor, rp, 0, nv1,
                                 rocprim::plus<int32_t>(), stream);
@@ -350,11 +591,11 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     if (e != hipSuccess) return e;
     if (nnz > 0)
         hipLaunchKernelGGL(xp_fill_rows_kernel, cgrid, dim3(256), 0, stream, d_x, d_i, d_p, nrow, ncol, nsplit, width,
-                           cursor, rc, rx);
+                           cursor, rc, rx, run_if);
     const long long grid = (long long)ncol * nsplit;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(crossprod_rows_kernel<kXDepth>, dim3((unsigned)grid), dim3(64), (size_t)width * 8, stream,
-                       d_x, d_i, d_p, rp, rc, rx, nrow, ncol, nsplit, width, d_out);
+                       d_x, d_i, d_p, rp, rc, rx, nrow, ncol, nsplit, width, d_out, run_if);
     return hipGetLastError();
 }
 

@@ -135,3 +135,83 @@ def test_crossprod_needs_row_indices(torch_cuda):
     with pytest.raises(capi.RspError):
         h.crossprod()
     h.close()
+
+
+# ---- the tall form (ncol <= 128, columns of >= 32768 entries): matrix cores, tolerance instead of bits ----
+
+TALL_SHAPES = [(400_000, 1, 0.5), (300_000, 16, 0.2), (300_000, 17, 0.15), (250_000, 48, 0.2), (200_000, 64, 0.25),
+               (200_000, 65, 0.2), (150_000, 100, 0.3), (150_000, 128, 0.25), (3_000_000, 20, 0.02)]
+
+
+@pytest.mark.parametrize("nrow,ncol,density", TALL_SHAPES)
+def test_crossprod_tall_form_within_tolerance_and_deterministic(torch_cuda, nrow, ncol, density):
+    """Few long columns: the workspace form densifies 64 rows at a time and runs t(P) P as f64 MFMA, every
+    workgroup over its own rows, results added in workgroup order.  Not the reference's order, so the bar is
+    the floating-point one: 1e-12 of sum|x1 x2| per entry against the oracle's merges (signed data), the
+    same bits on every run, an exactly symmetric result; and with rsp_set_crossprod_exact(1) the
+    bit-identical form is back."""
+    torch = torch_cuda
+    m = synth.rsparsematrix(nrow, ncol, density=density, seed=nrow % 97 + ncol, kind=0)
+    x, i, p = m["x"], m["i"], m["p"]
+    assert x.size // ncol >= 32768                                   # (the shape does select the tall form)
+    ref = oracle.crossprod(x, i, p)
+    scale = oracle.crossprod(np.abs(x), i, p)
+    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    again = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    assert got.tobytes() == again.tobytes()
+    assert np.array_equal(got, got.T)
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale), float(np.max(np.abs(got - ref) / np.maximum(scale, 1e-300)))
+    assert np.all(got[scale == 0] == 0)                              # column pairs without a common row
+    h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
+    via_handle = h.crossprod()
+    h.close()
+    assert via_handle.tobytes() == got.tobytes()                     # same form behind the handle
+    capi.set_crossprod_exact(True)
+    try:
+        exact = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    finally:
+        capi.set_crossprod_exact(False)
+    assert np.array_equal(exact, ref)
+
+
+def test_crossprod_tall_form_steps_aside_for_nonfinite_values(torch_cuda):
+    """A structural zero times an infinity would be NaN where the reference has no product at all: with any
+    NaN / Inf in x the tall kernels exit and the bit-identical kernel (standing by on the same row-major
+    form) produces the result -- the reference's, bit for bit."""
+    torch = torch_cuda
+    nrow, ncol = 250_000, 40
+    m = synth.rsparsematrix(nrow, ncol, density=0.2, seed=5, kind=0)
+    x, i, p = m["x"].copy(), m["i"], m["p"]
+    x[1234] = np.inf
+    x[x.size // 2] = np.nan
+    x[-7] = -np.inf
+    ref = oracle.crossprod(x, i, p)
+    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    assert np.array_equal(got, ref, equal_nan=True)
+    finite = np.isfinite(ref)
+    assert finite.sum() > 0.8 * ref.size                              # the non-finite values touched only their own columns
+
+
+def test_crossprod_tall_form_rows_without_entries_and_ragged_last_panel(torch_cuda):
+    """Row panels (64 rows) with no entry at all are skipped, the last panel is partial, and all entries may
+    sit in a few rows."""
+    torch = torch_cuda
+    nrow, ncol = 1_000_003, 24
+    rng = np.random.default_rng(3)
+    cols = []
+    for c in range(ncol):
+        lo = int(rng.integers(0, nrow - 200_000))
+        rows = np.sort(rng.choice(np.arange(lo, lo + 200_000), size=40_000, replace=False))
+        rows[-1] = nrow - 1 if c % 3 == 0 else rows[-1]
+        cols.append(np.unique(rows))
+    i = np.concatenate(cols).astype(np.int32)
+    p = np.concatenate(([0], np.cumsum([len(c) for c in cols]))).astype(np.int32)
+    x = rng.standard_normal(i.size)
+    ref = oracle.crossprod(x, i, p)
+    scale = oracle.crossprod(np.abs(x), i, p)
+    got = capi.crossprod_device(torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda(),
+                                nrow).cpu().numpy().T
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale)
+    assert np.all(got[scale == 0] == 0)
