@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timing of Matrix::crossprod on the device for the shape of the reference's vignette benchmark
 (rsparsematrix(100000, 1000, 0.1)) and two neighbours, with the oracle's pairwise-merge loop
-(1 thread) timed on a column subset and scaled by the number of column pairs."""
+(1 thread) timed on a column subset and scaled by the number of column pairs; `tall` as an argument
+times the tall (f64 MFMA) form against the bit-identical one on few-columns shapes instead."""
 import json
 import os
 import sys
@@ -15,7 +16,49 @@ import oracle
 from rcppsparse_amd import capi, synth
 
 
+def tall():
+    L = capi.load()
+    for nrow, ncol, nnz in ((1_000_000, 64, 32_000_000), (10_000_000, 16, 80_000_000), (2_000_000, 128, 128_000_000),
+                            (4_000_000, 48, 190_000_000), (45_000_000, 48, 2**31 - 1)):
+        p = np.linspace(0, nnz, ncol + 1).astype(np.int64).astype(np.int32)
+        pt = torch.from_numpy(p).cuda()
+        xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+        it = torch.empty(nnz, dtype=torch.int32, device="cuda")
+        capi.gen_values_device(xt, 3, 0, 0)
+        capi.gen_row_indices_device(it, pt, nrow, 3)
+        out = torch.empty((ncol, ncol), dtype=torch.float64, device="cuda")
+        ws = torch.empty(int(L.rsp_crossprod_workspace_bytes(nrow, ncol, nnz)), dtype=torch.uint8, device="cuda")
+        capi.crossprod_device(xt, it, pt, nrow, out, workspace=ws)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); capi.crossprod_device(xt, it, pt, nrow, out, workspace=ws); b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        row = {"shape": f"{nrow}x{ncol}, nnz {nnz}", "tall_form_ms": sorted(ts)[2], "workspace_GB": ws.numel() / 1e9,
+               "products": float(nnz) / nrow * nnz}
+        if nnz < 2**31 - 1:                     # (the bit-identical form takes 25 s there)
+            tall_out = out.clone()
+            capi.set_crossprod_exact(True)
+            ws2 = torch.empty(int(L.rsp_crossprod_workspace_bytes(nrow, ncol, nnz)), dtype=torch.uint8, device="cuda")
+            capi.crossprod_device(xt, it, pt, nrow, out, workspace=ws2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            capi.crossprod_device(xt, it, pt, nrow, out, workspace=ws2)
+            torch.cuda.synchronize()
+            row["bit_identical_form_ms"] = (time.perf_counter() - t0) * 1e3
+            capi.set_crossprod_exact(False)
+            row["max_abs_diff_over_max_abs"] = ((tall_out - out).abs().max() / out.abs().max()).item()
+            del ws2
+        print(json.dumps(row), flush=True)
+        del xt, it, ws
+        torch.cuda.empty_cache()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "tall":
+        return tall()
     capi.load()
     shapes = ((100_000, 1000, 10_000_000), (100_000, 4000, 8_000_000), (1_000_000, 500, 5_000_000))
     if len(sys.argv) > 1:                       # e.g. "0" or "0,2": a subset of the shapes

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Soak of crossprod's tall (f64 MFMA) form on one GPU: random matrices of 1..128 columns whose average
+column length puts them on that form, with columns of very different lengths (some empty), rows spread over
+the whole matrix, clustered into a few 64-row panels, or shared by all columns; against the oracle's merges
+within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric.
+
+    python3 tools/soak_crossprod_tall.py [seconds] [seed]
+"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import oracle
+from rcppsparse_amd import capi
+
+
+def one(rng, case):
+    ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, int(rng.integers(1, 129))]))
+    mean_len = int(rng.integers(32768, 40000)) if ncol > 40 else int(rng.integers(32768, 90000))
+    kind = int(rng.integers(0, 4))
+    lens = rng.integers(0, 2 * mean_len, ncol)
+    if ncol > 2 and kind != 3:
+        lens[rng.integers(0, ncol, max(1, ncol // 8))] = 0          # some empty columns
+    lens = np.maximum(lens, 0)
+    need = 32768 * ncol + ncol - int(lens.sum())
+    if need > 0:
+        lens[int(np.argmax(lens))] += need                            # keep the average on the tall side
+    span = int(lens.max())
+    if kind == 0:
+        nrow = int(span * rng.uniform(1.0, 30.0)) + 1                 # spread
+    elif kind == 1:
+        nrow = span + int(rng.integers(0, 64))                        # nearly dense columns
+    elif kind == 2:
+        nrow = int(span * rng.uniform(2.0, 6.0)) + 1                  # clustered: each column in its own window
+    else:
+        nrow = int(span * rng.uniform(1.0, 3.0)) + 1                  # all columns share most rows
+    cols = []
+    base = np.sort(rng.choice(nrow, size=span, replace=False)) if kind == 3 else None
+    for c in range(ncol):
+        n = int(lens[c])
+        if n == 0:
+            cols.append(np.zeros(0, np.int64))
+        elif kind == 2:
+            lo = int(rng.integers(0, nrow - n + 1)) if nrow > n else 0
+            width = min(nrow - lo, int(n * rng.uniform(1.0, 1.5)) + 1)
+            cols.append(np.sort(lo + rng.choice(width, size=n, replace=False)))
+        elif kind == 3:
+            cols.append(np.sort(rng.choice(base, size=n, replace=False)))
+        else:
+            cols.append(np.sort(rng.choice(nrow, size=n, replace=False)))
+    i = np.concatenate(cols).astype(np.int32)
+    p = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    x = rng.standard_normal(i.size) * np.exp(rng.uniform(-20, 20))
+    ref = oracle.crossprod(x, i, p)
+    scale = oracle.crossprod(np.abs(x), i, p)
+    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    again = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    ok = (got.tobytes() == again.tobytes() and np.array_equal(got, got.T)
+          and bool(np.all(np.abs(got - ref) <= 1e-12 * scale)) and bool(np.all(got[scale == 0] == 0)))
+    if not ok:
+        print(f"FAIL case {case}: {nrow}x{ncol} nnz {i.size} kind {kind} "
+              f"max {np.max(np.abs(got - ref) / np.maximum(scale, 1e-300))}", flush=True)
+    return ok
+
+
+def main():
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    capi.load()
+    rng = np.random.default_rng(seed)
+    t0, n, bad, last = time.time(), 0, 0, time.time()
+    while time.time() - t0 < secs:
+        bad += not one(rng, n)
+        n += 1
+        if time.time() - last > 30:
+            print(f"... {n} cases, {bad} failures", flush=True)
+            last = time.time()
+    print(f"soak_crossprod_tall: {n} cases, {bad} failures, seed {seed}", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
