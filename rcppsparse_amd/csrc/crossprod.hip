@@ -160,7 +160,8 @@ constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 constexpr int kTallMaxCols = 128;        // 8 column tiles of 16: 36 tile pairs, 9 per wavefront
 constexpr int kTallRows = 64;            // rows of A densified in LDS at a time (a "panel")
 constexpr int kTallMaxGroups = 1024;     // workgroups = partial results to add up
-constexpr int64_t kTallMinColumnLength = 32768;   // below this the exact form's serial walk is short enough
+constexpr int64_t kTallMinColumnLength = 4096;   // (average) below this the exact form's serial walk takes < 0.7 ms:
+                                                  // bit-identical results are worth more there than the 1.5-2.5x the tall form gains
 
 // The row-major form is kept per *slice* of result columns: "virtual row" k * nsplit + c / width
 // holds the entries (c, x) of row k whose column lies in slice c / width, so that the wave that
@@ -305,13 +306,14 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
 // what makes them bit-identical to the reference -- and what makes them slow on the shape crossprod is
 // meant for: few columns, many rows.  48 columns of 4.5e7 rows are 48 serial walks of 4.5e7 steps:
 // 24.8 s (round 2, 2^31 - 1 entries), the work itself being 1e11 multiply-adds.  For ncol <= 128 and
-// columns of >= 32768 entries on average the library therefore sums in a different order: the rows of
+// columns of >= 4096 entries on average the library therefore sums in a different order: the rows of
 // A are densified 64 at a time into an LDS panel P[64][ncol] (zero where nothing is stored) and
 // C += t(P) P runs as v_mfma_f64_16x16x4_f64 over the 16 x 16 tile pairs I <= J, every workgroup over
 // its own range of rows; the workgroups' results are added up in workgroup order.  Deterministic, within
 // 1e-12 * sum |x1 x2| of the reference's order (tests/test_gpu_crossprod.py), not bit-identical.
 // The same 48 x 4.5e7 matrix: 16.9 ms (3 ms of it the scan of x below, 13.4 ms the kernel, which reads
-// the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms.
+// the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms; 64 columns of 4096 entries
+// 0.26 ms against 0.68 ms (of 256 entries: 0.044 against 0.058 ms -- left to the bit-identical form).
 // A product of a structural zero with a non-finite value would be NaN where the reference has nothing:
 // xp_nonfinite_kernel looks at x first, and if anything is not finite the tall kernels exit at once and
 // the exact row-major path (whose kernels otherwise exit at once) does the work.

@@ -37,7 +37,13 @@ def test_crossprod_bit_exact_vs_oracle(torch_cuda, nrow, ncol, density, tiles):
     if x.size == 0:
         xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
         it = torch.zeros(2, dtype=torch.int32, device="cuda")[:0]
-    got = capi.crossprod_device(xt, it, pt, nrow, tiles=tiles).cpu().numpy().T   # column-major -> row-major view
+    # (a shape with few long columns would go to the tall MFMA form, which is tested further down: this test
+    # is about the two bit-identical kernels)
+    capi.set_crossprod_exact(True)
+    try:
+        got = capi.crossprod_device(xt, it, pt, nrow, tiles=tiles).cpu().numpy().T   # column-major -> row-major view
+    finally:
+        capi.set_crossprod_exact(False)
     assert got.shape == (ncol, ncol)
     assert np.array_equal(got, ref), float(np.max(np.abs(got - ref)))
     assert np.array_equal(got, got.T)                              # mirrored exactly
@@ -45,9 +51,13 @@ def test_crossprod_bit_exact_vs_oracle(torch_cuda, nrow, ncol, density, tiles):
     dense = (A.T @ A).toarray()
     assert np.allclose(got, dense, rtol=1e-12, atol=1e-12)
     if not tiles:
-        h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
-        via_handle = h.crossprod()
-        h.close()
+        capi.set_crossprod_exact(True)
+        try:
+            h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
+            via_handle = h.crossprod()
+            h.close()
+        finally:
+            capi.set_crossprod_exact(False)
         assert np.array_equal(via_handle, ref)
 
 
@@ -137,9 +147,9 @@ def test_crossprod_needs_row_indices(torch_cuda):
     h.close()
 
 
-# ---- the tall form (ncol <= 128, columns of >= 32768 entries): matrix cores, tolerance instead of bits ----
+# ---- the tall form (ncol <= 128, columns of >= 4096 entries): matrix cores, tolerance instead of bits ----
 
-TALL_SHAPES = [(400_000, 1, 0.5), (300_000, 16, 0.2), (300_000, 17, 0.15), (250_000, 48, 0.2), (200_000, 64, 0.25),
+TALL_SHAPES = [(41_000, 100, 0.1), (50_000, 7, 0.1), (400_000, 1, 0.5), (300_000, 16, 0.2), (300_000, 17, 0.15), (250_000, 48, 0.2), (200_000, 64, 0.25),
                (200_000, 65, 0.2), (150_000, 100, 0.3), (150_000, 128, 0.25), (3_000_000, 20, 0.02)]
 
 
@@ -153,7 +163,7 @@ def test_crossprod_tall_form_within_tolerance_and_deterministic(torch_cuda, nrow
     torch = torch_cuda
     m = synth.rsparsematrix(nrow, ncol, density=density, seed=nrow % 97 + ncol, kind=0)
     x, i, p = m["x"], m["i"], m["p"]
-    assert x.size // ncol >= 32768                                   # (the shape does select the tall form)
+    assert x.size // ncol >= 4096                                    # (the shape does select the tall form)
     ref = oracle.crossprod(x, i, p)
     scale = oracle.crossprod(np.abs(x), i, p)
     xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()

@@ -16,13 +16,13 @@ from rcppsparse_amd import capi
 
 def one(rng, case):
     ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, int(rng.integers(1, 129))]))
-    mean_len = int(rng.integers(32768, 40000)) if ncol > 40 else int(rng.integers(32768, 90000))
+    mean_len = int(rng.integers(4096, 40000)) if ncol > 40 else int(rng.integers(4096, 90000))
     kind = int(rng.integers(0, 4))
     lens = rng.integers(0, 2 * mean_len, ncol)
     if ncol > 2 and kind != 3:
         lens[rng.integers(0, ncol, max(1, ncol // 8))] = 0          # some empty columns
     lens = np.maximum(lens, 0)
-    need = 32768 * ncol + ncol - int(lens.sum())
+    need = 4096 * ncol + ncol - int(lens.sum())
     if need > 0:
         lens[int(np.argmax(lens))] += need                            # keep the average on the tall side
     span = int(lens.max())

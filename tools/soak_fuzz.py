@@ -36,6 +36,7 @@ def structure(rng):
 def soak_next_rows(a):
     """crossprod (both kernels, bit-exact), rowSums and row-restricted column sums on random
     small matrices with row indices."""
+    capi.set_crossprod_exact(True)   # (this soak is about the bit-identical kernels; tools/soak_crossprod_tall.py has the other)
     t0 = time.time()
     n = 0
     while time.time() - t0 < a.seconds:
