@@ -952,30 +952,45 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, OP_>), grid,   \
                        block, 0, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,   \
                        carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words)
-    // row-restricted sums with a bitmap of 16-128 KB (about 1e5-1e6 rows): bitmap in LDS
+    // row-restricted sums with a bitmap of 16-128 KB (about 1e5-1e6 rows): bitmap in LDS, shared by as many
+    // wavefronts as fit beside it (each brings 5.25 KB of its own): one workgroup of 16 / 8 / 6 / 4 per CU.
+    // (With 4 the call is bound by its occupancy: 32 KB of loads in flight per CU, 4.7 TB/s at 1e6 rows.)
     const size_t bitmap_bytes = (size_t)bitmap_words * 4;
+    constexpr size_t kLdsPerCu = 160 * 1024, kLdsPerWave = sizeof(double) * kStageSlots + sizeof(int32_t) * kPWin;
+#define RSP_LAUNCH_LDSMAP(WPG_)                                                                                      \
+    do {                                                                                                            \
+        static bool raised_##WPG_ = false; /* (benign if two threads both do it) */                                 \
+        if (!raised_##WPG_) {                                                                                       \
+            hipError_t ea = hipFuncSetAttribute(                                                                    \
+                (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedIn, true>,           \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsPerCu - (WPG_) * kLdsPerWave));                              \
+            if (ea == hipSuccess)                                                                                   \
+                ea = hipFuncSetAttribute(                                                                           \
+                    (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedOut, true>,      \
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsPerCu - (WPG_) * kLdsPerWave));                          \
+            if (ea != hipSuccess) return ea;                                                                        \
+            raised_##WPG_ = true;                                                                                   \
+        }                                                                                                           \
+        const dim3 g2((plan.nchunks + (WPG_) - 1) / (WPG_)), b2((WPG_) * 64);                                       \
+        if (op == kOpMaskedIn)                                                                                      \
+            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedIn, true>), g2,   \
+                               b2, bitmap_bytes, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,            \
+                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words);      \
+        else                                                                                                        \
+            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedOut, true>), g2,  \
+                               b2, bitmap_bytes, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,            \
+                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words);      \
+    } while (0)
     if ((op == kOpMaskedIn || op == kOpMaskedOut) && bitmap_bytes > kLdsBitmapMinBytes &&
         bitmap_bytes <= kLdsBitmapMaxBytes) {
-        static bool raised = false;   // (benign if two threads both do it)
-        if (!raised) {
-            hipError_t ea = hipFuncSetAttribute(
-                (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedIn, true>,
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBitmapMaxBytes);
-            if (ea == hipSuccess)
-                ea = hipFuncSetAttribute(
-                    (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedOut, true>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBitmapMaxBytes);
-            if (ea != hipSuccess) return ea;
-            raised = true;
-        }
-        if (op == kOpMaskedIn)
-            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedIn, true>),
-                               grid, block, bitmap_bytes, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,
-                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words);
+        if (bitmap_bytes + 16 * kLdsPerWave <= kLdsPerCu)
+            RSP_LAUNCH_LDSMAP(16);
+        else if (bitmap_bytes + 8 * kLdsPerWave <= kLdsPerCu)
+            RSP_LAUNCH_LDSMAP(8);
+        else if (bitmap_bytes + 6 * kLdsPerWave <= kLdsPerCu)
+            RSP_LAUNCH_LDSMAP(6);
         else
-            hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, kOpMaskedOut, true>),
-                               grid, block, bitmap_bytes, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,
-                               carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words);
+            RSP_LAUNCH_LDSMAP(4);
     } else if (op == kOpSumSquares) {
         RSP_LAUNCH_OP(kOpSumSquares);
     } else if (op == kOpSumAbs) {

@@ -15,8 +15,9 @@ from rcppsparse_amd import capi, synth
 
 def main():
     capi.load()
-    for nrow, ncol, nnz in ((30_000, 100_000, 500_000_000), (1_000_000, 1_000_000, 500_000_000),
-                            (10_000_000, 1_000_000, 500_000_000)):
+    for nrow, ncol, nnz in ((30_000, 100_000, 500_000_000), (200_000, 1_000_000, 500_000_000),
+                            (500_000, 1_000_000, 500_000_000), (900_000, 1_000_000, 500_000_000),
+                            (1_000_000, 1_000_000, 500_000_000), (10_000_000, 1_000_000, 500_000_000)):
         p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow))
         pt = torch.from_numpy(p).cuda()
         xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
