@@ -183,7 +183,9 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
  * global memory, bit-stable run to run, within 1e-12 * sum|x| of the reference's
  * order.  The handle variants (the handle must have been uploaded with i[])
  * build the row-major form on first use -- a stable device radix sort of (i, x)
- * by row, i.e. columnSums(t(A)) -- and keep it: repeated calls only reduce.
+ * by row, i.e. columnSums(t(A)) -- and keep it: repeated calls only reduce
+ * (matrices of up to 49152 rows are summed straight from x / i instead, like the
+ * device variants: no sort, no second copy of x).
  * The device variants accumulate in LDS, 16384 rows per workgroup: matrices of
  * up to 49152 rows are summed straight from x / i (workspace: the workgroups'
  * partial sums, at most a few hundred MB); larger ones are first regrouped by

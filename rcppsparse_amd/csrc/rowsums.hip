@@ -32,7 +32,7 @@
 //     block bits of the row index only (4096-row blocks), then rows_block_accumulate_kernel (one
 //     wavefront per block, sums in 32 KB of LDS).
 //
-//   row form (the handle API, which keeps it for repeated calls): full stable sort by row,
+//   row form (the handle API above 49152 rows, which keeps it for repeated calls): full stable sort by row,
 //     row offsets by a vectorised lower_bound, then the column-sum kernels on the row-major
 //     values (8 B/nnz per repeated call instead of 12).
 //
@@ -138,6 +138,9 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
     size_t sort_bytes = 0, search_bytes = 0, off = 0;
     hipError_t e;
     const int64_t part_blocks = ((int64_t)nrow + (1 << kPartShift) - 1) >> kPartShift;
+    // (a handle of a matrix with so few rows that nothing needs regrouping does not build the row form either:
+    // no sort on the first call, no second copy of x in HBM)
+    if (keep_row_form && part_blocks <= kDirectMaxBlocks) keep_row_form = false;
     if (!keep_row_form && part_blocks <= kPartMaxBlocks) {
         L->mode = 2;
         L->shift = kPartShift;
