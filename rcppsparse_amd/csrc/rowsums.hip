@@ -9,7 +9,7 @@
 //     those of their block: 12 B/nnz per block, no workspace beyond the parts' sums
 //     (5e8 nnz: 1.45 / 2.7 / 4.0 ms for 1 / 2 / 3 blocks; regrouping first costs 4.5-5.4 ms there).
 //
-//   tile partition (one-shot calls, rsp_row_sums_device, up to 1.36e7 rows) -- all hand-written:
+//   tile partition (one-shot calls, rsp_row_sums_device, 4 to 832 row blocks = up to 1.36e7 rows) -- all hand-written:
 //     the entries are regrouped by ROW BLOCK (16384 rows: what one CU's LDS holds as sums) in ONE
 //     pass, then added up block by block.
 //       1. rows_tile_histogram_kernel   entries per (block, supertile)              reads  4 B/nnz
