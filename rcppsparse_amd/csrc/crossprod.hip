@@ -159,7 +159,7 @@ constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 // tall form (few columns, long columns)
 constexpr int kTallMaxCols = 128;        // 8 column tiles of 16: 36 tile pairs, 9 per wavefront
 constexpr int kTallRows = 64;            // rows of A densified in LDS at a time (a "panel")
-constexpr int kTallMaxGroups = 1024;     // workgroups = partial results to add up
+constexpr int kTallMaxGroups = 1280;     // workgroups = partial results to add up
 constexpr int64_t kTallMinColumnLength = 4096;   // (average) below this the exact form's serial walk takes < 0.7 ms:
                                                   // bit-identical results are worth more there than the 1.5-2.5x the tall form gains
 
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
 // C += t(P) P runs as v_mfma_f64_16x16x4_f64 over the 16 x 16 tile pairs I <= J, every workgroup over
 // its own range of rows; the workgroups' results are added up in workgroup order.  Deterministic, within
 // 1e-12 * sum |x1 x2| of the reference's order (tests/test_gpu_crossprod.py), not bit-identical.
-// The same 48 x 4.5e7 matrix: 16.9 ms (3 ms of it the scan of x below, 13.4 ms the kernel, which reads
+// The same 48 x 4.5e7 matrix: 15.4 ms (3 ms of it the scan of x below, 12.4 ms the kernel, which reads
 // the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms; 64 columns of 4096 entries
 // 0.26 ms against 0.68 ms (of 256 entries: 0.044 against 0.058 ms -- left to the bit-identical form).
 // A product of a structural zero with a non-finite value would be NaN where the reference has nothing:
@@ -329,6 +329,12 @@ __global__ __launch_bounds__(256) void xp_nonfinite_kernel(const double* __restr
 
 typedef double xp_v4f64 __attribute__((ext_vector_type(4)));
 
+// workgroup barrier for LDS hand-offs only (__syncthreads() would also wait for the loads just issued for the
+// next panel: s_waitcnt vmcnt(0))
+__device__ __forceinline__ void xp_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // tile pair number q of the upper triangle (I <= J) of an NT x NT grid of tiles, row by row
 __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
     I = 0;
@@ -343,9 +349,13 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
 // in ascending row order, so the part of it that falls into the workgroup's rows is one contiguous piece
 // (two binary searches per column at the start) and every panel takes the next few entries of each piece.
 // NT = column tiles.  Wavefront w loads columns w * CPW .. w * CPW + CPW - 1 (64 entries of each per panel,
-// all loads issued before the first is used) and owns the tile pairs q = w, w + 4, ... (at most MAXP), whose
+// all loads issued before the first is used, the next panel's as soon as these sit in LDS) and owns the tile pairs q = w, w + 4, ... (at most MAXP), whose
 // 16 x 16 accumulators stay in registers.  Panels without entries are skipped: the next panel starts at the
 // smallest row any column has pending.
+// Measured on 48 columns x 4.5e7 rows (2^31 - 1 entries): 13.4 ms without the prefetch, 12.4 ms with it; panels of
+// 128 rows (pieces of 512 B / 1 KB per column instead of 256 / 512 B, but two workgroups per CU instead of three)
+// 14.1 ms; runs of 32 panels dealt round-robin, so that the resident workgroups read the same neighbourhood of
+// every column, 15.5 ms: 26 GB in 12.4 ms = 2.1 TB/s is what ~100 column streams per workgroup get.
 template <int NT>
 __global__ __launch_bounds__(256) void crossprod_tall_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p, int32_t nrow,
@@ -389,23 +399,31 @@ __global__ __launch_bounds__(256) void crossprod_tall_kernel(
         s_end[tid] = hi;
     }
     __syncthreads();
+    // 64 entries of each of this wavefront's columns travel in registers; the next 64 are requested as soon as
+    // these have gone into the panel (their count moves the cursor), so they arrive during the MFMA phase.
+    // Cursors and ends are wave-uniform and live in scalar registers.
+    int32_t row[CPW], cur[CPW], end[CPW];
+    double val[CPW];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const int32_t* rk = ri + cur[k];
+            const double* xk = x + cur[k];
+            const bool in = lane < end[k] - cur[k];
+            row[k] = in ? rk[lane] : 0x7fffffff;
+            val[k] = in ? xk[lane] : 0.0;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+        cur[k] = __builtin_amdgcn_readfirstlane(s_cur[wave * CPW + k]);
+        end[k] = __builtin_amdgcn_readfirstlane(s_end[wave * CPW + k]);
+    }
+    fetch();
     int64_t r0 = R0;
     while (r0 < R1) {
         for (int k = tid; k < kTallRows * W; k += 256) (&panel[0][0])[k] = 0.0;
-        __syncthreads();
-        // 64 entries of each of this wavefront's columns; those below r0 + 64 go into the panel
-        int32_t row[CPW];
-        double val[CPW];
-        int32_t cur[CPW], end[CPW];
-#pragma unroll
-        for (int k = 0; k < CPW; ++k) {
-            cur[k] = s_cur[wave * CPW + k];
-            end[k] = s_end[wave * CPW + k];
-            const int64_t e = (int64_t)cur[k] + lane;
-            const bool in = e < end[k];
-            row[k] = in ? ri[e] : 0x7fffffff;
-            val[k] = in ? x[e] : 0.0;
-        }
+        xp_lds_barrier();
         int32_t pending = 0x7fffffff;   // smallest row this wavefront's columns still have to deliver
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
@@ -413,19 +431,20 @@ __global__ __launch_bounds__(256) void crossprod_tall_kernel(
             const uint32_t local = (uint32_t)((int64_t)row[k] - r0);
             if (below && local < (uint32_t)kTallRows) panel[local][wave * CPW + k] = val[k];
             const int n = __popcll(__ballot(below));   // (also steps over rows below r0: an unsorted, invalid column)
-            if (lane == 0) s_cur[wave * CPW + k] = cur[k] + n;
             // next row of this column: its first entry not taken, or unknown (then: the next panel) if all 64 were
             int32_t nx = below ? 0x7fffffff : row[k];
             if (n == 64 && (int64_t)cur[k] + 64 < end[k]) nx = (int32_t)(r0 + kTallRows < 0x7fffffff ? r0 + kTallRows : 0x7fffffff);
             pending = nx < pending ? nx : pending;
+            cur[k] += n;
         }
+        fetch();
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             const int32_t o = __shfl_xor(pending, d, 64);
             pending = o < pending ? o : pending;
         }
         if (lane == 0) s_next[wave] = pending;
-        __syncthreads();
+        xp_lds_barrier();
 #pragma unroll 4
         for (int ks = 0; ks < kTallRows / 4; ++ks) {
             const double* prow = &panel[4 * ks + (lane >> 4)][lane & 15];
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(256) void crossprod_tall_kernel(
         int32_t nxt = s_next[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) nxt = s_next[w] < nxt ? s_next[w] : nxt;
-        __syncthreads();   // (panel and s_next are rewritten next)
+        xp_lds_barrier();   // (panel and s_next are rewritten next)
         const int64_t step = r0 + kTallRows;
         const int64_t jump = R0 + (((int64_t)nxt - R0) / kTallRows) * kTallRows;   // the panel that holds row nxt
         r0 = nxt == 0x7fffffff ? R1 : (jump > step ? jump : step);
@@ -509,7 +528,10 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         L->width = ncol;
         L->ntiles = tall_tiles(ncol);
         const int64_t npanels = ((int64_t)nrow + kTallRows - 1) / kTallRows;
-        int64_t per = (npanels + kTallMaxGroups - 1) / kTallMaxGroups;
+        // one round of workgroups: what fits on the chip at this tile count (registers / LDS per workgroup)
+        static const int per_cu[9] = {0, 5, 5, 3, 3, 0, 2, 0, 1};
+        const int64_t max_groups = 256 * per_cu[L->ntiles] < kTallMaxGroups ? 256 * per_cu[L->ntiles] : kTallMaxGroups;
+        int64_t per = (npanels + max_groups - 1) / max_groups;
         if (per < 1) per = 1;
         L->panels_per_group = (int32_t)per;
         L->ngroups = (int32_t)((npanels + per - 1) / per);
