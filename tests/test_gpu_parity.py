@@ -472,10 +472,13 @@ def test_column_max_min_count(torch_cuda, label, ncol, mean, chunk_rows):
 
 # ------------------------------------------- "next" row f4: row-restricted column sums
 @pytest.mark.parametrize("nrow,ncol,density", [(64, 300, 0.3), (5000, 2000, 0.01), (200_000, 500, 0.02),
-                                                (1000, 40_000, 0.004)])
+                                                (1000, 40_000, 0.004), (800_000, 300, 0.01), (1_000_000, 250, 0.01),
+                                                (1_048_576, 200, 0.01), (1_048_577, 200, 0.01)])
 @pytest.mark.parametrize("complement", [False, True])
 def test_column_sums_restricted_to_a_row_set(torch_cuda, nrow, ncol, density, complement):
-    """InnerIteratorInRange / NotInRange semantics (RcppSparse.h:238-321) as a device reduction."""
+    """InnerIteratorInRange / NotInRange semantics (RcppSparse.h:238-321) as a device reduction.  The row counts
+    cover every way the bitmap is probed: in L1 (up to 16 KB), as an LDS copy shared by 16 / 8 / 6 wavefronts
+    (25 KB, 100 KB, 125 KB and the largest that fits, 128 KB) and in L2 (one row more)."""
     torch = torch_cuda
     m = synth.rsparsematrix(nrow, ncol, density=density, seed=nrow % 97 + ncol, kind=0)
     x, i, p = m["x"], m["i"], m["p"]
