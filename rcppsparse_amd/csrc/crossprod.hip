@@ -311,22 +311,11 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
 // C += t(P) P runs as v_mfma_f64_16x16x4_f64 over the 16 x 16 tile pairs I <= J, every workgroup over
 // its own range of rows; the workgroups' results are added up in workgroup order.  Deterministic, within
 // 1e-12 * sum |x1 x2| of the reference's order (tests/test_gpu_crossprod.py), not bit-identical.
-// The same 48 x 4.5e7 matrix: 15.4 ms (3 ms of it the scan of x below, 12.4 ms the kernel, which reads
-// the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms; 64 columns of 4096 entries
+// The same 48 x 4.5e7 matrix: 12.7 ms (the kernel reads the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms; 64 columns of 4096 entries
 // 0.26 ms against 0.68 ms (of 256 entries: 0.044 against 0.058 ms -- left to the bit-identical form).
-// A product of a structural zero with a non-finite value would be NaN where the reference has nothing:
-// xp_nonfinite_kernel looks at x first, and if anything is not finite the tall kernels exit at once and
-// the exact row-major path (whose kernels otherwise exit at once) does the work.
-__global__ __launch_bounds__(256) void xp_nonfinite_kernel(const double* __restrict__ x, int64_t nnz,
-                                                           int32_t* __restrict__ flag) {
-    bool bad = false;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t u = (uint64_t)__double_as_longlong(x[j]);
-        bad |= ((u >> 52) & 0x7ff) == 0x7ff;
-    }
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
-
+// A product of a structural zero with a non-finite value would be NaN where the reference has nothing: the
+// tall kernel looks at every value it loads and raises a flag if one is not finite; the combine kernel then
+// leaves the output alone and the exact row-major path (whose kernels otherwise exit at once) does the work.
 typedef double xp_v4f64 __attribute__((ext_vector_type(4)));
 
 // workgroup barrier for LDS hand-offs only (__syncthreads() would also wait for the loads just issued for the
@@ -359,12 +348,12 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
 template <int NT>
 __global__ __launch_bounds__(256) void crossprod_tall_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p, int32_t nrow,
-    int32_t ncol, int64_t nnz, int32_t panels_per_group, const int32_t* __restrict__ nonfinite,
+    int32_t ncol, int64_t nnz, int32_t panels_per_group, int32_t* __restrict__ nonfinite,
     double* __restrict__ partial) {
     constexpr int W = NT * 16, NP = NT * (NT + 1) / 2, MAXP = (NP + 3) / 4, CPW = W / 4;
     __shared__ double panel[kTallRows][W];
     __shared__ int32_t s_cur[W], s_end[W], s_next[4];
-    if (*nonfinite) return;
+    bool bad = false;   // a NaN or an infinity among the values this lane has loaded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ti[MAXP], tj[MAXP];
     xp_v4f64 acc[MAXP];
@@ -412,6 +401,7 @@ __global__ __launch_bounds__(256) void crossprod_tall_kernel(
             const bool in = lane < end[k] - cur[k];
             row[k] = in ? rk[lane] : 0x7fffffff;
             val[k] = in ? xk[lane] : 0.0;
+            bad |= ((uint32_t)__double2hiint(val[k]) & 0x7ff00000u) == 0x7ff00000u;
         }
     };
 #pragma unroll
@@ -461,6 +451,9 @@ __global__ __launch_bounds__(256) void crossprod_tall_kernel(
         const int64_t jump = R0 + (((int64_t)nxt - R0) / kTallRows) * kTallRows;   // the panel that holds row nxt
         r0 = nxt == 0x7fffffff ? R1 : (jump > step ? jump : step);
     }
+    // (a structural zero has met a non-finite value in some product: the result below is not the reference's,
+    // the combine kernel will leave it alone and the bit-identical kernels take over)
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(nonfinite, 1);
     // tile (I, J), element (row, col) = C(16 I + row, 16 J + col); lane: col = lane & 15, row = (lane >> 4) + 4 r
     double* mine = partial + (size_t)blockIdx.x * NP * 256;
 #pragma unroll
@@ -561,7 +554,7 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
 
 template <int NT>
 static void launch_tall(const CrossprodLayout& L, const double* d_x, const int32_t* d_i, const int32_t* d_p,
-                        int32_t nrow, int32_t ncol, int64_t nnz, const int32_t* flag, double* partial,
+                        int32_t nrow, int32_t ncol, int64_t nnz, int32_t* flag, double* partial,
                         hipStream_t stream) {
     hipLaunchKernelGGL(crossprod_tall_kernel<NT>, dim3((unsigned)L.ngroups), dim3(256), 0, stream, d_x, d_i, d_p, nrow,
                        ncol, nnz, L.panels_per_group, flag, partial);
@@ -584,7 +577,6 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
         double* partial = (double*)((char*)ws + L.partial_off);
         e = hipMemsetAsync(flag, 0, 4, stream);
         if (e != hipSuccess) return e;
-        if (nnz > 0) hipLaunchKernelGGL(xp_nonfinite_kernel, dim3(2048), dim3(256), 0, stream, d_x, nnz, flag);
         switch (L.ntiles) {
             case 1: launch_tall<1>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
             case 2: launch_tall<2>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
