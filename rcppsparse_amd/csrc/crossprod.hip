@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
 // C += t(P) P runs as v_mfma_f64_16x16x4_f64 over the 16 x 16 tile pairs I <= J, every workgroup over
 // its own range of rows; the workgroups' results are added up in workgroup order.  Deterministic, within
 // 1e-12 * sum |x1 x2| of the reference's order (tests/test_gpu_crossprod.py), not bit-identical.
-// The same 48 x 4.5e7 matrix: 12.7 ms (the kernel reads the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms; 64 columns of 4096 entries
+// The same 48 x 4.5e7 matrix: 7.1 ms (the kernel reads the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms; 64 columns of 4096 entries
 // 0.26 ms against 0.68 ms (of 256 entries: 0.044 against 0.058 ms -- left to the bit-identical form).
 // A product of a structural zero with a non-finite value would be NaN where the reference has nothing: the
 // tall kernel looks at every value it loads and raises a flag if one is not finite; the combine kernel then
@@ -344,14 +344,17 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
 // Measured on 48 columns x 4.5e7 rows (2^31 - 1 entries): 13.4 ms without the prefetch, 12.4 ms with it; panels of
 // 128 rows (pieces of 512 B / 1 KB per column instead of 256 / 512 B, but two workgroups per CU instead of three)
 // 14.1 ms; runs of 32 panels dealt round-robin, so that the resident workgroups read the same neighbourhood of
-// every column, 15.5 ms: 26 GB in 12.4 ms = 2.1 TB/s is what ~100 column streams per workgroup get.
+// every column, 15.5 ms.  What did help: a panel row stride of W + 1 doubles (a column's 64 rows otherwise sit in
+// ONE LDS bank pair: 12.3 -> 10.7 ms) and telling the compiler to fit five workgroups per CU up to 48 columns (it
+// used 130 registers where 96 do: 10.7 -> 7.1 ms = 3.7 TB/s).
 template <int NT>
-__global__ __launch_bounds__(256) void crossprod_tall_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 4 : 1, NT <= 4 ? 8 : (NT <= 6 ? 2 : 1))))
+void crossprod_tall_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p, int32_t nrow,
     int32_t ncol, int64_t nnz, int32_t panels_per_group, int32_t* __restrict__ nonfinite,
     double* __restrict__ partial) {
     constexpr int W = NT * 16, NP = NT * (NT + 1) / 2, MAXP = (NP + 3) / 4, CPW = W / 4;
-    __shared__ double panel[kTallRows][W];
+    __shared__ double panel[kTallRows][W + 1];   // (+1: the 64 rows of a column would otherwise sit in ONE LDS bank pair)
     __shared__ int32_t s_cur[W], s_end[W], s_next[4];
     bool bad = false;   // a NaN or an infinity among the values this lane has loaded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void crossprod_tall_kernel(
     fetch();
     int64_t r0 = R0;
     while (r0 < R1) {
-        for (int k = tid; k < kTallRows * W; k += 256) (&panel[0][0])[k] = 0.0;
+        for (int k = tid; k < kTallRows * (W + 1); k += 256) (&panel[0][0])[k] = 0.0;
         xp_lds_barrier();
         int32_t pending = 0x7fffffff;   // smallest row this wavefront's columns still have to deliver
 #pragma unroll
@@ -522,7 +525,7 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         L->ntiles = tall_tiles(ncol);
         const int64_t npanels = ((int64_t)nrow + kTallRows - 1) / kTallRows;
         // one round of workgroups: what fits on the chip at this tile count (registers / LDS per workgroup)
-        static const int per_cu[9] = {0, 5, 5, 3, 3, 0, 2, 0, 1};
+        static const int per_cu[9] = {0, 5, 5, 5, 3, 0, 2, 0, 1};
         const int64_t max_groups = 256 * per_cu[L->ntiles] < kTallMaxGroups ? 256 * per_cu[L->ntiles] : kTallMaxGroups;
         int64_t per = (npanels + max_groups - 1) / max_groups;
         if (per < 1) per = 1;
