@@ -334,11 +334,11 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
     J = I + q;
 }
 
-// One workgroup (4 wavefronts) per range of row panels, straight from the CSC arrays: a column's entries are
+// One workgroup (NW = 4 wavefronts, 8 from 49 columns on) per range of row panels, straight from the CSC arrays: a column's entries are
 // in ascending row order, so the part of it that falls into the workgroup's rows is one contiguous piece
 // (two binary searches per column at the start) and every panel takes the next few entries of each piece.
-// NT = column tiles.  Wavefront w loads columns w * CPW .. w * CPW + CPW - 1 (64 entries of each per panel,
-// all loads issued before the first is used, the next panel's as soon as these sit in LDS) and owns the tile pairs q = w, w + 4, ... (at most MAXP), whose
+// NT = column tiles, CPW = 16 NT / NW.  Wavefront w loads columns w * CPW .. w * CPW + CPW - 1 (64 entries of each per panel,
+// all loads issued before the first is used, the next panel's as soon as these sit in LDS) and owns the tile pairs q = w, w + NW, ... (at most MAXP), whose
 // 16 x 16 accumulators stay in registers.  Panels without entries are skipped: the next panel starts at the
 // smallest row any column has pending.
 // Measured on 48 columns x 4.5e7 rows (2^31 - 1 entries): 13.4 ms without the prefetch, 12.4 ms with it; panels of
@@ -347,22 +347,22 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
 // every column, 15.5 ms.  What did help: a panel row stride of W + 1 doubles (a column's 64 rows otherwise sit in
 // ONE LDS bank pair: 12.3 -> 10.7 ms) and telling the compiler to fit five workgroups per CU up to 48 columns (it
 // used 130 registers where 96 do: 10.7 -> 7.1 ms = 3.7 TB/s).
-template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 4 : 1, NT <= 4 ? 8 : (NT <= 6 ? 2 : 1))))
+template <int NT, int NW>   // column tiles, wavefronts per workgroup
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT <= 3 || NW == 8 ? 4 : 1, 8)))
 void crossprod_tall_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p, int32_t nrow,
     int32_t ncol, int64_t nnz, int32_t panels_per_group, int32_t* __restrict__ nonfinite,
     double* __restrict__ partial) {
-    constexpr int W = NT * 16, NP = NT * (NT + 1) / 2, MAXP = (NP + 3) / 4, CPW = W / 4;
+    constexpr int W = NT * 16, NP = NT * (NT + 1) / 2, MAXP = (NP + NW - 1) / NW, CPW = W / NW;
     __shared__ double panel[kTallRows][W + 1];   // (+1: the 64 rows of a column would otherwise sit in ONE LDS bank pair)
-    __shared__ int32_t s_cur[W], s_end[W], s_next[4];
+    __shared__ int32_t s_cur[W], s_end[W], s_next[NW];
     bool bad = false;   // a NaN or an infinity among the values this lane has loaded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ti[MAXP], tj[MAXP];
     xp_v4f64 acc[MAXP];
 #pragma unroll
     for (int s = 0; s < MAXP; ++s) {
-        tall_pair(s * 4 + wave < NP ? s * 4 + wave : 0, NT, ti[s], tj[s]);
+        tall_pair(s * NW + wave < NP ? s * NW + wave : 0, NT, ti[s], tj[s]);
         acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
     }
     const int64_t R0 = (int64_t)blockIdx.x * panels_per_group * kTallRows;
@@ -415,7 +415,7 @@ void crossprod_tall_kernel(
     fetch();
     int64_t r0 = R0;
     while (r0 < R1) {
-        for (int k = tid; k < kTallRows * (W + 1); k += 256) (&panel[0][0])[k] = 0.0;
+        for (int k = tid; k < kTallRows * (W + 1); k += NW * 64) (&panel[0][0])[k] = 0.0;
         xp_lds_barrier();
         int32_t pending = 0x7fffffff;   // smallest row this wavefront's columns still have to deliver
 #pragma unroll
@@ -443,12 +443,12 @@ void crossprod_tall_kernel(
             const double* prow = &panel[4 * ks + (lane >> 4)][lane & 15];
 #pragma unroll
             for (int s = 0; s < MAXP; ++s)
-                if (s * 4 + wave < NP)   // (uniform per wavefront)
+                if (s * NW + wave < NP)   // (uniform per wavefront)
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(prow[16 * ti[s]], prow[16 * tj[s]], acc[s], 0, 0, 0);
         }
         int32_t nxt = s_next[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) nxt = s_next[w] < nxt ? s_next[w] : nxt;
+        for (int w = 1; w < NW; ++w) nxt = s_next[w] < nxt ? s_next[w] : nxt;
         xp_lds_barrier();   // (panel and s_next are rewritten next)
         const int64_t step = r0 + kTallRows;
         const int64_t jump = R0 + (((int64_t)nxt - R0) / kTallRows) * kTallRows;   // the panel that holds row nxt
@@ -461,8 +461,8 @@ void crossprod_tall_kernel(
     double* mine = partial + (size_t)blockIdx.x * NP * 256;
 #pragma unroll
     for (int s = 0; s < MAXP; ++s)
-        if (s * 4 + wave < NP) {
-            double* t = mine + (size_t)(s * 4 + wave) * 256;
+        if (s * NW + wave < NP) {
+            double* t = mine + (size_t)(s * NW + wave) * 256;
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[s][r];
         }
@@ -525,7 +525,7 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         L->ntiles = tall_tiles(ncol);
         const int64_t npanels = ((int64_t)nrow + kTallRows - 1) / kTallRows;
         // one round of workgroups: what fits on the chip at this tile count (registers / LDS per workgroup)
-        static const int per_cu[9] = {0, 5, 5, 5, 3, 0, 2, 0, 1};
+        static const int per_cu[9] = {0, 5, 5, 5, 2, 0, 2, 0, 2};
         const int64_t max_groups = 256 * per_cu[L->ntiles] < kTallMaxGroups ? 256 * per_cu[L->ntiles] : kTallMaxGroups;
         int64_t per = (npanels + max_groups - 1) / max_groups;
         if (per < 1) per = 1;
@@ -555,11 +555,11 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
     return hipSuccess;
 }
 
-template <int NT>
+template <int NT, int NW>
 static void launch_tall(const CrossprodLayout& L, const double* d_x, const int32_t* d_i, const int32_t* d_p,
                         int32_t nrow, int32_t ncol, int64_t nnz, int32_t* flag, double* partial,
                         hipStream_t stream) {
-    hipLaunchKernelGGL(crossprod_tall_kernel<NT>, dim3((unsigned)L.ngroups), dim3(256), 0, stream, d_x, d_i, d_p, nrow,
+    hipLaunchKernelGGL((crossprod_tall_kernel<NT, NW>), dim3((unsigned)L.ngroups), dim3(NW * 64), 0, stream, d_x, d_i, d_p, nrow,
                        ncol, nnz, L.panels_per_group, flag, partial);
 }
 
@@ -581,12 +581,12 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
         e = hipMemsetAsync(flag, 0, 4, stream);
         if (e != hipSuccess) return e;
         switch (L.ntiles) {
-            case 1: launch_tall<1>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            case 2: launch_tall<2>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            case 3: launch_tall<3>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            case 4: launch_tall<4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            case 6: launch_tall<6>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            default: launch_tall<8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 1: launch_tall<1, 4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 2: launch_tall<2, 4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 3: launch_tall<3, 4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 4: launch_tall<4, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 6: launch_tall<6, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            default: launch_tall<8, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
         }
         const int64_t outs = (int64_t)ncol * ncol;
         hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream,
