@@ -334,13 +334,14 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
     J = I + q;
 }
 
-// One workgroup (NW = 4 wavefronts, 8 from 49 columns on) per range of row panels, straight from the CSC arrays: a column's entries are
-// in ascending row order, so the part of it that falls into the workgroup's rows is one contiguous piece
-// (two binary searches per column at the start) and every panel takes the next few entries of each piece.
-// NT = column tiles, CPW = 16 NT / NW.  Wavefront w loads columns w * CPW .. w * CPW + CPW - 1 (64 entries of each per panel,
-// all loads issued before the first is used, the next panel's as soon as these sit in LDS) and owns the tile pairs q = w, w + NW, ... (at most MAXP), whose
-// 16 x 16 accumulators stay in registers.  Panels without entries are skipped: the next panel starts at the
-// smallest row any column has pending.
+// One workgroup (NW = 4 wavefronts, 8 from 49 columns on) per range of row panels, straight from the CSC
+// arrays: a column's entries are in ascending row order, so the part of it that falls into the workgroup's
+// rows is one contiguous piece (two binary searches per column at the start) and every panel takes the next
+// few entries of each piece.
+// NT = column tiles, CPW = 16 NT / NW.  Wavefront w loads columns w * CPW .. w * CPW + CPW - 1 (64 entries of
+// each per panel, all loads issued before the first is used, the next panel's as soon as these sit in LDS)
+// and owns the tile pairs q = w, w + NW, ... (at most MAXP), whose 16 x 16 accumulators stay in registers.
+// Panels without entries are skipped: the next panel starts at the smallest row any column has pending.
 // Measured on 48 columns x 4.5e7 rows (2^31 - 1 entries): 13.4 ms without the prefetch, 12.4 ms with it; panels of
 // 128 rows (pieces of 512 B / 1 KB per column instead of 256 / 512 B, but two workgroups per CU instead of three)
 // 14.1 ms; runs of 32 panels dealt round-robin, so that the resident workgroups read the same neighbourhood of
