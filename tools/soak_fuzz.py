@@ -67,6 +67,25 @@ def soak_next_rows(a):
                 ref = oracle.column_sums_in_rows(x, i, p, bm, comp)
                 scale = oracle.column_abs_sums(x, p)
                 assert np.all(np.abs(got - ref) <= 1e-12 * scale), (what, "in_rows", comp)
+        if n % 25 == 0:
+            # row-restricted sums with a bitmap that lives in LDS (shared by 16 / 8 / 6 wavefronts) or in L2:
+            # many rows, random column structure
+            nrow2 = int(rng.choice([140_000, 400_000, 700_000, 1_000_000, 1_048_576, 1_500_000]))
+            counts = structure(rng)
+            counts = np.minimum(counts, nrow2)
+            p2 = synth.offsets_from_counts(counts)
+            nnz2 = int(p2[-1])
+            if 0 < nnz2 < 3_000_000:
+                x2 = oracle.gen_values(nnz2, n, 0, 0)
+                i2 = oracle.gen_row_indices(p2, nrow2, n)
+                rows2 = np.flatnonzero(rng.random(nrow2) < rng.random())
+                bm2 = capi.row_set_bitmap(rows2, nrow2)
+                x2t, i2t, p2t = torch.from_numpy(x2).cuda(), torch.from_numpy(i2).cuda(), torch.from_numpy(p2).cuda()
+                for comp in (False, True):
+                    got = capi.column_sums_in_rows_device(x2t, i2t, p2t, nrow2, torch.from_numpy(bm2).cuda(), comp).cpu().numpy()
+                    ref = oracle.column_sums_in_rows(x2, i2, p2, bm2, comp)
+                    scale = oracle.column_abs_sums(x2, p2)
+                    assert np.all(np.abs(got - ref) <= 1e-12 * scale), (n, "in_rows, many rows", nrow2, comp)
         n += 1
         if n % 50 == 0:
             print(f"{n} cases ok, {time.time() - t0:.0f} s", flush=True)
@@ -110,6 +129,25 @@ def main():
             raise
         finally:
             capi.set_tuning(0)
+        if n % 25 == 0:
+            # row-restricted sums with a bitmap that lives in LDS (shared by 16 / 8 / 6 wavefronts) or in L2:
+            # many rows, random column structure
+            nrow2 = int(rng.choice([140_000, 400_000, 700_000, 1_000_000, 1_048_576, 1_500_000]))
+            counts = structure(rng)
+            counts = np.minimum(counts, nrow2)
+            p2 = synth.offsets_from_counts(counts)
+            nnz2 = int(p2[-1])
+            if 0 < nnz2 < 3_000_000:
+                x2 = oracle.gen_values(nnz2, n, 0, 0)
+                i2 = oracle.gen_row_indices(p2, nrow2, n)
+                rows2 = np.flatnonzero(rng.random(nrow2) < rng.random())
+                bm2 = capi.row_set_bitmap(rows2, nrow2)
+                x2t, i2t, p2t = torch.from_numpy(x2).cuda(), torch.from_numpy(i2).cuda(), torch.from_numpy(p2).cuda()
+                for comp in (False, True):
+                    got = capi.column_sums_in_rows_device(x2t, i2t, p2t, nrow2, torch.from_numpy(bm2).cuda(), comp).cpu().numpy()
+                    ref = oracle.column_sums_in_rows(x2, i2, p2, bm2, comp)
+                    scale = oracle.column_abs_sums(x2, p2)
+                    assert np.all(np.abs(got - ref) <= 1e-12 * scale), (n, "in_rows, many rows", nrow2, comp)
         n += 1
         if n % 50 == 0:
             print(f"{n} cases ok, {time.time() - t0:.0f} s", flush=True)
