@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void crossprod_rows_kernel(
 // C += t(P) P runs as v_mfma_f64_16x16x4_f64 over the 16 x 16 tile pairs I <= J, every workgroup over
 // its own range of rows; the workgroups' results are added up in workgroup order.  Deterministic, within
 // 1e-12 * sum |x1 x2| of the reference's order (tests/test_gpu_crossprod.py), not bit-identical.
-// The same 48 x 4.5e7 matrix: 7.1 ms (the kernel reads the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.84 ms against 89 ms; 64 columns of 4096 entries
+// The same 48 x 4.5e7 matrix: 6.6 ms (the kernel reads the 26 GB of x and i once); 1e6 x 64 with 3.2e7 entries 0.26 ms against 89 ms; 64 columns of 4096 entries
 // 0.26 ms against 0.68 ms (of 256 entries: 0.044 against 0.058 ms -- left to the bit-identical form).
 // A product of a structural zero with a non-finite value would be NaN where the reference has nothing: the
 // tall kernel looks at every value it loads and raises a flag if one is not finite; the combine kernel then
@@ -469,15 +469,19 @@ void crossprod_tall_kernel(
         }
 }
 
-// out(c1, c2) = the workgroups' results for that element, added in workgroup order (both triangles)
+// out(c1, c2) = the workgroups' results for that element (both triangles).  One wavefront per element: lane l
+// adds the results of workgroups l, l + 64, ... in that order, then the 64 lane sums meet in a fixed butterfly --
+// the same association on every run.  (One thread per element walking all ~1000 workgroups took 0.3-0.5 ms,
+// as much as the tall kernel itself on a 1e6 x 64 matrix.)
 __global__ __launch_bounds__(256) void crossprod_tall_combine_kernel(const double* __restrict__ partial,
                                                                      int32_t ngroups, int32_t nt, int32_t ncol,
                                                                      const int32_t* __restrict__ nonfinite,
                                                                      double* __restrict__ out) {
 #pragma clang fp contract(off)
     if (*nonfinite) return;
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= (int64_t)ncol * ncol) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= (int64_t)ncol * ncol) return;   // (whole wavefronts)
     const int c1 = (int)(k / ncol), c2 = (int)(k % ncol);
     const int a = c1 < c2 ? c1 : c2, b = c1 < c2 ? c2 : c1;   // a <= b: tile pair (a / 16, b / 16)
     const int I = a >> 4, J = b >> 4;
@@ -485,8 +489,10 @@ __global__ __launch_bounds__(256) void crossprod_tall_combine_kernel(const doubl
     const int np = nt * (nt + 1) / 2;
     const double* t = partial + (size_t)q * 256 + (size_t)(a & 15) * 16 + (b & 15);
     double sum = 0.0;
-    for (int g = 0; g < ngroups; ++g) sum += t[(size_t)g * np * 256];
-    out[k] = sum;
+    for (int g = lane; g < ngroups; g += 64) sum += t[(size_t)g * np * 256];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) out[k] = sum;
 }
 
 // nsplit slices of `width` result rows each: width <= kXMaxWidth, every slice non-empty.
@@ -590,7 +596,7 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             default: launch_tall<8, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
         }
         const int64_t outs = (int64_t)ncol * ncol;
-        hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, stream,
                            partial, L.ngroups, L.ntiles, ncol, flag, d_out);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
