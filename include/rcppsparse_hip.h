@@ -184,10 +184,10 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
  * order.  The handle variants (the handle must have been uploaded with i[])
  * build the row-major form on first use -- a stable device radix sort of (i, x)
  * by row, i.e. columnSums(t(A)) -- and keep it: repeated calls only reduce
- * (matrices of up to 49152 rows are summed straight from x / i instead, like the
+ * (matrices of up to 65536 rows are summed straight from x / i instead, like the
  * device variants: no sort, no second copy of x).
  * The device variants accumulate in LDS, 16384 rows per workgroup: matrices of
- * up to 49152 rows are summed straight from x / i (workspace: the workgroups'
+ * up to 65536 rows are summed straight from x / i (workspace: the workgroups'
  * partial sums, at most a few hundred MB); larger ones are first regrouped by
  * block of 16384 rows in the caller's workspace on every call (one hand-written
  * partition pass; more than 1.36e7 rows: a sort by 4096-row block instead), with

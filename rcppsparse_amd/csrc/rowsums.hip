@@ -4,10 +4,11 @@
 // columns.  On the device that is a reduction by key with 1e7 keys and no locality in the key.
 // Four forms, chosen in plan_row_sums:
 //
-//   direct (one-shot calls on matrices of up to 3 row blocks, 49152 rows): nothing is regrouped.  Steps 4
+//   direct (one-shot calls on matrices of up to 4 row blocks, 65536 rows): nothing is regrouped.  Steps 4
 //     and 5 below run on the caller's x / i, every block's workgroups scanning all entries and adding
 //     those of their block: 12 B/nnz per block, no workspace beyond the parts' sums
-//     (5e8 nnz: 1.45 / 2.7 / 4.0 ms for 1 / 2 / 3 blocks; regrouping first costs 4.5-5.4 ms there).
+//     (5e8 nnz: 1.0 / 1.4 / 2.9 / 2.8 ms for 1 / 2 / 3 / 4 blocks; regrouping first costs 4.2-4.9 ms, and from 5
+//     blocks on is the faster way: 4.4 against 4.8 ms).
 //
 //   tile partition (one-shot calls, rsp_row_sums_device, 4 to 832 row blocks = up to 1.36e7 rows) -- all hand-written:
 //     the entries are regrouped by ROW BLOCK (16384 rows: what one CU's LDS holds as sums) in ONE
@@ -21,7 +22,7 @@
 //          runs of ~37 entries instead of single 8-byte stores     reads 12 B/nnz, writes 12 B/nnz
 //       4. rows_tile_accumulate_kernel  16-wave workgroups, `nsplit` per block: the block's sums live
 //          in 128 KB of LDS; fifteen wavefronts stage entries, the sixteenth adds the previous step's
-//          with ds_add_f64, in slot order (the LDS unit's ~1.6 cycles per double add is the bound)
+//          with ds_add_f64, in slot order, from (byte offset, value) pairs the stagers prepared
 //                                                                   reads 12 B/nnz, writes 8 B/row
 //       5. rows_combine_parts_kernel    (nsplit > 1) adds the parts of every row in part order
 //     About 40 B/nnz of traffic and a workspace of 12 B/nnz + the count table.  An entry's slot is a
@@ -32,7 +33,7 @@
 //     block bits of the row index only (4096-row blocks), then rows_block_accumulate_kernel (one
 //     wavefront per block, sums in 32 KB of LDS).
 //
-//   row form (the handle API above 49152 rows, which keeps it for repeated calls): full stable sort by row,
+//   row form (the handle API above 65536 rows, which keeps it for repeated calls): full stable sort by row,
 //     row offsets by a vectorised lower_bound, then the column-sum kernels on the row-major
 //     values (8 B/nnz per repeated call instead of 12).
 //
@@ -67,7 +68,7 @@ constexpr int kAccThreads = 1024;         // accumulate workgroup: 15 wavefronts
 constexpr int kAccStagers = kAccThreads - 64;
 constexpr int kAccDepth = 8;              // steps of entries a staging thread has in flight (8 x 11.5 KB per CU)
 constexpr int kAccMaxSplit = 1024;        // workgroups that may share one row block
-constexpr int kDirectMaxBlocks = 3;       // up to here the accumulate pass scans the caller's x / i once per block instead
+constexpr int kDirectMaxBlocks = 4;       // up to here the accumulate pass scans the caller's x / i once per block instead
 
 // bits needed to hold every value up to and including v
 static unsigned bits_to_hold(uint32_t v) {
@@ -156,7 +157,7 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
         const int64_t rows_here = nrow < (1 << kPartShift) ? (nrow > 0 ? nrow : 1) : (1 << kPartShift);
         // Few blocks: no regrouping at all.  A block's workgroups scan the caller's x / i as they are and add
         // the entries of their block (12 B/nnz per block instead of ~40 B/nnz and the partition pass's LDS work;
-        // 5e8 nnz: 1.45 ms for one block, 2.7 ms for two; the partition form takes 4.5-5.4 ms at 2-61 blocks).
+        // 5e8 nnz: 1.0 ms for one block, 2.8 ms for four; the partition form takes 4.2-4.9 ms at 2-61 blocks).
         L->direct = L->nblocks <= kDirectMaxBlocks;
         L->nsplit = accumulate_split(L->nblocks, L->direct ? nnz : nnz / L->nblocks, rows_here);
         const size_t table_entries = (size_t)L->nsuper * (size_t)L->nblocks + 1;   // + the total
@@ -486,8 +487,8 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double* sums = (double*)s_raw;                          // 1 << shift
-    double* st_x = sums + ((size_t)1 << shift);             // 2 x kAccStagers
-    int32_t* st_r = (int32_t*)(st_x + 2 * kAccStagers);     // 2 x kAccStagers
+    double* st_x = sums + ((size_t)1 << shift) + 64;        // 2 x kAccStagers  (64 spare slots behind the sums: where nothing-to-add goes)
+    int32_t* st_r = (int32_t*)(st_x + 2 * kAccStagers);     // 2 x kAccStagers: byte offsets into sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit;
     const int rows_here = 1 << shift, mask = rows_here - 1;
@@ -523,8 +524,13 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
         for (int32_t q = 0; q < nrounds; ++q) {
 #pragma unroll
             for (int d = 0; d < kAccDepth; ++d) {
-                st_r[(d & 1) * kAccStagers + stid] = gr[d];
-                st_x[(d & 1) * kAccStagers + stid] = gv[d];
+                // what the adding wavefront needs and nothing more: the byte offset of the row's sum and the value.
+                // Its instruction stream is the pass's critical path (one extra branch per entry there: 2.8 -> 6.6 ms),
+                // so slots past the end, other blocks' entries (direct form) and invalid row indices are turned into
+                // "+0.0 to a spare slot" HERE, and the adder adds unconditionally.
+                const bool mine = (uint32_t)gr[d] < (uint32_t)nrow && (gr[d] >> shift) == b;
+                st_r[(d & 1) * kAccStagers + stid] = mine ? (gr[d] & mask) * 8 : (rows_here + (stid & 63)) * 8;   // (a spare slot per adder lane)
+                st_x[(d & 1) * kAccStagers + stid] = mine ? gv[d] : 0.0;
                 fetch(d, (q + 1) * kAccDepth + d);
                 lds_barrier();
             }
@@ -536,16 +542,14 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
                 lds_barrier();
                 const int32_t* br = st_r + (d & 1) * kAccStagers;
                 const double* bx = st_x + (d & 1) * kAccStagers;
-                int32_t rr[kAccStagers / 64];
+                int32_t off[kAccStagers / 64];
                 double xv[kAccStagers / 64];
 #pragma unroll
-                for (int u = 0; u < kAccStagers / 64; ++u) rr[u] = br[u * 64 + lane];
+                for (int u = 0; u < kAccStagers / 64; ++u) off[u] = br[u * 64 + lane];
 #pragma unroll
                 for (int u = 0; u < kAccStagers / 64; ++u) xv[u] = bx[u * 64 + lane];
 #pragma unroll
-                for (int u = 0; u < kAccStagers / 64; ++u)   // (slots past the end of the part hold row -1; the direct
-                    // form also meets other blocks' entries and whatever else the caller's i[] holds)
-                    if ((uint32_t)rr[u] < (uint32_t)nrow && (rr[u] >> shift) == b) lds_add_f64(&sums[rr[u] & mask], xv[u]);
+                for (int u = 0; u < kAccStagers / 64; ++u) lds_add_f64((double*)((char*)sums + off[u]), xv[u]);
             }
         }
     }
@@ -713,7 +717,7 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
     const int32_t* pr = direct ? d_i : (const int32_t*)((char*)persist + L.rows_off);
     const int32_t* boff = (const int32_t*)((char*)persist + L.boff_off);
     if (L.mode == 2) {
-        const size_t acc_lds = ((size_t)8 << L.shift) + (size_t)2 * kAccStagers * 12;
+        const size_t acc_lds = ((size_t)8 << L.shift) + 64 * 8 + (size_t)2 * kAccStagers * 12;
         static bool raised2 = false;
         if (!raised2) {
             hipError_t e = hipFuncSetAttribute((const void*)rows_tile_accumulate_kernel<true>,

@@ -110,10 +110,10 @@ def test_row_sums_1e8_against_oracle(torch_cuda):
 
 
 @pytest.mark.parametrize("nrow,nnz", [(13_700_000, 3_000_000), (40_000_000, 5_000_000), (16_384, 2_000_000),
-                                      (16_385, 400_000), (3, 5_000), (49_152, 900_000), (49_153, 900_000),
+                                      (16_385, 400_000), (3, 5_000), (49_153, 900_000), (65_536, 900_000), (65_537, 900_000),
                                       (13_631_488, 2_500_000)])
 def test_row_sums_forms_by_row_count(torch_cuda, nrow, nnz):
-    """The one-shot entry has three forms by row count: up to 3 blocks of 16384 rows nothing is regrouped
+    """The one-shot entry has three forms by row count: up to 4 blocks of 16384 rows nothing is regrouped
     (every block's workgroups scan x / i as they are), up to 832 blocks (1.36e7 rows) the hand-written
     tile partition regroups by block, above that a rocPRIM sort by 4096-row block.  Shapes on both sides
     of every edge.  Same oracle, same tolerance, bit-stable."""
