@@ -312,16 +312,24 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
     __syncthreads();
     const int64_t e0 = (int64_t)s * super_elems;
     const int64_t e1 = e0 + super_elems < nnz ? e0 + super_elems : nnz;
-    for (int64_t e = e0; e < e1; e += 8 * kPartThreads) {   // 8 coalesced loads in flight per thread
-        int32_t r[8];
+    // 16 bytes per lane and load (1 KB per wave instruction: 4-byte loads reach about two thirds of that rate), two
+    // loads in flight per thread; a buffer resource so that the last, partial quad reads zeros instead of faulting
+    const int32_t len = __builtin_amdgcn_readfirstlane((int32_t)(e1 - e0));
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ri + e0), 0, len * 4, 0x00020000);
+    typedef int32_t i4 __attribute__((ext_vector_type(4)));
+    for (int32_t e = 0; e < len; e += 8 * kPartThreads) {
+        i4 q[2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int64_t j = e + k * kPartThreads + tid;
-            r[k] = j < e1 ? ri[j] : -1;
-        }
+        for (int k = 0; k < 2; ++k)
+            q[k] = __builtin_bit_cast(i4, __builtin_amdgcn_raw_buffer_load_b128(res, tid * 16, (e + k * 4 * kPartThreads) * 4, 2));
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if ((uint32_t)r[k] < (uint32_t)nrow) atomicAdd(&s_hist[(uint32_t)r[k] >> shift], 1);
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int32_t j = e + k * 4 * kPartThreads + tid * 4 + c;
+                const int32_t r = q[k][c];
+                if (j < len && (uint32_t)r < (uint32_t)nrow) atomicAdd(&s_hist[(uint32_t)r >> shift], 1);
+            }
     }
     __syncthreads();
     for (int b = tid; b < nblocks; b += kPartThreads) table[(size_t)b * nsuper + s] = s_hist[b];

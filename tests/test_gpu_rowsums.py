@@ -169,6 +169,22 @@ def test_handle_row_sums_leave_out_invalid_row_indices(torch_cuda):
     assert np.allclose(cs, oracle.column_sums(x, p), rtol=0, atol=1e-9)    # column sums do not look at i[]
 
 
+def test_row_sums_with_arrays_that_are_only_4_and_8_byte_aligned(torch_cuda):
+    """x and i as an R session hands them over need not be 16-byte aligned: views that start one element into a
+    buffer go through the forms that load 16 bytes per lane (the histogram pass) and the others alike."""
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    for nrow, nnz in ((1000, 200_001), (300_000, 700_003), (14_000_000, 300_001)):
+        x = rng.standard_normal(nnz + 3)
+        i = rng.integers(0, nrow, nnz + 3).astype(np.int32)
+        xt, it = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda()
+        for off in (1, 3):
+            got = capi.row_sums_device(xt[off:off + nnz], it[off:off + nnz], nrow).cpu().numpy()
+            ref = np.bincount(i[off:off + nnz], weights=x[off:off + nnz], minlength=nrow)
+            scale = np.bincount(i[off:off + nnz], weights=np.abs(x[off:off + nnz]), minlength=nrow)
+            assert np.all(np.abs(got - ref) <= RTOL * scale), (nrow, off)
+
+
 @pytest.mark.parametrize("pattern", ["one_row", "first_tiles_invalid", "edge_blocks", "one_block_dense", "all_invalid"])
 def test_row_sums_skewed_tiles(torch_cuda, pattern):
     """Shapes of a partition tile the uniform generator never makes: every entry of a tile in ONE block
