@@ -481,10 +481,12 @@ __global__ void rows_tile_offsets_kernel(const int32_t* __restrict__ first_slot,
 // 4. `nsplit` 16-wave workgroups per row block, each over an equal part of the block's entries.  Fifteen
 //    wavefronts stage entries into one of two LDS buffers (coalesced loads, eight steps of them in
 //    flight per thread); the sixteenth adds the buffer staged in the previous step, 64 entries per LDS
-//    instruction, in slot order.  (An LDS double add costs the same whether 4 or 64 of its lanes are
-//    active, so letting every wavefront pick "its" rows out of each step is 16 times the LDS work:
-//    9.5 ms instead of 2.  Adding while the others stage keeps the LDS unit's ~0.7 ns per entry off
-//    the critical path; with one buffer the two alternated and the loads in flight could not cover it.)
+//    instruction, in slot order.  The adding wavefront's instruction stream is the critical path of the
+//    pass, so the stagers leave it nothing to decide: they hand over (byte offset of the row's sum, value)
+//    per entry, and it runs ds_read_b32, ds_read_b64, ds_add_f64 -- 45 instructions per 960 entries.
+//    (Letting every wavefront pick "its" rows out of each step instead is 16 times the instructions:
+//    9.5 ms; one buffer instead of two makes staging and adding alternate: 3.7 ms; now 2.0 ms on C3,
+//    which is the read of the 12 GB.)
 //    nsplit == 1: sums (or means) straight to `out`.  Otherwise each part's sums go to part_out + part * nrow
 //    and rows_combine_parts_kernel adds the parts up.
 template <bool MEANS>
