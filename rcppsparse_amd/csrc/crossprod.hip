@@ -153,7 +153,6 @@ __global__ __launch_bounds__(256) void crossprod_tiles_kernel(
 // row-major path
 // ---------------------------------------------------------------------------------------------
 
-constexpr int kXDepth = 16;       // (row, segment) units whose loads one wave keeps in flight
 constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 
 // tall form (few columns, long columns)
@@ -223,80 +222,157 @@ __device__ __forceinline__ void lds_add_f64(double* a, double v) {
     __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)a, v);
 }
 
-template <int kXD>
-__global__ __launch_bounds__(64) void crossprod_rows_kernel(
+// workgroup barrier for LDS hand-offs only (no wait for outstanding global loads)
+__device__ __forceinline__ void xr_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int kXRound = 12;   // units a round of the row-major kernel hands from the stagers to the adder
+
+// One workgroup of 4 wavefronts per (result column c1, slice).  A UNIT is (entry j of column c1, 64-wide
+// segment g of that entry's row in this slice); the units in ascending (j, g) order are the reference's order
+// of products for every output.  Round 2 split the work the way the rowSums accumulate pass does: wavefronts
+// 1-3 STAGE units -- find them, load the row segment, multiply by x1 (a separate multiply, as in the
+// reference) and put (byte offset of the accumulator, product) pairs into one of two LDS buffers, kXRound
+// units a round -- and wavefront 0 ADDS the buffer staged in the previous round, unit by unit in order, with
+// nothing to decide: ds_read_b32, ds_read_b64, ds_add_f64.  One wavefront doing both walked a column at
+// ~270 ns per unit; the adder alone needs ~10 ns, so the column's chain is no longer what a call waits for.
+// The headers of the next two groups of 64 entries (row, x1, extent of the row in the slice) travel while the
+// current group is worked on.  LDS: span accumulators + 64 spare ones ("nothing to add" goes there) + 18 KB.
+__global__ __launch_bounds__(256) void crossprod_rows_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p,
     const int32_t* __restrict__ rp, const int32_t* __restrict__ rc, const double* __restrict__ rx,
     int32_t nrow, int32_t ncol, int32_t nsplit, int32_t width, double* __restrict__ out,
     const int32_t* __restrict__ run_if) {
 #pragma clang fp contract(off)
-    extern __shared__ double acc[];                       // out(c_lo .. c_lo+span, c1) of this wave
+    extern __shared__ double xr_sh[];
+    double* acc = xr_sh;                                            // width accumulators + 64 spare slots
+    double* bprod = acc + width + 64;                               // 2 x kXRound x 64 products
+    int32_t* boff = (int32_t*)(bprod + 2 * kXRound * 64);           // 2 x kXRound x 64 byte offsets into acc
     if (run_if && *run_if == 0) return;                   // (stands by for the tall form, which then has run)
     const int c1 = blockIdx.x / nsplit, slice = blockIdx.x % nsplit, c_lo = slice * width;
     if (c1 >= ncol || c_lo >= ncol) return;               // (the launcher never creates such a slice)
     const unsigned span = (unsigned)(min(ncol - c_lo, width));
-    const int lane = threadIdx.x;
-    for (unsigned c = lane; c < span; c += 64) acc[c] = 0.0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (unsigned c = tid; c < span + 64; c += 256) acc[c] = 0.0;
     __syncthreads();
 
-    const int e_end = p[c1 + 1];
-    for (int64_t e0 = p[c1]; e0 < e_end; e0 += 64) {   // (64-bit: e_end may be 2^31 - 1)
-        // 64 entries of column c1 (ascending rows), one per lane, with the extent of their rows
-        const int n = __builtin_amdgcn_readfirstlane((int)min((int64_t)64, e_end - e0));
-        double va = 0.0;
-        int rs = 0, len = 0;
-        if (lane < n) {
-            const int k = ri[e0 + lane];
-            va = x[e0 + lane];
-            if ((unsigned)k < (unsigned)nrow) {
-                const int64_t vr = (int64_t)k * nsplit + slice;   // this slice's part of row k
-                rs = rp[vr];
-                len = rp[vr + 1] - rs;
-            }
+    const int64_t e_beg = p[c1], e_end = p[c1 + 1];
+    // header of a group of 64 entries of column c1, per lane: x1, first position and length of the entry's row
+    // in this slice; stage A = (row index, x1), stage B = (position, length), each one group apart
+    auto load_a = [&](int64_t e0, int& k, double& va) {
+        const bool in = e0 + lane < e_end;
+        k = in ? ri[e0 + lane] : -1;
+        va = in ? x[e0 + lane] : 0.0;
+    };
+    auto load_b = [&](int k, int& rs, int& len) {
+        rs = 0;
+        len = 0;
+        if ((unsigned)k < (unsigned)nrow) {
+            const int64_t vr = (int64_t)k * nsplit + slice;   // this slice's part of row k
+            rs = rp[vr];
+            len = rp[vr + 1] - rs;
         }
-        // units of work: (entry j of the group, 64-wide segment g of its row), walked in
-        // ascending order by a scalar cursor; kXD units have their loads in flight at once
-        int j = 0, g = 0;
-        while (j < n) {
-            int cb[kXD], ju[kXD];
-            double vb[kXD];
+    };
+    int k1, k2, rs0, len0, rs1, len1;
+    double va0, va1, va2;
+    {
+        int k0;
+        load_a(e_beg, k0, va0);
+        load_b(k0, rs0, len0);
+        load_a(e_beg + 64, k1, va1);
+    }
+    for (int64_t e0 = e_beg; e0 < e_end; e0 += 64) {   // (64-bit: e_end may be 2^31 - 1)
+        load_b(k1, rs1, len1);                 // group + 1: extents (its row indices arrived a group ago)
+        load_a(e0 + 128, k2, va2);             // group + 2: row indices and x1
+        // units of this group: lane j owns units [ustart, incl)
+        const int nun = (len0 + 63) >> 6;
+        int incl = nun;
 #pragma unroll
-            for (int u = 0; u < kXD; ++u) {
-                cb[u] = -1;
-                vb[u] = 0.0;
-                ju[u] = j < n ? j : 0;                    // (scalar) which entry unit u belongs to
-                if (j < n) {                              // uniform
-                    const int rs_j = __builtin_amdgcn_readlane(rs, j);
-                    const int len_j = __builtin_amdgcn_readlane(len, j);
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const int ustart = incl - nun;
+        const int U = __builtin_amdgcn_readlane(incl, 63);
+        const int nrounds = (U + kXRound - 1) / kXRound;
+        // Stagers fill round r while the adder drains round r - 1; the loads of round r + 1 are issued before
+        // round r is written out, so one L2 round trip per GROUP is exposed, not one per round.  Two register
+        // sets (even / odd rounds), hence the loop in steps of two.
+        constexpr int Q = kXRound / 3;
+        int cbA[Q], cbB[Q];
+        double vbA[Q], vbB[Q], x1A[Q], x1B[Q];
+        auto issue = [&](int r, int (&cb)[Q], double (&vb)[Q], double (&x1)[Q]) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int u = r * kXRound + (wave - 1) + 3 * q;     // (uniform)
+                cb[q] = -1;
+                vb[q] = 0.0;
+                x1[q] = 0.0;
+                if (u < U) {
+                    const int j = __popcll(__ballot(incl <= u));    // the lane that owns unit u
+                    const int g = u - __builtin_amdgcn_readlane(ustart, j);
+                    const int rs_j = __builtin_amdgcn_readlane(rs0, j);
+                    const int len_j = __builtin_amdgcn_readlane(len0, j);
+                    x1[q] = readlane_f64(va0, j);
                     const int t = g * 64 + lane;
                     if (t < len_j) {
-                        cb[u] = rc[rs_j + t];
-                        vb[u] = rx[rs_j + t];
-                    }
-                    if ((g + 1) * 64 < len_j) {
-                        ++g;
-                    } else {
-                        ++j;
-                        g = 0;
+                        cb[q] = rc[rs_j + t];
+                        vb[q] = rx[rs_j + t];
                     }
                 }
             }
-            // consume in the same (ascending row) order.  x1 is broadcast here, not in the issue
-            // loop: a read of `va` there makes the compiler drain the loads already in flight.
+        };
+        auto put = [&](int r, const int (&cb)[Q], const double (&vb)[Q], const double (&x1)[Q]) {
+            int32_t* bo = boff + (r & 1) * kXRound * 64;
+            double* bp = bprod + (r & 1) * kXRound * 64;
 #pragma unroll
-            for (int u = 0; u < kXD; ++u) {
-                const double x1 = readlane_f64(va, ju[u]);
-                const unsigned c = (unsigned)(cb[u] - c_lo);   // (every entry of the virtual row is in the slice)
-                if (cb[u] >= 0 && c < span) {
-                    const double prod = x1 * vb[u];
-                    lds_add_f64(&acc[c], prod);
+            for (int q = 0; q < Q; ++q) {
+                const int s = (wave - 1) + 3 * q;
+                const unsigned c = (unsigned)(cb[q] - c_lo);   // (every entry of the virtual row is in the slice)
+                const bool ok = cb[q] >= 0 && c < span;
+                bo[s * 64 + lane] = ok ? (int32_t)(c * 8u) : (int32_t)((span + lane) * 8u);
+                bp[s * 64 + lane] = ok ? x1[q] * vb[q] : 0.0;
+            }
+        };
+        auto drain = [&](int r) {
+            const int32_t* bo = boff + (r & 1) * kXRound * 64;
+            const double* bp = bprod + (r & 1) * kXRound * 64;
+            int32_t off[kXRound];
+            double pr[kXRound];
+#pragma unroll
+            for (int s = 0; s < kXRound; ++s) off[s] = bo[s * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < kXRound; ++s) pr[s] = bp[s * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < kXRound; ++s) lds_add_f64((double*)((char*)acc + off[s]), pr[s]);
+        };
+        if (wave != 0 && nrounds > 0) issue(0, cbA, vbA, x1A);
+        for (int r = 0; r <= nrounds; r += 2) {   // iterations r and r + 1; every wavefront meets the same barriers
+            if (wave != 0) {
+                if (r + 1 < nrounds) issue(r + 1, cbB, vbB, x1B);
+                if (r < nrounds) put(r, cbA, vbA, x1A);
+            } else if (r >= 1) {
+                drain(r - 1);
+            }
+            xr_lds_barrier();
+            if (r + 1 <= nrounds) {
+                if (wave != 0) {
+                    if (r + 2 < nrounds) issue(r + 2, cbA, vbA, x1A);
+                    if (r + 1 < nrounds) put(r + 1, cbB, vbB, x1B);
+                } else {
+                    drain(r);
                 }
+                xr_lds_barrier();
             }
         }
+        va0 = va1; rs0 = rs1; len0 = len1;
+        k1 = k2; va1 = va2;
     }
     __syncthreads();
     double* col = out + (size_t)c1 * ncol + c_lo;         // column c1 of the symmetric result
-    for (unsigned c = lane; c < span; c += 64) col[c] = acc[c];
+    for (unsigned c = tid; c < span; c += 256) col[c] = acc[c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,9 +578,9 @@ __global__ __launch_bounds__(256) void crossprod_tall_combine_kernel(const doubl
 // run empty and nothing is gained).
 void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, int32_t* width) {
     int ns = (ncol + kXMaxWidth - 1) / kXMaxWidth;
-    if (ncol < 2048 && ns == 1) {
+    if (ncol < 768 && ns == 1) {   // (workgroups of 4 wavefronts: 768 of them are half a round on 256 CUs)
         const int64_t avg_row = nrow > 0 ? nnz / nrow : 0;
-        int64_t want = (2048 + ncol - 1) / ncol;
+        int64_t want = (768 + ncol - 1) / ncol;
         if (want > avg_row / 32) want = avg_row / 32;
         if (want > 8) want = 8;
         if (want > ncol) want = ncol;
@@ -620,7 +696,15 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
                            cursor, rc, rx, run_if);
     const long long grid = (long long)ncol * nsplit;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(crossprod_rows_kernel<kXDepth>, dim3((unsigned)grid), dim3(64), (size_t)width * 8, stream,
+    const size_t rows_lds = ((size_t)width + 64) * 8 + (size_t)2 * kXRound * 64 * 12;
+    static bool raised = false;   // (benign if two threads both do it)
+    if (!raised) {
+        e = hipFuncSetAttribute((const void*)crossprod_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(((size_t)kXMaxWidth + 64) * 8 + (size_t)2 * kXRound * 64 * 12));
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(crossprod_rows_kernel, dim3((unsigned)grid), dim3(256), rows_lds, stream,
                        d_x, d_i, d_p, rp, rc, rx, nrow, ncol, nsplit, width, d_out, run_if);
     return hipGetLastError();
 }
