@@ -12,11 +12,12 @@
 //  * crossprod_rows_kernel (used when the caller provides a workspace).  The row-major form of
 //    A is built first (integer row histogram, exclusive scan, cursor fill; the order of the
 //    entries inside a row is irrelevant because a row contributes at most one product to any
-//    output).  One wavefront then owns a result column c1 -- or a slice of it, in which case
-//    the row-major form is kept per slice: it walks c1's entries in ascending row order and,
-//    for each (k, x1), adds x1 * x2 to acc[c2] for every stored (k, c2, x2) of row k, one lane
-//    per entry of the row, the accumulators in LDS.  The work is exactly the sum over rows of
-//    nnz(row)^2 products; nothing is spent on column pairs without common rows.
+//    output).  One workgroup of four wavefronts then owns a result column c1 -- or a slice of it, in
+//    which case the row-major form is kept per slice: c1's entries are taken in ascending row order
+//    and, for each (k, x1), x1 * x2 is added to acc[c2] for every stored (k, c2, x2) of row k, one
+//    lane per entry of the row, the accumulators in LDS (three wavefronts stage the products, the
+//    fourth adds them in order).  The work is exactly the sum over rows of nnz(row)^2 products;
+//    nothing is spent on column pairs without common rows.
 //
 //  * crossprod_tiles_kernel (no workspace needed).  One workgroup owns a 64 x 64 tile of the
 //    result (upper-triangular tile pairs only; the mirror image is written at the end).  It
