@@ -168,7 +168,8 @@ constexpr int64_t kTallMinColumnLength = 4096;   // (average) below this the exa
 // owns slice s of a result column reads exactly the entries it needs and nothing else.
 // (Entries whose row index is outside [0, nrow) -- not a valid dgCMatrix -- are left out rather
 // than allowed to address memory out of bounds.)
-// One wavefront per column (grid-stride) in both passes.
+// In both passes a column is walked by gridDim.x wavefronts (64 entries each per step), the columns are spread
+// over blockIdx.y and the 4 wavefronts of a block: long columns of a matrix with few of them still fill the chip.
 __global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __restrict__ ri,
                                                             const int32_t* __restrict__ p, int32_t nrow,
                                                             int32_t ncol, int32_t nsplit, int32_t width,
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ run_if) {
     if (run_if && *run_if == 0) return;   // (tall form: the row-major form is only needed if x is not all finite)
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
     for (int c = wave; c < ncol; c += nwaves) {
         const int e1 = p[c + 1], slice = c / width;
-        for (int64_t e = (int64_t)p[c] + lane; e < e1; e += 64) {   // (64-bit: e1 may be 2^31 - 1)
+        for (int64_t e = (int64_t)p[c] + (int64_t)blockIdx.x * 64 + lane; e < e1; e += (int64_t)gridDim.x * 64) {   // (64-bit: e1 may be 2^31 - 1)
             const int r = ri[e];
             if ((unsigned)r < (unsigned)nrow) atomicAdd(&cnt[(int64_t)r * nsplit + slice], 1);
         }
@@ -196,10 +197,10 @@ __global__ __launch_bounds__(256) void xp_fill_rows_kernel(const double* __restr
                                                            const int32_t* __restrict__ run_if) {
     if (run_if && *run_if == 0) return;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
     for (int c = wave; c < ncol; c += nwaves) {
         const int e1 = p[c + 1], slice = c / width;
-        for (int64_t e = (int64_t)p[c] + lane; e < e1; e += 64) {   // (64-bit: e1 may be 2^31 - 1)
+        for (int64_t e = (int64_t)p[c] + (int64_t)blockIdx.x * 64 + lane; e < e1; e += (int64_t)gridDim.x * 64) {   // (64-bit: e1 may be 2^31 - 1)
             const int r = ri[e];
             if ((unsigned)r >= (unsigned)nrow) continue;
             const int pos = atomicAdd(&cursor[(int64_t)r * nsplit + slice], 1);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void crossprod_rows_kernel(
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int u = r * kXRound + (wave - 1) + 3 * q;     // (uniform)
-                cb[q] = -1;
+                cb[q] = c_lo + (int)span + lane;   // (a lane with nothing to add: a spare accumulator, product x1 * 0)
                 vb[q] = 0.0;
                 x1[q] = 0.0;
                 if (u < U) {
@@ -331,10 +332,9 @@ __global__ __launch_bounds__(256) void crossprod_rows_kernel(
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int s = (wave - 1) + 3 * q;
-                const unsigned c = (unsigned)(cb[q] - c_lo);   // (every entry of the virtual row is in the slice)
-                const bool ok = cb[q] >= 0 && c < span;
-                bo[s * 64 + lane] = ok ? (int32_t)(c * 8u) : (int32_t)((span + lane) * 8u);
-                bp[s * 64 + lane] = ok ? x1[q] * vb[q] : 0.0;
+                // (every entry of the virtual row is in the slice, so c - c_lo < span; no decision left to make here)
+                bo[s * 64 + lane] = (cb[q] - c_lo) * 8;
+                bp[s * 64 + lane] = x1[q] * vb[q];
             }
         };
         auto drain = [&](int r) {
@@ -682,7 +682,12 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     e = hipMemsetAsync(cursor, 0, nv1 * 4, stream);
     if (e != hipSuccess) return e;
     const int want = (ncol + 3) / 4;
-    const dim3 cgrid((unsigned)(want < 4096 ? want : 4096));
+    // ~4096 wavefronts: columns over y (4 per block), parts of a column over x
+    const int ycols = want < 1024 ? want : 1024;
+    int xparts = (int)(nnz / ((int64_t)(ncol > 0 ? ncol : 1) * 2048));   // a part walks ~2048 entries or more
+    if (xparts > 1024 / ycols) xparts = 1024 / ycols;
+    if (xparts < 1) xparts = 1;
+    const dim3 cgrid((unsigned)xparts, (unsigned)ycols);
     if (nnz > 0)
         hipLaunchKernelGGL(xp_count_rows_kernel, cgrid, dim3(256), 0, stream, d_i, d_p, nrow, ncol, nsplit, width,
                            cursor, run_if);
