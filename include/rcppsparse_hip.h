@@ -223,7 +223,7 @@ int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
  * sparse data).  Both give the same bits.  rsp_crossprod_workspace_bytes needs a usable
  * device (it asks rocPRIM); 0 = error.
  *
- * One exception to "same bits": for ncol <= 128 and columns of >= 4096 stored entries on
+ * One exception to "same bits": for ncol <= 256 and columns of >= 4096 stored entries on
  * average (the tall matrices crossprod is meant for), the workspace form sums in a different
  * order -- rows are densified 64 at a time and t(P) P runs on the matrix cores, every workgroup
  * over its own range of rows, results added in workgroup order: deterministic, within

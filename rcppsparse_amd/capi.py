@@ -157,7 +157,7 @@ def set_tuning(chunk_rows: int = 0) -> None:
 
 def set_crossprod_exact(exact: bool) -> None:
     """True: crossprod keeps the reference's accumulation order (bit-identical) on every shape; False (default):
-    tall matrices (ncol <= 128, long columns) go to the matrix-core form (rsp_set_crossprod_exact)."""
+    tall matrices (ncol <= 256, long columns) go to the matrix-core form (rsp_set_crossprod_exact)."""
     _check(load().rsp_set_crossprod_exact(int(bool(exact))))
 
 

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void crossprod_tiles_kernel(
 constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 
 // tall form (few columns, long columns)
-constexpr int kTallMaxCols = 128;        // 8 column tiles of 16: 36 tile pairs, 9 per wavefront
+constexpr int kTallMaxCols = 256;        // 16 column tiles of 16: 136 tile pairs, 9 per wavefront of a 16-wave workgroup
 constexpr int kTallRows = 64;            // rows of A densified in LDS at a time (a "panel")
 constexpr int kTallMaxGroups = 1280;     // workgroups = partial results to add up
 constexpr int64_t kTallMinColumnLength = 4096;   // (average) below this the exact form's serial walk takes < 0.7 ms:
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void crossprod_rows_kernel(
 // The forms above give every output its products one after the other in ascending row order, which is
 // what makes them bit-identical to the reference -- and what makes them slow on the shape crossprod is
 // meant for: few columns, many rows.  48 columns of 4.5e7 rows are 48 serial walks of 4.5e7 steps:
-// 24.8 s (round 2, 2^31 - 1 entries), the work itself being 1e11 multiply-adds.  For ncol <= 128 and
+// 24.8 s (round 2, 2^31 - 1 entries), the work itself being 1e11 multiply-adds.  For ncol <= 256 and
 // columns of >= 4096 entries on average the library therefore sums in a different order: the rows of
 // A are densified 64 at a time into an LDS panel P[64][ncol] (zero where nothing is stored) and
 // C += t(P) P runs as v_mfma_f64_16x16x4_f64 over the 16 x 16 tile pairs I <= J, every workgroup over
@@ -411,7 +411,7 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
     J = I + q;
 }
 
-// One workgroup (NW = 4 wavefronts, 8 from 49 columns on) per range of row panels, straight from the CSC
+// One workgroup (NW = 4 wavefronts, 8 from 49 columns on, 16 from 129) per range of row panels, straight from the CSC
 // arrays: a column's entries are in ascending row order, so the part of it that falls into the workgroup's
 // rows is one contiguous piece (two binary searches per column at the start) and every panel takes the next
 // few entries of each piece.
@@ -426,7 +426,7 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
 // ONE LDS bank pair: 12.3 -> 10.7 ms) and telling the compiler to fit five workgroups per CU up to 48 columns (it
 // used 130 registers where 96 do: 10.7 -> 7.1 ms = 3.7 TB/s).
 template <int NT, int NW>   // column tiles, wavefronts per workgroup
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT <= 3 || NW == 8 ? 4 : 1, 8)))
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT <= 3 || NW >= 8 ? 4 : 1, 8)))
 void crossprod_tall_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p, int32_t nrow,
     int32_t ncol, int64_t nnz, int32_t panels_per_group, int32_t* __restrict__ nonfinite,
@@ -594,9 +594,9 @@ void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, i
 
 static inline size_t xp_align(size_t v) { return (v + 255) / 256 * 256; }
 
-static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiated for: 1, 2, 3, 4, 6 or 8
+static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiated for: 1, 2, 3, 4, 6, 8, 12 or 16
     const int nt = (ncol + 15) / 16;
-    return nt <= 4 ? (nt < 1 ? 1 : nt) : (nt <= 6 ? 6 : 8);
+    return nt <= 4 ? (nt < 1 ? 1 : nt) : (nt <= 6 ? 6 : (nt <= 8 ? 8 : (nt <= 12 ? 12 : 16)));
 }
 
 hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, CrossprodLayout* L) {
@@ -609,7 +609,7 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         L->ntiles = tall_tiles(ncol);
         const int64_t npanels = ((int64_t)nrow + kTallRows - 1) / kTallRows;
         // one round of workgroups: what fits on the chip at this tile count (registers / LDS per workgroup)
-        static const int per_cu[9] = {0, 5, 5, 5, 2, 0, 2, 0, 2};
+        static const int per_cu[17] = {0, 5, 5, 5, 2, 0, 2, 0, 2, 0, 0, 0, 1, 0, 0, 0, 1};
         const int64_t max_groups = 256 * per_cu[L->ntiles] < kTallMaxGroups ? 256 * per_cu[L->ntiles] : kTallMaxGroups;
         int64_t per = (npanels + max_groups - 1) / max_groups;
         if (per < 1) per = 1;
@@ -670,7 +670,9 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             case 3: launch_tall<3, 4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
             case 4: launch_tall<4, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
             case 6: launch_tall<6, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            default: launch_tall<8, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 8: launch_tall<8, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 12: launch_tall<12, 16>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            default: launch_tall<16, 16>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
         }
         const int64_t outs = (int64_t)ncol * ncol;
         hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, stream,

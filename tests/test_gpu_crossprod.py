@@ -147,9 +147,10 @@ def test_crossprod_needs_row_indices(torch_cuda):
     h.close()
 
 
-# ---- the tall form (ncol <= 128, columns of >= 4096 entries): matrix cores, tolerance instead of bits ----
+# ---- the tall form (ncol <= 256, columns of >= 4096 entries): matrix cores, tolerance instead of bits ----
 
-TALL_SHAPES = [(41_000, 100, 0.1), (50_000, 7, 0.1), (400_000, 1, 0.5), (300_000, 16, 0.2), (300_000, 17, 0.15), (250_000, 48, 0.2), (200_000, 64, 0.25),
+TALL_SHAPES = [(41_000, 100, 0.1), (50_000, 7, 0.1), (60_000, 129, 0.1), (50_000, 192, 0.1), (45_000, 200, 0.1),
+               (42_000, 256, 0.1), (400_000, 1, 0.5), (300_000, 16, 0.2), (300_000, 17, 0.15), (250_000, 48, 0.2), (200_000, 64, 0.25),
                (200_000, 65, 0.2), (150_000, 100, 0.3), (150_000, 128, 0.25), (3_000_000, 20, 0.02)]
 
 

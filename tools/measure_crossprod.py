@@ -19,7 +19,8 @@ from rcppsparse_amd import capi, synth
 def tall():
     L = capi.load()
     for nrow, ncol, nnz in ((1_000_000, 64, 32_000_000), (10_000_000, 16, 80_000_000), (2_000_000, 128, 128_000_000),
-                            (4_000_000, 48, 190_000_000), (45_000_000, 48, 2**31 - 1)):
+                            (4_000_000, 48, 190_000_000), (1_000_000, 192, 96_000_000), (1_000_000, 256, 128_000_000),
+                            (45_000_000, 48, 2**31 - 1)):
         p = np.linspace(0, nnz, ncol + 1).astype(np.int64).astype(np.int32)
         pt = torch.from_numpy(p).cuda()
         xt = torch.empty(nnz, dtype=torch.float64, device="cuda")

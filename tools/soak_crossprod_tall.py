@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of crossprod's tall (f64 MFMA) form on one GPU: random matrices of 1..128 columns whose average
+"""Soak of crossprod's tall (f64 MFMA) form on one GPU: random matrices of 1..256 columns whose average
 column length puts them on that form, with columns of very different lengths (some empty), rows spread over
 the whole matrix, clustered into a few 64-row panels, or shared by all columns; against the oracle's merges
 within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric.
@@ -15,7 +15,7 @@ from rcppsparse_amd import capi
 
 
 def one(rng, case):
-    ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, int(rng.integers(1, 129))]))
+    ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, 129, 160, 192, 193, 256, int(rng.integers(1, 257))]))
     mean_len = int(rng.integers(4096, 40000)) if ncol > 40 else int(rng.integers(4096, 90000))
     kind = int(rng.integers(0, 4))
     lens = rng.integers(0, 2 * mean_len, ncol)
