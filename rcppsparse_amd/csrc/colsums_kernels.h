@@ -3,6 +3,7 @@
 #define RSP_COLSUMS_KERNELS_H
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 namespace rsp {
@@ -87,6 +88,21 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double divisor, bool means, hipStream_t stream, int op = kOpSum,
                               const int32_t* rows_i = nullptr, const uint32_t* row_bitmap = nullptr,
                               int32_t bitmap_words = 0);
+
+// hipFuncSetAttribute(..MaxDynamicSharedMemorySize..) once per (kernel, device): the attribute belongs to the
+// device's copy of the function, so a process that uses a second device has to raise it there as well.
+struct DynamicLdsLimit {
+    std::atomic<uint64_t> done{0};   // one bit per device ordinal below 64 (benign if two threads both raise it)
+    hipError_t ensure(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1)) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && dev >= 0 && dev < 64) done.fetch_or((uint64_t)1 << dev, std::memory_order_relaxed);
+        return e;
+    }
+};
 
 // Workspace layout of the row-wise path (rowsums.hip); offsets in bytes, 256-aligned.
 // mode 0 (block form, one-shot calls): persistent = the entries grouped by row block (values, row indices)

@@ -959,18 +959,15 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     constexpr size_t kLdsPerCu = 160 * 1024, kLdsPerWave = sizeof(double) * kStageSlots + sizeof(int32_t) * kPWin;
 #define RSP_LAUNCH_LDSMAP(WPG_)                                                                                      \
     do {                                                                                                            \
-        static bool raised_##WPG_ = false; /* (benign if two threads both do it) */                                 \
-        if (!raised_##WPG_) {                                                                                       \
-            hipError_t ea = hipFuncSetAttribute(                                                                    \
-                (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedIn, true>,           \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsPerCu - (WPG_) * kLdsPerWave));                              \
-            if (ea == hipSuccess)                                                                                   \
-                ea = hipFuncSetAttribute(                                                                           \
-                    (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedOut, true>,      \
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsPerCu - (WPG_) * kLdsPerWave));                          \
-            if (ea != hipSuccess) return ea;                                                                        \
-            raised_##WPG_ = true;                                                                                   \
-        }                                                                                                           \
+        static DynamicLdsLimit lim_in_##WPG_, lim_out_##WPG_;                                                       \
+        hipError_t ea = lim_in_##WPG_.ensure(                                                                       \
+            (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedIn, true>,               \
+            (int)(kLdsPerCu - (WPG_) * kLdsPerWave));                                                               \
+        if (ea == hipSuccess)                                                                                       \
+            ea = lim_out_##WPG_.ensure(                                                                             \
+                (const void*)colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedOut, true>,          \
+                (int)(kLdsPerCu - (WPG_) * kLdsPerWave));                                                           \
+        if (ea != hipSuccess) return ea;                                                                            \
         const dim3 g2((plan.nchunks + (WPG_) - 1) / (WPG_)), b2((WPG_) * 64);                                       \
         if (op == kOpMaskedIn)                                                                                      \
             hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, WPG_, kOpMaskedIn, true>), g2,   \

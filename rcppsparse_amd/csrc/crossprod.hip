@@ -705,13 +705,10 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     const long long grid = (long long)ncol * nsplit;
     if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t rows_lds = ((size_t)width + 64) * 8 + (size_t)2 * kXRound * 64 * 12;
-    static bool raised = false;   // (benign if two threads both do it)
-    if (!raised) {
-        e = hipFuncSetAttribute((const void*)crossprod_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(((size_t)kXMaxWidth + 64) * 8 + (size_t)2 * kXRound * 64 * 12));
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    static DynamicLdsLimit rows_limit;
+    e = rows_limit.ensure((const void*)crossprod_rows_kernel,
+                          (int)(((size_t)kXMaxWidth + 64) * 8 + (size_t)2 * kXRound * 64 * 12));
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(crossprod_rows_kernel, dim3((unsigned)grid), dim3(256), rows_lds, stream,
                        d_x, d_i, d_p, rp, rc, rx, nrow, ncol, nsplit, width, d_out, run_if);
     return hipGetLastError();

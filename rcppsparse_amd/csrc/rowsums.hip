@@ -667,13 +667,10 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
         e = hipMemsetAsync(table + (table_entries - 1), 0, 4, stream);   // the slot that receives the total
         if (e != hipSuccess) return e;
         const size_t part_lds = (size_t)kStageElems * 12 + ((size_t)L.nblocks * (2 + kPartWaves) + 1) * 4;
-        static bool raised = false;   // (benign if two threads both do it)
-        if (!raised) {
-            e = hipFuncSetAttribute((const void*)rows_tile_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((size_t)kStageElems * 12 + ((size_t)kPartMaxBlocks * (2 + kPartWaves) + 1) * 4));
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
+        static DynamicLdsLimit part_limit;
+        e = part_limit.ensure((const void*)rows_tile_partition_kernel,
+                              (int)((size_t)kStageElems * 12 + ((size_t)kPartMaxBlocks * (2 + kPartWaves) + 1) * 4));
+        if (e != hipSuccess) return e;
         if (L.nsuper > 0) {
             hipLaunchKernelGGL(rows_tile_histogram_kernel, dim3(L.nsuper), dim3(kPartThreads),
                                (size_t)L.nblocks * 4, stream, d_i, nnz, nrow, L.shift, L.nblocks, L.super_elems,
@@ -728,16 +725,10 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
     const int32_t* boff = (const int32_t*)((char*)persist + L.boff_off);
     if (L.mode == 2) {
         const size_t acc_lds = ((size_t)8 << L.shift) + 64 * 8 + (size_t)2 * kAccStagers * 12;
-        static bool raised2 = false;
-        if (!raised2) {
-            hipError_t e = hipFuncSetAttribute((const void*)rows_tile_accumulate_kernel<true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)rows_tile_accumulate_kernel<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds);
-            if (e != hipSuccess) return e;
-            raised2 = true;
-        }
+        static DynamicLdsLimit acc_limit_means, acc_limit_sums;
+        hipError_t e = acc_limit_means.ensure((const void*)rows_tile_accumulate_kernel<true>, (int)acc_lds);
+        if (e == hipSuccess) e = acc_limit_sums.ensure((const void*)rows_tile_accumulate_kernel<false>, (int)acc_lds);
+        if (e != hipSuccess) return e;
         double* parts = (double*)((char*)persist + L.partial_off);
         const dim3 grid((unsigned)L.nblocks * (unsigned)L.nsplit);
         if (means)
@@ -746,7 +737,7 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
         else
             hipLaunchKernelGGL(rows_tile_accumulate_kernel<false>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
                                boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.nsplit, d_out, parts, divisor);
-        hipError_t e = hipGetLastError();
+        e = hipGetLastError();
         if (e != hipSuccess || L.nsplit <= 1) return e;
         if (L.nsplit >= 16) {
             const dim3 wgrid((unsigned)(((int64_t)nrow + 3) / 4));
