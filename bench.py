@@ -29,6 +29,9 @@ Also reported, as separate keys that never feed `value`:
 SURVEY.md 8d; i[] is never read) / mean launch duration from HIP events recorded
 on the launch stream around the kernels of the timed region (the gather is outside them).
 `parity` = EVERY column of the gathered result against the oracle, after the timed region.
+`--rendezvous gloo` is a REHEARSAL of the N > 1 control flow with real HIP compute on a box with
+fewer GPUs than ranks (ranks share devices; slices travel as host copies over gloo because RCCL
+refuses two ranks on one device).  Its line says so in `config`; it is never a multi-GPU number.
 `cpu_baseline` = the oracle (1-thread C restatement of the reference loop) timed
 on this box's host on a bounded prefix of the same matrix (rank 0, N = 1 only).
 """
@@ -43,6 +46,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# Multi-process GPU work on this pool's hosts: the kernel driver offers dmabuf IPC only, and without
+# this setting RCCL's exchange of device buffers between the ranks' processes fails with
+# "hipIpcGetMemHandle: invalid argument".  It has to be in the environment before the HIP runtime
+# starts, i.e. before torch is imported.  An explicit setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0     # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 SEED = 42
@@ -89,6 +98,12 @@ def parse_args(argv=None):
     ap.add_argument("--latency-calls", type=int, default=25,
                     help="calls timed one at a time for latency_ms_per_call")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the separate pipelined figure")
+    ap.add_argument("--rendezvous", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (default): one rank per GPU, torch.distributed over RCCL, the gatherv on the "
+                         "C-ABI RCCL communicator.  gloo: REHEARSAL of the N > 1 control flow on a box with "
+                         "fewer GPUs than ranks -- ranks share devices (rank r on device r %% device_count), "
+                         "rendezvous and barriers over gloo, and because RCCL refuses two ranks on one device "
+                         "the slices travel as host copies over gloo.  Its numbers are not multi-GPU numbers.")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: still create the RCCL communicator and run the gatherv in every "
                          "call (rehearsal of the N>1 code path on a 1-GPU box)")
@@ -226,17 +241,19 @@ def parity_whole_matrix(got, p, kind, seed=SEED, first_idx=0, slab_nnz=60_000_00
 
 
 def traffic_from_profiles(workload):
-    """HBM bytes per launch from the committed PMC passes (profiles/*traffic*.json)."""
+    """(HBM bytes per launch, file) from the latest committed PMC passes (profiles/*traffic*.json).
+    Counters cannot be collected inside this run (they need rocprofv3 --pmc passes of their own,
+    MI355X_MICROARCH.md), so the figure is a recorded one and `roofline.traffic_source` says so."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             d = json.load(open(f))
-            if d.get("workload") == workload:
-                best = d.get("hbm_bytes_per_launch")
+            if d.get("workload") == workload and d.get("hbm_bytes_per_launch") is not None:
+                best, src = d.get("hbm_bytes_per_launch"), os.path.relpath(f, ROOT)
         except Exception:
             pass
-    return best
+    return best, src
 
 
 def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev, shard, counts, displs,
@@ -305,11 +322,21 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = args.rendezvous == "gloo"
+    if rehearsal and args.force_comm:
+        raise SystemExit("--force-comm needs an RCCL communicator; --rendezvous gloo never creates one")
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # small host-visible statistics travel on the rendezvous backend: device tensors over RCCL,
+    # host tensors over gloo
+    stat_dev = torch.device("cpu") if rehearsal else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     capi.load()
     capi.set_tuning(args.chunk_rows)
 
@@ -330,7 +357,7 @@ def main(argv=None):
     use_comm = world > 1 or args.force_comm
     recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (use_comm and rank == 0) else None
     comm, fell_back = (None, False)
-    if use_comm:
+    if use_comm and not rehearsal:
         comm, fell_back = make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev,
                                             shard, counts, displs, recv)
 
@@ -342,6 +369,8 @@ def main(argv=None):
             return None
         if comm is not None:
             return sharded.RcclGather(comm, counts, displs, 0, stream=stream)
+        if rehearsal:
+            return sharded.HostStagedGather(dist, rank, world, counts, displs, 0, stream=stream)
         return sharded.TorchGather(dist, rank, world, counts, displs, 0, stream=stream)
 
     def fence():
@@ -433,7 +462,7 @@ def main(argv=None):
             pl.step()
         fence()
         pipe_elapsed = time.perf_counter() - t2
-        pstats = torch.tensor([pipe_elapsed], dtype=torch.float64, device=dev)
+        pstats = torch.tensor([pipe_elapsed], dtype=torch.float64, device=stat_dev)
         if world > 1:
             dist.all_reduce(pstats, op=dist.ReduceOp.MAX)
         pipe_elapsed = float(pstats[0])
@@ -444,10 +473,18 @@ def main(argv=None):
                             "NOT the protocol of `value`"}
         del prepared, launches, outs, wss
 
-    stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=stat_dev)
+    # what every rank owned and measured (rank order), so the line shows the whole partition
+    mine = torch.tensor([shard.c0, shard.c1, shard.x0, shard.x1, kernel_ms, gather_ms, dev_index],
+                        dtype=torch.float64, device=stat_dev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
     elapsed, kernel_ms_max, gather_ms_max, lat_med_max = (float(v) for v in stats)
+    per_rank = [[float(v) for v in t] for t in per_rank]
 
     # ------------------------------------------------------------------ parity: every column
     # one more call on copy 0 of x (seed SEED), outside every timed region
@@ -464,7 +501,12 @@ def main(argv=None):
         algo_bytes = 8 * shard.nnz + 4 * (shard.ncol + 1) + 8 * shard.ncol
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         value = nnz * args.steps / elapsed
-        gname = None if not use_comm else (sharded.TorchGather.name if fell_back else sharded.RcclGather.name)
+        traffic = traffic_from_profiles(args.workload) if world == 1 else (None, None)
+        traffic_source = (None if traffic[1] is None else
+                          f"{traffic[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in a "
+                          "SEPARATE earlier run (FETCH_SIZE doubled per MI355X_MICROARCH.md), not measured in this run")
+        gname = None if not use_comm else (sharded.HostStagedGather.name if rehearsal else
+                                           sharded.TorchGather.name if fell_back else sharded.RcclGather.name)
         result = {
             "metric": "columnSums nnz/s + achieved HBM GB/s vs roofline, 1e9-nnz CSC at 1/2/4/8 GPUs",
             "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps,
@@ -475,7 +517,14 @@ def main(argv=None):
                 "workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, "
                             f"values kind {args.kind}, seed {SEED}",
                 "parallelism": ("single GPU" if world == 1 else
+                                f"REHEARSAL on {torch.cuda.device_count()} device(s): {world} ranks share them; "
+                                f"column ranges as at N = {world}, slices gathered as host copies over gloo"
+                                if rehearsal else
                                 f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0"),
+                "rendezvous": args.rendezvous if world > 1 else None,
+                "shards": [{"rank": r, "device": int(t[6]), "c0": int(t[0]), "c1": int(t[1]), "x0": int(t[2]),
+                            "x1": int(t[3]), "nnz": int(t[3] - t[2]), "kernel_ms": t[4],
+                            "gather_ms": t[5] if use_comm else None} for r, t in enumerate(per_rank)],
                 "protocol": "K calls back to back; each call in order on one stream per rank: kernels, then "
                             "that call's gatherv (N > 1); identical at every N",
                 "partition": args.partition,
@@ -494,7 +543,7 @@ def main(argv=None):
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
+                "traffic": traffic[0], "traffic_source": traffic_source,
                 "kernel": "colsums_chunks_kernel (+ colsums_fixup_kernel)",
                 "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
                 "kernel_timing": f"HIP events on the launch stream around the kernels of {len(timed)} of the "

@@ -60,12 +60,16 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 def build_host_seam(force: bool = False, verbose: bool = False) -> str:
     """g++ build of the Rcpp-free host mirror (RcppSparse::Matrix over raw views)."""
     host = os.path.join(_HERE, "host")
-    srcs = [os.path.join(host, f) for f in os.listdir(host)] if os.path.isdir(host) else []
+    srcs = ([os.path.join(host, f) for f in os.listdir(host) if os.path.isfile(os.path.join(host, f))]
+            if os.path.isdir(host) else [])
     if not srcs:
         raise RuntimeError("host/ sources missing")
-    if force or _stale(HOST_SEAM_PATH, srcs + [LIB_PATH]):
+    # (the seam only links the C-ABI library by name: a newer librcppsparse_hip.so does not make it
+    # stale, and the host Makefile does not depend on it either)
+    srcs.append(os.path.join(_HERE, "..", "include", "rcppsparse_hip.h"))
+    if force or _stale(HOST_SEAM_PATH, srcs):
         with _build_lock("build_host"):
-            if force or _stale(HOST_SEAM_PATH, srcs + [LIB_PATH]):
+            if force or _stale(HOST_SEAM_PATH, srcs):
                 cmd = ["make", "-C", host] + (["-B"] if force else [])
                 subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
     return HOST_SEAM_PATH

@@ -11,7 +11,8 @@ the per-shard chunking (each shard is summed by the same single-GPU kernel).
 The compute step and the gather are injected, so the same driver runs
   * on GPUs (``bench.py``):  compute = C-ABI ``rsp_column_sums_device``,
     gather = ``RcclGather`` (or ``TorchGather`` if the C-ABI communicator
-    cannot be created);
+    cannot be created; ``HostStagedGather`` in the rehearsal mode where
+    several ranks share one GPU);
   * in the world_size-2 ``gloo`` CPU tests: compute = whatever the test passes
     in, gather = ``GlooGather``.
 
@@ -25,6 +26,7 @@ Two drivers:
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 
 import numpy as np
@@ -152,6 +154,56 @@ class TorchGather:
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+
+
+class HostStagedGather:
+    """Rehearsal exchange for ranks that SHARE a device (``bench.py --rendezvous gloo``: the N > 1
+    control flow of the bench with real HIP compute on a box with fewer GPUs than ranks).  RCCL
+    refuses two ranks on one device, so every slice is copied to page-locked host memory, sent to
+    the root over gloo and copied into the root's device result at its displacement.  Same
+    counts / displacements as the RCCL gatherv, and like it the call returns with the exchange
+    ordered after the kernels on `stream`; here it also waits for it (the host carries the data).
+    Never the exchange of a measured multi-GPU figure; ``config.gather`` names it."""
+    name = "gloo send/recv of host copies (rehearsal: ranks share a device; not RCCL)"
+
+    def __init__(self, dist, rank, world, counts, displs, root: int = 0, stream=None):
+        import torch
+        self.torch, self.dist, self.rank, self.world, self.root = torch, dist, rank, world, root
+        self.counts, self.displs, self.stream = [int(c) for c in counts], [int(d) for d in displs], stream
+        pin = torch.cuda.is_available()
+        if rank == root:
+            self.host = {r: torch.empty(self.counts[r], dtype=torch.float64, pin_memory=pin)
+                         for r in range(world) if r != root and self.counts[r] > 0}
+        else:
+            self.host = torch.empty(self.counts[rank], dtype=torch.float64, pin_memory=pin)
+
+    def __call__(self, send, recv):
+        torch, dist, root = self.torch, self.dist, self.root
+        on_device = send.is_cuda
+        stream = (self.stream or torch.cuda.current_stream()) if on_device else None
+        if self.rank != root:
+            if send.numel() == 0:
+                return
+            if on_device:
+                with torch.cuda.stream(stream):
+                    self.host.copy_(send, non_blocking=True)
+                stream.synchronize()              # the kernels before it on the stream have finished
+            else:
+                self.host.copy_(send)
+            dist.send(self.host, root)
+            return
+        reqs = [(r, dist.irecv(buf, src=r)) for r, buf in self.host.items()]
+        d0, c0 = self.displs[root], self.counts[root]
+        own = recv[d0:d0 + c0]
+        ctx = torch.cuda.stream(stream) if on_device else contextlib.nullcontext()
+        with ctx:
+            if c0 > 0 and own.data_ptr() != send.data_ptr():
+                own.copy_(send, non_blocking=True)
+            for r, req in reqs:
+                req.wait()
+                recv[self.displs[r]:self.displs[r] + self.counts[r]].copy_(self.host[r], non_blocking=True)
+        if on_device:
+            stream.synchronize()                  # the staging buffers are reused by the next call
 
 
 # ------------------------------------------------------------------------- drivers

@@ -7,6 +7,10 @@
     1e9-nnz uniform and Zipf matrices, generated in HBM at their offsets exactly as bench.py
     does, summed one after the other through rsp_column_sums_device and reassembled.
 
+  * bench.py with N > 1 ranks and real HIP compute: `--rendezvous gloo`
+    lets the ranks share this box's one GPU, so the rank != 0 branches of bench.py, the shard
+    offsets x0 > 0, the gathered whole-matrix parity and the max-over-ranks statistics all run.
+
 The 8-rank RCCL exchange itself needs 8 GPUs (the driver's node); its layout and driver are
 covered by tests/test_sharded_gloo.py, and a one-rank communicator runs here.
 """
@@ -38,8 +42,8 @@ def torch_cuda():
 
 
 def _run_bench(*flags, timeout=900):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, env=env,
+    # (bench.py itself puts HSA_ENABLE_IPC_MODE_LEGACY=0 into its environment before the HIP runtime starts)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -87,6 +91,47 @@ def test_bench_child_process_default_protocol_small(torch_cuda):
     assert d["parity"]["columns_checked"] == "all" and d["parity"]["columns_out_of_tolerance"] == 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.parametrize("workload,world,nnz,ncol", [("c4shard", 2, 125_000_000, 125_000),
+                                                     ("tiny", 3, 4_000_000, 40_000)])
+def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload, world, nnz, ncol):
+    """`bench.py --gpus N --rendezvous gloo`: bench.py starts N ranks under torch.distributed.run
+    (fresh child processes; nothing here re-executes a process that has touched the GPU), every
+    rank generates ITS column range of the matrix in HBM at shard.x0 and sums it through
+    rsp_column_sums_device, the slices are gathered to rank 0 (as host copies over gloo: RCCL
+    refuses two ranks on one device) and rank 0 checks EVERY column of the gathered result against
+    the oracle.  What this pins: the rank != 0 control flow of bench.py, the partition, the
+    displacements, the max-over-ranks statistics and the N > 1 shape of the JSON line."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--gpus", str(world), "--rendezvous", "gloo", "--workload", workload, "--steps", "8",
+                   "--warmup", "2", "--latency-calls", "5")
+    assert d["n_gpus"] == world and d["steps"] == 8 and d["scaling"] == "strong"
+    cfg = d["config"]
+    assert cfg["rendezvous"] == "gloo" and "REHEARSAL" in cfg["parallelism"]
+    assert cfg["gather"] == sharded.HostStagedGather.name and cfg["gather_fell_back_to_torch_distributed"] is False
+    shards = cfg["shards"]
+    assert [s["rank"] for s in shards] == list(range(world))
+    assert shards[0]["x0"] == 0 and shards[0]["c0"] == 0
+    assert shards[-1]["x1"] == nnz and shards[-1]["c1"] == ncol
+    for a, b in zip(shards, shards[1:]):
+        assert b["x0"] == a["x1"] > 0 and b["c0"] == a["c1"] > 0      # rank r > 0 starts inside x
+    assert all(s["kernel_ms"] > 0 for s in shards)                     # every rank timed its own launches
+    per = [s["nnz"] for s in shards]
+    assert cfg["shard_imbalance_max_over_mean"] == pytest.approx(max(per) / (sum(per) / world), rel=1e-12)
+    assert cfg["shard_imbalance_max_over_mean"] < 1.05
+    par = d["parity"]
+    assert par["columns_checked"] == "all" and par["ncol"] == ncol
+    assert par["columns_out_of_tolerance"] == 0 and par["max_abs_err_over_l1"] <= RTOL
+    assert par["empty_columns_exactly_plus_zero"] is True
+    assert d["latency_ms_per_call"] > 0 and d["latency"]["calls"] == 5
+    assert d["latency"]["ms_median_max_over_ranks"] >= d["latency"]["ms_min"]
+    assert d["pipelined"]["value"] > 0
+    assert d["value"] == pytest.approx(nnz * 8 / (d["ms_per_step"] * 8e-3), rel=1e-9)
+    roof = d["roofline"]
+    assert roof["kernel_ms_max_over_ranks"] >= max(s["kernel_ms"] for s in shards) * (1 - 1e-9)
+    assert roof["algorithmic_bytes_per_launch"] == 8 * shards[0]["nnz"] + 4 * (shards[0]["c1"] + 1) + 8 * shards[0]["c1"]
+    assert "cpu_baseline" not in d                                       # rank 0 at N = 1 only
 
 
 @pytest.mark.parametrize("shape", ["uniform", "zipf"])

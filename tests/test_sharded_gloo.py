@@ -86,7 +86,7 @@ def test_shards_tile_the_matrix_exactly():
         assert counts.sum() == len(p) - 1 and np.array_equal(displs, np.cumsum(counts) - counts)
 
 
-def _torch_gather_worker(rank, world, port, q):
+def _torch_gather_worker(rank, world, port, which, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -97,8 +97,9 @@ def _torch_gather_worker(rank, world, port, q):
         recv = torch.zeros(sum(counts), dtype=torch.float64) if rank == 0 else None
         # the same driver bench.py runs, with the fallback gather as its exchange step
         seen = []
+        gather_cls = {"torch": sharded.TorchGather, "staged": sharded.HostStagedGather}[which]
         driver = sharded.ShardedColumnSums(None, lambda _shard: send,
-                                           sharded.TorchGather(dist, rank, world, counts, displs, 0))
+                                           gather_cls(dist, rank, world, counts, displs, 0))
         assert driver.step(recv, on_computed=lambda: seen.append(1)) is send and seen == [1]
         if rank == 0:
             want = np.concatenate([np.full(c, r + 1.0) for r, c in enumerate(counts)])
@@ -107,11 +108,13 @@ def _torch_gather_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("which", ["torch", "staged"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_bench_fallback_gatherv_layout(world):
-    """sharded.TorchGather (bench.py uses it only if the C-ABI communicator cannot be created)
-    fills the same counts/displacements layout, including an empty slice."""
+def test_bench_fallback_gatherv_layout(world, which):
+    """sharded.TorchGather (bench.py uses it only if the C-ABI communicator cannot be created) and
+    sharded.HostStagedGather (bench.py --rendezvous gloo: ranks sharing a device) fill the same
+    counts/displacements layout as the RCCL gatherv, including an empty slice."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    mp.spawn(_torch_gather_worker, args=(world, _free_port(), q), nprocs=world, join=True)
+    mp.spawn(_torch_gather_worker, args=(world, _free_port(), which, q), nprocs=world, join=True)
     assert q.get()
