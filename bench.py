@@ -104,6 +104,10 @@ def parse_args(argv=None):
                          "fewer GPUs than ranks -- ranks share devices (rank r on device r %% device_count), "
                          "rendezvous and barriers over gloo, and because RCCL refuses two ranks on one device "
                          "the slices travel as host copies over gloo.  Its numbers are not multi-GPU numbers.")
+    ap.add_argument("--try-comm", action="store_true",
+                    help="--rendezvous gloo only: also take the C-ABI communicator through its multi-rank "
+                         "bootstrap (unique id from rank 0, rsp_comm_init on every rank).  With ranks sharing a "
+                         "device RCCL must refuse it; the refusal is recorded in config.comm_init_rehearsal")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: still create the RCCL communicator and run the gatherv in every "
                          "call (rehearsal of the N>1 code path on a 1-GPU box)")
@@ -306,6 +310,25 @@ def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank,
     return None, True
 
 
+def rehearse_comm_init(torch, dist, capi, rank, world, dev_index):
+    """The multi-rank bootstrap of the C-ABI communicator between ranks that share a device: the unique
+    id travels from rank 0 (here over gloo), every rank calls rsp_comm_init, RCCL's bootstrap connects
+    the processes and then has to refuse the duplicate device.  Returns what every rank saw."""
+    uid = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, 0)
+    try:
+        c = capi.Comm(bytes(uid.numpy().tobytes()), world, rank, dev_index)
+        c.close()
+        seen = "created (unexpected: the ranks share a device)"
+    except capi.RspError as e:
+        seen = str(e)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, seen)
+    return everyone
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -357,6 +380,9 @@ def main(argv=None):
     use_comm = world > 1 or args.force_comm
     recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (use_comm and rank == 0) else None
     comm, fell_back = (None, False)
+    comm_rehearsal = None
+    if rehearsal and args.try_comm and world > 1:
+        comm_rehearsal = rehearse_comm_init(torch, dist, capi, rank, world, dev_index)
     if use_comm and not rehearsal:
         comm, fell_back = make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev,
                                             shard, counts, displs, recv)
@@ -522,6 +548,7 @@ def main(argv=None):
                                 if rehearsal else
                                 f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0"),
                 "rendezvous": args.rendezvous if world > 1 else None,
+                "comm_init_rehearsal": comm_rehearsal,
                 "shards": [{"rank": r, "device": int(t[6]), "c0": int(t[0]), "c1": int(t[1]), "x0": int(t[2]),
                             "x1": int(t[3]), "nnz": int(t[3] - t[2]), "kernel_ms": t[4],
                             "gather_ms": t[5] if use_comm else None} for r, t in enumerate(per_rank)],

@@ -104,8 +104,8 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     the oracle.  What this pins: the rank != 0 control flow of bench.py, the partition, the
     displacements, the max-over-ranks statistics and the N > 1 shape of the JSON line."""
     torch_cuda.cuda.empty_cache()
-    d = _run_bench("--gpus", str(world), "--rendezvous", "gloo", "--workload", workload, "--steps", "8",
-                   "--warmup", "2", "--latency-calls", "5")
+    d = _run_bench("--gpus", str(world), "--rendezvous", "gloo", "--try-comm", "--workload", workload,
+                   "--steps", "8", "--warmup", "2", "--latency-calls", "5")
     assert d["n_gpus"] == world and d["steps"] == 8 and d["scaling"] == "strong"
     cfg = d["config"]
     assert cfg["rendezvous"] == "gloo" and "REHEARSAL" in cfg["parallelism"]
@@ -132,6 +132,10 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     assert roof["kernel_ms_max_over_ranks"] >= max(s["kernel_ms"] for s in shards) * (1 - 1e-9)
     assert roof["algorithmic_bytes_per_launch"] == 8 * shards[0]["nnz"] + 4 * (shards[0]["c1"] + 1) + 8 * shards[0]["c1"]
     assert "cpu_baseline" not in d                                       # rank 0 at N = 1 only
+    # --try-comm: the C-ABI communicator's multi-rank bootstrap ran between the rank processes (unique id
+    # from rank 0, rsp_comm_init everywhere) and RCCL refused the shared device on EVERY rank, cleanly
+    seen = cfg["comm_init_rehearsal"]
+    assert len(seen) == world and all("ncclCommInitRank" in s and "error 5" in s for s in seen), seen
 
 
 @pytest.mark.parametrize("shape", ["uniform", "zipf"])
