@@ -272,6 +272,27 @@ int rsp_comm_init(const void *id_bytes, int nranks, int rank, int device,
 int rsp_comm_gatherv(rsp_comm_t comm, const double *d_send, int64_t send_count,
                      double *d_recv, const int64_t *counts, const int64_t *displs,
                      int root, void *stream);
+/*
+ * Matrix::rowSums / rowMeans (reference RcppSparse.h:138-144, :151-156) over column-range shards: every rank
+ * has computed the partial row sums of ITS columns (rsp_row_sums_device on its x / i slices: nrow doubles in
+ * d_partial); the full sums are the partials added in rank order = column order, whatever the topology --
+ * bit-identical to one process adding the shards' vectors in order (rsp_add_partials_device) and independent
+ * of how RCCL would schedule a reduce.  Rows are cut into nranks slices, every rank receives its slice of
+ * every other rank's vector (grouped ncclSend / ncclRecv, one pair per xGMI link), adds the nranks pieces in
+ * rank order with one kernel, and the reduced slices are gathered to d_result on `root` (nrow doubles; only
+ * read there).  ncol_for_means > 0 divides by it (rowMeans), 0 = sums.
+ * Workspace: rsp_comm_reduce_rows_workspace_bytes(nranks, nrow), about (1 + 1 / nranks) * nrow * 8 bytes.
+ * Enqueued on `stream`.
+ */
+size_t rsp_comm_reduce_rows_workspace_bytes(int nranks, int32_t nrow);
+int rsp_comm_reduce_rows(rsp_comm_t comm, const double *d_partial, int32_t nrow,
+                         int32_t ncol_for_means, double *d_result, void *d_workspace,
+                         size_t workspace_bytes, int root, void *stream);
+/* The add step on its own (one process holding several shards' partial vectors): d_out[j] =
+ * ((part_0[j] + part_1[j]) + ...) + part_{nparts-1}[j], part_k = d_parts + k * stride, j in [0, n);
+ * ncol_for_means as above. */
+int rsp_add_partials_device(const double *d_parts, int32_t nparts, int64_t stride, int64_t n,
+                            int32_t ncol_for_means, double *d_out, void *stream);
 int rsp_comm_destroy(rsp_comm_t comm);
 
 /* ---- synthetic inputs (bench / tests) ---------------------------------- */

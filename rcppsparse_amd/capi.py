@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
+    "rsp_comm_reduce_rows_workspace_bytes", "rsp_comm_reduce_rows", "rsp_add_partials_device",
     "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe", "rsp_set_crossprod_exact",
     "rsp_set_experiment",
 )
@@ -115,6 +116,10 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_comm_init.argtypes = [vp, c.c_int, c.c_int, c.c_int, c.POINTER(vp)]
     L.rsp_comm_gatherv.argtypes = [vp, vp, i64, vp, c.POINTER(i64), c.POINTER(i64), c.c_int, vp]
     L.rsp_comm_destroy.argtypes = [vp]
+    L.rsp_comm_reduce_rows_workspace_bytes.argtypes = [c.c_int, i32]
+    L.rsp_comm_reduce_rows_workspace_bytes.restype = c.c_size_t
+    L.rsp_comm_reduce_rows.argtypes = [vp, vp, i32, i32, vp, vp, c.c_size_t, c.c_int, vp]
+    L.rsp_add_partials_device.argtypes = [vp, i32, i64, i64, i32, vp, vp]
     L.rsp_gen_values_device.argtypes = [vp, i64, u64, u64, c.c_int, vp]
     L.rsp_gen_row_indices_device.argtypes = [vp, vp, i32, i32, u64, vp]
     L.rsp_set_tuning.argtypes = [c.c_int]
@@ -507,7 +512,38 @@ class Comm:
                 _check(rc)
         return run
 
+    def reduce_rows(self, partial_t, result_t, root: int = 0, workspace=None, ncol_for_means: int = 0,
+                    stream=None):
+        """Partial row sums of every rank (nrow doubles each) -> their sum in rank order on `root`
+        (rsp_comm_reduce_rows).  result_t is only needed on the root."""
+        import torch
+        nrow = partial_t.numel()
+        if workspace is None:
+            workspace = torch.empty(reduce_rows_workspace_bytes(self.nranks, nrow), dtype=torch.uint8,
+                                    device=partial_t.device)
+        _check(load().rsp_comm_reduce_rows(self._h, partial_t.data_ptr(), nrow, int(ncol_for_means),
+                                           result_t.data_ptr() if result_t is not None else None,
+                                           workspace.data_ptr(), workspace.numel(), root, _stream_ptr(stream)))
+        return result_t
+
     def close(self) -> None:
         if self._h:
             load().rsp_comm_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+
+def reduce_rows_workspace_bytes(nranks: int, nrow: int) -> int:
+    return int(load().rsp_comm_reduce_rows_workspace_bytes(int(nranks), int(nrow)))
+
+
+def add_partials_device(parts_t, out_t=None, ncol_for_means: int = 0, stream=None):
+    """parts_t: (nparts, n) contiguous tensor of partial sums -> their sum over the parts in part order
+    (rsp_add_partials_device): what rsp_comm_reduce_rows computes, for one process holding all shards."""
+    import torch
+    assert parts_t.dim() == 2 and parts_t.is_contiguous() and parts_t.dtype == torch.float64
+    nparts, n = parts_t.shape
+    if out_t is None:
+        out_t = torch.empty(n, dtype=torch.float64, device=parts_t.device)
+    _check(load().rsp_add_partials_device(parts_t.data_ptr(), nparts, n, n, int(ncol_for_means),
+                                          out_t.data_ptr(), _stream_ptr(stream)))
+    return out_t

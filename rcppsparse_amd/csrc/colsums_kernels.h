@@ -126,6 +126,12 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
                              const RowSumsLayout& L, void* persist, double* d_out,
                              double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream);
 
+// out[j] = ((part_0[j] + part_1[j]) + ...) + part_{nparts-1}[j] (+ 0.0, / divisor): the shards' partial row sums
+// added in shard order.  part_k = parts + k * stride, except part own_idx = own (own_idx < 0: none).
+hipError_t launch_add_partials(const double* parts, int32_t nparts, int64_t stride, const double* own,
+                               int32_t own_idx, int64_t n, double* out, double divisor, bool means,
+                               hipStream_t stream);
+
 // Matrix::crossprod on the device (crossprod.hip): dense ncol x ncol, column-major.
 struct CrossprodLayout {   // workspace of the row-major path
     size_t rp_off, cursor_off, rc_off, rx_off, temp_off, temp_bytes, total_bytes;

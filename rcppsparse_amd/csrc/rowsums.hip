@@ -626,6 +626,51 @@ __global__ __launch_bounds__(256) void rows_combine_many_parts_kernel(const doub
     if (lane == 0) out[row] = t;
 }
 
+// 6. Several devices (or shards): a row's sum = the shards' partial sums of that row, added in SHARD order
+//    (= column order, the order the reference's scatter loop meets them in), whatever way they arrived.
+//    Part k is `parts + k * stride`, except part `own_idx`, which is read from `own` (a rank's own partial
+//    vector is not copied into the receive area).  Two rows per thread (16-byte loads); HBM-bound:
+//    8 B x nparts read + 8 B written per row.
+template <bool MEANS>
+__global__ __launch_bounds__(256) void rows_add_partials_kernel(const double* __restrict__ parts, int32_t nparts,
+                                                                int64_t stride, const double* __restrict__ own,
+                                                                int32_t own_idx, int64_t n, double* __restrict__ out,
+                                                                double divisor) {
+#pragma clang fp contract(off)
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (j >= n) return;
+    const bool two = j + 1 < n;
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < nparts; ++k) {
+        const double* src = (k == own_idx ? own : parts + (size_t)k * (size_t)stride) + j;
+        const double a = src[0], b = two ? src[1] : 0.0;
+        t0 = k == 0 ? a : t0 + a;
+        t1 = k == 0 ? b : t1 + b;
+    }
+    t0 = t0 + 0.0;   // (a row whose partial sums are all -0.0 comes out +0.0, like everywhere else)
+    t1 = t1 + 0.0;
+    if (MEANS) {
+        t0 = t0 / divisor;   // RcppSparse.h:153-154
+        t1 = t1 / divisor;
+    }
+    out[j] = t0;
+    if (two) out[j + 1] = t1;
+}
+
+hipError_t launch_add_partials(const double* parts, int32_t nparts, int64_t stride, const double* own,
+                               int32_t own_idx, int64_t n, double* out, double divisor, bool means,
+                               hipStream_t stream) {
+    if (n <= 0 || nparts <= 0) return hipSuccess;
+    const dim3 grid((unsigned)(((n + 1) / 2 + 255) / 256));
+    if (means)
+        hipLaunchKernelGGL(rows_add_partials_kernel<true>, grid, dim3(256), 0, stream, parts, nparts, stride, own,
+                           own_idx, n, out, divisor);
+    else
+        hipLaunchKernelGGL(rows_add_partials_kernel<false>, grid, dim3(256), 0, stream, parts, nparts, stride, own,
+                           own_idx, n, out, divisor);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------

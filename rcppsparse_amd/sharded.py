@@ -227,6 +227,68 @@ class ShardedColumnSums:
         return local
 
 
+# ------------------------------------------------------------------ rowSums over column-range shards
+class GlooReduceRows:
+    """Host-side stand-in for rsp_comm_reduce_rows (CPU tests; the rehearsal with ranks sharing a GPU):
+    every rank's partial vector goes to the root, which adds them in RANK order -- the same sum, term
+    for term, as the device form's slice-wise add (rows_add_partials_kernel)."""
+    name = "gloo gather of the partial vectors, added in rank order on the root"
+
+    def __init__(self, dist, rank, world, root: int = 0):
+        self.dist, self.rank, self.world, self.root = dist, rank, world, root
+
+    def __call__(self, partial, result, ncol_for_means: int = 0):
+        import torch
+        host = partial.detach().to("cpu").contiguous()
+        bufs = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.root else None
+        self.dist.gather(host, bufs, dst=self.root)
+        if self.rank != self.root:
+            return None
+        total = bufs[0].numpy().copy()
+        for k in range(1, self.world):
+            total = total + bufs[k].numpy()          # one rounding per add, rank order
+        total = total + 0.0
+        if ncol_for_means:
+            total = total / float(ncol_for_means)    # RcppSparse.h:153-154
+        result.copy_(torch.from_numpy(total))
+        return result
+
+
+class RcclReduceRows:
+    """rsp_comm_reduce_rows through the C ABI: slices all-to-all over xGMI, rank-ordered add, gatherv."""
+    name = "rsp_comm_reduce_rows (C ABI, RCCL)"
+
+    def __init__(self, comm: capi.Comm, nrow: int, device, root: int = 0, stream=None):
+        import torch
+        self.comm, self.root, self.stream = comm, root, stream
+        self.ws = torch.empty(capi.reduce_rows_workspace_bytes(comm.nranks, nrow), dtype=torch.uint8, device=device)
+
+    def __call__(self, partial, result, ncol_for_means: int = 0):
+        return self.comm.reduce_rows(partial, result, self.root, self.ws, ncol_for_means, stream=self.stream)
+
+
+class ShardedRowSums:
+    """Matrix::rowSums / rowMeans (reference RcppSparse.h:138-156) of a column-range sharded matrix.
+
+    Unlike columnSums, a shard does not own output elements: every shard's columns touch every row, so
+    the exchange step is a REDUCE of f64[nrow] (80 MB at nrow = 1e7), not a gather of slices.
+    compute(shard) -> partial row sums of the shard's columns (nrow doubles; rsp_row_sums_device on the
+                      shard's x / i slices);
+    reduce(partial, result, ncol_for_means) -> on the root, the partials added in rank order (= column
+                      order, the order the reference's scatter loop meets the entries in).
+    The result does not depend on the topology or on how many ranks there are beyond the blocking of
+    that one sum, and is bit-identical from run to run."""
+
+    def __init__(self, shard: Shard, compute, reduce):
+        self.shard, self.compute, self.reduce = shard, compute, reduce
+
+    def step(self, result, ncol_for_means: int = 0, on_computed=None):
+        partial = self.compute(self.shard)
+        if on_computed is not None:
+            on_computed()
+        return self.reduce(partial, result, ncol_for_means)
+
+
 class PipelinedColumnSums:
     """GPU only.  Call n runs its kernel on compute stream n % S into output buffer n % B and its
     gather on the communication stream, so the gather of call n overlaps the kernel of call n+1

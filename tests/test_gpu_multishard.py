@@ -197,3 +197,48 @@ def test_c4_c5_eight_shards_at_full_size_on_one_gpu(torch_cuda, shape):
     l1 = capi.column_reduce_device(xt, pt, capi.OP_SUM_ABS)
     assert bool(torch.all((whole - full).abs() <= 2 * RTOL * l1))
     assert [int(d) for d in displs] == [sh.c0 for sh in shards]     # slices land at their columns
+
+
+# ------------------------------------------------------------------ rowSums over column-range shards
+def test_row_sums_eight_shards_reduce_in_rank_order(torch_cuda):
+    """Multi-GPU rowSums (the collective is a reduce of f64[nrow]) rehearsed on one GPU at
+    1e8 entries: 1e6 x 1e5 cut into 8 nnz-balanced column ranges; every shard's partial row sums come from
+    rsp_row_sums_device on its x / i slices (as a rank would compute them), the 8 vectors are added in rank
+    order by the kernel rsp_comm_reduce_rows uses (rsp_add_partials_device).  Against the oracle's scatter loop
+    over the WHOLE matrix with 1e-12 * sum|x| per row; bit-identical to adding the partial vectors one after
+    the other; and a one-rank communicator runs rsp_comm_reduce_rows itself (add kernel + gatherv, no peers)."""
+    torch = torch_cuda
+    nrow, ncol, nnz, G = 1_000_000, 100_000, 100_000_000, 8
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow))
+    pt = torch.from_numpy(p).cuda()
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    it = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    capi.gen_values_device(xt, 42, 0, 0)
+    capi.gen_row_indices_device(it, pt, nrow, 42)
+    shards = [sharded.make_shard(p, r, G) for r in range(G)]
+    parts = torch.empty((G, nrow), dtype=torch.float64, device="cuda")
+    for sh in shards:
+        capi.row_sums_device(xt[sh.x0:sh.x1], it[sh.x0:sh.x1], nrow, parts[sh.rank])
+    total = capi.add_partials_device(parts)
+    # the same sum, one vector after the other (torch adds elementwise with one rounding per add)
+    seq = parts[0].clone()
+    for k in range(1, G):
+        seq += parts[k]
+    assert torch.equal(total, seq + 0.0)
+    got = total.cpu().numpy()
+    x = oracle.gen_values(nnz, 42, 0, 0)
+    i = oracle.gen_row_indices(p, nrow, 42)
+    ref = oracle.row_sums(x, i, p, nrow)
+    scale = np.bincount(i, weights=np.abs(x), minlength=nrow)
+    assert np.all(np.abs(got - ref) <= RTOL * scale), float(np.max(np.abs(got - ref) / np.maximum(scale, 1e-300)))
+    means = capi.add_partials_device(parts, ncol_for_means=ncol).cpu().numpy()
+    assert means.tobytes() == (got / ncol).tobytes()
+    # the collective itself with one rank: no peers, so its add step and its gatherv to the root's result
+    comm = capi.Comm(capi.comm_unique_id(), 1, 0, 0)
+    try:
+        res = torch.full((nrow,), -1.0, dtype=torch.float64, device="cuda")
+        comm.reduce_rows(parts[3], res, root=0)
+        torch.cuda.synchronize()
+        assert torch.equal(res, parts[3] + 0.0)
+    finally:
+        comm.close()

@@ -118,3 +118,56 @@ def test_bench_fallback_gatherv_layout(world, which):
     q = ctx.SimpleQueue()
     mp.spawn(_torch_gather_worker, args=(world, _free_port(), which, q), nprocs=world, join=True)
     assert q.get()
+
+
+# ------------------------------------------------------------------ rowSums over column-range shards
+def _row_matrix():
+    m = synth.rsparsematrix(700, 90, density=0.08, seed=21)
+    return m["x"], m["i"], m["p"], 700
+
+
+def _rowsums_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, i, p, nrow = _row_matrix()
+        shard = sharded.make_shard(p, rank, world)
+
+        def compute(sh):   # stand-in for rsp_row_sums_device on this rank's x / i slices
+            return torch.from_numpy(oracle.row_sums(x[sh.x0:sh.x1], i[sh.x0:sh.x1], sh.p_local, nrow))
+
+        result = torch.empty(nrow, dtype=torch.float64) if rank == 0 else None
+        driver = sharded.ShardedRowSums(shard, compute, sharded.GlooReduceRows(dist, rank, world))
+        driver.step(result)
+        means = torch.empty(nrow, dtype=torch.float64) if rank == 0 else None
+        driver.step(means, ncol_for_means=len(p) - 1)
+        if rank == 0:
+            q.put((result.numpy().copy(), means.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_rowsums_reduce_in_rank_order_over_gloo(world):
+    """rowSums of a column-range sharded matrix (reference RcppSparse.h:138-144): every rank sums the rows of
+    ITS columns, the partial vectors are added in rank order on the root.  That is a blocking of the
+    reference's own column-major scatter order, so: bit-identical to adding the shards' oracle results in
+    order, within 1e-12 * sum|x| per row of the oracle on the whole matrix, empty rows exactly +0.0."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_rowsums_worker, args=(world, _free_port(), q), nprocs=world, join=True)
+    got, means = q.get()
+    x, i, p, nrow = _row_matrix()
+    blocked = None
+    for r in range(world):
+        sh = sharded.make_shard(p, r, world)
+        part = oracle.row_sums(x[sh.x0:sh.x1], i[sh.x0:sh.x1], sh.p_local, nrow)
+        blocked = part if blocked is None else blocked + part
+    assert got.tobytes() == (blocked + 0.0).tobytes()
+    ref = oracle.row_sums(x, i, p, nrow)
+    scale = np.bincount(i, weights=np.abs(x), minlength=nrow)
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale)
+    empty = np.bincount(i, minlength=nrow) == 0
+    assert np.all(got[empty] == 0.0) and not np.any(np.signbit(got[empty]))
+    assert means.tobytes() == (got / (len(p) - 1)).tobytes()        # RcppSparse.h:153-154
