@@ -104,6 +104,11 @@ def parse_args(argv=None):
                          "fewer GPUs than ranks -- ranks share devices (rank r on device r %% device_count), "
                          "rendezvous and barriers over gloo, and because RCCL refuses two ranks on one device "
                          "the slices travel as host copies over gloo.  Its numbers are not multi-GPU numbers.")
+    ap.add_argument("--planned", action="store_true",
+                    help="inspector-executor form: the offsets are inspected once (rsp_column_sums_plan_create, "
+                         "reported as plan_ms, outside every timed region) and every call is "
+                         "rsp_column_sums_planned_device -- one launch without column search, carries or fix-up "
+                         "where no long column crosses a chunk edge.  The headline C3 `value` stays plan-free.")
     ap.add_argument("--try-comm", action="store_true",
                     help="--rendezvous gloo only: also take the C-ABI communicator through its multi-rank "
                          "bootstrap (unique id from rank 0, rsp_comm_init on every rank).  With ranks sharing a "
@@ -418,7 +423,16 @@ def main(argv=None):
     out_main = (recv[int(displs[0]):int(displs[0]) + shard.ncol] if (recv is not None and comm is not None)
                 else new_out())
     ws_main = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
-    launch_main = [capi.prepared_column_sums(xk, pt, out_main, ws_main, stream=s_main) for xk in xs]
+    plan = None
+    if args.planned:
+        plan = capi.ColumnSumsPlan(shard.p_local, nnz=shard.nnz, device=dev_index)
+
+    def prepare(xk, out, ws, stream):
+        if plan is not None:
+            return plan.prepared(xk, pt, out, ws, stream=stream)
+        return capi.prepared_column_sums(xk, pt, out, ws, stream=stream)
+
+    launch_main = [prepare(xk, out_main, ws_main, s_main) for xk in xs]
     calls = [0]
 
     def compute(_shard):
@@ -474,7 +488,7 @@ def main(argv=None):
         s_comm = torch.cuda.Stream() if use_comm else None
         wss = [capi.alloc_workspace(shard.ncol, shard.nnz, dev) for _ in range(ncs)]
         outs = [new_out() for _ in range(nbuf)]
-        prepared = [[[capi.prepared_column_sums(xk, pt, o, wss[q], stream=s_computes[q]) for xk in xs]
+        prepared = [[[prepare(xk, o, wss[q], s_computes[q]) for xk in xs]
                      for o in outs] for q in range(ncs)]
         launches = [[(lambda n, f=prepared[q][k]: f[n % ncopies]()) for k in range(nbuf)] for q in range(ncs)]
         g = new_gather(s_comm)
@@ -557,6 +571,11 @@ def main(argv=None):
                 "partition": args.partition,
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
+                "planned": (None if plan is None else
+                            {"snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
+                             "entries_per_chunk": plan.chunk_elems, "max_skip": plan.max_skip,
+                             "note": "inspection of p[] on the host, once, outside every timed region; a snapped "
+                                     "plan makes a call ONE launch (no column search, carries or fix-up)"}),
                 "x_copies_rotated": ncopies,
                 "gather": gname,
                 "gather_fell_back_to_torch_distributed": bool(fell_back),
@@ -571,7 +590,8 @@ def main(argv=None):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic[0], "traffic_source": traffic_source,
-                "kernel": "colsums_chunks_kernel (+ colsums_fixup_kernel)",
+                "kernel": ("colsums_chunks_kernel<PLANNED> (one launch)" if plan is not None and plan.snapped
+                           else "colsums_chunks_kernel (+ colsums_fixup_kernel)"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
                 "kernel_timing": f"HIP events on the launch stream around the kernels of {len(timed)} of the "
                                  f"{args.steps} timed calls (the gather is outside the pair)",

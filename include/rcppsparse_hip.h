@@ -137,6 +137,33 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
                             void *d_workspace, size_t workspace_bytes,
                             void *stream);
 /*
+ * Inspector-executor form for callers that can show p[] to the host once (a resident matrix summed many
+ * times; rsp_csc_upload and rsp_column_sums_host do this by themselves).  The inspector walks the chunk
+ * grid over p[] (reference RcppSparse.h:220-221: a column is [p[c], p[c+1])) and records for every chunk the
+ * first column that starts in it, with chunk boundaries snapped to that column start.  If no column reaches
+ * more than one group (512 entries) past a chunk edge, a planned call is ONE launch: no per-chunk column search,
+ * no carries, no fix-up launch, no workspace -- what a latency-bound call (BASELINE config 2: 1e7 entries)
+ * spends a third of its time on.  Otherwise the plan is marked "not snapped" and the executor runs the general
+ * kernels (it then needs the workspace of rsp_column_sums_workspace_bytes).  Results are those of
+ * rsp_column_sums_device within the same tolerance; the short-column paths are the same code, so columns of up
+ * to 16 entries inside a group stay bit-identical to the reference loop.  A plan belongs to the p[] it was made
+ * from (same ncol, nnz, offsets) and to the chunking in force when it was made.
+ * info4 = { snapped (0/1), chunks, entries per chunk, largest distance from a chunk's grid start to its first
+ * column start }; *inspect_ms = host time the inspection took (reported separately from the calls).
+ * nrow_for_means > 0: colMeans (RcppSparse.h:145-150), 0: sums.
+ */
+typedef struct rsp_colsums_plan *rsp_colsums_plan_t;
+int rsp_column_sums_plan_create(const int32_t *p, int32_t ncol, int64_t nnz, int device,
+                                rsp_colsums_plan_t *plan);
+/* The same for offsets that live in HBM: copies them to the host once (synchronises `stream`). */
+int rsp_column_sums_plan_create_device(const int32_t *d_p, int32_t ncol, int64_t nnz,
+                                       void *stream, rsp_colsums_plan_t *plan);
+int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t *info4, double *inspect_ms);
+int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double *d_x,
+                                   const int32_t *d_p, int32_t nrow_for_means, double *d_sums,
+                                   void *d_workspace, size_t workspace_bytes, void *stream);
+int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan);
+/*
  * Generic column reduction ("next" row f3): the same column-iteration loop with a
  * different per-element body, out[c] = sum_j f(x[j]) over column c's stored entries --
  * what a user writes with Matrix::InnerIterator for column norms

@@ -34,6 +34,8 @@ EXPORTED_SYMBOLS = (
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
+    "rsp_column_sums_plan_create", "rsp_column_sums_plan_create_device", "rsp_column_sums_plan_info",
+    "rsp_column_sums_planned_device", "rsp_column_sums_plan_destroy",
     "rsp_csc_crossprod", "rsp_crossprod_workspace_bytes", "rsp_crossprod_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
@@ -100,6 +102,11 @@ def load(build: bool = True) -> ctypes.CDLL:
                                                  c.c_size_t, vp]
     L.rsp_column_sums_device_timed.argtypes = [vp, vp, i32, i64, vp, vp, c.c_size_t, vp, c.c_int,
                                                c.POINTER(c.c_float)]
+    L.rsp_column_sums_plan_create.argtypes = [ip, i32, i64, c.c_int, c.POINTER(vp)]
+    L.rsp_column_sums_plan_create_device.argtypes = [vp, i32, i64, vp, c.POINTER(vp)]
+    L.rsp_column_sums_plan_info.argtypes = [vp, ip, c.POINTER(c.c_double)]
+    L.rsp_column_sums_planned_device.argtypes = [vp, vp, vp, i32, vp, vp, c.c_size_t, vp]
+    L.rsp_column_sums_plan_destroy.argtypes = [vp]
     L.rsp_csc_crossprod.argtypes = [vp, dp]
     L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_crossprod_workspace_bytes.argtypes = [i32, i32, i64]
@@ -431,6 +438,72 @@ def prepared_column_sums(x_t, p_t, out_t, workspace, stream=None):
         if rc != RSP_OK:
             _check(rc)
     return launch
+
+
+class ColumnSumsPlan:
+    """Inspector-executor plan of a column-sum call (rsp_column_sums_plan_*): made once from p[] (a host
+    array, or a device tensor that is copied to the host once), then every call is one launch without
+    column search, carries or fix-up -- where the matrix allows it (``snapped``); otherwise the executor
+    runs the general kernels and needs their workspace."""
+
+    def __init__(self, p, nnz: int = None, device: int = 0, stream=None):
+        L = load()
+        self._h = ctypes.c_void_p()
+        if isinstance(p, np.ndarray):
+            p = np.ascontiguousarray(p, dtype=np.int32)
+            self.ncol = len(p) - 1
+            self.nnz = int(p[-1]) if nnz is None else int(nnz)
+            _check(L.rsp_column_sums_plan_create(_ip(p), self.ncol, self.nnz, int(device), ctypes.byref(self._h)))
+        else:   # a device tensor of offsets
+            self.ncol = p.numel() - 1
+            if nnz is None:
+                raise ValueError("nnz is needed with device offsets")
+            self.nnz = int(nnz)
+            _check(L.rsp_column_sums_plan_create_device(p.data_ptr(), self.ncol, self.nnz, _stream_ptr(stream),
+                                                        ctypes.byref(self._h)))
+        info = np.zeros(4, dtype=np.int32)
+        ms = ctypes.c_double(0)
+        _check(L.rsp_column_sums_plan_info(self._h, _ip(info), ctypes.byref(ms)))
+        self.snapped, self.nchunks, self.chunk_elems, self.max_skip = bool(info[0]), int(info[1]), int(info[2]), int(info[3])
+        self.inspect_ms = float(ms.value)
+
+    def column_sums(self, x_t, p_t, out_t=None, workspace=None, stream=None, nrow_for_means: int = 0):
+        import torch
+        assert x_t.numel() == self.nnz and p_t.numel() == self.ncol + 1
+        if out_t is None:
+            out_t = torch.empty(self.ncol, dtype=torch.float64, device=x_t.device)
+        if workspace is None and not self.snapped:
+            workspace = alloc_workspace(self.ncol, self.nnz, x_t.device)
+        _check(load().rsp_column_sums_planned_device(
+            self._h, x_t.data_ptr(), p_t.data_ptr(), int(nrow_for_means), out_t.data_ptr(),
+            workspace.data_ptr() if workspace is not None else None,
+            workspace.numel() if workspace is not None else 0, _stream_ptr(stream)))
+        return out_t
+
+    def prepared(self, x_t, p_t, out_t, workspace=None, stream=None):
+        """Pre-bound launcher for hot loops (bench): one foreign call per launch."""
+        fn = load().rsp_column_sums_planned_device
+        args = (self._h, ctypes.c_void_p(x_t.data_ptr()), ctypes.c_void_p(p_t.data_ptr()), ctypes.c_int32(0),
+                ctypes.c_void_p(out_t.data_ptr()),
+                ctypes.c_void_p(workspace.data_ptr() if workspace is not None else None),
+                ctypes.c_size_t(workspace.numel() if workspace is not None else 0), _stream_ptr(stream))
+
+        def launch():
+            rc = fn(*args)
+            if rc != RSP_OK:
+                _check(rc)
+        return launch
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            load().rsp_column_sums_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def column_sums_device_timed(x_t, p_t, out_t, workspace, reps: int, stream=None) -> float:

@@ -5,6 +5,9 @@
 // output; nothing here knows about R, Rcpp or torch.  No CPU fallback: without
 // a HIP device every compute entry fails with RSP_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <vector>
 
 #include <atomic>
 #include <climits>
@@ -220,7 +223,45 @@ int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, do
 
 }  // namespace
 
+// ---- inspector-executor plan of a column-sum call (callers that can show p[] to the host once) ----
+struct rsp_colsums_plan {
+    int device;
+    int32_t ncol;
+    int64_t nnz;
+    rsp::LaunchPlan lp;      // the chunking the records were made for
+    bool snapped;            // every chunk starts at most one group before a column start: the planned kernel applies
+    int32_t max_skip;        // largest distance from a chunk's grid start to its first column start
+    int2* d_rec;             // nchunks + 1 records {first column, first owned element} on the device
+    double inspect_ms;       // host time of the inspection (searches + upload of the records)
+};
+
+namespace {
+// The inspection: for every chunk of the grid, the first column start at or after its grid position and the
+// LAST column starting there (empty columns at that position end where the previous chunk ends: they are its).
+// Pure integer work on the host copy of p[]: nchunks x 2 binary searches.
+int inspect_offsets(const int32_t* p, int32_t ncol, int64_t nnz, const rsp::LaunchPlan& lp,
+                    std::vector<int2>* rec, int32_t* max_skip) {
+    const rsp::ChunkMap cmap{lp.chunk_elems, lp.nbody, lp.tail_elems};
+    rec->resize((size_t)lp.nchunks + 1);
+    int32_t worst = 0;
+    const int32_t* pend = p + (size_t)ncol + 1;
+    for (int32_t w = 0; w < lp.nchunks; ++w) {
+        const int64_t cs = cmap.start(w);
+        const int32_t* first = std::lower_bound(p, pend, (int32_t)cs);          // p[ncol] = nnz > cs: always found
+        const int32_t xs0 = *first;
+        const int32_t* past = std::upper_bound(first, pend, xs0);
+        (*rec)[w] = make_int2((int32_t)(past - p) - 1, xs0);
+        const int64_t skip = (int64_t)xs0 - cs;
+        if (skip > worst) worst = (int32_t)(skip > INT32_MAX ? INT32_MAX : skip);
+    }
+    (*rec)[lp.nchunks] = make_int2(ncol, (int32_t)nnz);
+    *max_skip = worst;
+    return RSP_OK;
+}
+}  // namespace
+
 struct rsp_csc {
+    rsp_colsums_plan* plan;   // made at upload (p[] is on the host then); nullptr: not applicable
     int device;
     int32_t nrow, ncol;
     int64_t nnz;
@@ -315,6 +356,126 @@ int rsp_column_means_device(const double* d_x, const int32_t* d_p, int32_t nrow,
                    (hipStream_t)stream);
 }
 
+// ---- inspector-executor: plan once (p[] seen by the host), then one launch per call -------------------
+static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int device, rsp_colsums_plan** out) {
+    *out = nullptr;
+    if (ncol <= 0 || nnz <= 0) return RSP_OK;   // nothing to plan: the general entry handles these shapes
+    const auto t0 = std::chrono::steady_clock::now();
+    rsp_colsums_plan* pl = new (std::nothrow) rsp_colsums_plan();
+    if (!pl) return fail(RSP_ERR_ALLOC, "out of host memory");
+    pl->device = device;
+    pl->ncol = ncol;
+    pl->nnz = nnz;
+    pl->lp = make_plan(nnz);
+    pl->d_rec = nullptr;
+    try {
+        std::vector<int2> rec;
+        inspect_offsets(p_host, ncol, nnz, pl->lp, &rec, &pl->max_skip);
+        pl->snapped = pl->max_skip <= rsp::kGroupElems;
+        if (pl->snapped) {
+            hipError_t e = hipMalloc((void**)&pl->d_rec, rec.size() * sizeof(int2));
+            if (e == hipSuccess) e = hipMemcpy(pl->d_rec, rec.data(), rec.size() * sizeof(int2), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (pl->d_rec) (void)hipFree(pl->d_rec);
+                delete pl;
+                return fail(RSP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+            }
+        }
+    } catch (...) {
+        delete pl;
+        return fail(RSP_ERR_ALLOC, "out of host memory while planning");
+    }
+    pl->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = pl;
+    return RSP_OK;
+}
+
+int rsp_column_sums_plan_create(const int32_t* p, int32_t ncol, int64_t nnz, int device,
+                                rsp_colsums_plan_t* plan) {
+    if (!plan) return fail(RSP_ERR_BAD_ARG, "plan is null");
+    *plan = nullptr;
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (!p) return fail(RSP_ERR_BAD_ARG, "p is null");
+    if (int rc = check_offsets_host(p, ncol, nnz)) return rc;
+    if (int rc = require_device(device)) return rc;
+    DeviceGuard on(device);
+    HIP_TRY(on.error());
+    rsp_colsums_plan* pl = nullptr;
+    if (int rc = plan_make(p, ncol, nnz, device, &pl)) return rc;
+    if (!pl) {   // an empty matrix: a plan object that simply sends the call to the general entry
+        pl = new (std::nothrow) rsp_colsums_plan();
+        if (!pl) return fail(RSP_ERR_ALLOC, "out of host memory");
+        pl->device = device;
+        pl->ncol = ncol;
+        pl->nnz = nnz;
+        pl->lp = make_plan(nnz);
+        pl->snapped = false;
+        pl->max_skip = 0;
+        pl->d_rec = nullptr;
+        pl->inspect_ms = 0.0;
+    }
+    *plan = pl;
+    return RSP_OK;
+}
+
+int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t nnz, void* stream,
+                                       rsp_colsums_plan_t* plan) {
+    if (!plan) return fail(RSP_ERR_BAD_ARG, "plan is null");
+    *plan = nullptr;
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (!d_p) return fail(RSP_ERR_BAD_ARG, "d_p is null");
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    try {
+        std::vector<int32_t> host((size_t)ncol + 1);
+        HIP_TRY(hipMemcpyAsync(host.data(), d_p, host.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        return rsp_column_sums_plan_create(host.data(), ncol, nnz, device, plan);
+    } catch (...) {
+        return fail(RSP_ERR_ALLOC, "out of host memory while planning");
+    }
+}
+
+int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t* info4, double* inspect_ms) {
+    if (!plan || !info4) return fail(RSP_ERR_BAD_ARG, "null plan or output");
+    info4[0] = plan->snapped ? 1 : 0;
+    info4[1] = plan->lp.nchunks;
+    info4[2] = plan->lp.chunk_elems;
+    info4[3] = plan->max_skip;
+    if (inspect_ms) *inspect_ms = plan->inspect_ms;
+    return RSP_OK;
+}
+
+int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
+    if (!plan) return RSP_OK;
+    if (plan->d_rec) {
+        DeviceGuard on(plan->device);
+        (void)hipFree(plan->d_rec);
+    }
+    delete plan;
+    return RSP_OK;
+}
+
+static int planned_enqueue(rsp_colsums_plan_t plan, const double* d_x, const int32_t* d_p, double* d_out,
+                           void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+    if (!plan->snapped)   // a column longer than a group crosses a chunk edge somewhere: the general kernels
+        return enqueue(d_x, d_p, plan->ncol, plan->nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
+    if (!d_p || !d_out || !d_x) return fail(RSP_ERR_BAD_ARG, "null device pointer");
+    if (((uintptr_t)d_x & 15) != 0) return fail(RSP_ERR_BAD_ARG, "d_x must be 16-byte aligned");
+    HIP_TRY(rsp::launch_column_sums(d_x, d_p, plan->ncol, (int32_t)plan->nnz, d_out, plan->lp, nullptr, divisor,
+                                    means, stream, rsp::kOpSum, nullptr, nullptr, 0, plan->d_rec));
+    return RSP_OK;
+}
+
+int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double* d_x, const int32_t* d_p,
+                                   int32_t nrow_for_means, double* d_sums, void* d_workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!plan || nrow_for_means < 0) return fail(RSP_ERR_BAD_ARG, "null plan or negative nrow_for_means");
+    return planned_enqueue(plan, d_x, d_p, d_sums, d_workspace, workspace_bytes,
+                           nrow_for_means > 0 ? (double)nrow_for_means : 1.0, nrow_for_means > 0,
+                           (hipStream_t)stream);
+}
+
 int rsp_column_reduce_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, int op,
                              double* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
     int kop;
@@ -395,6 +556,7 @@ int rsp_csc_free(rsp_csc_t h) {
     if (h->d_row_persist) (void)hipFree(h->d_row_persist);
     if (h->d_row_out) (void)hipFree(h->d_row_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->plan) rsp_column_sums_plan_destroy(h->plan);
     delete h;
     return RSP_OK;
 }
@@ -438,6 +600,10 @@ int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t 
         rsp_csc_free(h);
         return fail(RSP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
+    // p[] is in host memory right now: inspect it once, so that every columnSums on this handle is one launch
+    // without column search, carries or fix-up wherever the matrix allows (no column longer than a group across
+    // a chunk edge); a plan that does not apply costs nothing later
+    if (plan_make(p, ncol, nnz, device, &h->plan) != RSP_OK) h->plan = nullptr;
     *handle = h;
     return RSP_OK;
 }
@@ -447,8 +613,12 @@ static int csc_run(rsp_csc_t h, double* host_out, bool means) {
     DeviceGuard on(h->device);
     HIP_TRY(on.error());
     if (h->ncol == 0) return RSP_OK;
-    if (int rc = enqueue(h->d_x, h->d_p, h->ncol, h->nnz, h->d_out, h->d_ws, h->ws_bytes,
-                         means ? (double)h->nrow : 1.0, means, h->stream))
+    if (h->plan && h->plan->snapped) {
+        if (int rc = planned_enqueue(h->plan, h->d_x, h->d_p, h->d_out, h->d_ws, h->ws_bytes,
+                                     means ? (double)h->nrow : 1.0, means, h->stream))
+            return rc;
+    } else if (int rc = enqueue(h->d_x, h->d_p, h->ncol, h->nnz, h->d_out, h->d_ws, h->ws_bytes,
+                                means ? (double)h->nrow : 1.0, means, h->stream))
         return rc;
     HIP_TRY(hipMemcpyAsync(host_out, h->d_out, (size_t)h->ncol * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -87,7 +87,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
                               double divisor, bool means, hipStream_t stream, int op = kOpSum,
                               const int32_t* rows_i = nullptr, const uint32_t* row_bitmap = nullptr,
-                              int32_t bitmap_words = 0);
+                              int32_t bitmap_words = 0, const int2* plan_rec = nullptr);
 
 // hipFuncSetAttribute(..MaxDynamicSharedMemorySize..) once per (kernel, device): the attribute belongs to the
 // device's copy of the function, so a process that uses a second device has to raise it there as well.

@@ -549,13 +549,23 @@ __device__ __forceinline__ void process_row(double v0, double v1, int rs, int la
 // probed there.  With ~1e6 rows the bitmap (125 KB) is too big for the 32 KB L1, and 64 random 4-byte
 // probes per wave instruction into L2 cost more than the 12 B/nnz stream itself; in LDS they are a
 // couple of cycles.  One workgroup (WPG wavefronts) per CU then.
-template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG, int OP = kOpSum, bool LDSMAP = false>
+// PLANNED (inspector-executor, rsp_column_sums_plan_*): a host-side inspector that has seen p[] hands every
+// chunk a record {c0, xs0}: the first element it owns (xs0 = the first column start at or after the chunk's
+// grid position, at most one group of 512 elements into it) and the column that starts there.  Chunk w then owns
+// exactly the columns [c0_w, c0_{w+1}) = the elements [xs0_w, xs0_{w+1}): it gives the identity to what
+// precedes xs0 (the previous chunk's), streams its grid rows exactly like the general kernel, and finishes the
+// one column that reaches past its grid end with a single extra load (the `tail`, requested as soon as the
+// records are there) and one wave reduction.  No column search (four dependent round trips before the first
+// add in a short call), no carries, no fix-up launch.  The grid loads start immediately, before the records
+// have arrived.
+template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG, int OP = kOpSum, bool LDSMAP = false,
+          bool PLANNED = false>
 __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     ChunkMap cmap, int32_t nchunks, double* __restrict__ out,
     double* __restrict__ carry_head, double* __restrict__ carry_tail,
     int4* __restrict__ carry_info, double divisor, const int32_t* __restrict__ rows_i,
-    const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words) {
+    const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words, const int2* __restrict__ plan_rec = nullptr) {
     static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
     typedef Policy<MEANS, OP> P;
     constexpr bool MASKED = (OP == kOpMaskedIn || OP == kOpMaskedOut);
@@ -584,6 +594,11 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const int64_t ce64 = (int64_t)cs + cmap.elems(w);
     const int32_t ce = ce64 < (int64_t)nnz ? (int32_t)ce64 : nnz;
     const int32_t nrows = (int32_t)(((int64_t)ce - cs + 127) >> 7);
+    int2 rec = make_int2(0, 0), rec_next = make_int2(0, 0);
+    if (PLANNED) {
+        rec = plan_rec[w];
+        rec_next = plan_rec[w + 1];
+    }
 
     const double* xb = x + cs;
     const uint32_t xbytes = (uint32_t)(ce - cs) * 8u;
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     // masked reductions also stream the row indices of the chunk (4 B/nnz) and probe a
     // row bitmap (L2-resident: nrow / 8 bytes) when a row of x is consumed
     const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(MASKED ? rows_i + cs : nullptr), 0, MASKED ? (int)((uint32_t)(ce - cs) * 4u) : 0, 0x00020000);
+        (void*)(MASKED ? rows_i + cs : nullptr), 0, MASKED ? (int)(xbytes >> 1) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)row_bitmap, 0, MASKED ? bitmap_words * 4 : 0, 0x00020000);
 
@@ -608,7 +623,10 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     }
 
     int lo = 0, hi = ncol;   // invariant: p[lo] <= cs < p[hi]
-    if (BATCH_ROWS == 4 && ncol >= kGuessWindow) {
+    if (PLANNED) {
+        lo = __builtin_amdgcn_readfirstlane(rec.x);   // the inspector's answer: nothing to search
+        hi = lo + 1;
+    } else if (BATCH_ROWS == 4 && ncol >= kGuessWindow) {
         // Short calls (one round of waves, nothing to hide the search behind): guess the column from
         // "all columns equally long" and read kGuessWindow offsets around the guess in ONE round trip.
         // For uniform matrices the chunk's first column is in there (C2: within +-160 columns in 95 % of the
@@ -643,6 +661,19 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         hi = nhi < hi ? (int)nhi : hi;
     }
     const int c0 = lo;
+    const int32_t xs0 = PLANNED ? __builtin_amdgcn_readfirstlane(rec.y) : cs;   // first element this chunk owns
+    // PLANNED: the column open at the grid end reaches `ext` elements (at most one group) past it; they are
+    // requested now and added after the last grid row
+    const int32_t c_end = PLANNED ? __builtin_amdgcn_readfirstlane(rec_next.x) : 0;   // first column of the next chunk
+    const int32_t ext = PLANNED ? __builtin_amdgcn_readfirstlane(rec_next.y) - ce : 0;
+    d2 tail[PLANNED ? kGroupRows : 1];
+    if (PLANNED) {
+        const __amdgpu_buffer_rsrc_t tr =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(x + ce), 0, ext > 0 ? ext * 8 : 0, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < kGroupRows; ++r)   // (rows past `ext` cost no traffic: the bounds check answers them)
+            tail[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(tr, voff, r * 1024, AUX));
+    }
     RSP_STAMP(1);
     if (w == 0)
         for (int c = lane; c < c0; c += 64) out[c] = P::finish(P::id(), divisor);
@@ -651,7 +682,7 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     st.ccur = c0;
     st.wbase = c0;
     fill_window(win, p, c0, ncol, lane);
-    st.head_open = true;
+    st.head_open = !PLANNED;   // (a planned chunk starts on a column start: its first column is its own)
     st.acc_in_lane0 = true;   // (both accumulators start as the identity in every lane)
     const int32_t p_c0 = __builtin_amdgcn_readfirstlane(win[0]);   // first element of column c0
     st.head_complete = p_c0 >= cs;
@@ -698,6 +729,15 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
                 for (int rr = 0; rr < kGroupRows; ++rr) {
                     t[rr].x = xf<OP>(v[g * kGroupRows + rr].x);
                     t[rr].y = xf<OP>(v[g * kGroupRows + rr].y);
+                }
+            }
+            if (PLANNED && g == 0 && b == 0) {
+                // what precedes the chunk's first column start belongs to the previous chunk (at most one group)
+#pragma unroll
+                for (int rr = 0; rr < kGroupRows; ++rr) {
+                    const int e = gs + rr * kRowElems + 2 * lane;
+                    if (e < xs0) t[rr].x = P::id();
+                    if (e + 1 < xs0) t[rr].y = P::id();
                 }
             }
             if (!P::kSum && ce - gs < kGroupElems) {   // (gs <= ce; written so that nothing overflows near 2^31)
@@ -754,6 +794,22 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     }
 
     RSP_STAMP(5);
+    if (PLANNED) {
+        // The column still open at the grid end (if one reaches past it: ext > 0) is this chunk's: its running
+        // result plus the tail's elements, one wave reduction.  Columns after it up to the next chunk's first
+        // column are empty columns sitting exactly at that column's start: theirs is the identity.
+        // (a chunk without a column start in its grid range, xs0 >= ce, owns nothing: the column crossing it is
+        // finished by the chunk it starts in)
+        if (ext > 0 && xs0 < ce) {
+            double a = P::comb(acc0, acc1);
+#pragma unroll
+            for (int r = 0; r < kGroupRows; ++r) a = P::comb(a, P::comb(tail[r].x, tail[r].y));
+            const double total = wave_allreduce<P>(a);
+            if (lane == 0 && st.ccur < ncol) out[st.ccur] = P::finish(total, divisor);
+            for (int c = st.ccur + 1 + lane; c < c_end; c += 64) out[c] = P::finish(P::id(), divisor);
+        }
+        return;
+    }
     const double T = wave_allreduce<P>(P::comb(acc0, acc1));
     if (lane == 0) {
         if (st.head_open) {
@@ -902,7 +958,8 @@ __global__ void gen_row_indices_kernel(int32_t* __restrict__ i, const int32_t* _
 hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t nnz,
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
                               double divisor, bool means, hipStream_t stream, int op,
-                              const int32_t* rows_i, const uint32_t* row_bitmap, int32_t bitmap_words) {
+                              const int32_t* rows_i, const uint32_t* row_bitmap, int32_t bitmap_words,
+                              const int2* plan_rec) {
     if (ncol <= 0) return hipSuccess;
     if (op == kOpCount) {   // nnz per column: offsets only, x is not read
         hipLaunchKernelGGL(colsums_count_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_p, d_out, ncol);
@@ -923,6 +980,21 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     // experiment ids >= 16: (id - 16) KiB of unused dynamic LDS per workgroup, which lowers the number of
     // resident waves per CU (occupancy sweeps, tools/taper_sweep.py)
     const unsigned extra_lds = plan.variant >= 16 ? (unsigned)(plan.variant - 16) * 1024u : 0u;
+    if (plan_rec != nullptr && op == kOpSum && nnz > 0) {
+        // inspector-executor form: ONE launch, no workspace (rsp_column_sums_planned_device)
+#define RSP_LAUNCH_PLANNED(BR, MEANS_)                                                                          \
+        hipLaunchKernelGGL((colsums_chunks_kernel<BR, MEANS_, kLoadAux, kWavesPerWG, kOpSum, false, true>), grid,   \
+                           block, 0, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out, (double*)nullptr,     \
+                           (double*)nullptr, (int4*)nullptr, divisor, (const int32_t*)nullptr,                      \
+                           (const uint32_t*)nullptr, 0, plan_rec)
+        if (plan.short_pipeline) {
+            if (means) RSP_LAUNCH_PLANNED(4, true); else RSP_LAUNCH_PLANNED(4, false);
+        } else {
+            if (means) RSP_LAUNCH_PLANNED(kBatchRows, true); else RSP_LAUNCH_PLANNED(kBatchRows, false);
+        }
+#undef RSP_LAUNCH_PLANNED
+        return hipGetLastError();
+    }
 #define RSP_LAUNCH_K(KERNEL, BR, AUX_)                                                              \
     do {                                                                                           \
         if (means)                                                                                 \

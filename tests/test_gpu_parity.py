@@ -53,11 +53,39 @@ def assert_parity(got, x, p, positive=False):
         assert np.all(np.abs(got - ref) <= RTOL * np.abs(ref))
 
 
+_MODE = {"launch": "general"}
+PLANS_SEEN = {"snapped": 0, "general": 0}
+
+
+@pytest.fixture(params=["general", "planned"])
+def launch_mode(request):
+    """The same parity tests through rsp_column_sums_device (per-chunk column search, carries, fix-up launch)
+    and through the inspector-executor form (rsp_column_sums_plan_create + rsp_column_sums_planned_device: one
+    launch when no long column crosses a chunk edge, the general kernels behind the same entry otherwise)."""
+    _MODE["launch"] = request.param
+    yield request.param
+    _MODE["launch"] = "general"
+
+
 def dev_colsums(torch, x, p, **kw):
     xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
     pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int32)).cuda()
     if xt.numel() == 0:
         xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
+    if _MODE["launch"] == "planned" and not kw:
+        # the plan is made from the offsets in HBM on every other call, from the host array otherwise
+        PLANS_SEEN["n"] = PLANS_SEEN.get("n", 0) + 1
+        if PLANS_SEEN["n"] % 2:
+            plan = capi.ColumnSumsPlan(np.ascontiguousarray(p, dtype=np.int32), nnz=int(x.size))
+        else:
+            plan = capi.ColumnSumsPlan(pt, nnz=int(x.size))
+        PLANS_SEEN["snapped" if plan.snapped else "general"] += 1
+        out = plan.column_sums(xt, pt)
+        torch.cuda.synchronize()
+        again = plan.column_sums(xt, pt)                    # bit-stable, and the plan is reusable
+        assert out.cpu().numpy().tobytes() == again.cpu().numpy().tobytes()
+        plan.close()
+        return out.cpu().numpy()
     out = capi.column_sums_device(xt, pt, **kw)
     torch.cuda.synchronize()
     return out.cpu().numpy()
@@ -78,8 +106,13 @@ def test_golden_all_three_entry_points(torch_cuda, name):
     h.close()
     dev = dev_colsums(torch_cuda, x, p)
     assert_parity(dev, x, p, positive)
-    # same kernel, same chunking -> identical bits through every entry point
-    assert host.tobytes() == resident.tobytes() == dev.tobytes()
+    # the host entry and the handle inspect p[] at upload and run the planned form; the same form on device
+    # pointers gives their bits (same kernel, same chunking), the plan-free device entry its own
+    xt = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda() if x.size else torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")[:0]
+    plan = capi.ColumnSumsPlan(np.ascontiguousarray(p, dtype=np.int32), nnz=int(x.size))
+    planned = plan.column_sums(xt, torch_cuda.from_numpy(np.ascontiguousarray(p, dtype=np.int32)).cuda()).cpu().numpy()
+    plan.close()
+    assert host.tobytes() == resident.tobytes() == planned.tobytes()
     if dim[0] > 0:
         want = resident / dim[0]          # RcppSparse.h:147-148 divides the sums
         same = (means == want) | (np.isnan(means) & np.isnan(want))
@@ -112,7 +145,7 @@ REGIMES = [
 @pytest.mark.parametrize("label,ncol,mean", REGIMES)
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("chunk_rows", [0, 1, 3, 64])
-def test_uniform_regimes(torch_cuda, label, ncol, mean, kind, chunk_rows):
+def test_uniform_regimes(torch_cuda, label, ncol, mean, kind, chunk_rows, launch_mode):
     nnz = int(ncol * mean)
     counts = synth.uniform_counts(ncol, nnz, seed=sum(map(ord, label)), nrow=None)
     p = synth.offsets_from_counts(counts)
@@ -128,7 +161,7 @@ def test_uniform_regimes(torch_cuda, label, ncol, mean, kind, chunk_rows):
 @pytest.mark.parametrize("pattern", ["all_ones", "ones_and_empties", "one_two", "blocks_of_eight",
                                      "long_then_ones", "empties_every_third_of_512"])
 @pytest.mark.parametrize("chunk_rows", [0, 1, 5])
-def test_extreme_column_length_patterns(torch_cuda, pattern, chunk_rows):
+def test_extreme_column_length_patterns(torch_cuda, pattern, chunk_rows, launch_mode):
     """Every element its own column, columns of 1 separated by empty columns, exact 8-element
     blocks (the dense path's lane granularity), a long column followed by singletons, ...:
     the corners of the dense-group / few-ends / general slow paths and their hand-offs."""
@@ -185,7 +218,7 @@ def _random_structure(rng):
 
 
 @pytest.mark.parametrize("seed", range(60))
-def test_fuzz_random_structures(torch_cuda, seed):
+def test_fuzz_random_structures(torch_cuda, seed, launch_mode):
     rng = np.random.default_rng(1000 + seed)
     counts = _random_structure(rng)
     p = synth.offsets_from_counts(counts)
@@ -201,7 +234,7 @@ def test_fuzz_random_structures(torch_cuda, seed):
         assert_parity(got, x, p, positive=(kind == 1))
 
 
-def test_short_columns_come_out_in_reference_order_bit_exact(torch_cuda):
+def test_short_columns_come_out_in_reference_order_bit_exact(torch_cuda, launch_mode):
     """The dense-group path hands out whole columns to lanes and adds each column's elements from
     LDS in storage order, continuing the running sum across groups inside a chunk.  So in the
     short-column regime (BASELINE C2: ~10 nnz per column) every column that does not straddle a
@@ -221,7 +254,7 @@ def test_short_columns_come_out_in_reference_order_bit_exact(torch_cuda):
 
 @pytest.mark.parametrize("order", ["shuffled", "descending"])
 @pytest.mark.parametrize("chunk_rows", [0, 2, 16])
-def test_zipf_skew(torch_cuda, order, chunk_rows):
+def test_zipf_skew(torch_cuda, order, chunk_rows, launch_mode):
     counts = synth.zipf_counts(20000, 3_000_001, seed=5, nrow=400_000, order=order)
     p = synth.offsets_from_counts(counts)
     x = synth.gen_values(int(p[-1]), seed=9, kind=1)
@@ -236,7 +269,7 @@ def test_zipf_skew(torch_cuda, order, chunk_rows):
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("nnz", [1, 2, 3, 127, 128, 129, 255, 256, 257, 2047, 2048, 2049, 4097, 70001])
 @pytest.mark.parametrize("ncol", [1, 2, 7])
-def test_sizes_around_row_and_chunk_edges(torch_cuda, nnz, ncol):
+def test_sizes_around_row_and_chunk_edges(torch_cuda, nnz, ncol, launch_mode):
     rng = np.random.default_rng(nnz * 31 + ncol)
     cuts = np.sort(rng.integers(0, nnz + 1, size=ncol - 1)) if ncol > 1 else np.array([], dtype=np.int64)
     p = np.concatenate([[0], cuts, [nnz]]).astype(np.int32)
@@ -250,7 +283,7 @@ def test_sizes_around_row_and_chunk_edges(torch_cuda, nnz, ncol):
         assert_parity(got, x, p)
 
 
-def test_column_ends_exactly_on_row_and_chunk_edges(torch_cuda):
+def test_column_ends_exactly_on_row_and_chunk_edges(torch_cuda, launch_mode):
     # every column is a whole number of 128-element rows; chunk = 1 row
     counts = np.array([128, 256, 0, 128, 384, 0, 0, 128, 2048, 128], dtype=np.int64)
     p = synth.offsets_from_counts(counts)
@@ -264,7 +297,7 @@ def test_column_ends_exactly_on_row_and_chunk_edges(torch_cuda):
         assert_parity(got, x, p, positive=True)
 
 
-def test_leading_trailing_and_runs_of_empty_columns(torch_cuda):
+def test_leading_trailing_and_runs_of_empty_columns(torch_cuda, launch_mode):
     counts = np.concatenate([np.zeros(300), [5], np.zeros(1000), [700, 1], np.zeros(129), [64],
                              np.zeros(5000)]).astype(np.int64)
     p = synth.offsets_from_counts(counts)
@@ -273,14 +306,14 @@ def test_leading_trailing_and_runs_of_empty_columns(torch_cuda):
     assert_parity(got, x, p)
 
 
-def test_all_empty_and_zero_columns(torch_cuda):
+def test_all_empty_and_zero_columns(torch_cuda, launch_mode):
     p = np.zeros(1001, dtype=np.int32)
     got = dev_colsums(torch_cuda, np.array([], dtype=np.float64), p)
     assert got.shape == (1000,) and np.all(got == 0.0) and not np.any(np.signbit(got))
     assert capi.column_sums_host(np.array([], dtype=np.float64), np.zeros(1, dtype=np.int32)).shape == (0,)
 
 
-def test_nonfinite_values_do_not_leak_between_columns(torch_cuda):
+def test_nonfinite_values_do_not_leak_between_columns(torch_cuda, launch_mode):
     counts = np.full(200, 37, dtype=np.int64)
     p = synth.offsets_from_counts(counts)
     x = synth.gen_values(int(p[-1]), seed=6, kind=0)
@@ -746,3 +779,76 @@ def test_handle_calls_leave_the_current_device_alone(torch_cuda):
     assert torch.cuda.current_device() == before
     t = torch.ones(4, device="cuda")
     assert t.device.index == before
+
+
+# ------------------------------------------------ inspector-executor plan
+def test_c2_full_size_planned_against_oracle(torch_cuda):
+    """BASELINE config 2 (1e6 x 1e6, nnz 1e7, ~10 per column) through the planned form: the plan snaps (no column
+    of C2 is longer than a group), the call is one launch, every column against the oracle; colMeans through the
+    same plan; the resident handle picks the same path by itself; and the planned launch is graph-capture safe."""
+    torch = torch_cuda
+    nrow, ncol, nnz = 1_000_000, 1_000_000, 10_000_000
+    p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow))
+    pt = torch.from_numpy(p).cuda()
+    plan = capi.ColumnSumsPlan(p)
+    assert plan.snapped and plan.max_skip <= 512 and plan.nchunks > 1000 and plan.inspect_ms >= 0
+    for kind in (0, 1):
+        xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+        capi.gen_values_device(xt, seed=42, kind=kind)
+        got = plan.column_sums(xt, pt).cpu().numpy()
+        x = oracle.gen_values(nnz, 42, 0, kind)
+        assert_parity(got, x, p, positive=(kind == 1))
+        means = plan.column_sums(xt, pt, nrow_for_means=nrow).cpu().numpy()
+        assert means.tobytes() == (got / nrow).tobytes()                  # RcppSparse.h:147-148
+        # short columns inside a group are added in storage order on both paths: same bits as the general entry
+        general = capi.column_sums_device(xt, pt).cpu().numpy()
+        assert np.all(np.abs(general - got) <= 2 * RTOL * oracle.column_abs_sums(x, p))
+    h = capi.DeviceCSC(x, p, (nrow, ncol))
+    assert h.column_sums().tobytes() == got.tobytes()                     # the handle planned at upload
+    h.close()
+    # capture and replay
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        plan.column_sums(xt, pt, out)
+        s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            plan.column_sums(xt, pt, out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == got.tobytes()
+    plan.close()
+
+
+@pytest.mark.parametrize("shape,snaps", [("short", True), ("into512", True), ("into513", False), ("long", False),
+                                          ("zipf", False)])
+def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_cuda, shape, snaps):
+    """The inspector's decision and both outcomes of the executor.  The chunk before an edge finishes the column
+    that crosses it, the chunk after gives the identity to those entries -- inside its first group, so a column
+    may reach up to 512 entries (one group) past an edge: 512 snaps, 513 does not; unsnapped plans run the
+    general kernels behind the same entry.  Parity either way."""
+    torch = torch_cuda
+    if shape == "short":
+        counts = synth.uniform_counts(300_000, 3_000_000, seed=1, nrow=None)
+    elif shape in ("into512", "into513"):
+        # columns of 8 everywhere, except one that starts 40 entries before the edge of chunk 7 (2560-entry
+        # chunks at this size) and reaches 512 / 513 entries past it
+        reach = 512 if shape == "into512" else 513
+        counts = np.concatenate([np.full((7 * 2560 - 40) // 8, 8), [40 + reach], np.full(50_000, 8)]).astype(np.int64)
+    elif shape == "long":
+        counts = np.full(300, 10_000, dtype=np.int64)
+    else:
+        counts = synth.zipf_counts(20_000, 3_000_000, seed=3, nrow=1_000_000)
+    p = synth.offsets_from_counts(counts)
+    nnz = int(p[-1])
+    x = synth.gen_values(nnz, seed=5, kind=0)
+    plan = capi.ColumnSumsPlan(p)
+    if shape.startswith("into"):
+        assert plan.chunk_elems == 2560 and plan.max_skip == reach
+    assert plan.snapped is snaps, (shape, plan.max_skip)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    got = plan.column_sums(xt, pt).cpu().numpy()
+    plan.close()
+    assert_parity(got, x, p)
