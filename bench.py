@@ -443,30 +443,48 @@ def main(argv=None):
     driver = sharded.ShardedColumnSums(shard, compute, new_gather(s_main))
     for _ in range(args.warmup):
         driver.step(recv)
-    # a shard's kernel is ~0.15 ms at N = 8 and a C2-sized call ~25 us, so with a gather or a small
-    # matrix the timing events (one queue packet each, plus their host cost) sit on every 4th step
-    # only; the large single-GPU workloads time every launch
-    stride = 4 if (use_comm or shard.nnz < 200_000_000) else 1
-    timed = list(range(0, args.steps, stride))
+    # Timing events are queue packets of their own: a pair around a call leaves the queue idle for a few
+    # microseconds (rocprofv3 kernel trace of C2 with events on every 4th call: 16 us of gaps per 4 calls,
+    # profiles/r03_c2.md).  Harmless around a 1.2 ms call, a fifth of a 20 us one.  So:
+    #   * large single-GPU workloads (C3): an event pair around the kernels of EVERY timed call;
+    #   * small calls without a gather (C2, a C4 shard alone): ONE event pair around the whole timed region,
+    #     kernel time per launch = the region's device time / K (launches back to back, gaps included);
+    #   * calls with a gather (N > 1): the timed region carries no events at all (`value` is the clean
+    #     back-to-back rate); the kernel / gather split comes from the same K calls issued once more right
+    #     after it, with events around every call.
+    whole_region = (not use_comm) and shard.nnz < 200_000_000
+    per_call_events = not use_comm and not whole_region
     mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
-    ev = {k: (mk(), mk(), mk()) for k in timed}
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        e = ev.get(k)
-        if e is None:
-            driver.step(recv)
-        else:
-            e[0].record(s_main)
-            driver.step(recv, on_computed=lambda e=e: e[1].record(s_main))
-            e[2].record(s_main)
-    fence()
-    elapsed = time.perf_counter() - t0
 
-    ktimes = sorted(ev[k][0].elapsed_time(ev[k][1]) for k in timed)
+    def run_calls(with_events):
+        evs = [(mk(), mk(), mk()) for _ in range(args.steps)] if with_events else None
+        region = (mk(), mk())
+        fence()
+        t_begin = time.perf_counter()
+        region[0].record(s_main)
+        for k in range(args.steps):
+            if evs is None:
+                driver.step(recv)
+            else:
+                e = evs[k]
+                e[0].record(s_main)
+                driver.step(recv, on_computed=lambda e=e: e[1].record(s_main))
+                e[2].record(s_main)
+        region[1].record(s_main)
+        fence()
+        return time.perf_counter() - t_begin, evs, region
+
+    elapsed, evs, region = run_calls(per_call_events)
+    if use_comm:
+        _, evs, _ = run_calls(True)          # the split, outside the timed region
+    if evs is None:
+        ktimes = [region[0].elapsed_time(region[1]) / args.steps]
+    else:
+        ktimes = sorted(e[0].elapsed_time(e[1]) for e in evs)
     kernel_ms = sum(ktimes) / len(ktimes)
-    gtimes = sorted(ev[k][1].elapsed_time(ev[k][2]) for k in timed) if use_comm else [0.0]
+    gtimes = sorted(e[1].elapsed_time(e[2]) for e in evs) if use_comm else [0.0]
     gather_ms = sum(gtimes) / len(gtimes)
+    n_event_calls = 0 if evs is None else len(evs)
 
     # ------------------------------------------------------------------ latency of one call
     lat = []
@@ -593,8 +611,14 @@ def main(argv=None):
                 "kernel": ("colsums_chunks_kernel<PLANNED> (one launch)" if plan is not None and plan.snapped
                            else "colsums_chunks_kernel (+ colsums_fixup_kernel)"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
-                "kernel_timing": f"HIP events on the launch stream around the kernels of {len(timed)} of the "
-                                 f"{args.steps} timed calls (the gather is outside the pair)",
+                "kernel_timing": (f"ONE HIP event pair on the launch stream around the {args.steps} timed calls, "
+                                  "divided by their number (small calls: an event pair per call would idle the queue)"
+                                  if whole_region else
+                                  f"HIP events on the launch stream around the kernels (and the gather) of each of "
+                                  f"{n_event_calls} calls issued again right after the timed region, which itself "
+                                  "carries no events" if use_comm else
+                                  f"HIP events on the launch stream around the kernels of each of the "
+                                  f"{n_event_calls} timed calls"),
                 "kernel_ms_max_over_ranks": kernel_ms_max,
                 "gather_ms": gather_ms if use_comm else None,
                 "gather_ms_min_max": [gtimes[0], gtimes[-1]] if use_comm else None,

@@ -103,7 +103,7 @@ void taper_setting(int* permille, int* rows, bool* chosen) {
 // of resident waves, the end of x is cut into shorter chunks (the taper): they are
 // dispatched last and fill the chip while the long chunks of the last round finish
 // at different times.
-rsp::LaunchPlan make_plan(int64_t nnz) {
+rsp::LaunchPlan make_plan(int64_t nnz, bool planned = false) {
     rsp::LaunchPlan plan;
     const int64_t total_rows = (nnz + rsp::kRowElems - 1) / rsp::kRowElems;
     int rows = chunk_rows_setting();
@@ -115,8 +115,12 @@ rsp::LaunchPlan make_plan(int64_t nnz) {
         if (r > 256) r = 256;
         rows = (int)r;
         if (total_rows <= rsp::kShortCallRows && rows < rsp::kShortCallChunkRows) rows = rsp::kShortCallChunkRows;
+        // a planned chunk has no column search to amortise: shorter chunks (whole groups of 4 rows) put more
+        // wavefronts on the call's drain -- C2 20.5 us at 20 rows, 19.2 at 8 or 12, 21.7 at 6 or 10
+        // (profiles/r03_c2.md)
+        if (planned && total_rows <= rsp::kShortCallRows) rows = rsp::kPlannedShortCallChunkRows;
     }
-    plan.short_pipeline = automatic && total_rows <= rsp::kShortCallRows;
+    plan.short_pipeline = total_rows <= rsp::kShortCallRows;   // (whatever the chunk length: the call is one round of waves)
     // byte counts and offsets inside one chunk are 32-bit in the kernel (buffer descriptor size,
     // soffset): a chunk never exceeds 1 GiB of x, whatever the knob says
     if (rows > rsp::kMaxChunkRows) rows = rsp::kMaxChunkRows;
@@ -366,7 +370,7 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
     pl->device = device;
     pl->ncol = ncol;
     pl->nnz = nnz;
-    pl->lp = make_plan(nnz);
+    pl->lp = make_plan(nnz, true);
     pl->d_rec = nullptr;
     try {
         std::vector<int2> rec;

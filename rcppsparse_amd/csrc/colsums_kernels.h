@@ -56,6 +56,7 @@ struct LaunchPlan {
 // column work starts earlier: C2 26.6 -> 24.6 us (profiles/r02_c2.md); longer calls keep 8.
 constexpr int kShortCallRows = 131072;
 constexpr int kShortCallChunkRows = 20;
+constexpr int kPlannedShortCallChunkRows = 8;   // inspector-executor form of such calls: no search to amortise
 constexpr int kGuessWindow = 1024;   // offsets read around the guessed first column of a chunk (short calls)
 constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
