@@ -245,11 +245,13 @@ def test_short_columns_come_out_in_reference_order_bit_exact(torch_cuda, launch_
     got = dev_colsums(torch_cuda, x, p)
     ref = oracle.column_sums(x, p)
     assert_parity(got, x, p)
-    chunk = 20 * 128                                   # automatic chunking at this size (kShortCallChunkRows)
+    # automatic chunking at this size: kShortCallChunkRows, kPlannedShortCallChunkRows for a planned call (whose
+    # chunk finishes the column crossing its end with one wave reduction over the rest: not the reference's order)
+    chunk = (8 if launch_mode == "planned" else 20) * 128
     inside = (p[:-1] // chunk) == ((np.maximum(p[1:], p[:-1] + 1) - 1) // chunk)
     exact = got.view(np.uint64) == ref.view(np.uint64)
     assert np.all(exact[inside]), int(np.count_nonzero(~exact[inside]))
-    assert np.count_nonzero(inside) > 0.99 * ncol
+    assert np.count_nonzero(inside) > 0.985 * ncol
 
 
 @pytest.mark.parametrize("order", ["shuffled", "descending"])
@@ -833,10 +835,10 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
     if shape == "short":
         counts = synth.uniform_counts(300_000, 3_000_000, seed=1, nrow=None)
     elif shape in ("into512", "into513"):
-        # columns of 8 everywhere, except one that starts 40 entries before the edge of chunk 7 (2560-entry
-        # chunks at this size) and reaches 512 / 513 entries past it
+        # columns of 8 everywhere, except one that starts 40 entries before the edge of chunk 7 (planned calls of
+        # this size use 1024-entry chunks) and reaches 512 / 513 entries past it
         reach = 512 if shape == "into512" else 513
-        counts = np.concatenate([np.full((7 * 2560 - 40) // 8, 8), [40 + reach], np.full(50_000, 8)]).astype(np.int64)
+        counts = np.concatenate([np.full((7 * 1024 - 40) // 8, 8), [40 + reach], np.full(50_000, 8)]).astype(np.int64)
     elif shape == "long":
         counts = np.full(300, 10_000, dtype=np.int64)
     else:
@@ -846,7 +848,7 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
     x = synth.gen_values(nnz, seed=5, kind=0)
     plan = capi.ColumnSumsPlan(p)
     if shape.startswith("into"):
-        assert plan.chunk_elems == 2560 and plan.max_skip == reach
+        assert plan.chunk_elems == 1024 and plan.max_skip == reach
     assert plan.snapped is snaps, (shape, plan.max_skip)
     xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
     got = plan.column_sums(xt, pt).cpu().numpy()
