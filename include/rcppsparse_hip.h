@@ -93,6 +93,18 @@ typedef struct rsp_mcsc *rsp_mcsc_t;
 int rsp_mcsc_upload(const double *x, const int32_t *p, int32_t nrow, int32_t ncol,
                     int64_t nnz, const int *devices, int ndevices, rsp_mcsc_t *handle);
 int rsp_mcsc_column_sums(rsp_mcsc_t handle, double *sums);
+/* Matrix::colMeans (RcppSparse.h:145-150) on the shards: sums divided by Dim[0]. */
+int rsp_mcsc_column_means(rsp_mcsc_t handle, double *means);
+/* The same handle with the row indices kept on the devices (i[] cut like x[]), for the row-wise entries:
+ * Matrix::rowSums / rowMeans (RcppSparse.h:138-156).  Every shard sums the rows of its own columns
+ * (rsp_csc_row_sums), the partial vectors come back over the shards' own host links and are added on the host
+ * in shard order = column order -- the single-process form of rsp_comm_reduce_rows, same sum term for term.
+ * `sums` / `means`: nrow doubles, host. */
+int rsp_mcsc_upload_csc(const double *x, const int32_t *i, const int32_t *p, int32_t nrow,
+                        int32_t ncol, int64_t nnz, const int *devices, int ndevices,
+                        rsp_mcsc_t *handle);
+int rsp_mcsc_row_sums(rsp_mcsc_t handle, double *sums);
+int rsp_mcsc_row_means(rsp_mcsc_t handle, double *means);
 int rsp_mcsc_free(rsp_mcsc_t handle);
 
 /* ---- device-resident dgCMatrix handle (upload once, sum many) ---------- */

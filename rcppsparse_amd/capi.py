@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "rsp_version", "rsp_last_error", "rsp_device_count",
     "rsp_column_sums_host", "rsp_column_sums_host_multi",
     "rsp_mcsc_upload", "rsp_mcsc_column_sums", "rsp_mcsc_free",
+    "rsp_mcsc_upload_csc", "rsp_mcsc_column_means", "rsp_mcsc_row_sums", "rsp_mcsc_row_means",
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
@@ -88,6 +89,10 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_host_multi.argtypes = [dp, ip, i32, i64, dp, c.POINTER(c.c_int), c.c_int]
     L.rsp_mcsc_upload.argtypes = [dp, ip, i32, i32, i64, c.POINTER(c.c_int), c.c_int, c.POINTER(vp)]
     L.rsp_mcsc_column_sums.argtypes = [vp, dp]
+    L.rsp_mcsc_upload_csc.argtypes = [dp, ip, ip, i32, i32, i64, c.POINTER(c.c_int), c.c_int, c.POINTER(vp)]
+    L.rsp_mcsc_column_means.argtypes = [vp, dp]
+    L.rsp_mcsc_row_sums.argtypes = [vp, dp]
+    L.rsp_mcsc_row_means.argtypes = [vp, dp]
     L.rsp_mcsc_free.argtypes = [vp]
     L.rsp_csc_upload.argtypes = [dp, ip, ip, i32, i32, i64, c.c_int, c.POINTER(vp)]
     L.rsp_csc_column_sums.argtypes = [vp, dp]
@@ -217,9 +222,10 @@ def column_sums_host_multi(x, p, ncol=None, devices=None) -> np.ndarray:
 
 
 class MultiDeviceCSC:
-    """dgCMatrix resident on several GPUs of the node (column ranges), one process."""
+    """dgCMatrix resident on several GPUs of the node (column ranges), one process.  With `i` the row indices
+    are kept on the devices too and the row-wise entries work (rsp_mcsc_upload_csc)."""
 
-    def __init__(self, x, p, dim, devices=None):
+    def __init__(self, x, p, dim, devices=None, i=None):
         x = np.ascontiguousarray(x, dtype=np.float64)
         p = np.ascontiguousarray(p, dtype=np.int32)
         self.nrow, self.ncol = int(dim[0]), int(dim[1])
@@ -229,13 +235,30 @@ class MultiDeviceCSC:
         else:
             n = len(devices)
             arr = (ctypes.c_int * n)(*[int(d) for d in devices])
-        _check(load().rsp_mcsc_upload(_dp(x), _ip(p), self.nrow, self.ncol, x.size, arr, n,
-                                      ctypes.byref(self._h)))
+        if i is None:
+            _check(load().rsp_mcsc_upload(_dp(x), _ip(p), self.nrow, self.ncol, x.size, arr, n,
+                                          ctypes.byref(self._h)))
+        else:
+            i = np.ascontiguousarray(i, dtype=np.int32)
+            _check(load().rsp_mcsc_upload_csc(_dp(x), _ip(i), _ip(p), self.nrow, self.ncol, x.size, arr, n,
+                                              ctypes.byref(self._h)))
+
+    def _out(self, fn, n):
+        out = np.empty(n, dtype=np.float64)
+        _check(fn(self._h, _dp(out)))
+        return out
 
     def column_sums(self) -> np.ndarray:
-        out = np.empty(self.ncol, dtype=np.float64)
-        _check(load().rsp_mcsc_column_sums(self._h, _dp(out)))
-        return out
+        return self._out(load().rsp_mcsc_column_sums, self.ncol)
+
+    def column_means(self) -> np.ndarray:
+        return self._out(load().rsp_mcsc_column_means, self.ncol)
+
+    def row_sums(self) -> np.ndarray:
+        return self._out(load().rsp_mcsc_row_sums, self.nrow)
+
+    def row_means(self) -> np.ndarray:
+        return self._out(load().rsp_mcsc_row_means, self.nrow)
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:

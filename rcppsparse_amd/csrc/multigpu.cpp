@@ -190,7 +190,8 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
 struct rsp_mcsc {
     std::vector<rsp_csc_t> shards;
     std::vector<int32_t> bounds;   // column range of shard k: [bounds[k], bounds[k+1])
-    int32_t ncol;
+    int32_t nrow, ncol;
+    bool has_rows;                 // uploaded with i[]: the row-wise entries are available
 };
 
 int rsp_mcsc_free(rsp_mcsc_t h) {
@@ -200,8 +201,8 @@ int rsp_mcsc_free(rsp_mcsc_t h) {
     return RSP_OK;
 }
 
-int rsp_mcsc_upload(const double* x, const int32_t* p, int32_t nrow, int32_t ncol, int64_t nnz,
-                    const int* devices, int ndevices, rsp_mcsc_t* handle) {
+static int mcsc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t nrow, int32_t ncol, int64_t nnz,
+                       const int* devices, int ndevices, rsp_mcsc_t* handle) {
     if (!handle) return fail(RSP_ERR_BAD_ARG, "handle is null");
     *handle = nullptr;
     if (!p || (nnz > 0 && !x) || ncol < 0 || nnz < 0) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_mcsc_upload");
@@ -221,7 +222,9 @@ int rsp_mcsc_upload(const double* x, const int32_t* p, int32_t nrow, int32_t nco
             return fail(RSP_ERR_BAD_ARG, "p[0] must be 0 and p[ncol] must equal nnz");
         const int G = (int)devs.size();
         h = new rsp_mcsc();
+        h->nrow = nrow;
         h->ncol = ncol;
+        h->has_rows = i != nullptr || nnz == 0;
         h->bounds.assign((size_t)G + 1, 0);
         h->shards.assign((size_t)G, nullptr);
         if (int rc = rsp_partition_columns(p, ncol, G, h->bounds.data())) {
@@ -237,8 +240,8 @@ int rsp_mcsc_upload(const double* x, const int32_t* p, int32_t nrow, int32_t nco
                 std::vector<int32_t> pk((size_t)(c1 - c0) + 1);
                 for (int32_t j = 0; j <= c1 - c0; ++j) pk[j] = p[c0 + j] - p[c0];
                 const int64_t nk = (int64_t)p[c1] - p[c0];
-                status[k] = rsp_csc_upload(nk ? x + p[c0] : x, nullptr, pk.data(), nrow, c1 - c0, nk, devs[k],
-                                           &h->shards[k]);
+                status[k] = rsp_csc_upload(nk ? x + p[c0] : x, (i && nk) ? i + p[c0] : nullptr, pk.data(), nrow,
+                                           c1 - c0, nk, devs[k], &h->shards[k]);
                 if (status[k] != RSP_OK) message[k] = rsp_last_error();
             } catch (...) {   // (a shard that was uploaded stays in h->shards and is freed below)
                 status[k] = RSP_ERR_ALLOC;
@@ -262,14 +265,26 @@ int rsp_mcsc_upload(const double* x, const int32_t* p, int32_t nrow, int32_t nco
     return RSP_OK;
 }
 
-int rsp_mcsc_column_sums(rsp_mcsc_t h, double* sums) try {
+int rsp_mcsc_upload(const double* x, const int32_t* p, int32_t nrow, int32_t ncol, int64_t nnz,
+                    const int* devices, int ndevices, rsp_mcsc_t* handle) {
+    return mcsc_upload(x, nullptr, p, nrow, ncol, nnz, devices, ndevices, handle);
+}
+
+int rsp_mcsc_upload_csc(const double* x, const int32_t* i, const int32_t* p, int32_t nrow, int32_t ncol,
+                        int64_t nnz, const int* devices, int ndevices, rsp_mcsc_t* handle) {
+    if (nnz > 0 && !i) return fail(RSP_ERR_BAD_ARG, "i is null (rsp_mcsc_upload takes a matrix without row indices)");
+    return mcsc_upload(x, i, p, nrow, ncol, nnz, devices, ndevices, handle);
+}
+
+static int mcsc_columns(rsp_mcsc_t h, double* sums, bool means) try {
     if (!h || (h->ncol > 0 && !sums)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
     const int G = (int)h->shards.size();
     std::vector<int> status((size_t)G, RSP_OK);
     std::vector<std::string> message((size_t)G);
     auto work = [&](int k) noexcept {
         if (h->bounds[k + 1] == h->bounds[k]) return;
-        status[k] = rsp_csc_column_sums(h->shards[k], sums + h->bounds[k]);   // slice lands in place
+        status[k] = means ? rsp_csc_column_means(h->shards[k], sums + h->bounds[k])   // (every shard knows Dim[0])
+                          : rsp_csc_column_sums(h->shards[k], sums + h->bounds[k]);    // slice lands in place
         if (status[k] != RSP_OK) {
             try {
                 message[k] = rsp_last_error();
@@ -284,6 +299,54 @@ int rsp_mcsc_column_sums(rsp_mcsc_t h, double* sums) try {
 } catch (...) {
     return fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_column_sums");
 }
+
+int rsp_mcsc_column_sums(rsp_mcsc_t h, double* sums) { return mcsc_columns(h, sums, false); }
+int rsp_mcsc_column_means(rsp_mcsc_t h, double* means) { return mcsc_columns(h, means, true); }
+
+// Matrix::rowSums / rowMeans (reference RcppSparse.h:138-156) of the resident shards: every shard's partial row
+// sums come back over its own device's link into a host vector, and the host adds the vectors in SHARD order
+// (= column order) -- the single-process form of rsp_comm_reduce_rows, same sum term for term.
+static int mcsc_rows(rsp_mcsc_t h, double* out, bool means) try {
+    if (!h || (h->nrow > 0 && !out)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    if (!h->has_rows)
+        return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: use rsp_mcsc_upload_csc for the row-wise entries");
+    const int G = (int)h->shards.size();
+    const size_t nrow = (size_t)h->nrow;
+    if (nrow == 0) return RSP_OK;
+    std::vector<double> partial((size_t)G * nrow);
+    std::vector<int> status((size_t)G, RSP_OK);
+    std::vector<std::string> message((size_t)G);
+    auto work = [&](int k) noexcept {
+        double* mine = partial.data() + (size_t)k * nrow;
+        if (h->bounds[k + 1] == h->bounds[k]) {   // a shard without columns adds nothing
+            for (size_t r = 0; r < nrow; ++r) mine[r] = 0.0;
+            return;
+        }
+        status[k] = rsp_csc_row_sums(h->shards[k], mine);
+        if (status[k] != RSP_OK) {
+            try {
+                message[k] = rsp_last_error();
+            } catch (...) {
+            }
+        }
+    };
+    if (!run_shards(G, work)) return fail(RSP_ERR_ALLOC, "out of host memory or threads while summing the shards");
+    for (int k = 0; k < G; ++k)
+        if (status[k] != RSP_OK) return fail(status[k], "shard %d: %s", k, message[k].c_str());
+    const double divisor = (double)h->ncol;
+    for (size_t r = 0; r < nrow; ++r) {
+        double t = partial[r];
+        for (int k = 1; k < G; ++k) t += partial[(size_t)k * nrow + r];
+        t += 0.0;
+        out[r] = means ? t / divisor : t;   // RcppSparse.h:153-154
+    }
+    return RSP_OK;
+} catch (...) {
+    return fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_row_sums");
+}
+
+int rsp_mcsc_row_sums(rsp_mcsc_t h, double* sums) { return mcsc_rows(h, sums, false); }
+int rsp_mcsc_row_means(rsp_mcsc_t h, double* means) { return mcsc_rows(h, means, true); }
 
 int rsp_comm_unique_id(void* id_bytes) {
     if (!id_bytes) return fail(RSP_ERR_BAD_ARG, "id_bytes is null");

@@ -69,6 +69,102 @@ Rcpp::NumericVector gpuColumnSums(SEXP handle) {
     return sums;
 }
 
+//' Column means, row sums and row means of a GPU-resident matrix
+//'
+//' The device forms of \code{Matrix::colSums()}, \code{colMeans()}, \code{rowSums()} and \code{rowMeans()}
+//' of the C++ class (reference inst/include/RcppSparse.h:131-156) on the resident copy.
+//' @param handle a \code{"gpuMatrix"}
+//' @param what 0 column sums, 1 column means, 2 row sums, 3 row means
+//' @return numeric vector of length \code{ncol} (0, 1) or \code{nrow} (2, 3)
+//[[Rcpp::export]]
+Rcpp::NumericVector gpuReduce(SEXP handle, int what) {
+    rsp_csc* h = resident(handle);
+    if (what < 0 || what > 3) throw std::invalid_argument("what must be 0 (colSums), 1 (colMeans), 2 (rowSums) or 3 (rowMeans)");
+    Rcpp::IntegerVector dim = GpuMatrixPtr(handle).attr("Dim");
+    const int n = what < 2 ? dim[1] : dim[0];
+    Rcpp::NumericVector out(n);                      // allocated by R, on the R main thread
+    if (n == 0) return out;
+    const int rc = what == 0 ? rsp_csc_column_sums(h, &out[0]) : what == 1 ? rsp_csc_column_means(h, &out[0])
+                 : what == 2 ? rsp_csc_row_sums(h, &out[0]) : rsp_csc_row_means(h, &out[0]);
+    if (rc != RSP_OK) throw std::runtime_error(std::string("RcppSparse gpuMatrix (HIP): ") + rsp_last_error());
+    return out;
+}
+
+//' t(A) %*% A of a GPU-resident matrix
+//'
+//' The device form of \code{Matrix::crossprod()} (reference inst/include/RcppSparse.h:159-194): dense
+//' \code{ncol x ncol}.
+//' @param handle a \code{"gpuMatrix"}
+//' @return numeric matrix
+//[[Rcpp::export]]
+Rcpp::NumericMatrix gpuCrossprod(SEXP handle) {
+    rsp_csc* h = resident(handle);
+    Rcpp::IntegerVector dim = GpuMatrixPtr(handle).attr("Dim");
+    const int n = dim[1];
+    Rcpp::NumericMatrix out(n, n);
+    if (n == 0) return out;
+    if (rsp_csc_crossprod(h, &out(0, 0)) != RSP_OK)
+        throw std::runtime_error(std::string("RcppSparse crossprod (HIP): ") + rsp_last_error());
+    return out;
+}
+
+// ---- the same handle spread over several GPUs of the node (rsp_mcsc_*) ---------------------------------
+namespace {
+
+void release_gpu_matrix_multi(rsp_mcsc* h) { rsp_mcsc_free(h); }
+
+typedef Rcpp::XPtr<rsp_mcsc, Rcpp::PreserveStorage, release_gpu_matrix_multi, true> GpuMatrixMultiPtr;
+
+}  // namespace
+
+//' Keep a sparse matrix in the memory of several GPUs
+//'
+//' The columns are cut into nnz-balanced contiguous ranges, one per entry of \code{devices} (an ordinal may
+//' repeat); every range is uploaded over its own GPU's host link and stays resident there.
+//' @param A a \code{dgCMatrix}
+//' @param devices GPU ordinals, one per shard
+//' @return external pointer of class \code{"gpuMatrixMulti"} with attribute \code{Dim}
+//[[Rcpp::export]]
+SEXP gpuMatrixMulti(RcppSparse::Matrix& A, Rcpp::IntegerVector devices) {
+    const long long nnz = (long long)A.n_nonzero();
+    if (devices.size() < 1) throw std::invalid_argument("devices must name at least one GPU");
+    rsp_mcsc_t h = 0;
+    const int rc = rsp_mcsc_upload_csc(nnz ? &A.x[0] : (const double*)0, nnz ? &A.i[0] : (const int*)0, &A.p[0],
+                                       (int)A.rows(), (int)A.cols(), nnz, &devices[0], (int)devices.size(), &h);
+    if (rc != RSP_OK) throw std::runtime_error(std::string("RcppSparse gpuMatrix (HIP): ") + rsp_last_error());
+    GpuMatrixMultiPtr ptr(h, true);
+    ptr.attr("class") = "gpuMatrixMulti";
+    ptr.attr("Dim") = Rcpp::IntegerVector::create((int)A.rows(), (int)A.cols());
+    return ptr;
+}
+
+//' Column / row sums and means of a matrix resident on several GPUs
+//' @param handle a \code{"gpuMatrixMulti"}
+//' @param what 0 column sums, 1 column means, 2 row sums, 3 row means
+//[[Rcpp::export]]
+Rcpp::NumericVector gpuMultiReduce(SEXP handle, int what) {
+    GpuMatrixMultiPtr ptr(handle);
+    rsp_mcsc* h = ptr.get();
+    if (!h) throw std::invalid_argument("this gpuMatrix handle has been released");
+    if (what < 0 || what > 3) throw std::invalid_argument("what must be 0 (colSums), 1 (colMeans), 2 (rowSums) or 3 (rowMeans)");
+    Rcpp::IntegerVector dim = ptr.attr("Dim");
+    const int n = what < 2 ? dim[1] : dim[0];
+    Rcpp::NumericVector out(n);
+    if (n == 0) return out;
+    const int rc = what == 0 ? rsp_mcsc_column_sums(h, &out[0]) : what == 1 ? rsp_mcsc_column_means(h, &out[0])
+                 : what == 2 ? rsp_mcsc_row_sums(h, &out[0]) : rsp_mcsc_row_means(h, &out[0]);
+    if (rc != RSP_OK) throw std::runtime_error(std::string("RcppSparse gpuMatrix (HIP): ") + rsp_last_error());
+    return out;
+}
+
+//' @rdname gpuMatrixMulti
+//' @param handle a \code{"gpuMatrixMulti"}
+//[[Rcpp::export]]
+void gpuFreeMulti(SEXP handle) {
+    GpuMatrixMultiPtr ptr(handle);
+    ptr.release();
+}
+
 //' Release the GPU copy now instead of at garbage collection
 //' @param handle a \code{"gpuMatrix"}
 //[[Rcpp::export]]

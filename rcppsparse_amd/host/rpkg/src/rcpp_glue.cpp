@@ -5,7 +5,7 @@
 // has to export the reference's two symbols under the reference's names (reference
 // src/RcppExports.cpp:16 and :31) and register `_RcppSparse_columnSums` with arity 1 and dynamic
 // symbol lookup switched off, because the R wrapper calls it by its registered name
-// (`.Call(`_RcppSparse_columnSums`, A)`).  The three gpuMatrix routines after it are additions
+// (`.Call(`_RcppSparse_columnSums`, A)`).  The gpuMatrix routines after it are additions
 // of this package.
 //
 // Rcpp::compileAttributes() can regenerate an equivalent file from the [[Rcpp::export]]
@@ -27,6 +27,11 @@ Rcpp::NumericVector columnSums(RcppSparse::Matrix& A);
 SEXP gpuMatrix(RcppSparse::Matrix& A, int device);
 Rcpp::NumericVector gpuColumnSums(SEXP handle);
 void gpuFree(SEXP handle);
+Rcpp::NumericVector gpuReduce(SEXP handle, int what);
+Rcpp::NumericMatrix gpuCrossprod(SEXP handle);
+SEXP gpuMatrixMulti(RcppSparse::Matrix& A, Rcpp::IntegerVector devices);
+Rcpp::NumericVector gpuMultiReduce(SEXP handle, int what);
+void gpuFreeMulti(SEXP handle);
 
 namespace {
 
@@ -74,6 +79,51 @@ SEXP call_gpuFree(SEXP handle) {
     END_RCPP
 }
 
+SEXP call_gpuReduce(SEXP handle, SEXP what) {
+    BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
+    result = Rcpp::wrap(gpuReduce(handle, Rcpp::as<int>(what)));
+    return result;
+    END_RCPP
+}
+
+SEXP call_gpuCrossprod(SEXP handle) {
+    BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
+    result = Rcpp::wrap(gpuCrossprod(handle));
+    return result;
+    END_RCPP
+}
+
+SEXP call_gpuMatrixMulti(SEXP dgCMatrix, SEXP devices) {
+    BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
+    Rcpp::traits::input_parameter<RcppSparse::Matrix&>::type A(dgCMatrix);
+    result = gpuMatrixMulti(A, Rcpp::IntegerVector(devices));
+    return result;
+    END_RCPP
+}
+
+SEXP call_gpuMultiReduce(SEXP handle, SEXP what) {
+    BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
+    result = Rcpp::wrap(gpuMultiReduce(handle, Rcpp::as<int>(what)));
+    return result;
+    END_RCPP
+}
+
+SEXP call_gpuFreeMulti(SEXP handle) {
+    BEGIN_RCPP
+    Rcpp::RNGScope rng_state;
+    gpuFreeMulti(handle);
+    return R_NilValue;
+    END_RCPP
+}
+
 }  // namespace
 
 extern "C" {
@@ -82,6 +132,11 @@ SEXP _RcppSparse_columnSums(SEXP A) { return call_columnSums(A); }
 SEXP _RcppSparse_gpuMatrix(SEXP A, SEXP device) { return call_gpuMatrix(A, device); }
 SEXP _RcppSparse_gpuColumnSums(SEXP handle) { return call_gpuColumnSums(handle); }
 SEXP _RcppSparse_gpuFree(SEXP handle) { return call_gpuFree(handle); }
+SEXP _RcppSparse_gpuReduce(SEXP handle, SEXP what) { return call_gpuReduce(handle, what); }
+SEXP _RcppSparse_gpuCrossprod(SEXP handle) { return call_gpuCrossprod(handle); }
+SEXP _RcppSparse_gpuMatrixMulti(SEXP A, SEXP devices) { return call_gpuMatrixMulti(A, devices); }
+SEXP _RcppSparse_gpuMultiReduce(SEXP handle, SEXP what) { return call_gpuMultiReduce(handle, what); }
+SEXP _RcppSparse_gpuFreeMulti(SEXP handle) { return call_gpuFreeMulti(handle); }
 
 void R_init_RcppSparse(DllInfo* dll) {
     static const R_CallMethodDef routines[] = {
@@ -89,6 +144,11 @@ void R_init_RcppSparse(DllInfo* dll) {
         {"_RcppSparse_gpuMatrix", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuMatrix), 2},
         {"_RcppSparse_gpuColumnSums", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuColumnSums), 1},
         {"_RcppSparse_gpuFree", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuFree), 1},
+        {"_RcppSparse_gpuReduce", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuReduce), 2},
+        {"_RcppSparse_gpuCrossprod", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuCrossprod), 1},
+        {"_RcppSparse_gpuMatrixMulti", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuMatrixMulti), 2},
+        {"_RcppSparse_gpuMultiReduce", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuMultiReduce), 2},
+        {"_RcppSparse_gpuFreeMulti", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuFreeMulti), 1},
         {NULL, NULL, 0}};
     R_registerRoutines(dll, /*.C*/ NULL, /*.Call*/ routines, /*.Fortran*/ NULL, /*.External*/ NULL);
     R_useDynamicSymbols(dll, FALSE);   // only registered names resolve

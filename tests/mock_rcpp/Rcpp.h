@@ -84,6 +84,7 @@ public:
     double& operator()(int r, int c) { return d_[(R_xlen_t)c * nr_ + r]; }
     int nrow() const { return nr_; }
     int ncol() const { return nc_; }
+    const NumericVector& data() const { return d_; }
 
 private:
     NumericVector d_;
@@ -92,6 +93,12 @@ private:
 
 inline SEXP wrap(const NumericVector& v) { SEXP s = mock_new(); s->num = v.storage(); return s; }
 inline SEXP wrap(const IntegerVector& v) { SEXP s = mock_new(); s->integer = v.storage(); return s; }
+inline SEXP wrap(const NumericMatrix& m) {   // a numeric vector with a dim attribute, like R's matrices
+    SEXP s = mock_new();
+    s->num = m.data().storage();
+    s->attrs["dim"] = wrap(IntegerVector::create(m.nrow(), m.ncol()));
+    return s;
+}
 template <class V>
 inline V clone(const V& v) {
     V c(v.size());

@@ -6,6 +6,8 @@
 //   driver kat                 -> Documentation.Rmd:213-216 matrix through .Call (needs a GPU)
 //   driver handle              -> gpuMatrix(A) external pointer: resident sums, copy semantics, finalizer (GPU)
 //   driver handle_nogpu        -> gpuMatrix(A) on a machine without a GPU must be an R error
+//   driver handle_methods      -> colMeans / rowSums / rowMeans / crossprod on the handle, and the same matrix
+//                                 spread over three shards (gpuMatrix(A, devices = c(0, 0, 0))) (GPU)
 #include "../../rcppsparse_amd/host/RcppSparse.h"
 
 #include <cstdio>
@@ -79,6 +81,68 @@ int main(int argc, char** argv) {
         if (!gpu_free(h)->error.empty()) return 31;     // releasing twice is harmless
         if (Rcpp::RNGScope::live() != 0 || Rcpp::RNGScope::entered() < 6) return 32;
         std::printf("gpuMatrix handle ok\n");
+        return 0;
+    }
+    if (mode == "handle_methods") {
+        // R: h <- gpuMatrix(A); gpuColMeans(h); gpuRowSums(h); gpuRowMeans(h); gpuCrossprod(h)
+        //    m <- gpuMatrix(A, devices = c(0, 0, 0)); columnSums(m); gpuColMeans(m); gpuRowSums(m); gpuRowMeans(m)
+        call2 gpu_matrix = 0, gpu_reduce = 0, gpu_multi = 0, multi_reduce = 0;
+        call1 gpu_cross = 0, gpu_free = 0, multi_free = 0;
+        for (int k = 0; dll.registered[k].name; ++k) {
+            const std::string nm = dll.registered[k].name;
+            if (nm == "_RcppSparse_gpuMatrix") gpu_matrix = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuReduce") gpu_reduce = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuCrossprod") gpu_cross = (call1)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuFree") gpu_free = (call1)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuMatrixMulti") gpu_multi = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuMultiReduce") multi_reduce = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuFreeMulti") multi_free = (call1)dll.registered[k].fun;
+        }
+        if (!gpu_matrix || !gpu_reduce || !gpu_cross || !gpu_free || !gpu_multi || !multi_reduce || !multi_free) return 40;
+        // the matrix of Documentation.Rmd:213-216: columns {}, {(0, .41)}, {(2, .35)}, {(0, .84), (1, .37)}, {(1, .26)}
+        const double cs[5] = {0.0, 0.41, 0.35, 0.84 + 0.37, 0.26};
+        const double rs[5] = {0.41 + 0.84, 0.37 + 0.26, 0.35, 0.0, 0.0};
+        double cm[5], rm[5], xp[25] = {0};
+        for (int k = 0; k < 5; ++k) { cm[k] = cs[k] / 5; rm[k] = rs[k] / 5; }
+        xp[1 * 5 + 1] = 0.41 * 0.41;
+        xp[2 * 5 + 2] = 0.35 * 0.35;
+        xp[3 * 5 + 3] = 0.84 * 0.84 + 0.37 * 0.37;
+        xp[4 * 5 + 4] = 0.26 * 0.26;
+        xp[1 * 5 + 3] = xp[3 * 5 + 1] = 0.41 * 0.84;          // columns 1 and 3 share row 0
+        xp[3 * 5 + 4] = xp[4 * 5 + 3] = 0.37 * 0.26;          // columns 3 and 4 share row 1
+        const double* want[4] = {cs, cm, rs, rm};
+        SEXP A = dgc(true);
+        SEXP h = gpu_matrix(A, Rcpp::wrap(Rcpp::IntegerVector::create(0, 0)));
+        if (!h->error.empty()) { std::printf("R error: %s\n", h->error.c_str()); return 41; }
+        for (int what = 0; what < 4; ++what) {
+            SEXP r = gpu_reduce(h, Rcpp::wrap(Rcpp::IntegerVector::create(what, 0)));
+            if (!r->error.empty()) { std::printf("R error: %s\n", r->error.c_str()); return 42; }
+            if (r->num->size() != 5 || std::memcmp(&(*r->num)[0], want[what], 5 * sizeof(double)) != 0) return 43 + what;
+        }
+        if (gpu_reduce(h, Rcpp::wrap(Rcpp::IntegerVector::create(7, 0)))->error.find("what must be") == std::string::npos) return 47;
+        SEXP c = gpu_cross(h);
+        if (!c->error.empty()) { std::printf("R error: %s\n", c->error.c_str()); return 48; }
+        if (c->num->size() != 25 || std::memcmp(&(*c->num)[0], xp, sizeof xp) != 0) return 49;
+        if ((*c->attrs.at("dim")->integer)[0] != 5 || (*c->attrs.at("dim")->integer)[1] != 5) return 50;
+        if (!gpu_free(h)->error.empty()) return 51;
+        if (gpu_reduce(h, Rcpp::wrap(Rcpp::IntegerVector::create(2, 0)))->error.find("released") == std::string::npos) return 52;
+        if (gpu_cross(h)->error.find("released") == std::string::npos) return 53;
+        // three shards (all on device 0 here): same answers, bit for bit on this matrix
+        const int three[3] = {0, 0, 0};
+        SEXP m = gpu_multi(A, Rcpp::wrap(Rcpp::IntegerVector(three, three + 3)));
+        if (!m->error.empty()) { std::printf("R error: %s\n", m->error.c_str()); return 54; }
+        if (!m->is_extptr || m->attrs.at("class")->str != "gpuMatrixMulti") return 55;
+        for (int what = 0; what < 4; ++what) {
+            SEXP r = multi_reduce(m, Rcpp::wrap(Rcpp::IntegerVector::create(what, 0)));
+            if (!r->error.empty()) { std::printf("R error: %s\n", r->error.c_str()); return 56; }
+            if (r->num->size() != 5 || std::memcmp(&(*r->num)[0], want[what], 5 * sizeof(double)) != 0) return 57 + what;
+        }
+        Rcpp::mock_collect(m);                          // the collector's finalizer frees every shard
+        if (m->extptr != 0) return 61;
+        if (multi_reduce(m, Rcpp::wrap(Rcpp::IntegerVector::create(0, 0)))->error.find("released") == std::string::npos) return 62;
+        if (!multi_free(m)->error.empty()) return 63;
+        if (Rcpp::RNGScope::live() != 0) return 64;
+        std::printf("gpuMatrix methods ok\n");
         return 0;
     }
     if (mode == "missing_slot") {

@@ -640,6 +640,46 @@ def test_multi_device_resident_handle(torch_cuda, devices):
     assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0], [0] * 8])
+def test_multi_device_resident_handle_row_entries(torch_cuda, devices):
+    """rsp_mcsc_upload_csc + colMeans / rowSums / rowMeans (reference RcppSparse.h:138-156): every shard sums
+    the rows of its own columns, the host adds the partial vectors in shard order.  Within 1e-12 * sum|x| per
+    row of the oracle's scatter loop over the whole matrix, bit-identical to adding the shards' own results in
+    order, and a handle uploaded without i[] says so instead of answering."""
+    nrow, ncol = 70_000, 900
+    m = synth.rsparsematrix(nrow, ncol, density=0.004, seed=31)
+    x, i, p = m["x"], m["i"], m["p"]
+    h = capi.MultiDeviceCSC(x, p, (nrow, ncol), devices=devices, i=i)
+    rs, rs2, rm = h.row_sums(), h.row_sums(), h.row_means()
+    cs, cm = h.column_sums(), h.column_means()
+    h.close()
+    ref = oracle.row_sums(x, i, p, nrow)
+    scale = np.bincount(i, weights=np.abs(x), minlength=nrow)
+    assert np.all(np.abs(rs - ref) <= RTOL * scale)
+    assert rs.tobytes() == rs2.tobytes() and rm.tobytes() == (rs / ncol).tobytes()
+    empty = np.bincount(i, minlength=nrow) == 0
+    assert np.all(rs[empty] == 0.0) and not np.any(np.signbit(rs[empty]))
+    assert_parity(cs, x, p)
+    assert cm.tobytes() == (cs / nrow).tobytes()
+    # the same blocking of the sum, shard by shard
+    bounds = capi.partition_columns(p, len(devices))
+    blocked = None
+    for k in range(len(devices)):
+        c0, c1 = int(bounds[k]), int(bounds[k + 1])
+        if c1 == c0:
+            continue
+        hk = capi.DeviceCSC(x[p[c0]:p[c1]], capi.rebase_offsets(p, c0, c1), (nrow, c1 - c0), i=i[p[c0]:p[c1]])
+        part = hk.row_sums()
+        hk.close()
+        blocked = part if blocked is None else blocked + part
+    assert rs.tobytes() == (blocked + 0.0).tobytes()
+    h2 = capi.MultiDeviceCSC(x, p, (nrow, ncol), devices=devices)          # no i[]
+    with pytest.raises(capi.RspError) as e:
+        h2.row_sums()
+    assert e.value.code == capi.RSP_ERR_BAD_ARG
+    h2.close()
+
+
 # ------------------------------------------------------------------ RCCL plumbing
 def test_rccl_single_rank_gatherv_roundtrip(torch_cuda):
     """One-rank communicator on the one GPU of this box: unique id, init, gatherv (root's own

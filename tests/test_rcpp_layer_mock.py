@@ -43,7 +43,9 @@ def test_package_registers_the_reference_routine_first(driver):
     rows = [ln.split() for ln in r.stdout.splitlines()]
     assert rows[0] == ["_RcppSparse_columnSums", "1"]
     assert rows[1:] == [["_RcppSparse_gpuMatrix", "2"], ["_RcppSparse_gpuColumnSums", "1"],
-                        ["_RcppSparse_gpuFree", "1"]]
+                        ["_RcppSparse_gpuFree", "1"], ["_RcppSparse_gpuReduce", "2"],
+                        ["_RcppSparse_gpuCrossprod", "1"], ["_RcppSparse_gpuMatrixMulti", "2"],
+                        ["_RcppSparse_gpuMultiReduce", "2"], ["_RcppSparse_gpuFreeMulti", "1"]]
 
 
 def test_glue_also_builds_with_global_rostream(tmp_path):
@@ -95,6 +97,18 @@ def test_gpu_matrix_external_pointer_handle(driver):
     r = run(driver, "handle")
     assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
     assert "gpuMatrix handle ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_matrix_handle_methods_and_multi_gpu_handle(driver):
+    """The rest of the handle at the R level: colMeans / rowSums / rowMeans /
+    crossprod on a "gpuMatrix" (reference RcppSparse.h:131-194 on the resident copy) and the same matrix spread
+    over three shards by gpuMatrix(A, devices = c(0, 0, 0)) (rsp_mcsc_*), driven through the registered .Call
+    routines: the vignette's 5 x 5 matrix, expected values bit for bit, released handles are R errors, the
+    collector's finalizer frees every shard."""
+    r = run(driver, "handle_methods")
+    assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
+    assert "gpuMatrix methods ok" in r.stdout
 
 
 @pytest.mark.gpu
