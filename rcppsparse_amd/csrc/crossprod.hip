@@ -394,6 +394,13 @@ __global__ __launch_bounds__(256) void crossprod_rows_kernel(
 // tall kernel looks at every value it loads and raises a flag if one is not finite; the combine kernel then
 // leaves the output alone and the exact row-major path (whose kernels otherwise exit at once) does the work.
 typedef double xp_v4f64 __attribute__((ext_vector_type(4)));
+#ifndef RSP_TALL_SPLIT16
+#define RSP_TALL_SPLIT16 2
+#endif
+#ifndef RSP_TALL_SPLIT12
+#define RSP_TALL_SPLIT12 1
+#endif
+constexpr int kTallSplit16 = RSP_TALL_SPLIT16, kTallSplit12 = RSP_TALL_SPLIT12;   // workgroups sharing a row range at 16 / 12 column tiles
 
 // workgroup barrier for LDS hand-offs only (__syncthreads() would also wait for the loads just issued for the
 // next panel: s_waitcnt vmcnt(0))
@@ -425,25 +432,33 @@ __device__ __forceinline__ void tall_pair(int q, int nt, int& I, int& J) {
 // every column, 15.5 ms.  What did help: a panel row stride of W + 1 doubles (a column's 64 rows otherwise sit in
 // ONE LDS bank pair: 12.3 -> 10.7 ms) and telling the compiler to fit five workgroups per CU up to 48 columns (it
 // used 130 registers where 96 do: 10.7 -> 7.1 ms = 3.7 TB/s).
-template <int NT, int NW>   // column tiles, wavefronts per workgroup
+// SPLIT (round 3; 2 from 193 columns on): the tile pairs of one range of rows are dealt to SPLIT workgroups,
+// each of which densifies the panels for itself.  At 16 column tiles one workgroup of 16 wavefronts holds 9
+// accumulator tiles per wavefront beside the 16 columns it loads -- more than the 128 registers a wavefront
+// of a 1024-thread workgroup can have, and the spills made 1e6 x 256 cost 3.6 ms against 1.1 ms at 192 columns;
+// with 5 tiles per wavefront nothing spills, at the price of reading x and i twice.
+template <int NT, int NW, int SPLIT = 1>   // column tiles, wavefronts per workgroup, workgroups sharing a row range
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT <= 3 || NW >= 8 ? 4 : 1, 8)))
 void crossprod_tall_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ p, int32_t nrow,
     int32_t ncol, int64_t nnz, int32_t panels_per_group, int32_t* __restrict__ nonfinite,
     double* __restrict__ partial) {
-    constexpr int W = NT * 16, NP = NT * (NT + 1) / 2, MAXP = (NP + NW - 1) / NW, CPW = W / NW;
+    constexpr int W = NT * 16, NP = NT * (NT + 1) / 2, MAXP = (NP + NW * SPLIT - 1) / (NW * SPLIT), CPW = W / NW;
     __shared__ double panel[kTallRows][W + 1];   // (+1: the 64 rows of a column would otherwise sit in ONE LDS bank pair)
     __shared__ int32_t s_cur[W], s_end[W], s_next[NW];
     bool bad = false;   // a NaN or an infinity among the values this lane has loaded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ti[MAXP], tj[MAXP];
     xp_v4f64 acc[MAXP];
+    // this wavefront's tile pairs: q = (s * NW + wave) * SPLIT + half
+    const int group = blockIdx.x / SPLIT, half = blockIdx.x - group * SPLIT;
+    auto pair_of = [&](int s) { return (s * NW + wave) * SPLIT + half; };
 #pragma unroll
     for (int s = 0; s < MAXP; ++s) {
-        tall_pair(s * NW + wave < NP ? s * NW + wave : 0, NT, ti[s], tj[s]);
+        tall_pair(pair_of(s) < NP ? pair_of(s) : 0, NT, ti[s], tj[s]);
         acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
     }
-    const int64_t R0 = (int64_t)blockIdx.x * panels_per_group * kTallRows;
+    const int64_t R0 = (int64_t)group * panels_per_group * kTallRows;
     const int64_t R1 = R0 + (int64_t)panels_per_group * kTallRows < nrow ? R0 + (int64_t)panels_per_group * kTallRows : nrow;
     // this workgroup's piece of every column: [first entry with row >= R0, first entry with row >= R1)
     if (tid < W) {
@@ -472,23 +487,34 @@ void crossprod_tall_kernel(
     // 64 entries of each of this wavefront's columns travel in registers; the next 64 are requested as soon as
     // these have gone into the panel (their count moves the cursor), so they arrive during the MFMA phase.
     // Cursors and ends are wave-uniform and live in scalar registers.
-    int32_t row[CPW], cur[CPW], end[CPW];
+    // (16-wave workgroups, 12 or 16 columns per wavefront: the cursors stay in LDS -- only this wavefront touches
+    // its columns' slots, and a wavefront's LDS operations execute in order -- because 32 of them in scalar
+    // registers, plus the addresses made from them, spilled ~140 scalar registers into vector registers)
+    constexpr bool kCursorsInLds = false;   // (tried for 16-wave workgroups: the loads then carry vector addresses, 1.9 instead of 1.1 ms at 192 columns)
+    int32_t row[CPW], cur[kCursorsInLds ? 1 : CPW], end[kCursorsInLds ? 1 : CPW];
     double val[CPW];
+    volatile int32_t* v_cur = s_cur + wave * CPW;
+    volatile int32_t* v_end = s_end + wave * CPW;
+    auto cursor = [&](int k) { return kCursorsInLds ? __builtin_amdgcn_readfirstlane(v_cur[k]) : cur[k]; };
+    auto limit = [&](int k) { return kCursorsInLds ? __builtin_amdgcn_readfirstlane(v_end[k]) : end[k]; };
     auto fetch = [&]() {
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
-            const int32_t* rk = ri + cur[k];
-            const double* xk = x + cur[k];
-            const bool in = lane < end[k] - cur[k];
+            const int32_t ck = cursor(k), ek = limit(k);
+            const int32_t* rk = ri + ck;
+            const double* xk = x + ck;
+            const bool in = lane < ek - ck;
             row[k] = in ? rk[lane] : 0x7fffffff;
             val[k] = in ? xk[lane] : 0.0;
             bad |= ((uint32_t)__double2hiint(val[k]) & 0x7ff00000u) == 0x7ff00000u;
         }
     };
+    if (!kCursorsInLds) {
 #pragma unroll
-    for (int k = 0; k < CPW; ++k) {
-        cur[k] = __builtin_amdgcn_readfirstlane(s_cur[wave * CPW + k]);
-        end[k] = __builtin_amdgcn_readfirstlane(s_end[wave * CPW + k]);
+        for (int k = 0; k < CPW; ++k) {
+            cur[k] = __builtin_amdgcn_readfirstlane(s_cur[wave * CPW + k]);
+            end[k] = __builtin_amdgcn_readfirstlane(s_end[wave * CPW + k]);
+        }
     }
     fetch();
     int64_t r0 = R0;
@@ -504,9 +530,14 @@ void crossprod_tall_kernel(
             const int n = __popcll(__ballot(below));   // (also steps over rows below r0: an unsorted, invalid column)
             // next row of this column: its first entry not taken, or unknown (then: the next panel) if all 64 were
             int32_t nx = below ? 0x7fffffff : row[k];
-            if (n == 64 && (int64_t)cur[k] + 64 < end[k]) nx = (int32_t)(r0 + kTallRows < 0x7fffffff ? r0 + kTallRows : 0x7fffffff);
+            const int32_t ck = cursor(k);
+            if (n == 64 && (int64_t)ck + 64 < limit(k)) nx = (int32_t)(r0 + kTallRows < 0x7fffffff ? r0 + kTallRows : 0x7fffffff);
             pending = nx < pending ? nx : pending;
-            cur[k] += n;
+            if (kCursorsInLds) {
+                if (lane == 0) v_cur[k] = ck + n;
+            } else {
+                cur[k] += n;
+            }
         }
         fetch();
 #pragma unroll
@@ -516,12 +547,14 @@ void crossprod_tall_kernel(
         }
         if (lane == 0) s_next[wave] = pending;
         xp_lds_barrier();
-#pragma unroll 4
+        // (operands of UNR k-steps are in registers at once: 2 x MAXP doubles each)
+        constexpr int UNR = MAXP >= 5 ? 2 : 4;
+#pragma unroll UNR
         for (int ks = 0; ks < kTallRows / 4; ++ks) {
             const double* prow = &panel[4 * ks + (lane >> 4)][lane & 15];
 #pragma unroll
             for (int s = 0; s < MAXP; ++s)
-                if (s * NW + wave < NP)   // (uniform per wavefront)
+                if (pair_of(s) < NP)   // (uniform per wavefront)
                     acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(prow[16 * ti[s]], prow[16 * tj[s]], acc[s], 0, 0, 0);
         }
         int32_t nxt = s_next[0];
@@ -536,11 +569,11 @@ void crossprod_tall_kernel(
     // the combine kernel will leave it alone and the bit-identical kernels take over)
     if (__ballot(bad) != 0ull && lane == 0) atomicOr(nonfinite, 1);
     // tile (I, J), element (row, col) = C(16 I + row, 16 J + col); lane: col = lane & 15, row = (lane >> 4) + 4 r
-    double* mine = partial + (size_t)blockIdx.x * NP * 256;
+    double* mine = partial + (size_t)group * NP * 256;
 #pragma unroll
     for (int s = 0; s < MAXP; ++s)
-        if (s * NW + wave < NP) {
-            double* t = mine + (size_t)(s * NW + wave) * 256;
+        if (pair_of(s) < NP) {
+            double* t = mine + (size_t)pair_of(s) * 256;
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[s][r];
         }
@@ -610,7 +643,10 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         const int64_t npanels = ((int64_t)nrow + kTallRows - 1) / kTallRows;
         // one round of workgroups: what fits on the chip at this tile count (registers / LDS per workgroup)
         static const int per_cu[17] = {0, 5, 5, 5, 2, 0, 2, 0, 2, 0, 0, 0, 1, 0, 0, 0, 1};
-        const int64_t max_groups = 256 * per_cu[L->ntiles] < kTallMaxGroups ? 256 * per_cu[L->ntiles] : kTallMaxGroups;
+        // (16 tiles: two workgroups share every row range, so half as many ranges make one round)
+        int64_t max_groups = 256 * per_cu[L->ntiles] < kTallMaxGroups ? 256 * per_cu[L->ntiles] : kTallMaxGroups;
+        if (L->ntiles == 16) max_groups /= kTallSplit16;
+        if (L->ntiles == 12) max_groups /= kTallSplit12;
         int64_t per = (npanels + max_groups - 1) / max_groups;
         if (per < 1) per = 1;
         L->panels_per_group = (int32_t)per;
@@ -639,12 +675,12 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
     return hipSuccess;
 }
 
-template <int NT, int NW>
+template <int NT, int NW, int SPLIT = 1>
 static void launch_tall(const CrossprodLayout& L, const double* d_x, const int32_t* d_i, const int32_t* d_p,
                         int32_t nrow, int32_t ncol, int64_t nnz, int32_t* flag, double* partial,
                         hipStream_t stream) {
-    hipLaunchKernelGGL((crossprod_tall_kernel<NT, NW>), dim3((unsigned)L.ngroups), dim3(NW * 64), 0, stream, d_x, d_i, d_p, nrow,
-                       ncol, nnz, L.panels_per_group, flag, partial);
+    hipLaunchKernelGGL((crossprod_tall_kernel<NT, NW, SPLIT>), dim3((unsigned)L.ngroups * SPLIT), dim3(NW * 64), 0, stream,
+                       d_x, d_i, d_p, nrow, ncol, nnz, L.panels_per_group, flag, partial);
 }
 
 hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
@@ -671,8 +707,8 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             case 4: launch_tall<4, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
             case 6: launch_tall<6, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
             case 8: launch_tall<8, 8>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            case 12: launch_tall<12, 16>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
-            default: launch_tall<16, 16>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            case 12: launch_tall<12, 16, kTallSplit12>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
+            default: launch_tall<16, 16, kTallSplit16>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
         }
         const int64_t outs = (int64_t)ncol * ncol;
         hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, stream,

@@ -16,11 +16,11 @@ import oracle
 from rcppsparse_amd import capi, synth
 
 
-def tall():
+def tall(only_tall=False, shapes=None):
     L = capi.load()
-    for nrow, ncol, nnz in ((1_000_000, 64, 32_000_000), (10_000_000, 16, 80_000_000), (2_000_000, 128, 128_000_000),
-                            (4_000_000, 48, 190_000_000), (1_000_000, 192, 96_000_000), (1_000_000, 256, 128_000_000),
-                            (45_000_000, 48, 2**31 - 1)):
+    for nrow, ncol, nnz in shapes or ((1_000_000, 64, 32_000_000), (10_000_000, 16, 80_000_000), (2_000_000, 128, 128_000_000),
+                                      (4_000_000, 48, 190_000_000), (1_000_000, 192, 96_000_000), (1_000_000, 256, 128_000_000),
+                                      (45_000_000, 48, 2**31 - 1)):
         p = np.linspace(0, nnz, ncol + 1).astype(np.int64).astype(np.int32)
         pt = torch.from_numpy(p).cuda()
         xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
@@ -39,7 +39,7 @@ def tall():
             ts.append(a.elapsed_time(b))
         row = {"shape": f"{nrow}x{ncol}, nnz {nnz}", "tall_form_ms": sorted(ts)[2], "workspace_GB": ws.numel() / 1e9,
                "products": float(nnz) / nrow * nnz}
-        if nnz < 2**31 - 1:                     # (the bit-identical form takes 25 s there)
+        if nnz < 2**31 - 1 and not only_tall:   # (the bit-identical form takes 25 s there)
             tall_out = out.clone()
             capi.set_crossprod_exact(True)
             ws2 = torch.empty(int(L.rsp_crossprod_workspace_bytes(nrow, ncol, nnz)), dtype=torch.uint8, device="cuda")
@@ -60,6 +60,9 @@ def tall():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "tall":
         return tall()
+    if len(sys.argv) > 1 and sys.argv[1] == "tallfast":    # the tall form only, 1e6 rows x the given column counts
+        cols = [int(a) for a in sys.argv[2:]] or [128, 160, 192, 224, 256]
+        return tall(True, [(1_000_000, c, 500_000 * c) for c in cols])
     capi.load()
     shapes = ((100_000, 1000, 10_000_000), (100_000, 4000, 8_000_000), (1_000_000, 500, 5_000_000))
     if len(sys.argv) > 1:                       # e.g. "0" or "0,2": a subset of the shapes
