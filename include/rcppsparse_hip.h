@@ -220,17 +220,16 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
  * Reference RcppSparse.h:138-144 / :151-156: sums[i[j]] += x[j] over all stored
  * entries (rowMeans divides by Dim[1]).  Deterministic, no float atomics in
  * global memory, bit-stable run to run, within 1e-12 * sum|x| of the reference's
- * order.  The handle variants (the handle must have been uploaded with i[])
- * build the row-major form on first use -- a stable device radix sort of (i, x)
- * by row, i.e. columnSums(t(A)) -- and keep it: repeated calls only reduce
- * (matrices of up to 65536 rows are summed straight from x / i instead, like the
- * device variants: no sort, no second copy of x).
- * The device variants accumulate in LDS, 16384 rows per workgroup: matrices of
- * up to 65536 rows are summed straight from x / i (workspace: the workgroups'
- * partial sums, at most a few hundred MB); larger ones are first regrouped by
- * block of 16384 rows in the caller's workspace on every call (one hand-written
- * partition pass; more than 1.36e7 rows: a sort by 4096-row block instead), with
- * a workspace of 12 B/nnz + up to 64 B/row + a count table of at most 64 MB.
+ * order.  All forms accumulate in LDS, 16384 rows per workgroup, and are hand-written
+ * (no library sort): matrices of up to 65536 rows are summed straight from x / i
+ * (workspace: the workgroups' partial sums, at most a few hundred MB); larger ones are
+ * first regrouped by block of 16384 rows in ONE partition pass (up to 1.36e7 rows), by
+ * coarse block of 2 / 4 / 8 such blocks (up to 1.09e8 rows; every row block then picks
+ * its entries out of its coarse block's), or in two passes (more rows still), with a
+ * workspace of 12 B/nnz (two passes: 24 B/nnz) + up to 64 B/row + a count table of at
+ * most 64 MB.  The handle variants (the handle must have been uploaded with i[]) build
+ * that regrouped copy on first use and keep it: repeated calls only accumulate
+ * (12 B/nnz); the device variants regroup in the caller's workspace on every call.
  * Entries whose row index is outside [0, nrow) are left out, not added elsewhere.
  * Ask for the workspace size with the device current that will run the call
  * (the plan looks at its CU count).

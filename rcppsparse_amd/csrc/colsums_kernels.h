@@ -106,18 +106,17 @@ struct DynamicLdsLimit {
 };
 
 // Workspace layout of the row-wise path (rowsums.hip); offsets in bytes, 256-aligned.
-// mode 0 (block form, one-shot calls): persistent = the entries grouped by row block (values, row indices)
-// and the first entry of every block; scratch = rocPRIM temp.
-// mode 1 (row form, kept by the handle): persistent = row-major values + row offsets + the column-sum
-// carries; scratch = sort keys + rocPRIM temp.
-// mode 2 (tile partition, one-shot calls up to 1.6e7 rows): persistent as mode 0; scratch = the
-// (block, supertile) count table + rocPRIM scan temp.
+// persistent = the entries grouped by 16384-row block (values, row indices; not in the direct form), the first
+// slot of every block and the parts' sums: what a handle keeps between calls.  scratch = the (block, supertile)
+// count table + scan temp, and in the two-level form (mode 3, more than 832 blocks) the intermediate copy grouped
+// by bucket of 512 blocks with the buckets' first slots; free again once the build has run.
 struct RowSumsLayout {
-    int mode;
-    size_t vals_off, rows_off, boff_off, prow_off, colsums_off, partial_off, persistent_bytes;
-    size_t table_off, keys_off, temp_off, temp_bytes, scratch_bytes;
-    int32_t shift, nblocks, nsuper, nsplit;   // nsplit: accumulate workgroups per row block (mode 2)
-    bool direct;   // mode 2, one row block: no regrouping, the accumulate pass reads the caller's x / i
+    int mode;   // 2 = one partition pass (or none: direct), 3 = two passes
+    size_t vals_off, rows_off, boff_off, partial_off, persistent_bytes;
+    size_t table_off, temp_off, temp_bytes, mid_vals_off, mid_rows_off, bucket_off, scratch_bytes;
+    int32_t shift, nblocks, nsuper, nsplit, nbuckets;   // nsplit: accumulate workgroups per row block
+    int32_t sub, ncoarse;   // the partition pass groups by coarse block of 2^sub row blocks (ncoarse of them)
+    bool direct;   // up to 4 row blocks: no regrouping, the accumulate pass reads the caller's x / i
     int64_t super_elems;
 };
 hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form, RowSumsLayout* L);

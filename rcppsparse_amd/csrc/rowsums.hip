@@ -2,17 +2,15 @@
 //
 // Reference inst/include/RcppSparse.h:138-144 scatters sums(i[j]) += x[j] while walking the
 // columns.  On the device that is a reduction by key with 1e7 keys and no locality in the key.
-// Four forms, chosen in plan_row_sums:
+// All hand-written; forms chosen in plan_row_sums by the number of 16384-row blocks (what one CU's LDS holds as sums):
 //
-//   direct (one-shot calls on matrices of up to 4 row blocks, 65536 rows): nothing is regrouped.  Steps 4
-//     and 5 below run on the caller's x / i, every block's workgroups scanning all entries and adding
-//     those of their block: 12 B/nnz per block, no workspace beyond the parts' sums
-//     (5e8 nnz: 1.0 / 1.4 / 2.9 / 2.8 ms for 1 / 2 / 3 / 4 blocks; regrouping first costs 4.2-4.9 ms, and from 5
-//     blocks on is the faster way: 4.4 against 4.8 ms).
+//   direct (up to 4 row blocks, 65536 rows): nothing is regrouped.  Steps 4 and 5 below run on the caller's
+//     x / i, every block's workgroups scanning all entries and adding those of their block: 12 B/nnz per block,
+//     no workspace beyond the parts' sums (5e8 nnz: 1.0 / 1.4 / 2.9 / 2.8 ms for 1 / 2 / 3 / 4 blocks; regrouping
+//     first costs 4.2-4.9 ms, and from 5 blocks on is the faster way: 4.4 against 4.8 ms).
 //
-//   tile partition (one-shot calls, rsp_row_sums_device, 4 to 832 row blocks = up to 1.36e7 rows) -- all hand-written:
-//     the entries are regrouped by ROW BLOCK (16384 rows: what one CU's LDS holds as sums) in ONE
-//     pass, then added up block by block.
+//   tile partition (5 to 832 row blocks = up to 1.36e7 rows): the entries are regrouped by ROW BLOCK in ONE pass,
+//     then added up block by block.
 //       1. rows_tile_histogram_kernel   entries per (block, supertile)              reads  4 B/nnz
 //       2. one exclusive scan over that table (rocPRIM; a few MB) = first output slot of every pair
 //       3. rows_tile_partition_kernel   a workgroup walks its supertile in tiles of 22528 entries (22
@@ -29,15 +27,19 @@
 //     function of the data alone (no global atomics, wave-private counters combined in a fixed
 //     order), and a row's terms are added by one wavefront in slot order: bit-stable run to run.
 //
-//   block sort (one-shot calls on matrices with more rows): a stable rocPRIM radix sort over the
-//     block bits of the row index only (4096-row blocks), then rows_block_accumulate_kernel (one
-//     wavefront per block, sums in 32 KB of LDS).
+//   coarse blocks (round 3; up to 8 x 832 row blocks = 1.09e8 rows): the same single pass regroups by COARSE block
+//     of 2 / 4 / 8 row blocks, and in step 4 every row block scans its coarse block's entries for its own (12 B/nnz
+//     x 2 / 4 / 8 there).  1e9 entries: 12.9 ms at 2e7 rows, 17.3 ms at 4e7 (a library radix sort by block: 18.8 ms
+//     at 2e7).
 //
-//   row form (the handle API above 65536 rows, which keeps it for repeated calls): full stable sort by row,
-//     row offsets by a vectorised lower_bound, then the column-sum kernels on the row-major
-//     values (8 B/nnz per repeated call instead of 12).
+//   two levels (round 3; more rows still): a first pass regroups by BUCKET of 512 row blocks into an intermediate
+//     copy, a second regroups every bucket by its blocks (the same kernels on the bucket's range): 21.2 ms for 1e9
+//     entries in 1.2e8 rows, workspace 24 B/nnz.
 //
-// All are deterministic and within the usual 1e-12 * sum|x| of the reference's order.
+// A handle (rsp_csc_row_sums) keeps the regrouped copy and repeats steps 4 and 5 only (12 B/nnz per call).
+// Rounds 1-2 sorted with rocPRIM here (by 4096-row block above 1.36e7 rows, fully by row behind the handle); the
+// only library call left is the exclusive scan of the count table.
+// All forms are deterministic and within the usual 1e-12 * sum|x| of the reference's order.
 // Round-2 history (profiles/r02_rowsums.md): partitioning WITHOUT sorting each tile in LDS first
 // (every lane storing its entry straight to its block's cursor) took 47 ms for the scatter alone.
 #include <hip/hip_runtime.h>
@@ -52,11 +54,12 @@ namespace rsp {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr int kRowBlockShift = 12;   // block sort: 4096 rows per block, 32 KB of LDS sums per wavefront, 5 per CU
-
 // tile partition
 constexpr int kPartShift = 14;            // 16384 rows per block: 128 KB of LDS sums per workgroup
 constexpr int kPartMaxBlocks = 832;       // LDS counters / cursors of the partition kernel (with the stage: < 160 KB)
+constexpr int kPartBucketShift = kPartShift + 9;   // two-level form: a bucket of the first pass = 512 blocks = 8.4e6 rows
+constexpr int kPartMaxSub = 3;            // up to 2^3 row blocks per coarse block before the two-level form takes over
+constexpr int kPartTwoLevelBlocks = 512;  // blocks either pass of the two-level form separates (first pass: <= 256 buckets)
 constexpr int kPartThreads = 1024;        // partition workgroup: 16 wavefronts
 constexpr int kPartWaves = kPartThreads / 64;
 constexpr int kPartPerThread = 22;        // entries a thread holds in registers while its tile is ranked (24 spills)
@@ -69,32 +72,6 @@ constexpr int kAccStagers = kAccThreads - 64;
 constexpr int kAccDepth = 8;              // steps of entries a staging thread has in flight (8 x 11.5 KB per CU)
 constexpr int kAccMaxSplit = 1024;        // workgroups that may share one row block
 constexpr int kDirectMaxBlocks = 4;       // up to here the accumulate pass scans the caller's x / i once per block instead
-
-// bits needed to hold every value up to and including v
-static unsigned bits_to_hold(uint32_t v) {
-    unsigned b = 1;
-    while (b < 32 && (v >> b) != 0) ++b;
-    return b;
-}
-
-// Sort key of an entry: its row index, or ONE value past every valid key when the index is not in
-// [0, nrow) -- not a valid dgCMatrix.  Such entries then sort behind all others, outside every row's
-// (or row block's) range; left as they are their upper bits would scatter them among the valid entries
-// and the offsets searched below would be those of an unsorted array.
-struct RowKey {
-    uint32_t nrow, past;
-    __host__ __device__ uint32_t operator()(uint32_t row) const { return row < nrow ? row : past; }
-};
-using RowKeyIterator = rocprim::transform_iterator<const uint32_t*, RowKey, uint32_t>;
-
-// block sort: the key past the valid ones is the first row of the block after the last
-static uint32_t block_sort_past(int32_t nblocks) { return (uint32_t)nblocks << kRowBlockShift; }
-
-// block id of an entry, as the offsets search sees the sorted row indices
-struct RowBlockOf {
-    int shift;
-    __host__ __device__ uint32_t operator()(uint32_t row) const { return row >> shift; }
-};
 
 // ---------------------------------------------------------------------------------------------
 // planning
@@ -135,146 +112,79 @@ static int accumulate_split(int32_t nblocks, int64_t stream_entries, int64_t row
 
 hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form,
                          RowSumsLayout* L) {
+    (void)colsums_ws_bytes;
+    (void)keep_row_form;   // (a handle keeps the regrouped copy -- `persistent` -- and repeats the accumulate pass only)
     memset(L, 0, sizeof(*L));
-    size_t sort_bytes = 0, search_bytes = 0, off = 0;
+    size_t off = 0;
     hipError_t e;
     const int64_t part_blocks = ((int64_t)nrow + (1 << kPartShift) - 1) >> kPartShift;
-    // (a handle of a matrix with so few rows that nothing needs regrouping does not build the row form either:
-    // no sort on the first call, no second copy of x in HBM)
-    if (keep_row_form && part_blocks <= kDirectMaxBlocks) keep_row_form = false;
-    if (!keep_row_form && part_blocks <= kPartMaxBlocks) {
-        L->mode = 2;
-        L->shift = kPartShift;
-        L->nblocks = (int32_t)(part_blocks > 0 ? part_blocks : 1);
-        // supertile: whole tiles, small enough for ~1000 workgroups when the matrix allows, large enough
-        // for the count table to fit its budget
-        int64_t tiles = nnz / ((int64_t)1024 * kTileElems);
-        tiles = tiles < 1 ? 1 : tiles > kTilesPerSuper ? kTilesPerSuper : tiles;
-        int64_t super = (int64_t)kTileElems * tiles;
-        while (((nnz + super - 1) / super) * L->nblocks * 4 > (int64_t)kCountTableMaxBytes) super *= 2;
-        L->super_elems = super;
-        L->nsuper = (int32_t)((nnz + super - 1) / super);
-        const int64_t rows_here = nrow < (1 << kPartShift) ? (nrow > 0 ? nrow : 1) : (1 << kPartShift);
-        // Few blocks: no regrouping at all.  A block's workgroups scan the caller's x / i as they are and add
-        // the entries of their block (12 B/nnz per block instead of ~40 B/nnz and the partition pass's LDS work;
-        // 5e8 nnz: 1.0 ms for one block, 2.8 ms for four; the partition form takes 4.2-4.9 ms at 2-61 blocks).
-        L->direct = L->nblocks <= kDirectMaxBlocks;
-        L->nsplit = accumulate_split(L->nblocks, L->direct ? nnz : nnz / L->nblocks, rows_here);
-        const size_t table_entries = (size_t)L->nsuper * (size_t)L->nblocks + 1;   // + the total
-        size_t temp = 0;
-        e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, table_entries,
-                                    rocprim::plus<int32_t>(), (hipStream_t)0);
-        if (e != hipSuccess) return e;
-        if (!L->direct) {
-            L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);            // x grouped by row block
-            L->rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);            // their row indices
-        }
-        L->boff_off = off;  off = align_up(off + ((size_t)L->nblocks + 1) * 4, 256);   // first slot of every block
-        L->partial_off = off;                                                          // sums per (part, row)
-        if (L->nsplit > 1) off = align_up(off + (size_t)L->nsplit * (size_t)(nrow > 0 ? nrow : 0) * 8, 256);
-        L->persistent_bytes = off;
-        off = 0;
-        L->table_off = off; off = align_up(off + table_entries * 4, 256);
-        L->temp_off = off;
-        L->temp_bytes = temp;
-        L->scratch_bytes = align_up(off + temp, 256);
-        return hipSuccess;
+    L->shift = kPartShift;
+    L->nblocks = (int32_t)(part_blocks > 0 ? part_blocks : 1);
+    // More row blocks than one partition pass separates (832 = 1.36e7 rows): regroup by COARSE block of 2, 4 or 8
+    // row blocks -- still one pass -- and let every row block scan its coarse block's entries for its own in the
+    // accumulate pass (12 B/nnz x 2, 4, 8 there: 2e7 rows 13 ms where two partition passes take 21 and a radix sort
+    // by block took 19).  Beyond 8 (1.09e8 rows) the two-level form takes over.
+    L->sub = 0;
+    while (L->sub < kPartMaxSub && ((L->nblocks + (1 << L->sub) - 1) >> L->sub) > kPartMaxBlocks) ++L->sub;
+    L->ncoarse = (L->nblocks + (1 << L->sub) - 1) >> L->sub;
+    L->mode = L->ncoarse <= kPartMaxBlocks ? 2 : 3;
+    if (L->mode == 3) {
+        L->sub = 0;
+        L->ncoarse = L->nblocks;
     }
-    if (!keep_row_form) {
-        L->mode = 0;
-        L->shift = kRowBlockShift;
-        L->nblocks = (int32_t)(((int64_t)nrow + (1 << kRowBlockShift) - 1) >> kRowBlockShift);
-        if (L->nblocks < 1) L->nblocks = 1;
-        {
-            const RowKey key{(uint32_t)nrow, block_sort_past(L->nblocks)};
-            e = rocprim::radix_sort_pairs(nullptr, sort_bytes, RowKeyIterator((const uint32_t*)nullptr, key),
-                                          (uint32_t*)nullptr, (const double*)nullptr, (double*)nullptr, (size_t)nnz,
-                                          (unsigned)kRowBlockShift, bits_to_hold(key.past), (hipStream_t)0);
-            if (e != hipSuccess) return e;
-        }
-        auto ids = rocprim::make_transform_iterator((const uint32_t*)nullptr, RowBlockOf{kRowBlockShift});
-        e = rocprim::lower_bound(nullptr, search_bytes, ids, rocprim::counting_iterator<uint32_t>(0),
-                                 (int32_t*)nullptr, (size_t)nnz, (size_t)L->nblocks + 1, rocprim::less<uint32_t>(),
-                                 (hipStream_t)0);
-        if (e != hipSuccess) return e;
-        L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);                // x grouped by row block
-        L->rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);                // their row indices
-        L->boff_off = off;  off = align_up(off + ((size_t)L->nblocks + 1) * 4, 256);   // first entry of every block
-        L->persistent_bytes = off;
-        off = 0;
-    } else {
-        L->mode = 1;
-        const RowKey key{(uint32_t)nrow, (uint32_t)nrow};
-        e = rocprim::radix_sort_pairs(nullptr, sort_bytes, RowKeyIterator((const uint32_t*)nullptr, key),
-                                      (uint32_t*)nullptr, (const double*)nullptr, (double*)nullptr, (size_t)nnz, 0u,
-                                      bits_to_hold(key.past), (hipStream_t)0);
-        if (e != hipSuccess) return e;
-        e = rocprim::lower_bound(nullptr, search_bytes, (const uint32_t*)nullptr,
-                                 rocprim::counting_iterator<uint32_t>(0), (int32_t*)nullptr, (size_t)nnz,
-                                 (size_t)nrow + 1, rocprim::less<uint32_t>(), (hipStream_t)0);
-        if (e != hipSuccess) return e;
-        L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);         // x sorted by row
-        L->prow_off = off;  off = align_up(off + ((size_t)nrow + 1) * 4, 256);  // row offsets
-        L->colsums_off = off; off = align_up(off + colsums_ws_bytes, 256);      // chunk carries
-        L->persistent_bytes = off;
-        off = 0;
-        L->keys_off = off;  off = align_up(off + (size_t)nnz * 4, 256);         // sorted row indices
+    // supertile: whole tiles, small enough for ~1000 workgroups when the matrix allows, large enough
+    // for the count table to fit its budget
+    int64_t tiles = nnz / ((int64_t)1024 * kTileElems);
+    tiles = tiles < 1 ? 1 : tiles > kTilesPerSuper ? kTilesPerSuper : tiles;
+    int64_t super = (int64_t)kTileElems * tiles;
+    const int32_t table_blocks = L->mode == 2 ? L->ncoarse : kPartTwoLevelBlocks;   // blocks one pass separates
+    while (((nnz + super - 1) / super) * table_blocks * 4 > (int64_t)kCountTableMaxBytes) super *= 2;
+    L->super_elems = super;
+    L->nsuper = (int32_t)((nnz + super - 1) / super);
+    const int64_t rows_here = nrow < (1 << kPartShift) ? (nrow > 0 ? nrow : 1) : (1 << kPartShift);
+    // Few blocks: no regrouping at all.  A block's workgroups scan the caller's x / i as they are and add
+    // the entries of their block (12 B/nnz per block instead of ~40 B/nnz and the partition pass's LDS work;
+    // 5e8 nnz: 1.0 ms for one block, 2.8 ms for four; the partition form takes 4.2-4.9 ms at 2-61 blocks).
+    L->direct = L->nblocks <= kDirectMaxBlocks;
+    L->nsplit = accumulate_split(L->nblocks, L->direct ? nnz : nnz / L->ncoarse, rows_here);
+    // Many blocks (more than one pass's LDS counters hold: 832 = 1.36e7 rows): two levels.  The first pass regroups
+    // by BUCKET of 512 blocks (8.4e6 rows; at most 256 buckets for 2^31 rows) into an intermediate copy, the second
+    // regroups every bucket by its blocks -- the same two kernels, run on the bucket's range of the intermediate.
+    L->nbuckets = L->mode == 3 ? (int32_t)(((int64_t)nrow + ((int64_t)1 << kPartBucketShift) - 1) >> kPartBucketShift) : 0;
+    const size_t table_entries = (size_t)L->nsuper * (size_t)table_blocks + 1;   // + the total
+    size_t temp = 0;
+    e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, table_entries,
+                                rocprim::plus<int32_t>(), (hipStream_t)0);
+    if (e != hipSuccess) return e;
+    if (!L->direct) {
+        L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);            // x grouped by row block
+        L->rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);            // their row indices
     }
-    L->temp_bytes = sort_bytes > search_bytes ? sort_bytes : search_bytes;
-    L->temp_off = off;
-    L->scratch_bytes = align_up(off + L->temp_bytes, 256);
+    L->boff_off = off;  off = align_up(off + ((size_t)L->ncoarse + 1) * 4, 256);   // first slot of every (coarse) block
+    L->partial_off = off;                                                          // sums per (part, row)
+    if (L->nsplit > 1) off = align_up(off + (size_t)L->nsplit * (size_t)(nrow > 0 ? nrow : 0) * 8, 256);
+    L->persistent_bytes = off;
+    off = 0;
+    L->table_off = off; off = align_up(off + table_entries * 4, 256);
+    L->temp_off = off;  off = align_up(off + temp, 256);
+    L->temp_bytes = temp;
+    if (L->mode == 3) {   // the intermediate copy (grouped by bucket) and the buckets' first slots
+        L->mid_vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);
+        L->mid_rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);
+        L->bucket_off = off;    off = align_up(off + ((size_t)L->nbuckets + 1) * 4, 256);
+    }
+    L->scratch_bytes = off;
     return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------
-// block form: accumulate
+// LDS adds
 // ---------------------------------------------------------------------------------------------
 // sums[r] += v as one LDS instruction (an IEEE double add performed by the LDS unit).  A wave's LDS
 // instructions execute in issue order; lanes of one instruction that hit the same row are serialised
 // by the hardware, always the same way.
 __device__ __forceinline__ void lds_add_f64(double* a, double v) {
     __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)a, v);
-}
-
-// One wavefront per row block: its entries (storage order) into LDS sums, then out.
-template <bool MEANS>
-__global__ __launch_bounds__(64) void rows_block_accumulate_kernel(
-    const double* __restrict__ px, const int32_t* __restrict__ pr, const int32_t* __restrict__ boff,
-    int32_t nrow, int32_t shift, double* __restrict__ out, double divisor) {
-#pragma clang fp contract(off)
-    extern __shared__ double s_sums[];
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    const int rows_here = 1 << shift;
-    const int mask = rows_here - 1;
-    for (int r = lane; r < rows_here; r += 64) s_sums[r] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-    const int32_t s0 = boff[b], s1 = boff[b + 1];
-    // 16 steps of 64 entries in flight (12 KB per wavefront, 5 wavefronts per CU)
-    for (int64_t s = s0; s < s1; s += 16 * 64) {   // (64-bit: s1 may be 2^31 - 1)
-        int32_t r[16];
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int64_t j = s + k * 64 + lane;
-            const bool in = j < s1;
-            r[k] = in ? pr[j] : -1;
-            v[k] = in ? px[j] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (r[k] >= 0) lds_add_f64(&s_sums[r[k] & mask], v[k]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int64_t row0 = (int64_t)b << shift;
-    for (int r = lane; r < rows_here; r += 64) {
-        const int64_t row = row0 + r;
-        if (row < nrow) {
-            double t = s_sums[r] + 0.0;   // a sum of -0.0 terms comes out +0.0, like the reference's accumulator
-            if (MEANS) t = t / divisor;   // RcppSparse.h:153-154
-            out[row] = t;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -302,16 +212,22 @@ __device__ __forceinline__ void* uniform_ptr(const void* p) {
 //    scan yields for every pair the number of entries in earlier blocks plus those of the same block
 //    in earlier supertiles: its first output slot.  (Row indices outside [0, nrow) -- not a valid
 //    dgCMatrix -- are neither counted here nor moved below.)
+//    `seg` (two-level form): the pass works on entries [seg[0], seg[1]) only -- one bucket of the first level --
+//    and on rows [row_base, row_base + nrow); nullptr = all nnz entries.  The grid is sized for the worst case
+//    (the host does not know the bucket sizes), supertiles past the segment's end count nothing.
 __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
     const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift, int32_t nblocks,
-    int64_t super_elems, int32_t nsuper, int32_t* __restrict__ table) {
+    int64_t super_elems, int32_t nsuper, int32_t* __restrict__ table, const int32_t* __restrict__ seg,
+    int32_t row_base) {
     extern __shared__ int32_t s_hist[];
     const int tid = threadIdx.x;
     const int s = blockIdx.x;
     for (int b = tid; b < nblocks; b += kPartThreads) s_hist[b] = 0;
     __syncthreads();
-    const int64_t e0 = (int64_t)s * super_elems;
-    const int64_t e1 = e0 + super_elems < nnz ? e0 + super_elems : nnz;
+    const int64_t seg0 = seg ? seg[0] : 0, seg1 = seg ? seg[1] : nnz;
+    int64_t e0 = seg0 + (int64_t)s * super_elems;
+    e0 = e0 < seg1 ? e0 : seg1;
+    const int64_t e1 = e0 + super_elems < seg1 ? e0 + super_elems : seg1;
     // 16 bytes per lane and load (1 KB per wave instruction: 4-byte loads reach about two thirds of that rate), two
     // loads in flight per thread; a buffer resource so that the last, partial quad reads zeros instead of faulting
     const int32_t len = __builtin_amdgcn_readfirstlane((int32_t)(e1 - e0));
@@ -327,8 +243,8 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int32_t j = e + k * 4 * kPartThreads + tid * 4 + c;
-                const int32_t r = q[k][c];
-                if (j < len && (uint32_t)r < (uint32_t)nrow) atomicAdd(&s_hist[(uint32_t)r >> shift], 1);
+                const uint32_t r = (uint32_t)q[k][c] - (uint32_t)row_base;
+                if (j < len && r < (uint32_t)nrow) atomicAdd(&s_hist[r >> shift], 1);
             }
     }
     __syncthreads();
@@ -347,7 +263,7 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
 __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift,
     int32_t nblocks, int64_t super_elems, int32_t nsuper, const int32_t* __restrict__ first_slot,
-    double* __restrict__ px, int32_t* __restrict__ pr) {
+    double* __restrict__ px, int32_t* __restrict__ pr, const int32_t* __restrict__ seg, int32_t row_base) {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double* stage_x = (double*)s_raw;                                   // kStageElems
     int32_t* stage_r = (int32_t*)(stage_x + kStageElems);               // kStageElems
@@ -356,9 +272,13 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
     int32_t* cnt = tstart + nblocks + 1;                                // kPartWaves x nblocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x;
-    for (int b = tid; b < nblocks; b += kPartThreads) cursor[b] = first_slot[(size_t)b * nsuper + s];
-    const int64_t e0 = (int64_t)s * super_elems;
-    const int64_t e1 = e0 + super_elems < nnz ? e0 + super_elems : nnz;
+    // (two-level form: this launch regroups one bucket of the first level, entries [seg[0], seg[1]) of x / ri,
+    // by rows relative to row_base, into the same range of px / pr)
+    const int64_t seg0 = seg ? seg[0] : 0, seg1 = seg ? seg[1] : nnz;
+    for (int b = tid; b < nblocks; b += kPartThreads) cursor[b] = first_slot[(size_t)b * nsuper + s] + (int32_t)seg0;
+    int64_t e0 = seg0 + (int64_t)s * super_elems;
+    e0 = e0 < seg1 ? e0 : seg1;
+    const int64_t e1 = e0 + super_elems < seg1 ? e0 + super_elems : seg1;
     int32_t* mycnt = cnt + (size_t)wave * nblocks;
     // the supertile as two buffer resources: a load is then one VGPR offset (the thread) plus a scalar
     // offset (tile, k) -- no address registers, of which 48 loads would need 96 -- and reads past the
@@ -391,8 +311,11 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
         // program order inside the wavefront, hardware order inside one LDS instruction -- both fixed
 #pragma unroll
         for (int k = 0; k < kPartPerThread; ++k) {
-            if (tile + k * kPartThreads + tid >= len) r[k] = -1;   // (a load past the end returned 0)
-            pos[k] = (uint32_t)r[k] < (uint32_t)nrow ? atomicAdd(&mycnt[(uint32_t)r[k] >> shift], 1) : -1;
+            // (a load past the end returned 0: give it, like every row outside [row_base, row_base + nrow), the mark -1)
+            const uint32_t rel = (uint32_t)r[k] - (uint32_t)row_base;
+            const bool ok = tile + k * kPartThreads + tid < len && rel < (uint32_t)nrow;
+            r[k] = ok ? r[k] : -1;
+            pos[k] = ok ? atomicAdd(&mycnt[rel >> shift], 1) : -1;
         }
         lds_barrier();
         // per block: counts of the wavefronts -> exclusive prefix over the wavefronts, total into tstart
@@ -434,7 +357,7 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
 #pragma unroll
         for (int k = 0; k < kPartPerThread; ++k)
             if (pos[k] >= 0) {
-                const int b = (uint32_t)r[k] >> shift;
+                const int b = ((uint32_t)r[k] - (uint32_t)row_base) >> shift;
                 pos[k] += tstart[b] + mycnt[b];
             }
         const int total = __builtin_amdgcn_readfirstlane(tstart[nblocks]);   // (uniform, and the compiler knows)
@@ -452,7 +375,7 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
             const int n = total - base < kStageElems ? total - base : kStageElems;
             for (int j = tid; j < n; j += kPartThreads) {
                 const int32_t rr = stage_r[j];
-                const int b = (uint32_t)rr >> shift;
+                const int b = ((uint32_t)rr - (uint32_t)row_base) >> shift;
                 const int32_t dest = cursor[b] + (base + j - tstart[b]);
                 px[dest] = stage_x[j];
                 pr[dest] = rr;
@@ -471,11 +394,14 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
 
 // boff[b] = first slot of block b (= the scanned table's entry for supertile 0), boff[nblocks] = number of
 // entries with a valid row index (the scan's last element)
+//    (two-level form: the slots are relative to the bucket's first entry seg[0]; only the last bucket writes the
+//    closing entry, which is then the end of the last block)
 __global__ void rows_tile_offsets_kernel(const int32_t* __restrict__ first_slot, int32_t nblocks, int32_t nsuper,
-                                         int32_t* __restrict__ boff) {
+                                         int32_t* __restrict__ boff, const int32_t* __restrict__ seg, int32_t close) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nblocks) boff[b] = first_slot[(size_t)b * nsuper];
-    if (b == nblocks) boff[b] = first_slot[(size_t)nblocks * nsuper];
+    const int32_t base = seg ? seg[0] : 0;
+    if (b < nblocks) boff[b] = base + first_slot[(size_t)b * nsuper];
+    if (b == nblocks && close) boff[b] = base + first_slot[(size_t)nblocks * nsuper];
 }
 
 // 4. `nsplit` 16-wave workgroups per row block, each over an equal part of the block's entries.  Fifteen
@@ -492,7 +418,7 @@ __global__ void rows_tile_offsets_kernel(const int32_t* __restrict__ first_slot,
 template <bool MEANS>
 __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     const double* __restrict__ px, const int32_t* __restrict__ pr, const int32_t* __restrict__ boff,
-    int64_t direct_nnz, int32_t nrow, int32_t shift, int32_t nsplit, double* __restrict__ out,
+    int64_t direct_nnz, int32_t nrow, int32_t shift, int32_t sub, int32_t nsplit, double* __restrict__ out,
     double* __restrict__ part_out, double divisor) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -505,7 +431,10 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     for (int r = tid; r < rows_here; r += kAccThreads) sums[r] = 0.0;
     // this workgroup's part of the block: whole steps, the same for every run
     // (direct form: every block scans all of x / i, which are then the caller's arrays)
-    const int32_t s0 = direct_nnz >= 0 ? 0 : boff[b], s1 = direct_nnz >= 0 ? (int32_t)direct_nnz : boff[b + 1];
+    // (sub > 0: the entries are grouped by COARSE block of 2^sub row blocks -- matrices of more than 832 row blocks --
+    // and each of its row blocks scans the coarse block's entries for its own, like the direct form does with all)
+    const int cb = b >> sub;
+    const int32_t s0 = direct_nnz >= 0 ? 0 : boff[cb], s1 = direct_nnz >= 0 ? (int32_t)direct_nnz : boff[cb + 1];
     const int32_t steps_all = (int32_t)(((int64_t)s1 - s0 + kAccStagers - 1) / kAccStagers);
     const int32_t steps_per = (steps_all + nsplit - 1) / nsplit;
     const int64_t u0_ = (int64_t)s0 + (int64_t)part * steps_per * kAccStagers;
@@ -593,19 +522,6 @@ __global__ void rows_combine_parts_kernel(const double* __restrict__ part_out, i
     out[row] = t;
 }
 
-// row form: the values of entries whose row index was not in [0, nrow) (sorted behind all rows) become +0.0
-__global__ void rows_clear_invalid_tail_kernel(double* __restrict__ vals, const int32_t* __restrict__ prow,
-                                               int32_t nrow, int64_t nnz) {
-    const int64_t first = prow[nrow];
-    for (int64_t j = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz;
-         j += (int64_t)gridDim.x * blockDim.x)
-        vals[j] = 0.0;
-}
-
-__global__ void rows_close_offsets_kernel(int32_t* __restrict__ prow, int32_t nrow, int64_t nnz) {
-    prow[nrow] = (int32_t)nnz;
-}
-
 // 5b. the same for many parts (the direct form splits a block among up to 1024 workgroups): one wavefront per
 //     row, lane l adding parts l, l + 64, ... in that order and the 64 lane sums meeting in a fixed butterfly
 //     (one thread walking 256 parts costs 256 memory round trips: 0.1 ms of a 1.4 ms call)
@@ -674,142 +590,113 @@ hipError_t launch_add_partials(const double* parts, int32_t nparts, int64_t stri
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-// Builds the row-wise form in `persist`; `scratch` is free again when the stream has passed this point.
-hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
-                            const RowSumsLayout& L, void* persist, void* scratch, hipStream_t stream) {
-    void* temp = (char*)scratch + L.temp_off;
-    size_t temp_bytes = L.temp_bytes;
-    hipError_t e = hipSuccess;
-    if (L.mode == 1) {
-        double* vals = (double*)((char*)persist + L.vals_off);
-        int32_t* prow = (int32_t*)((char*)persist + L.prow_off);
-        uint32_t* keys = (uint32_t*)((char*)scratch + L.keys_off);
-        if (nnz > 0) {
-            const RowKey key{(uint32_t)nrow, (uint32_t)nrow};   // (entries outside [0, nrow) sort behind row nrow - 1)
-            e = rocprim::radix_sort_pairs(temp, temp_bytes, RowKeyIterator((const uint32_t*)d_i, key), keys, d_x, vals,
-                                          (size_t)nnz, 0u, bits_to_hold(key.past), stream);
-            if (e != hipSuccess) return e;
-        }
-        temp_bytes = L.temp_bytes;
-        // prow[r] = first position whose key is >= r  (r = 0..nrow; prow[nrow] = number of valid entries)
-        e = rocprim::lower_bound(temp, temp_bytes, (const uint32_t*)keys, rocprim::counting_iterator<uint32_t>(0),
-                                 prow, (size_t)nnz, (size_t)nrow + 1, rocprim::less<uint32_t>(), stream);
-        if (e != hipSuccess || nnz == 0) return e;
-        // What lies behind prow[nrow] belongs to no row.  Those values become +0.0 and the last row takes them
-        // in (prow[nrow] = nnz), so that the column-sum kernels see offsets that end at nnz, like a valid p[]:
-        // adding +0.0 changes no sum (the accumulator starts at +0.0, so no partial sum is -0.0).
-        hipLaunchKernelGGL(rows_clear_invalid_tail_kernel, dim3(256), dim3(256), 0, stream, vals, prow, nrow, nnz);
-        hipLaunchKernelGGL(rows_close_offsets_kernel, dim3(1), dim3(1), 0, stream, prow, nrow, nnz);
-        return hipGetLastError();
-    }
-    if (L.mode == 2 && L.direct) return hipSuccess;   // nothing to regroup
-    if (L.mode == 2) {
-        double* px = (double*)((char*)persist + L.vals_off);
-        int32_t* pr = (int32_t*)((char*)persist + L.rows_off);
-        int32_t* boff = (int32_t*)((char*)persist + L.boff_off);
-        int32_t* table = (int32_t*)((char*)scratch + L.table_off);
-        const size_t table_entries = (size_t)L.nsuper * (size_t)L.nblocks + 1;
-        e = hipMemsetAsync(table + (table_entries - 1), 0, 4, stream);   // the slot that receives the total
-        if (e != hipSuccess) return e;
-        const size_t part_lds = (size_t)kStageElems * 12 + ((size_t)L.nblocks * (2 + kPartWaves) + 1) * 4;
-        static DynamicLdsLimit part_limit;
-        e = part_limit.ensure((const void*)rows_tile_partition_kernel,
-                              (int)((size_t)kStageElems * 12 + ((size_t)kPartMaxBlocks * (2 + kPartWaves) + 1) * 4));
-        if (e != hipSuccess) return e;
-        if (L.nsuper > 0) {
-            hipLaunchKernelGGL(rows_tile_histogram_kernel, dim3(L.nsuper), dim3(kPartThreads),
-                               (size_t)L.nblocks * 4, stream, d_i, nnz, nrow, L.shift, L.nblocks, L.super_elems,
-                               L.nsuper, table);
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-        }
-        e = rocprim::exclusive_scan(temp, temp_bytes, (const int32_t*)table, table, 0, table_entries,
-                                    rocprim::plus<int32_t>(), stream);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(rows_tile_offsets_kernel, dim3((L.nblocks + 1 + 255) / 256), dim3(256), 0, stream, table,
-                           L.nblocks, L.nsuper, boff);
+// One partition pass: histogram -> scan -> first slots -> partition.  With `seg` the pass regroups one bucket
+// of the two-level form (entries [seg[0], seg[1]) of src, rows [row_base, row_base + nrow_here)).
+static hipError_t partition_pass(const double* src_x, const int32_t* src_i, int64_t nnz, int32_t nrow_here, int32_t shift,
+                                 int32_t nblocks, const RowSumsLayout& L, int32_t* table, void* temp, double* dst_x,
+                                 int32_t* dst_i, int32_t* boff, const int32_t* seg, int32_t row_base, int32_t close,
+                                 hipStream_t stream) {
+    const size_t table_entries = (size_t)L.nsuper * (size_t)nblocks + 1;
+    hipError_t e = hipMemsetAsync(table + (table_entries - 1), 0, 4, stream);   // the slot that receives the total
+    if (e != hipSuccess) return e;
+    const size_t part_lds = (size_t)kStageElems * 12 + ((size_t)nblocks * (2 + kPartWaves) + 1) * 4;
+    static DynamicLdsLimit part_limit;
+    e = part_limit.ensure((const void*)rows_tile_partition_kernel,
+                          (int)((size_t)kStageElems * 12 + ((size_t)kPartMaxBlocks * (2 + kPartWaves) + 1) * 4));
+    if (e != hipSuccess) return e;
+    if (L.nsuper > 0) {
+        hipLaunchKernelGGL(rows_tile_histogram_kernel, dim3(L.nsuper), dim3(kPartThreads), (size_t)nblocks * 4, stream,
+                           src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, seg, row_base);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        if (L.nsuper > 0) {
-            hipLaunchKernelGGL(rows_tile_partition_kernel, dim3(L.nsuper), dim3(kPartThreads), part_lds, stream, d_x,
-                               d_i, nnz, nrow, L.shift, L.nblocks, L.super_elems, L.nsuper, table, px, pr);
-            e = hipGetLastError();
-        }
-        return e;
     }
-    double* px = (double*)((char*)persist + L.vals_off);
-    uint32_t* pr = (uint32_t*)((char*)persist + L.rows_off);
-    int32_t* boff = (int32_t*)((char*)persist + L.boff_off);
-    if (nnz > 0) {
-        // stable, on the block bits only: the entries of a block keep their storage order; entries that are
-        // not in [0, nrow) get the key past the last block and end up behind boff[nblocks]
-        const RowKey key{(uint32_t)nrow, block_sort_past(L.nblocks)};
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, RowKeyIterator((const uint32_t*)d_i, key), pr, d_x, px,
-                                      (size_t)nnz, (unsigned)kRowBlockShift, bits_to_hold(key.past), stream);
-        if (e != hipSuccess) return e;
+    size_t temp_bytes = L.temp_bytes;
+    e = rocprim::exclusive_scan(temp, temp_bytes, (const int32_t*)table, table, 0, table_entries,
+                                rocprim::plus<int32_t>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rows_tile_offsets_kernel, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, stream, table, nblocks,
+                       L.nsuper, boff, seg, close);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (L.nsuper > 0) {
+        hipLaunchKernelGGL(rows_tile_partition_kernel, dim3(L.nsuper), dim3(kPartThreads), part_lds, stream, src_x, src_i,
+                           nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i, seg, row_base);
+        e = hipGetLastError();
     }
-    temp_bytes = L.temp_bytes;
-    // boff[b] = first position whose block id is >= b  (b = 0..nblocks)
-    auto ids = rocprim::make_transform_iterator((const uint32_t*)pr, RowBlockOf{L.shift});
-    return rocprim::lower_bound(temp, temp_bytes, ids, rocprim::counting_iterator<uint32_t>(0), boff, (size_t)nnz,
-                                (size_t)L.nblocks + 1, rocprim::less<uint32_t>(), stream);
+    return e;
 }
 
-// Row sums / means from the row-wise form in `persist`.
+// Builds the regrouped copy in `persist`; `scratch` is free again when the stream has passed this point.
+hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
+                            const RowSumsLayout& L, void* persist, void* scratch, hipStream_t stream) {
+    if (L.direct) return hipSuccess;   // nothing to regroup
+    double* px = (double*)((char*)persist + L.vals_off);
+    int32_t* pr = (int32_t*)((char*)persist + L.rows_off);
+    int32_t* boff = (int32_t*)((char*)persist + L.boff_off);
+    int32_t* table = (int32_t*)((char*)scratch + L.table_off);
+    void* temp = (char*)scratch + L.temp_off;
+    if (L.mode == 2)
+        return partition_pass(d_x, d_i, nnz, nrow, L.shift + L.sub, L.ncoarse, L, table, temp, px, pr, boff, nullptr, 0, 1,
+                              stream);
+    // two levels: by bucket into the intermediate copy, then every bucket by its blocks into the final one
+    double* mx = (double*)((char*)scratch + L.mid_vals_off);
+    int32_t* mr = (int32_t*)((char*)scratch + L.mid_rows_off);
+    int32_t* bucket = (int32_t*)((char*)scratch + L.bucket_off);
+    hipError_t e = partition_pass(d_x, d_i, nnz, nrow, kPartBucketShift, L.nbuckets, L, table, temp, mx, mr, bucket, nullptr,
+                                  0, 1, stream);
+    for (int32_t s = 0; s < L.nbuckets && e == hipSuccess; ++s) {
+        const int64_t row_base = (int64_t)s << kPartBucketShift;
+        const int64_t rows_left = (int64_t)nrow - row_base;
+        const int32_t nrow_here = (int32_t)(rows_left < ((int64_t)1 << kPartBucketShift) ? rows_left : ((int64_t)1 << kPartBucketShift));
+        const int32_t blocks_here = (int32_t)(((int64_t)nrow_here + (1 << kPartShift) - 1) >> kPartShift);
+        e = partition_pass(mx, mr, nnz, nrow_here, L.shift, blocks_here, L, table, temp, px, pr,
+                           boff + (size_t)s * kPartTwoLevelBlocks, bucket + s, (int32_t)row_base, s == L.nbuckets - 1, stream);
+    }
+    return e;
+}
+
+// Row sums / means from the regrouped copy in `persist` (direct form: from the caller's x / i).
 hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
                              const RowSumsLayout& L, void* persist, double* d_out,
                              double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream) {
+    (void)colsums_plan;
     if (nrow <= 0) return hipSuccess;
-    if (L.mode == 1)   // rowSums(A) = columnSums(t(A)): same kernels, row offsets in place of p
-        return launch_column_sums((const double*)((char*)persist + L.vals_off),
-                                  (const int32_t*)((char*)persist + L.prow_off), nrow, (int32_t)nnz, d_out,
-                                  colsums_plan, (char*)persist + L.colsums_off, divisor, means, stream);
-    const bool direct = L.mode == 2 && L.direct;
+    const bool direct = L.direct;
     const double* px = direct ? d_x : (const double*)((char*)persist + L.vals_off);
     const int32_t* pr = direct ? d_i : (const int32_t*)((char*)persist + L.rows_off);
     const int32_t* boff = (const int32_t*)((char*)persist + L.boff_off);
-    if (L.mode == 2) {
-        const size_t acc_lds = ((size_t)8 << L.shift) + 64 * 8 + (size_t)2 * kAccStagers * 12;
-        static DynamicLdsLimit acc_limit_means, acc_limit_sums;
-        hipError_t e = acc_limit_means.ensure((const void*)rows_tile_accumulate_kernel<true>, (int)acc_lds);
-        if (e == hipSuccess) e = acc_limit_sums.ensure((const void*)rows_tile_accumulate_kernel<false>, (int)acc_lds);
-        if (e != hipSuccess) return e;
-        double* parts = (double*)((char*)persist + L.partial_off);
-        const dim3 grid((unsigned)L.nblocks * (unsigned)L.nsplit);
+    const size_t acc_lds = ((size_t)8 << L.shift) + 64 * 8 + (size_t)2 * kAccStagers * 12;
+    static DynamicLdsLimit acc_limit_means, acc_limit_sums;
+    hipError_t e = acc_limit_means.ensure((const void*)rows_tile_accumulate_kernel<true>, (int)acc_lds);
+    if (e == hipSuccess) e = acc_limit_sums.ensure((const void*)rows_tile_accumulate_kernel<false>, (int)acc_lds);
+    if (e != hipSuccess) return e;
+    double* parts = (double*)((char*)persist + L.partial_off);
+    const dim3 grid((unsigned)L.nblocks * (unsigned)L.nsplit);
+    if (means)
+        hipLaunchKernelGGL(rows_tile_accumulate_kernel<true>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
+                           boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor);
+    else
+        hipLaunchKernelGGL(rows_tile_accumulate_kernel<false>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
+                           boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor);
+    e = hipGetLastError();
+    if (e != hipSuccess || L.nsplit <= 1) return e;
+    if (L.nsplit >= 16) {
+        const dim3 wgrid((unsigned)(((int64_t)nrow + 3) / 4));
         if (means)
-            hipLaunchKernelGGL(rows_tile_accumulate_kernel<true>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
-                               boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.nsplit, d_out, parts, divisor);
+            hipLaunchKernelGGL(rows_combine_many_parts_kernel<true>, wgrid, dim3(256), 0, stream, parts, nrow,
+                               L.nsplit, d_out, divisor);
         else
-            hipLaunchKernelGGL(rows_tile_accumulate_kernel<false>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
-                               boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.nsplit, d_out, parts, divisor);
-        e = hipGetLastError();
-        if (e != hipSuccess || L.nsplit <= 1) return e;
-        if (L.nsplit >= 16) {
-            const dim3 wgrid((unsigned)(((int64_t)nrow + 3) / 4));
-            if (means)
-                hipLaunchKernelGGL(rows_combine_many_parts_kernel<true>, wgrid, dim3(256), 0, stream, parts, nrow,
-                                   L.nsplit, d_out, divisor);
-            else
-                hipLaunchKernelGGL(rows_combine_many_parts_kernel<false>, wgrid, dim3(256), 0, stream, parts, nrow,
-                                   L.nsplit, d_out, divisor);
-            return hipGetLastError();
-        }
-        const dim3 cgrid((unsigned)(((int64_t)nrow + 255) / 256));
-        if (means)
-            hipLaunchKernelGGL(rows_combine_parts_kernel<true>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
-                               d_out, divisor);
-        else
-            hipLaunchKernelGGL(rows_combine_parts_kernel<false>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
-                               d_out, divisor);
+            hipLaunchKernelGGL(rows_combine_many_parts_kernel<false>, wgrid, dim3(256), 0, stream, parts, nrow,
+                               L.nsplit, d_out, divisor);
         return hipGetLastError();
     }
-    const size_t lds = (size_t)8 << L.shift;
+    const dim3 cgrid((unsigned)(((int64_t)nrow + 255) / 256));
     if (means)
-        hipLaunchKernelGGL(rows_block_accumulate_kernel<true>, dim3(L.nblocks), dim3(64), lds, stream, px, pr, boff,
-                           nrow, L.shift, d_out, divisor);
+        hipLaunchKernelGGL(rows_combine_parts_kernel<true>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
+                           d_out, divisor);
     else
-        hipLaunchKernelGGL(rows_block_accumulate_kernel<false>, dim3(L.nblocks), dim3(64), lds, stream, px, pr, boff,
-                           nrow, L.shift, d_out, divisor);
+        hipLaunchKernelGGL(rows_combine_parts_kernel<false>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
+                           d_out, divisor);
     return hipGetLastError();
 }
 

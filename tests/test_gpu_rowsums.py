@@ -111,12 +111,16 @@ def test_row_sums_1e8_against_oracle(torch_cuda):
 
 @pytest.mark.parametrize("nrow,nnz", [(13_700_000, 3_000_000), (40_000_000, 5_000_000), (16_384, 2_000_000),
                                       (16_385, 400_000), (3, 5_000), (49_153, 900_000), (65_536, 900_000), (65_537, 900_000),
-                                      (13_631_488, 2_500_000)])
+                                      (13_631_488, 2_500_000), (27_262_976, 2_500_000), (27_262_977, 2_500_000),
+                                      (60_000_000, 3_000_000), (109_051_904, 2_000_000), (109_051_905, 2_000_000),
+                                      (150_000_000, 4_000_000)])
 def test_row_sums_forms_by_row_count(torch_cuda, nrow, nnz):
-    """The one-shot entry has three forms by row count: up to 4 blocks of 16384 rows nothing is regrouped
-    (every block's workgroups scan x / i as they are), up to 832 blocks (1.36e7 rows) the hand-written
-    tile partition regroups by block, above that a rocPRIM sort by 4096-row block.  Shapes on both sides
-    of every edge.  Same oracle, same tolerance, bit-stable."""
+    """The one-shot entry's forms by row count: up to 4 blocks of 16384 rows nothing is regrouped (every block's
+    workgroups scan x / i as they are); up to 832 blocks (1.36e7 rows) the hand-written tile partition regroups by
+    block; up to 8 x 832 blocks (1.09e8 rows) it regroups by coarse block of 2 / 4 / 8 row blocks and every row
+    block picks its entries out of its coarse block's; above that two partition passes (buckets of 512 blocks,
+    then blocks).  Shapes on both sides of every edge.  Same oracle, same tolerance, bit-stable.  All hand-written:
+    no library sort anywhere on the row-wise path."""
     torch = torch_cuda
     ncol = 2_000
     p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=nrow % 1000, nrow=nrow))
