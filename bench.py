@@ -74,6 +74,9 @@ WORKLOADS = {
     "m100": (10_000_000, 10_000_000, 1_000_000_000, "uniform"),
     "m300": (10_000_000, 3_300_000, 1_000_000_000, "uniform"),
     "m10": (10_000_000, 100_000_000, 1_000_000_000, "uniform"),
+    # ~10 per column at sizes between C2 and 1e9 (where the lean planned form stops paying)
+    "m10_3e7": (3_000_000, 3_000_000, 30_000_000, "uniform"),
+    "m10_1e8": (10_000_000, 10_000_000, 100_000_000, "uniform"),
     # small shapes for the -m gpu test that runs this file as a child process
     "tiny": (200_000, 40_000, 4_000_000, "zipf"),
 }
@@ -109,6 +112,7 @@ def parse_args(argv=None):
                          "reported as plan_ms, outside every timed region) and every call is "
                          "rsp_column_sums_planned_device -- one launch without column search, carries or fix-up "
                          "where no long column crosses a chunk edge.  The headline C3 `value` stays plan-free.")
+    ap.add_argument("--no-lean", action="store_true", help="--planned: keep the plan out of the lean form (A/B)")
     ap.add_argument("--try-comm", action="store_true",
                     help="--rendezvous gloo only: also take the C-ABI communicator through its multi-rank "
                          "bootstrap (unique id from rank 0, rsp_comm_init on every rank).  With ranks sharing a "
@@ -425,6 +429,7 @@ def main(argv=None):
     ws_main = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
     plan = None
     if args.planned:
+        capi.set_lean(not args.no_lean)
         plan = capi.ColumnSumsPlan(shard.p_local, nnz=shard.nnz, device=dev_index)
 
     def prepare(xk, out, ws, stream):
@@ -590,7 +595,8 @@ def main(argv=None):
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
                 "planned": (None if plan is None else
-                            {"snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
+                            {"form": {2: "lean", 1: "snapped", 0: "general kernels"}[plan.form],
+                             "snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
                              "entries_per_chunk": plan.chunk_elems, "max_skip": plan.max_skip,
                              "note": "inspection of p[] on the host, once, outside every timed region; a snapped "
                                      "plan makes a call ONE launch (no column search, carries or fix-up)"}),
@@ -608,7 +614,8 @@ def main(argv=None):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic[0], "traffic_source": traffic_source,
-                "kernel": ("colsums_chunks_kernel<PLANNED> (one launch)" if plan is not None and plan.snapped
+                "kernel": ("colsums_lean_kernel (one launch)" if plan is not None and plan.lean else
+                           "colsums_chunks_kernel<PLANNED> (one launch)" if plan is not None and plan.snapped
                            else "colsums_chunks_kernel (+ colsums_fixup_kernel)"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
                 "kernel_timing": (f"ONE HIP event pair on the launch stream around the {args.steps} timed calls, "

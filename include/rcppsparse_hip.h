@@ -150,7 +150,7 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
                             void *stream);
 /*
  * Inspector-executor form for callers that can show p[] to the host once (a resident matrix summed many
- * times; rsp_csc_upload and rsp_column_sums_host do this by themselves).  The inspector walks the chunk
+ * times; rsp_csc_upload does this by itself, the one-shot rsp_column_sums_host does not: it sums once).  The inspector walks the chunk
  * grid over p[] (reference RcppSparse.h:220-221: a column is [p[c], p[c+1])) and records for every chunk the
  * first column that starts in it, with chunk boundaries snapped to that column start.  If no column reaches
  * more than one group (512 entries) past a chunk edge, a planned call is ONE launch: no per-chunk column search,
@@ -160,8 +160,15 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
  * rsp_column_sums_device within the same tolerance; the short-column paths are the same code, so columns of up
  * to 16 entries inside a group stay bit-identical to the reference loop.  A plan belongs to the p[] it was made
  * from (same ncol, nnz, offsets) and to the chunking in force when it was made.
- * info4 = { snapped (0/1), chunks, entries per chunk, largest distance from a chunk's grid start to its first
- * column start }; *inspect_ms = host time the inspection took (reported separately from the calls).
+ * When in addition every column is short (at most 64 entries; BASELINE config 2) the plan takes the LEAN form:
+ * the inspector rewrites the offsets a chunk needs as 16-bit column starts relative to the chunk, at a fixed
+ * stride, so that a wavefront requests its rows of x, its header and its offsets in the same instant (2 B per
+ * column, p[] itself is not read again), puts both into LDS and adds every column in storage order from +0.0:
+ * every column then comes out BIT-IDENTICAL to the reference loop.  rsp_set_lean(0) / RSP_LEAN=0 keeps plans
+ * out of that form (A/B measurements).
+ * info4 = { form (0 general kernels, 1 snapped, 2 lean), chunks, entries per chunk, largest distance from a
+ * chunk's grid start to its first column start (lean: most columns in one chunk) }; *inspect_ms = host time the
+ * inspection took (reported separately from the calls).
  * nrow_for_means > 0: colMeans (RcppSparse.h:145-150), 0: sums.
  */
 typedef struct rsp_colsums_plan *rsp_colsums_plan_t;
@@ -175,6 +182,7 @@ int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double *d_x,
                                    const int32_t *d_p, int32_t nrow_for_means, double *d_sums,
                                    void *d_workspace, size_t workspace_bytes, void *stream);
 int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan);
+int rsp_set_lean(int on);
 /*
  * Generic column reduction ("next" row f3): the same column-iteration loop with a
  * different per-element body, out[c] = sum_j f(x[j]) over column c's stored entries --

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
     "rsp_column_sums_plan_create", "rsp_column_sums_plan_create_device", "rsp_column_sums_plan_info",
-    "rsp_column_sums_planned_device", "rsp_column_sums_plan_destroy",
+    "rsp_column_sums_planned_device", "rsp_column_sums_plan_destroy", "rsp_set_lean",
     "rsp_csc_crossprod", "rsp_crossprod_workspace_bytes", "rsp_crossprod_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
@@ -112,6 +112,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_plan_info.argtypes = [vp, ip, c.POINTER(c.c_double)]
     L.rsp_column_sums_planned_device.argtypes = [vp, vp, vp, i32, vp, vp, c.c_size_t, vp]
     L.rsp_column_sums_plan_destroy.argtypes = [vp]
+    L.rsp_set_lean.argtypes = [c.c_int]
     L.rsp_csc_crossprod.argtypes = [vp, dp]
     L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_crossprod_workspace_bytes.argtypes = [i32, i32, i64]
@@ -188,6 +189,11 @@ def plan_describe(nnz: int) -> dict:
     out = np.zeros(4, dtype=np.int32)
     _check(load().rsp_plan_describe(int(nnz), _ip(out)))
     return {"body_elems": int(out[0]), "nbody": int(out[1]), "tail_elems": int(out[2]), "nchunks": int(out[3])}
+
+
+def set_lean(on: bool = True) -> None:
+    """False: plans made from now on never take the lean form (rsp_set_lean; A/B measurements, tests)."""
+    _check(load().rsp_set_lean(int(bool(on))))
 
 
 def set_experiment(variant: int = 0) -> None:
@@ -487,7 +493,11 @@ class ColumnSumsPlan:
         info = np.zeros(4, dtype=np.int32)
         ms = ctypes.c_double(0)
         _check(L.rsp_column_sums_plan_info(self._h, _ip(info), ctypes.byref(ms)))
-        self.snapped, self.nchunks, self.chunk_elems, self.max_skip = bool(info[0]), int(info[1]), int(info[2]), int(info[3])
+        # form 2 = lean (all columns short: one launch, reference bits for every column), 1 = snapped (one launch),
+        # 0 = the general kernels behind the same entry
+        self.form = int(info[0])
+        self.lean, self.snapped = self.form == 2, self.form >= 1
+        self.nchunks, self.chunk_elems, self.max_skip = int(info[1]), int(info[2]), int(info[3])
         self.inspect_ms = float(ms.value)
 
     def column_sums(self, x_t, p_t, out_t=None, workspace=None, stream=None, nrow_for_means: int = 0):

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include <atomic>
@@ -63,6 +64,36 @@ using rsp::fail;
             return fail(RSP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                               \
     } while (0)
+
+std::atomic<int> g_lean{-1};   // rsp_set_lean: 1 / 0; -1 = RSP_LEAN from the environment, else on
+bool lean_allowed() {
+    int v = g_lean.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static const int env = [] {
+            const char* s = getenv("RSP_LEAN");
+            return s ? (atoi(s) != 0 ? 1 : 0) : 1;
+        }();
+        v = env;
+    }
+    return v != 0;
+}
+
+// Rows of x per chunk of the lean form.  A chunk's columns are handed to the 64 lanes of its wavefront, so the chunk
+// should hold about 64 of them and rarely more: the largest of 2 / 3 / 4 / 5 / 6 / 8 / 12 / 16 rows that keeps the MEAN
+// number of columns per chunk at or below kLeanTargetColumns (C2, 10 per column: 4 rows = 51 columns, never more than
+// 61 in a chunk: 17.2 us; 8 rows 18.1, 3 rows 17.4-18.2, 2 rows 20.7 -- profiles/r03_c2.md).  RSP_LEAN_ROWS overrides.
+int lean_rows_setting(int32_t ncol, int64_t nnz) {
+    static const int env = env_int("RSP_LEAN_ROWS");
+    static const int allowed[] = {2, 3, 4, 5, 6, 8, 12, 16};
+    for (int a : allowed)
+        if (env == a) return a;
+    const double mean_len = ncol > 0 ? (double)nnz / (double)ncol : 1.0;
+    const double want = rsp::kLeanTargetColumns * mean_len / rsp::kRowElems;
+    int rows = allowed[0];
+    for (int a : allowed)
+        if ((double)a <= want) rows = a;
+    return rows;
+}
 
 int chunk_rows_setting() {
     const int o = g_chunk_rows_override.load(std::memory_order_relaxed);
@@ -237,6 +268,11 @@ struct rsp_colsums_plan {
     int32_t max_skip;        // largest distance from a chunk's grid start to its first column start
     int2* d_rec;             // nchunks + 1 records {first column, first owned element} on the device
     double inspect_ms;       // host time of the inspection (searches + upload of the records)
+    // lean form (every column short): the chunks' headers {first column, columns} and their 16-bit column starts
+    bool lean;
+    int32_t lean_chunks, lean_stride_dwords, lean_max_columns, lean_rows;
+    int2* d_lean_hdr;
+    uint32_t* d_lean_offs;
 };
 
 namespace {
@@ -261,6 +297,90 @@ int inspect_offsets(const int32_t* p, int32_t ncol, int64_t nnz, const rsp::Laun
     (*rec)[lp.nchunks] = make_int2(ncol, (int32_t)nnz);
     *max_skip = worst;
     return RSP_OK;
+}
+// Runs fn(begin, end) over [0, n) on a few host threads when the range is long (a plan for 1e7 columns is ~50 ms of
+// integer work on one thread); anything that goes wrong with the threads falls back to the calling thread.
+template <class Fn>
+void inspect_parallel(int64_t n, int64_t grain, Fn&& fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    int64_t parts = n / (grain > 0 ? grain : 1);
+    if (parts > 8) parts = 8;
+    if (hw > 0 && parts > (int64_t)hw) parts = hw;
+    if (parts <= 1) {
+        fn((int64_t)0, n);
+        return;
+    }
+    auto range = [&](int64_t k) { fn(n * k / parts, n * (k + 1) / parts); };   // (fn only writes its own range's outputs)
+    std::vector<std::thread> pool;
+    int64_t started = 0;   // ranges 1..started run on threads of their own
+    try {
+        pool.reserve((size_t)parts - 1);
+        for (int64_t k = 1; k < parts; ++k) {
+            pool.emplace_back([&range, k] { range(k); });
+            started = k;
+        }
+    } catch (...) {   // out of threads or memory: the rest runs here
+    }
+    range(0);
+    for (int64_t k = started + 1; k < parts; ++k) range(k);
+    for (auto& t : pool) t.join();
+}
+
+// The lean form's inspection (colsums_lean_kernel): applies when no column is longer than kLeanMaxColumn entries,
+// no chunk (2..16 rows of x, lean_rows_setting) holds more than kLeanMaxColumns column starts, and no column reaches
+// more than one row past its chunk's grid end.  Chunk w owns the columns that START in its grid range
+// [cs_w, cs_{w+1}) (the last chunk: all that remain); their starts relative to cs_w fit 16 bits.  The result is ONE
+// host buffer: nchunks headers {first column, columns} followed by the 16-bit offsets at a fixed stride.
+bool inspect_lean(const int32_t* p, int32_t ncol, int64_t nnz, int32_t rows, std::vector<uint32_t>* image,
+                  int32_t* nchunks_out, int32_t* stride_dwords, int32_t* max_columns) {
+    const int64_t chunk = (int64_t)rows * rsp::kRowElems;
+    const int64_t nchunks = (nnz + chunk - 1) / chunk;
+    if (nchunks <= 0 || nchunks > INT32_MAX / 4) return false;
+    std::atomic<int> too_long{0};
+    inspect_parallel(ncol, 1 << 20, [&](int64_t c0, int64_t c1) {
+        int bad = 0;
+        for (int64_t c = c0; c < c1; ++c) bad |= (p[c + 1] - p[c] > rsp::kLeanMaxColumn);
+        if (bad) too_long.store(1, std::memory_order_relaxed);
+    });
+    if (too_long.load()) return false;
+    // first column starting at or after every chunk's grid position (chunk nchunks: ncol)
+    std::vector<int32_t> first((size_t)nchunks + 1);
+    const int32_t* pend = p + (size_t)ncol + 1;
+    inspect_parallel(nchunks, 1 << 14, [&](int64_t w0, int64_t w1) {
+        const int32_t* at = p;
+        for (int64_t w = w0; w < w1; ++w) {
+            at = std::lower_bound(at, pend, (int32_t)(w * chunk));   // (chunk starts ascend: search on from the last hit)
+            int64_t c = at - p;
+            first[(size_t)w] = (int32_t)(c > ncol ? ncol : c);
+        }
+    });
+    first[(size_t)nchunks] = ncol;
+    int32_t widest = 0;
+    for (int64_t w = 0; w < nchunks; ++w) {
+        const int32_t c0 = first[(size_t)w], c1 = first[(size_t)w + 1];
+        if (c1 - c0 > widest) widest = c1 - c0;
+        // the last owned column ends at p[c1]; the chunk has its own rows and one more
+        if (c1 > c0 && (int64_t)p[c1] - w * chunk > chunk + rsp::kRowElems) return false;
+    }
+    if (widest > rsp::kLeanMaxColumns) return false;
+    const int32_t stride = ((widest + 2 + 1) / 2 + 3) & ~3;   // 16-bit offsets, two per dword, whole 16-byte pieces
+    image->assign((size_t)nchunks * 2 + (size_t)nchunks * (size_t)stride, 0u);
+    int2* hdr = (int2*)image->data();
+    uint32_t* offs = image->data() + (size_t)nchunks * 2;
+    inspect_parallel(nchunks, 1 << 13, [&](int64_t w0, int64_t w1) {
+        for (int64_t w = w0; w < w1; ++w) {
+            const int32_t c0 = first[(size_t)w], n = first[(size_t)w + 1] - c0;
+            hdr[w] = make_int2(c0, n);
+            uint16_t* o = (uint16_t*)(offs + (size_t)w * (size_t)stride);
+            const int64_t cs = w * chunk;
+            if (n > 0)
+                for (int32_t j = 0; j <= n; ++j) o[j] = (uint16_t)((int64_t)p[c0 + j] - cs);
+        }
+    });
+    *nchunks_out = (int32_t)nchunks;
+    *stride_dwords = stride;
+    *max_columns = widest;
+    return true;
 }
 }  // namespace
 
@@ -372,21 +492,43 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
     pl->nnz = nnz;
     pl->lp = make_plan(nnz, true);
     pl->d_rec = nullptr;
+    pl->lean = false;
+    pl->d_lean_hdr = nullptr;
+    pl->d_lean_offs = nullptr;
     try {
-        std::vector<int2> rec;
-        inspect_offsets(p_host, ncol, nnz, pl->lp, &rec, &pl->max_skip);
-        pl->snapped = pl->max_skip <= rsp::kGroupElems;
-        if (pl->snapped) {
-            hipError_t e = hipMalloc((void**)&pl->d_rec, rec.size() * sizeof(int2));
-            if (e == hipSuccess) e = hipMemcpy(pl->d_rec, rec.data(), rec.size() * sizeof(int2), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                if (pl->d_rec) (void)hipFree(pl->d_rec);
-                delete pl;
-                return fail(RSP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+        if (lean_allowed()) {
+            std::vector<uint32_t> image;
+            pl->lean_rows = lean_rows_setting(ncol, nnz);
+            if (inspect_lean(p_host, ncol, nnz, pl->lean_rows, &image, &pl->lean_chunks, &pl->lean_stride_dwords,
+                             &pl->lean_max_columns)) {
+                // headers and offsets in ONE device allocation and ONE copy
+                hipError_t e = hipMalloc((void**)&pl->d_lean_hdr, image.size() * 4);
+                if (e == hipSuccess) e = hipMemcpy(pl->d_lean_hdr, image.data(), image.size() * 4, hipMemcpyHostToDevice);
+                if (e != hipSuccess) {
+                    rsp_column_sums_plan_destroy(pl);
+                    return fail(RSP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+                }
+                pl->d_lean_offs = (uint32_t*)(pl->d_lean_hdr + pl->lean_chunks);
+                pl->lean = true;
+                pl->snapped = true;     // (the lean form is a planned, one-launch form too)
+                pl->max_skip = 0;
+            }
+        }
+        if (!pl->lean) {
+            std::vector<int2> rec;
+            inspect_offsets(p_host, ncol, nnz, pl->lp, &rec, &pl->max_skip);
+            pl->snapped = pl->max_skip <= rsp::kGroupElems;
+            if (pl->snapped) {
+                hipError_t e = hipMalloc((void**)&pl->d_rec, rec.size() * sizeof(int2));
+                if (e == hipSuccess) e = hipMemcpy(pl->d_rec, rec.data(), rec.size() * sizeof(int2), hipMemcpyHostToDevice);
+                if (e != hipSuccess) {
+                    rsp_column_sums_plan_destroy(pl);
+                    return fail(RSP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+                }
             }
         }
     } catch (...) {
-        delete pl;
+        rsp_column_sums_plan_destroy(pl);
         return fail(RSP_ERR_ALLOC, "out of host memory while planning");
     }
     pl->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -417,6 +559,9 @@ int rsp_column_sums_plan_create(const int32_t* p, int32_t ncol, int64_t nnz, int
         pl->max_skip = 0;
         pl->d_rec = nullptr;
         pl->inspect_ms = 0.0;
+        pl->lean = false;
+        pl->d_lean_hdr = nullptr;
+        pl->d_lean_offs = nullptr;
     }
     *plan = pl;
     return RSP_OK;
@@ -440,21 +585,27 @@ int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t
     }
 }
 
+int rsp_set_lean(int on) {
+    g_lean.store(on ? 1 : 0, std::memory_order_relaxed);
+    return RSP_OK;
+}
+
 int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t* info4, double* inspect_ms) {
     if (!plan || !info4) return fail(RSP_ERR_BAD_ARG, "null plan or output");
-    info4[0] = plan->snapped ? 1 : 0;
-    info4[1] = plan->lp.nchunks;
-    info4[2] = plan->lp.chunk_elems;
-    info4[3] = plan->max_skip;
+    info4[0] = plan->lean ? 2 : (plan->snapped ? 1 : 0);
+    info4[1] = plan->lean ? plan->lean_chunks : plan->lp.nchunks;
+    info4[2] = plan->lean ? plan->lean_rows * rsp::kRowElems : plan->lp.chunk_elems;
+    info4[3] = plan->lean ? plan->lean_max_columns : plan->max_skip;
     if (inspect_ms) *inspect_ms = plan->inspect_ms;
     return RSP_OK;
 }
 
 int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
     if (!plan) return RSP_OK;
-    if (plan->d_rec) {
+    if (plan->d_rec || plan->d_lean_hdr) {
         DeviceGuard on(plan->device);
-        (void)hipFree(plan->d_rec);
+        if (plan->d_rec) (void)hipFree(plan->d_rec);
+        if (plan->d_lean_hdr) (void)hipFree(plan->d_lean_hdr);   // (the offsets live behind the headers in the same allocation)
     }
     delete plan;
     return RSP_OK;
@@ -462,6 +613,14 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
 
 static int planned_enqueue(rsp_colsums_plan_t plan, const double* d_x, const int32_t* d_p, double* d_out,
                            void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+    if (plan->lean) {   // every column short: rows, header and 16-bit offsets of a chunk requested at once
+        if (!d_out || !d_x) return fail(RSP_ERR_BAD_ARG, "null device pointer");
+        if (((uintptr_t)d_x & 15) != 0) return fail(RSP_ERR_BAD_ARG, "d_x must be 16-byte aligned");
+        HIP_TRY(rsp::launch_column_sums_lean(d_x, (int32_t)plan->nnz, plan->d_lean_hdr, plan->d_lean_offs,
+                                             plan->lean_stride_dwords, plan->lean_chunks, plan->lean_rows, d_out, divisor,
+                                             means, stream));
+        return RSP_OK;
+    }
     if (!plan->snapped)   // a column longer than a group crosses a chunk edge somewhere: the general kernels
         return enqueue(d_x, d_p, plan->ncol, plan->nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
     if (!d_p || !d_out || !d_x) return fail(RSP_ERR_BAD_ARG, "null device pointer");
@@ -565,8 +724,8 @@ int rsp_csc_free(rsp_csc_t h) {
     return RSP_OK;
 }
 
-int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t nrow, int32_t ncol,
-                   int64_t nnz, int device, rsp_csc_t* handle) {
+static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t nrow, int32_t ncol,
+                      int64_t nnz, int device, bool with_plan, rsp_csc_t* handle) {
     if (!handle) return fail(RSP_ERR_BAD_ARG, "handle is null");
     *handle = nullptr;
     if (int rc = check_sizes(ncol, nnz)) return rc;
@@ -607,9 +766,15 @@ int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t 
     // p[] is in host memory right now: inspect it once, so that every columnSums on this handle is one launch
     // without column search, carries or fix-up wherever the matrix allows (no column longer than a group across
     // a chunk edge); a plan that does not apply costs nothing later
-    if (plan_make(p, ncol, nnz, device, &h->plan) != RSP_OK) h->plan = nullptr;
+    // (the one-shot host entry sums once: an inspection of 1e7 columns costs as much as uploading them)
+    if (with_plan && plan_make(p, ncol, nnz, device, &h->plan) != RSP_OK) h->plan = nullptr;
     *handle = h;
     return RSP_OK;
+}
+
+int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t nrow, int32_t ncol,
+                   int64_t nnz, int device, rsp_csc_t* handle) {
+    return csc_upload(x, i, p, nrow, ncol, nnz, device, true, handle);
 }
 
 static int csc_run(rsp_csc_t h, double* host_out, bool means) {
@@ -803,7 +968,7 @@ int rsp_column_sums_host(const double* x, const int32_t* p, int32_t ncol, int64_
                          int device) {
     if (!sums && ncol > 0) return fail(RSP_ERR_BAD_ARG, "sums is null");
     rsp_csc_t h = nullptr;
-    if (int rc = rsp_csc_upload(x, nullptr, p, 0, ncol, nnz, device, &h)) return rc;
+    if (int rc = csc_upload(x, nullptr, p, 0, ncol, nnz, device, false, &h)) return rc;
     const int rc = rsp_csc_column_sums(h, sums);
     rsp_csc_free(h);
     return rc;

@@ -57,6 +57,12 @@ struct LaunchPlan {
 constexpr int kShortCallRows = 131072;
 constexpr int kShortCallChunkRows = 20;
 constexpr int kPlannedShortCallChunkRows = 8;   // inspector-executor form of such calls: no search to amortise
+// lean planned kernel (all columns short): chunk of 2..16 rows (capi.hip lean_rows_setting); a chunk may hold up to kLeanMaxColumns columns,
+// no column is longer than kLeanMaxColumn entries or reaches more than one row past its chunk's grid end
+constexpr int kLeanTargetColumns = 52;                    // mean number of columns per chunk the row count aims at
+constexpr int kLeanMaxColumn = 64;
+constexpr int kLeanMaxColumns = 1278;                     // + 1 closing offset + 1 pad = 1280 16-bit offsets
+constexpr int kLeanMaxOffsetDwords = 640;                 // = 10 x 64 lanes
 constexpr int kGuessWindow = 1024;   // offsets read around the guessed first column of a chunk (short calls)
 constexpr int kTaperPermille = 100;  // default taper: the last 10 % of x ...
 constexpr int kTaperRows = 64;       // ... in chunks of 64 rows (when the body's chunks are longer)
@@ -125,6 +131,10 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
 hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
                              const RowSumsLayout& L, void* persist, double* d_out,
                              double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream);
+
+hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d_hdr, const uint32_t* d_offs,
+                                   int32_t stride_dwords, int32_t nchunks, int32_t rows, double* d_out, double divisor,
+                                   bool means, hipStream_t stream);
 
 // out[j] = ((part_0[j] + part_1[j]) + ...) + part_{nparts-1}[j] (+ 0.0, / divisor): the shards' partial row sums
 // added in shard order.  part_k = parts + k * stride, except part own_idx = own (own_idx < 0: none).

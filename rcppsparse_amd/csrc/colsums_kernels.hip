@@ -1107,6 +1107,112 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// lean planned kernel: short columns, everything a chunk needs requested at once
+// ---------------------------------------------------------------------------
+// Inspector-executor form for matrices whose columns are all short (<= kLeanMaxColumn entries; BASELINE
+// config 2: ~10 per column).  The inspector (capi.hip, inspect_lean) does not only locate the chunks' first
+// columns, it REWRITES the part of p[] a chunk needs in the form the executor wants: for chunk w (R rows
+// of x on the 1 KiB grid) a header {c0, ncols} and the ncols + 1 column starts relative to the chunk's grid
+// position as 16-bit numbers, at a fixed stride -- so the wavefront asks for its rows of x, its header and its
+// offsets in the same instant (2 B per column instead of 4, no dependent round trip, p[] itself is never
+// read), puts rows and offsets into LDS and hands out the columns to its lanes, 64 at a time.  A lane adds its
+// column's entries from LDS in storage order from +0.0: EVERY column comes out bit-identical to the reference
+// loop (src/example.cpp:28-30), also the one that reaches past the chunk's grid end (the chunk reads one row
+// more: the inspector guarantees no column reaches further).  One launch, no carries, no workspace.
+template <bool MEANS, int R>   // R = rows of x per chunk
+__global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
+    const double* __restrict__ x, int32_t nnz, const int2* __restrict__ hdr, const uint32_t* __restrict__ offs,
+    int32_t stride_dwords, int32_t nchunks, double* __restrict__ out, double divisor) {
+#pragma clang fp contract(off)
+    typedef Policy<MEANS, kOpSum> P;
+    constexpr int kElems = (R + 1) * kRowElems;   // the chunk's rows and the one after
+    __shared__ __attribute__((aligned(16))) double s_stage[kWavesPerWG][kElems + 32];
+    extern __shared__ uint32_t s_offs[];   // kWavesPerWG x stride_dwords (as many offsets as the fullest chunk has)
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = blockIdx.x * kWavesPerWG + wave_in_wg;
+    if (w >= nchunks) return;
+    const int32_t cs = w * (R * kRowElems);
+    const int32_t left = nnz - cs;
+    const int32_t avail = left < kElems ? left : kElems;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + cs), 0, avail * 8, 0x00020000);
+    d2 v[R + 1];
+#pragma unroll
+    for (int r = 0; r <= R; ++r)
+        v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16, r * 1024, kLoadAux));
+    const int2 h = hdr[w];
+    // the chunk's offsets: stride_dwords dwords (two 16-bit offsets each), the same count for every chunk
+    const uint32_t* mine = offs + (size_t)w * (size_t)stride_dwords;
+    uint32_t od[kLeanMaxOffsetDwords / 64];
+#pragma unroll
+    for (int t = 0; t < kLeanMaxOffsetDwords / 64; ++t)
+        od[t] = (t * 64 + lane) < stride_dwords ? mine[t * 64 + lane] : 0u;
+    double* stage = s_stage[wave_in_wg];
+    uint32_t* so = s_offs + (size_t)wave_in_wg * stride_dwords;
+#pragma unroll
+    for (int t = 0; t < kLeanMaxOffsetDwords / 64; ++t)
+        if (t * 64 + lane < stride_dwords) so[t * 64 + lane] = od[t];
+#pragma unroll
+    for (int r = 0; r <= R; ++r) *(d2*)&stage[r * kRowElems + 2 * lane] = v[r];
+    __builtin_amdgcn_wave_barrier();
+    const int c0 = __builtin_amdgcn_readfirstlane(h.x), ncols = __builtin_amdgcn_readfirstlane(h.y);
+    const uint16_t* off16 = (const uint16_t*)so;
+    for (int t0 = 0; t0 < ncols; t0 += 64) {
+        const int col = t0 + lane;
+        const bool active = col < ncols;
+        const int lo = active ? (int)off16[col] : 0;
+        const int hi = active ? (int)off16[col + 1] : 0;
+        const int n = hi - lo;   // (0 <= lo <= hi <= kElems by construction of the plan)
+        const double* sp = stage + lo;
+        double s = 0.0;
+        const int nquads = n >> 2;
+        for (int q = 0; __ballot(q < nquads) != 0ull; ++q) {   // whole quads first, then the last 0-3 (as in dense_group)
+            const double e0 = sp[4 * q], e1 = sp[4 * q + 1], e2 = sp[4 * q + 2], e3 = sp[4 * q + 3];
+            const double t = (((s + e0) + e1) + e2) + e3;
+            s = q < nquads ? t : s;
+        }
+        {
+            const double* tp = sp + 4 * nquads;
+            const int rem = n & 3;
+            const double e0 = tp[0], e1 = tp[1], e2 = tp[2];
+            const double t0_ = s + e0, t1 = t0_ + e1, t2 = t1 + e2;
+            s = rem == 0 ? s : (rem == 1 ? t0_ : (rem == 2 ? t1 : t2));
+        }
+        if (active) out[c0 + col] = P::finish(s, divisor);
+    }
+}
+
+hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d_hdr, const uint32_t* d_offs,
+                                   int32_t stride_dwords, int32_t nchunks, int32_t rows, double* d_out, double divisor,
+                                   bool means, hipStream_t stream) {
+    if (nchunks <= 0) return hipSuccess;
+    const dim3 grid((nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
+    const size_t lds = (size_t)kWavesPerWG * (size_t)stride_dwords * 4;
+#define RSP_LEAN(R_)                                                                                               \
+    do {                                                                                                            \
+        if (means)                                                                                                  \
+            hipLaunchKernelGGL((colsums_lean_kernel<true, R_>), grid, block, lds, stream, d_x, nnz, d_hdr, d_offs,    \
+                               stride_dwords, nchunks, d_out, divisor);                                             \
+        else                                                                                                        \
+            hipLaunchKernelGGL((colsums_lean_kernel<false, R_>), grid, block, lds, stream, d_x, nnz, d_hdr, d_offs,   \
+                               stride_dwords, nchunks, d_out, divisor);                                             \
+    } while (0)
+    switch (rows) {
+        case 2: RSP_LEAN(2); break;
+        case 3: RSP_LEAN(3); break;
+        case 4: RSP_LEAN(4); break;
+        case 5: RSP_LEAN(5); break;
+        case 6: RSP_LEAN(6); break;
+        case 8: RSP_LEAN(8); break;
+        case 12: RSP_LEAN(12); break;
+        case 16: RSP_LEAN(16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RSP_LEAN
+    return hipGetLastError();
+}
+
 hipError_t launch_gen_row_indices(int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,
                                   uint64_t seed, hipStream_t stream) {
     if (ncol <= 0) return hipSuccess;

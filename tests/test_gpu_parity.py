@@ -57,13 +57,16 @@ _MODE = {"launch": "general"}
 PLANS_SEEN = {"snapped": 0, "general": 0}
 
 
-@pytest.fixture(params=["general", "planned"])
+@pytest.fixture(params=["general", "planned", "planned_no_lean"])
 def launch_mode(request):
     """The same parity tests through rsp_column_sums_device (per-chunk column search, carries, fix-up launch)
     and through the inspector-executor form (rsp_column_sums_plan_create + rsp_column_sums_planned_device: one
     launch when no long column crosses a chunk edge, the general kernels behind the same entry otherwise)."""
     _MODE["launch"] = request.param
+    capi.load()
+    capi.set_lean(request.param != "planned_no_lean")   # (the lean form would otherwise take every short-column case)
     yield request.param
+    capi.set_lean(True)
     _MODE["launch"] = "general"
 
 
@@ -72,14 +75,14 @@ def dev_colsums(torch, x, p, **kw):
     pt = torch.from_numpy(np.ascontiguousarray(p, dtype=np.int32)).cuda()
     if xt.numel() == 0:
         xt = torch.zeros(2, dtype=torch.float64, device="cuda")[:0]
-    if _MODE["launch"] == "planned" and not kw:
+    if _MODE["launch"].startswith("planned") and not kw:
         # the plan is made from the offsets in HBM on every other call, from the host array otherwise
         PLANS_SEEN["n"] = PLANS_SEEN.get("n", 0) + 1
         if PLANS_SEEN["n"] % 2:
             plan = capi.ColumnSumsPlan(np.ascontiguousarray(p, dtype=np.int32), nnz=int(x.size))
         else:
             plan = capi.ColumnSumsPlan(pt, nnz=int(x.size))
-        PLANS_SEEN["snapped" if plan.snapped else "general"] += 1
+        PLANS_SEEN[{2: "lean", 1: "snapped", 0: "general"}[plan.form]] = PLANS_SEEN.get({2: "lean", 1: "snapped", 0: "general"}[plan.form], 0) + 1
         out = plan.column_sums(xt, pt)
         torch.cuda.synchronize()
         again = plan.column_sums(xt, pt)                    # bit-stable, and the plan is reusable
@@ -106,13 +109,13 @@ def test_golden_all_three_entry_points(torch_cuda, name):
     h.close()
     dev = dev_colsums(torch_cuda, x, p)
     assert_parity(dev, x, p, positive)
-    # the host entry and the handle inspect p[] at upload and run the planned form; the same form on device
-    # pointers gives their bits (same kernel, same chunking), the plan-free device entry its own
+    # the handle inspects p[] at upload and runs the planned form: the same form on device pointers gives its
+    # bits (same kernel, same chunking); the one-shot host entry and the plan-free device entry share theirs
     xt = torch_cuda.from_numpy(np.ascontiguousarray(x)).cuda() if x.size else torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")[:0]
     plan = capi.ColumnSumsPlan(np.ascontiguousarray(p, dtype=np.int32), nnz=int(x.size))
     planned = plan.column_sums(xt, torch_cuda.from_numpy(np.ascontiguousarray(p, dtype=np.int32)).cuda()).cpu().numpy()
     plan.close()
-    assert host.tobytes() == resident.tobytes() == planned.tobytes()
+    assert resident.tobytes() == planned.tobytes() and host.tobytes() == dev.tobytes()
     if dim[0] > 0:
         want = resident / dim[0]          # RcppSparse.h:147-148 divides the sums
         same = (means == want) | (np.isnan(means) & np.isnan(want))
@@ -247,11 +250,13 @@ def test_short_columns_come_out_in_reference_order_bit_exact(torch_cuda, launch_
     assert_parity(got, x, p)
     # automatic chunking at this size: kShortCallChunkRows, kPlannedShortCallChunkRows for a planned call (whose
     # chunk finishes the column crossing its end with one wave reduction over the rest: not the reference's order)
-    chunk = (8 if launch_mode == "planned" else 20) * 128
+    chunk = (20 if launch_mode == "general" else 8) * 128
     inside = (p[:-1] // chunk) == ((np.maximum(p[1:], p[:-1] + 1) - 1) // chunk)
     exact = got.view(np.uint64) == ref.view(np.uint64)
     assert np.all(exact[inside]), int(np.count_nonzero(~exact[inside]))
     assert np.count_nonzero(inside) > 0.985 * ncol
+    if launch_mode == "planned":      # the lean form: a lane adds its whole column in storage order, chunk edge or not
+        assert np.all(exact)
 
 
 @pytest.mark.parametrize("order", ["shuffled", "descending"])
@@ -833,13 +838,19 @@ def test_c2_full_size_planned_against_oracle(torch_cuda):
     p = synth.offsets_from_counts(synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow))
     pt = torch.from_numpy(p).cuda()
     plan = capi.ColumnSumsPlan(p)
-    assert plan.snapped and plan.max_skip <= 512 and plan.nchunks > 1000 and plan.inspect_ms >= 0
+    assert plan.lean and plan.snapped and plan.nchunks > 1000 and plan.inspect_ms >= 0     # C2's columns are all short
+    capi.set_lean(False)
+    plan_snapped = capi.ColumnSumsPlan(p)                                                   # the form for longer columns
+    capi.set_lean(True)
+    assert plan_snapped.form == 1 and plan_snapped.max_skip <= 512
     for kind in (0, 1):
         xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
         capi.gen_values_device(xt, seed=42, kind=kind)
         got = plan.column_sums(xt, pt).cpu().numpy()
         x = oracle.gen_values(nnz, 42, 0, kind)
         assert_parity(got, x, p, positive=(kind == 1))
+        assert got.tobytes() == oracle.column_sums(x, p).tobytes()       # lean form: the reference's bits, every column
+        assert_parity(plan_snapped.column_sums(xt, pt).cpu().numpy(), x, p, positive=(kind == 1))
         means = plan.column_sums(xt, pt, nrow_for_means=nrow).cpu().numpy()
         assert means.tobytes() == (got / nrow).tobytes()                  # RcppSparse.h:147-148
         # short columns inside a group are added in storage order on both paths: same bits as the general entry
@@ -862,6 +873,7 @@ def test_c2_full_size_planned_against_oracle(torch_cuda):
     torch.cuda.synchronize()
     assert out.cpu().numpy().tobytes() == got.tobytes()
     plan.close()
+    plan_snapped.close()
 
 
 @pytest.mark.parametrize("shape,snaps", [("short", True), ("into512", True), ("into513", False), ("long", False),
@@ -890,7 +902,49 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
     if shape.startswith("into"):
         assert plan.chunk_elems == 1024 and plan.max_skip == reach
     assert plan.snapped is snaps, (shape, plan.max_skip)
+    assert plan.lean is (shape == "short")            # only there is every column at most 64 entries long
     xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
     got = plan.column_sums(xt, pt).cpu().numpy()
     plan.close()
     assert_parity(got, x, p)
+
+
+@pytest.mark.parametrize("pattern", ["len64", "len65", "all_ones", "many_empties_then_ones", "reach_one_row",
+                                     "too_many_columns", "tail_columns_empty", "single_short_column"])
+def test_lean_plan_edges(torch_cuda, pattern):
+    """Where the lean form begins and ends: columns of exactly 64 entries (lean) and 65 (not); 1024 one-entry
+    columns per chunk (lean, 16 passes of 64 lanes); a chunk with more column starts than the offsets hold (not);
+    a 64-entry column starting one entry before a chunk's grid end (it reaches 63 past it; with columns of at most 64
+    entries none can reach more than the one extra row a chunk reads); trailing empty columns;
+    a matrix smaller than one chunk.  Lean results are the reference's bits in every column."""
+    torch = torch_cuda
+    if pattern == "len64":
+        counts, lean = np.full(5000, 64), True
+    elif pattern == "len65":
+        counts, lean = np.full(5000, 65), False
+    elif pattern == "all_ones":
+        counts, lean = np.ones(300_000), True
+    elif pattern == "many_empties_then_ones":           # 1279 column starts at one position: one more than a chunk holds
+        counts, lean = np.concatenate([np.ones(5000), np.zeros(1279), np.ones(5000)]), False
+    elif pattern == "too_many_columns":
+        counts, lean = np.concatenate([np.zeros(2000), np.full(3000, 8)]), False
+    elif pattern == "reach_one_row":                    # starts 1 entry before the edge of chunk 3, 64 long: ends 63 past it
+        counts, lean = np.concatenate([np.full((3 * 1024 - 1) // 1, 1), [64], np.full(4000, 3)]), True
+    elif pattern == "tail_columns_empty":
+        counts, lean = np.concatenate([np.full(700, 9), np.zeros(500)]), True
+    else:
+        counts, lean = np.array([5]), True
+    counts = counts.astype(np.int64)
+    p = synth.offsets_from_counts(counts)
+    nnz = int(p[-1])
+    x = synth.gen_values(nnz, seed=8, kind=0)
+    plan = capi.ColumnSumsPlan(p)
+    assert plan.lean is lean, (pattern, plan.form, plan.max_skip)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    got = plan.column_sums(xt, pt).cpu().numpy()
+    means = plan.column_sums(xt, pt, nrow_for_means=977).cpu().numpy()
+    plan.close()
+    assert_parity(got, x, p)
+    assert means.tobytes() == (got / 977).tobytes()
+    if lean:
+        assert got.tobytes() == oracle.column_sums(x, p).tobytes()
