@@ -19,6 +19,7 @@ import torch
 
 import oracle
 from rcppsparse_amd import capi, synth
+import test_gpu_parity
 from test_gpu_parity import _random_structure, assert_parity, dev_colsums
 
 
@@ -97,8 +98,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--what", default="colsums", choices=["colsums", "next"])
+    ap.add_argument("--mode", default="general", choices=["general", "planned", "mixed"],
+                    help="colsums: rsp_column_sums_device, the inspector-executor form (a third of the cases with every "
+                         "column clipped to 64 entries so that the lean form applies, a third with the lean form "
+                         "switched off), or both alternating")
     a = ap.parse_args()
     capi.load()
+    forms = {}
     if a.what == "next":
         return soak_next_rows(a)
     t0 = time.time()
@@ -106,6 +112,12 @@ def main():
     while time.time() - t0 < a.seconds:
         rng = np.random.default_rng(a.seed * 1_000_003 + n)
         counts = structure(rng)
+        planned = a.mode == "planned" or (a.mode == "mixed" and n % 2 == 1)
+        lean_case = planned and n % 3 == 0
+        if lean_case:
+            counts = np.minimum(counts, 64)
+        test_gpu_parity._MODE["launch"] = "planned" if planned else "general"
+        capi.set_lean(not (planned and n % 3 == 1))
         p = synth.offsets_from_counts(counts)
         nnz = int(p[-1])
         kind = int(rng.integers(0, 2))
@@ -113,8 +125,14 @@ def main():
         rows = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 13, 16, 31, 64, 200]))
         capi.set_tuning(rows)
         try:
+            before = dict(test_gpu_parity.PLANS_SEEN)
             got = dev_colsums(torch, x, p)
             assert_parity(got, x, p, positive=(kind == 1))
+            for k, v in test_gpu_parity.PLANS_SEEN.items():
+                if k != "n" and v != before.get(k, 0):
+                    forms[k] = forms.get(k, 0) + 1
+                    if k == "lean":      # the lean form's promise: the reference's bits in every column
+                        assert got.tobytes() == oracle.column_sums(x, p).tobytes(), (n, "lean form is not bit-identical")
             if n % 4 == 0 and nnz > 0:               # the other combine policies on the same structure
                 xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
                 for op in (capi.OP_MAX, capi.OP_MIN, capi.OP_SUM_SQUARES):
@@ -151,7 +169,9 @@ def main():
         n += 1
         if n % 50 == 0:
             print(f"{n} cases ok, {time.time() - t0:.0f} s", flush=True)
-    print(f"soak ok: {n} cases in {time.time() - t0:.0f} s", flush=True)
+    test_gpu_parity._MODE["launch"] = "general"
+    capi.set_lean(True)
+    print(f"soak ok: {n} cases in {time.time() - t0:.0f} s; plan forms seen: {forms}", flush=True)
 
 
 if __name__ == "__main__":
