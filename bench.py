@@ -564,7 +564,9 @@ def main(argv=None):
         algo_bytes = 8 * shard.nnz + 4 * (shard.ncol + 1) + 8 * shard.ncol
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         value = nnz * args.steps / elapsed
-        traffic = traffic_from_profiles(args.workload) if world == 1 else (None, None)
+        # (a one-launch planned call has counter passes of its own: profiles/*_<workload>planned_traffic.json)
+        traffic_key = args.workload + ("planned" if plan is not None and plan.snapped else "")
+        traffic = traffic_from_profiles(traffic_key) if world == 1 else (None, None)
         traffic_source = (None if traffic[1] is None else
                           f"{traffic[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in a "
                           "SEPARATE earlier run (FETCH_SIZE doubled per MI355X_MICROARCH.md), not measured in this run")

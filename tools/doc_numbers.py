@@ -25,35 +25,73 @@ def kernel_avgs(path):
     if not os.path.exists(path):
         return None, None
     for r in csv.DictReader(open(path)):
-        if "colsums_chunks_kernel" in r["Name"]:
+        if "colsums_chunks_kernel" in r["Name"] or "colsums_lean_kernel" in r["Name"]:
             main = float(r["AverageNs"]) / 1e3
         if "colsums_fixup_kernel" in r["Name"]:
             fix = float(r["AverageNs"]) / 1e3
     return main, fix
 
 
+def driver_record(rnd):
+    """(round tag, parsed bench line) of the driver's own N = 1 run: BENCH_<rnd>.json if the driver has run this
+    round's code already, else the latest earlier one (a record of THAT round's code)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json"))):
+        tag = os.path.basename(f)[6:-5]
+        if tag <= rnd:
+            try:
+                parsed = json.load(open(f)).get("parsed")
+            except Exception:
+                parsed = None
+            if parsed:
+                best = (tag, parsed)
+    return best
+
+
+def row_of(d, label, m=None, f=None, tr=None):
+    r = d["roofline"]
+    pipe = d.get("pipelined") or {}
+    gather = f" (+ gatherv {r['gather_ms'] * 1e3:.1f} us)" if r.get("gather_ms") else ""
+    prof = "-" if m is None else (f"{m:.1f} + {f:.1f}" if f is not None else f"{m:.1f} (one launch)")
+    return (f"| {label} | {d['ms_per_step']:.4f} | {r['kernel_ms']:.4f}{gather} | {d['value']:.3e} | {r['achieved']:.0f} | "
+            f"{100 * r['frac']:.1f} % | {d['latency_ms_per_call']:.4f} | {pipe.get('ms_per_step', float('nan')):.4f} | "
+            f"{prof} | {'-' if tr is None else f'{tr:.3f}'} | {d['parity']['max_abs_err_over_l1']:.1e} |")
+
+
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     lines = [json.loads(l) for l in open(os.path.join(P, f"{rnd}_bench_lines.jsonl")) if l.strip()]
     out = ["| workload (`bench.py --workload`) | ms per call (wall, K calls back to back) | kernels per call, HIP events | "
            "nnz/s | algorithmic GB/s | of 8 TB/s | one call alone, launch to host (ms) | calls overlapped (ms per call) | "
            "rocprofv3 main + fix-up (us) | HBM bytes / algorithmic | parity: max err / column 1-norm (all columns) |",
            "|---|---|---|---|---|---|---|---|---|---|---|"]
+    drv = driver_record(rnd)
+    if drv and drv[0] == rnd:     # the driver's own run of this round's code is the headline
+        out.append(row_of(drv[1], f"c3 -- the driver's run (`BENCH_{rnd}.json`)"))
     for d in lines:
         tag = d["config"]["workload"].split(":")[0]
-        r = d["roofline"]
-        m, f = kernel_avgs(os.path.join(P, f"{rnd}_{tag}_kernel_stats.csv"))
-        tr = None
-        tf = os.path.join(P, f"{rnd}_{tag}_traffic.json")
-        if os.path.exists(tf):
-            tr = json.load(open(tf))["hbm_bytes_per_launch"] / r["algorithmic_bytes_per_launch"]
-        pipe = d.get("pipelined") or {}
-        gather = f" (+ gatherv {r['gather_ms'] * 1e3:.1f} us)" if r.get("gather_ms") else ""
-        out.append(
-            f"| {tag} | {d['ms_per_step']:.4f} | {r['kernel_ms']:.4f}{gather} | {d['value']:.3e} | {r['achieved']:.0f} | "
-            f"{100 * r['frac']:.1f} % | {d['latency_ms_per_call']:.4f} | {pipe.get('ms_per_step', float('nan')):.4f} | "
-            f"{'-' if m is None else f'{m:.1f} + {f:.1f}'} | {'-' if tr is None else f'{tr:.3f}'} | "
-            f"{d['parity']['max_abs_err_over_l1']:.1e} |")
+        form = (d["config"].get("planned") or {}).get("form")
+        ptag = tag + ("planned" if form in ("lean", "snapped") else "")
+        label = tag if form is None else f"{tag} `--planned` ({form} form)"
+        if form == "snapped" and any((x["config"].get("planned") or {}).get("form") == "lean" and
+                                     x["config"]["workload"].split(":")[0] == tag for x in lines):
+            ptag = None               # (the committed planned profile of this workload is the lean run's)
+            label = f"{tag} `--planned --no-lean` (snapped form)"
+        m = f = tr = None
+        if ptag:
+            m, f = kernel_avgs(os.path.join(P, f"{rnd}_{ptag}_kernel_stats.csv"))
+            tf = os.path.join(P, f"{rnd}_{ptag}_traffic.json")
+            if os.path.exists(tf):
+                tr = json.load(open(tf))["hbm_bytes_per_launch"] / d["roofline"]["algorithmic_bytes_per_launch"]
+        out.append(row_of(d, label, m, f, tr))
+    if drv and drv[0] != rnd:
+        p = drv[1]
+        out.append("")
+        out.append(f"The driver's latest own record is `BENCH_{drv[0]}.json` (round {drv[0][1:]}'s code, a device of its choosing): "
+                   f"c3 {p['ms_per_step']:.4f} ms per call, kernels {p['roofline']['kernel_ms']:.4f} ms = "
+                   f"{100 * p['roofline']['frac']:.1f} % of 8 TB/s.  The rows above are the builder's runs of THIS round's code on "
+                   f"the devices `gpurun` handed out (c3 on them: 1.19-1.24 ms, 81-85 %, device to device).")
     cpu = [d for d in lines if d.get("cpu_baseline")]
     if cpu:
         c = cpu[0]["cpu_baseline"]

@@ -19,9 +19,17 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(paths):
+    """gpurun merges a call's output into gpurun_out/ next to what earlier calls left there: only the newest
+    run's files of a directory count."""
+    return max(paths, key=os.path.getmtime) if paths else None
+
+
 def counters(path):
     d = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True):
+    for f in [newest(glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True))]:
+        if f is None:
+            continue
         for r in csv.DictReader(open(f)):
             d[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(
                 float(r["Counter_Value"]))
@@ -39,7 +47,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     base = f"{a.round}_{a.tag}"
     stats = glob.glob(os.path.join(src, f"prof_{a.tag}_stats", "**", "*_kernel_stats.csv"), recursive=True)
-    shutil.copy(stats[0], os.path.join(dst, base + "_kernel_stats.csv"))
+    shutil.copy(newest(stats), os.path.join(dst, base + "_kernel_stats.csv"))
     log = os.path.join(src, f"prof_{a.tag}_stats.log")
     bench_line = [l for l in open(log) if l.startswith('{"metric"')]
     if bench_line:
@@ -50,7 +58,7 @@ def main():
     for (k, c), v in sorted({**fetch, **write}.items()):
         rows.append({"kernel": k, "counter": c, "launches": len(v), "mean_KiB": sum(v) / len(v),
                      "min_KiB": min(v), "max_KiB": max(v)})
-        if "colsums_chunks_kernel" in k:
+        if "colsums_chunks_kernel" in k or "colsums_lean_kernel" in k:   # (one of them per profiled command)
             main_kernel = k
     with open(os.path.join(dst, base + "_pmc_summary.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0]))
@@ -68,7 +76,7 @@ def main():
         "read_bytes": rd, "write_bytes": wr,
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB -> bytes; "
                   "FETCH_SIZE doubled (gfx950 counts 128-B requests of a 16 B/lane stream as 64 B); "
-                  "main kernel + fix-up kernel of one columnSums call",
+                  "main kernel (+ fix-up kernel, when the form has one) of one columnSums call",
     }
     gen = [k for (k, c) in write if "gen_values" in k]
     if gen:
