@@ -194,3 +194,42 @@ def test_automatic_chunk_plan_policy():
         assert fixed["nchunks"] == fixed["nbody"] == -(-total_rows // 256)
     finally:
         capi.set_tuning(0)
+
+
+def test_plan_entries_validate_arguments_and_do_not_answer_without_a_device():
+    """rsp_column_sums_plan_*: a bad p[] is rejected on the host before any device is touched; without a device
+    the inspector says so (it uploads its records) instead of handing out a plan nothing could execute."""
+    good = np.array([0, 2, 2, 5], dtype=np.int32)
+    for p in ([1, 2, 3, 4], [0, 3, 2, 4], [0, 1, 2, 3]):
+        with pytest.raises(capi.RspError) as e:
+            capi.ColumnSumsPlan(np.array(p, dtype=np.int32), nnz=4)
+        assert e.value.code == capi.RSP_ERR_BAD_ARG
+    L = capi.load()
+    assert L.rsp_column_sums_plan_destroy(None) == capi.RSP_OK           # destroying nothing is fine
+    assert L.rsp_column_sums_plan_info(None, None, None) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_column_sums_planned_device(None, None, None, 0, None, None, 0, None) == capi.RSP_ERR_BAD_ARG
+    if _no_gpu():
+        with pytest.raises(capi.RspError) as e:
+            capi.ColumnSumsPlan(good)
+        assert e.value.code == capi.RSP_ERR_NO_DEVICE
+    capi.set_lean(False)
+    capi.set_lean(True)
+
+
+def test_row_reduce_workspace_arithmetic_and_argument_checks():
+    """rsp_comm_reduce_rows_workspace_bytes: nranks incoming pieces + the reduced slice, slices of whole 16-byte
+    pairs; the entries reject null communicators / buffers instead of dereferencing them."""
+    for nranks, nrow in [(1, 1), (1, 7), (2, 7), (3, 10), (8, 10_000_000), (8, 10_000_001), (5, 0)]:
+        per = -(-nrow // nranks)
+        per += per & 1
+        want = ((nranks + 1) * per * 8 + 255) // 256 * 256
+        assert capi.reduce_rows_workspace_bytes(nranks, nrow) == want, (nranks, nrow)
+    assert capi.reduce_rows_workspace_bytes(0, 5) == 0 and capi.reduce_rows_workspace_bytes(2, -1) == 0
+    L = capi.load()
+    assert L.rsp_comm_reduce_rows(None, None, 5, 0, None, None, 0, 0, None) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_add_partials_device(None, 0, 4, 4, 0, None, None) == capi.RSP_ERR_BAD_ARG      # no parts
+    assert L.rsp_add_partials_device(None, 2, 3, 4, 0, None, None) == capi.RSP_ERR_BAD_ARG      # stride < n
+    assert L.rsp_add_partials_device(None, 2, 4, 4, 0, None, None) == capi.RSP_ERR_BAD_ARG      # null buffers
+    assert L.rsp_add_partials_device(None, 2, 0, 0, 0, None, None) == capi.RSP_OK               # nothing to add
+    assert L.rsp_mcsc_row_sums(None, None) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_mcsc_column_means(None, None) == capi.RSP_ERR_BAD_ARG
