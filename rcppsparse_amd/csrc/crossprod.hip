@@ -506,6 +506,11 @@ void crossprod_tall_kernel(
             const bool in = lane < ek - ck;
             row[k] = in ? rk[lane] : 0x7fffffff;
             val[k] = in ? xk[lane] : 0.0;
+            // (This look at the value just requested makes the wavefront wait for it here.  Checking at the point of
+            // use instead -- a true prefetch across the MFMA phase -- was measured in round 3 and LOSES: the 3 registers
+            // per column then stay live through the MFMA phase and spill, 1e6 x 128 / 192 / 256: 0.73 -> 1.11,
+            // 1.19 -> 1.67, 2.45 -> 4.14 ms.  Phase split at 256 columns, profiles/r03_crossprod.json: loads and cursor
+            // bookkeeping alone 1.23 ms, the MFMA phase 1.2 ms on top, the LDS panel writes 0.1 ms.)
             bad |= ((uint32_t)__double2hiint(val[k]) & 0x7ff00000u) == 0x7ff00000u;
         }
     };
