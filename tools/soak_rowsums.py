@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the one-shot rowSums kernels on one GPU: random row counts around the block (16384), tile
-(22528) and form (832 blocks) edges, uniform / clustered / single-block / mostly-invalid row indices,
+(22528), form (4, 832, 2 / 4 / 8 x 832 blocks: direct, partition, coarse-block, two-level) and bucket (512 blocks)
+edges, uniform / clustered / single-block / mostly-invalid row indices,
 against numpy's bincount; every case also run twice for bit-stability and once as rowMeans.
 
     python3 tools/soak_rowsums.py [seconds] [seed]
@@ -15,8 +16,13 @@ RTOL = 1e-12
 
 
 def one(rng, case):
-    nrow = int(rng.choice([1, 5, 16383, 16384, 16385, 32768, 100_000, 1_000_000, 13_631_488, 13_631_489,
-                           int(rng.integers(1, 14_000_000))]))
+    # around the block (16384), form (4 / 832 / 2 x 832 / 4 x 832 / 8 x 832 blocks) and bucket (512 blocks) edges;
+    # the big ones (coarse-block and two-level forms) on every 8th case: their outputs are 0.2-1.3 GB
+    small = [1, 5, 16383, 16384, 16385, 32768, 65536, 65537, 100_000, 1_000_000, 8_388_608, 8_388_609, 13_631_488,
+             13_631_489, int(rng.integers(1, 14_000_000))]
+    big = [27_262_976, 27_262_977, 54_525_952, 54_525_953, 109_051_904, 109_051_905, 117_440_513,
+           int(rng.integers(14_000_000, 170_000_000))]
+    nrow = int(rng.choice(big if case % 8 == 7 else small))
     nnz = int(rng.choice([0, 1, 63, 64, 65, 22527, 22528, 22529, 157_696, 157_697,
                           int(rng.integers(1, 3_000_000))]))
     kind = int(rng.integers(0, 6))
@@ -47,7 +53,7 @@ def one(rng, case):
     scale = np.bincount(i[keep], weights=np.abs(x[keep]), minlength=nrow)
     ok = (got.tobytes() == again.tobytes() and means.tobytes() == (got / ncol).tobytes()
           and bool(np.all(np.abs(got - ref) <= RTOL * scale)) and not np.any(np.signbit(got[scale == 0])))
-    if ok and 0 < nnz <= 200_000 and nrow <= 2_000_000:     # the handle's row-major form (full sort by row)
+    if ok and 0 < nnz <= 200_000 and nrow <= 2_000_000:     # the handle (keeps the regrouped copy, repeats the accumulate pass)
         pc = np.sort(rng.integers(0, nnz + 1, ncol - 1)).astype(np.int32) if ncol > 1 else np.zeros(0, np.int32)
         p = np.concatenate(([0], pc, [nnz])).astype(np.int32)
         h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
