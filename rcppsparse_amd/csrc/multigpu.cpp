@@ -192,6 +192,7 @@ struct rsp_mcsc {
     std::vector<int32_t> bounds;   // column range of shard k: [bounds[k], bounds[k+1])
     int32_t nrow, ncol;
     bool has_rows;                 // uploaded with i[]: the row-wise entries are available
+    std::vector<double> row_partials;   // shards x nrow: where the shards' partial row sums land (kept between calls)
 };
 
 int rsp_mcsc_free(rsp_mcsc_t h) {
@@ -313,7 +314,8 @@ static int mcsc_rows(rsp_mcsc_t h, double* out, bool means) try {
     const int G = (int)h->shards.size();
     const size_t nrow = (size_t)h->nrow;
     if (nrow == 0) return RSP_OK;
-    std::vector<double> partial((size_t)G * nrow);
+    if (h->row_partials.size() != (size_t)G * nrow) h->row_partials.assign((size_t)G * nrow, 0.0);
+    std::vector<double>& partial = h->row_partials;
     std::vector<int> status((size_t)G, RSP_OK);
     std::vector<std::string> message((size_t)G);
     auto work = [&](int k) noexcept {
