@@ -226,3 +226,42 @@ def test_row_restricted_column_sums_full_size(torch_cuda, nrow, ncol, nnz, struc
     plain = capi.column_sums_device(xt, pt)
     l1 = capi.column_reduce_device(xt, pt, capi.OP_SUM_ABS)
     assert bool(torch.all((res[False] + res[True] - plain).abs() <= 3 * RTOL * l1))
+
+
+# --------------------------------------------------- the lean planned form of the hot path at the 32-bit limit
+def test_lean_form_at_the_int32_limit(torch_cuda):
+    """2^31 - 1 entries in columns of 1..64 entries (3.4e7 columns): the inspector-executor plan takes the lean form
+    (1.4e6 chunks of 12 rows, 16-bit chunk-local offsets), whose promise is the reference's bits in EVERY column: the oracle on
+    column ranges at both ends of the arrays and in the middle, bit for bit; the plan-free kernels on the whole
+    matrix within tolerance; identical bits on a second run."""
+    torch = torch_cuda
+    need_hbm(torch, 40)
+    nnz = INT32_MAX
+    rng = np.random.default_rng(11)
+    counts = rng.integers(1, 65, size=70_000_000).astype(np.int64)
+    ends = np.cumsum(counts)
+    ncol = int(np.searchsorted(ends, nnz, side="left")) + 1          # first prefix reaching nnz
+    counts = counts[:ncol]
+    counts[-1] -= int(ends[ncol - 1]) - nnz                          # trim the last column to end exactly at nnz
+    assert counts[-1] >= 1 and int(counts.sum()) == nnz
+    p = synth.offsets_from_counts(counts)
+    del ends, counts
+    pt = torch.from_numpy(p).cuda()
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    capi.gen_values_device(xt, 17, 0, 0)
+    plan = capi.ColumnSumsPlan(p)
+    assert plan.lean and plan.nchunks > 1_000_000, (plan.form, plan.nchunks)      # (12-row chunks at 32.5 per column)
+    out = plan.column_sums(xt, pt)
+    again = plan.column_sums(xt, pt)
+    assert torch.equal(out, again)
+    got = out.cpu().numpy()
+    for c0 in (0, ncol // 2, ncol - 5000):
+        c1 = c0 + 5000
+        lo, hi = int(p[c0]), int(p[c1])
+        xs = oracle.gen_values(hi - lo, 17, lo, 0)
+        pl = (p[c0:c1 + 1].astype(np.int64) - lo).astype(np.int32)
+        assert got[c0:c1].tobytes() == oracle.column_sums(xs, pl).tobytes(), c0
+    general = capi.column_sums_device(xt, pt)
+    l1 = capi.column_reduce_device(xt, pt, capi.OP_SUM_ABS)
+    assert bool(torch.all((general - out).abs() <= RTOL * l1))
+    plan.close()
