@@ -20,6 +20,7 @@
 
 #include "../../include/rcppsparse_hip.h"
 #include "colsums_kernels.h"
+#include "inspect.hpp"
 
 #ifdef RSP_STAMPS
 namespace rsp { hipError_t read_stamps(unsigned long long* host, size_t n); }
@@ -275,115 +276,6 @@ struct rsp_colsums_plan {
     uint32_t* d_lean_offs;
 };
 
-namespace {
-// The inspection: for every chunk of the grid, the first column start at or after its grid position and the
-// LAST column starting there (empty columns at that position end where the previous chunk ends: they are its).
-// Pure integer work on the host copy of p[]: nchunks x 2 binary searches.
-int inspect_offsets(const int32_t* p, int32_t ncol, int64_t nnz, const rsp::LaunchPlan& lp,
-                    std::vector<int2>* rec, int32_t* max_skip) {
-    const rsp::ChunkMap cmap{lp.chunk_elems, lp.nbody, lp.tail_elems};
-    rec->resize((size_t)lp.nchunks + 1);
-    int32_t worst = 0;
-    const int32_t* pend = p + (size_t)ncol + 1;
-    for (int32_t w = 0; w < lp.nchunks; ++w) {
-        const int64_t cs = cmap.start(w);
-        const int32_t* first = std::lower_bound(p, pend, (int32_t)cs);          // p[ncol] = nnz > cs: always found
-        const int32_t xs0 = *first;
-        const int32_t* past = std::upper_bound(first, pend, xs0);
-        (*rec)[w] = make_int2((int32_t)(past - p) - 1, xs0);
-        const int64_t skip = (int64_t)xs0 - cs;
-        if (skip > worst) worst = (int32_t)(skip > INT32_MAX ? INT32_MAX : skip);
-    }
-    (*rec)[lp.nchunks] = make_int2(ncol, (int32_t)nnz);
-    *max_skip = worst;
-    return RSP_OK;
-}
-// Runs fn(begin, end) over [0, n) on a few host threads when the range is long (a plan for 1e7 columns is ~50 ms of
-// integer work on one thread); anything that goes wrong with the threads falls back to the calling thread.
-template <class Fn>
-void inspect_parallel(int64_t n, int64_t grain, Fn&& fn) {
-    const unsigned hw = std::thread::hardware_concurrency();
-    int64_t parts = n / (grain > 0 ? grain : 1);
-    if (parts > 8) parts = 8;
-    if (hw > 0 && parts > (int64_t)hw) parts = hw;
-    if (parts <= 1) {
-        fn((int64_t)0, n);
-        return;
-    }
-    auto range = [&](int64_t k) { fn(n * k / parts, n * (k + 1) / parts); };   // (fn only writes its own range's outputs)
-    std::vector<std::thread> pool;
-    int64_t started = 0;   // ranges 1..started run on threads of their own
-    try {
-        pool.reserve((size_t)parts - 1);
-        for (int64_t k = 1; k < parts; ++k) {
-            pool.emplace_back([&range, k] { range(k); });
-            started = k;
-        }
-    } catch (...) {   // out of threads or memory: the rest runs here
-    }
-    range(0);
-    for (int64_t k = started + 1; k < parts; ++k) range(k);
-    for (auto& t : pool) t.join();
-}
-
-// The lean form's inspection (colsums_lean_kernel): applies when no column is longer than kLeanMaxColumn entries,
-// no chunk (2..16 rows of x, lean_rows_setting) holds more than kLeanMaxColumns column starts, and no column reaches
-// more than one row past its chunk's grid end.  Chunk w owns the columns that START in its grid range
-// [cs_w, cs_{w+1}) (the last chunk: all that remain); their starts relative to cs_w fit 16 bits.  The result is ONE
-// host buffer: nchunks headers {first column, columns} followed by the 16-bit offsets at a fixed stride.
-bool inspect_lean(const int32_t* p, int32_t ncol, int64_t nnz, int32_t rows, std::vector<uint32_t>* image,
-                  int32_t* nchunks_out, int32_t* stride_dwords, int32_t* max_columns) {
-    const int64_t chunk = (int64_t)rows * rsp::kRowElems;
-    const int64_t nchunks = (nnz + chunk - 1) / chunk;
-    if (nchunks <= 0 || nchunks > INT32_MAX / 4) return false;
-    std::atomic<int> too_long{0};
-    inspect_parallel(ncol, 1 << 20, [&](int64_t c0, int64_t c1) {
-        int bad = 0;
-        for (int64_t c = c0; c < c1; ++c) bad |= (p[c + 1] - p[c] > rsp::kLeanMaxColumn);
-        if (bad) too_long.store(1, std::memory_order_relaxed);
-    });
-    if (too_long.load()) return false;
-    // first column starting at or after every chunk's grid position (chunk nchunks: ncol)
-    std::vector<int32_t> first((size_t)nchunks + 1);
-    const int32_t* pend = p + (size_t)ncol + 1;
-    inspect_parallel(nchunks, 1 << 14, [&](int64_t w0, int64_t w1) {
-        const int32_t* at = p;
-        for (int64_t w = w0; w < w1; ++w) {
-            at = std::lower_bound(at, pend, (int32_t)(w * chunk));   // (chunk starts ascend: search on from the last hit)
-            int64_t c = at - p;
-            first[(size_t)w] = (int32_t)(c > ncol ? ncol : c);
-        }
-    });
-    first[(size_t)nchunks] = ncol;
-    int32_t widest = 0;
-    for (int64_t w = 0; w < nchunks; ++w) {
-        const int32_t c0 = first[(size_t)w], c1 = first[(size_t)w + 1];
-        if (c1 - c0 > widest) widest = c1 - c0;
-        // the last owned column ends at p[c1]; the chunk has its own rows and one more
-        if (c1 > c0 && (int64_t)p[c1] - w * chunk > chunk + rsp::kRowElems) return false;
-    }
-    if (widest > rsp::kLeanMaxColumns) return false;
-    const int32_t stride = ((widest + 2 + 1) / 2 + 3) & ~3;   // 16-bit offsets, two per dword, whole 16-byte pieces
-    image->assign((size_t)nchunks * 2 + (size_t)nchunks * (size_t)stride, 0u);
-    int2* hdr = (int2*)image->data();
-    uint32_t* offs = image->data() + (size_t)nchunks * 2;
-    inspect_parallel(nchunks, 1 << 13, [&](int64_t w0, int64_t w1) {
-        for (int64_t w = w0; w < w1; ++w) {
-            const int32_t c0 = first[(size_t)w], n = first[(size_t)w + 1] - c0;
-            hdr[w] = make_int2(c0, n);
-            uint16_t* o = (uint16_t*)(offs + (size_t)w * (size_t)stride);
-            const int64_t cs = w * chunk;
-            if (n > 0)
-                for (int32_t j = 0; j <= n; ++j) o[j] = (uint16_t)((int64_t)p[c0 + j] - cs);
-        }
-    });
-    *nchunks_out = (int32_t)nchunks;
-    *stride_dwords = stride;
-    *max_columns = widest;
-    return true;
-}
-}  // namespace
-
 struct rsp_csc {
     rsp_colsums_plan* plan;   // made at upload (p[] is on the host then); nullptr: not applicable
     int device;
@@ -499,8 +391,9 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
         if (lean_allowed()) {
             std::vector<uint32_t> image;
             pl->lean_rows = lean_rows_setting(ncol, nnz);
-            if (inspect_lean(p_host, ncol, nnz, pl->lean_rows, &image, &pl->lean_chunks, &pl->lean_stride_dwords,
-                             &pl->lean_max_columns)) {
+            const rsp::inspect::LeanLimits lim{rsp::kRowElems, rsp::kLeanMaxColumn, rsp::kLeanMaxColumns};
+            if (rsp::inspect::inspect_lean(p_host, ncol, nnz, pl->lean_rows, lim, &image, &pl->lean_chunks,
+                                           &pl->lean_stride_dwords, &pl->lean_max_columns)) {
                 // headers and offsets in ONE device allocation and ONE copy
                 hipError_t e = hipMalloc((void**)&pl->d_lean_hdr, image.size() * 4);
                 if (e == hipSuccess) e = hipMemcpy(pl->d_lean_hdr, image.data(), image.size() * 4, hipMemcpyHostToDevice);
@@ -508,6 +401,7 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
                     rsp_column_sums_plan_destroy(pl);
                     return fail(RSP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
                 }
+                static_assert(sizeof(int2) == sizeof(rsp::inspect::Rec), "a record is two 32-bit numbers");
                 pl->d_lean_offs = (uint32_t*)(pl->d_lean_hdr + pl->lean_chunks);
                 pl->lean = true;
                 pl->snapped = true;     // (the lean form is a planned, one-launch form too)
@@ -515,8 +409,9 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
             }
         }
         if (!pl->lean) {
-            std::vector<int2> rec;
-            inspect_offsets(p_host, ncol, nnz, pl->lp, &rec, &pl->max_skip);
+            std::vector<rsp::inspect::Rec> rec;
+            const rsp::inspect::Grid grid{pl->lp.chunk_elems, pl->lp.nbody, pl->lp.tail_elems, pl->lp.nchunks};
+            rsp::inspect::inspect_offsets(p_host, ncol, nnz, grid, &rec, &pl->max_skip);
             pl->snapped = pl->max_skip <= rsp::kGroupElems;
             if (pl->snapped) {
                 hipError_t e = hipMalloc((void**)&pl->d_rec, rec.size() * sizeof(int2));
