@@ -122,6 +122,8 @@ struct RowSumsLayout {
     size_t table_off, temp_off, temp_bytes, mid_vals_off, mid_rows_off, bucket_off, scratch_bytes;
     int32_t shift, nblocks, nsuper, nsplit, nbuckets;   // nsplit: accumulate workgroups per row block
     int32_t sub, ncoarse;   // the partition pass groups by coarse block of 2^sub row blocks (ncoarse of them)
+    bool aligned;           // the pass writes whole groups of 8 entries only; regions padded with entries of no row
+    int64_t slots;          // capacity of the regrouped copy in entries (nnz, or nnz + the padding)
     bool direct;   // up to 4 row blocks: no regrouping, the accumulate pass reads the caller's x / i
     int64_t super_elems;
 };
