@@ -70,6 +70,8 @@ def load(build: bool = True) -> ctypes.CDLL:
     except Exception:  # pragma: no cover - torch is optional for pure-host use
         pass
     path = _build.LIB_PATH
+    if os.environ.get("RSP_AB_LIB"):          # A/B measurements: a saved build of the library instead of the tree's
+        path, build = os.environ["RSP_AB_LIB"], False
     if build and _build.have_hipcc():
         try:
             _build.build_library()

@@ -27,6 +27,11 @@
 //     function of the data alone (no global atomics, wave-private counters combined in a fixed
 //     order), and a row's terms are added by one wavefront in slot order: bit-stable run to run.
 //
+//     Round 3, 512-640 blocks (8.4e6-1.05e7 rows, C3): step 3 runs in its QUEUE form (rows_tile_partition_queue_kernel)
+//     -- only whole aligned groups of 16 entries leave for HBM, through one queue per block in LDS -- because the pass
+//     is bound by its write side (profiles/r03_rowsums_write_side.json); clustered row indices (a cell of the count
+//     table above 96 entries per tile) take the staged form above, which stands by on the same table.
+//
 //   coarse blocks (round 3; up to 8 x 832 row blocks = 1.09e8 rows): the same single pass regroups by COARSE block
 //     of 2 / 4 / 8 row blocks, and in step 4 every row block scans its coarse block's entries for its own (12 B/nnz
 //     x 2 / 4 / 8 there).  1e9 entries: 12.9 ms at 2e7 rows, 17.3 ms at 4e7 (a library radix sort by block: 18.8 ms
@@ -43,6 +48,7 @@
 // Round-2 history (profiles/r02_rowsums.md): partitioning WITHOUT sorting each tile in LDS first
 // (every lane storing its entry straight to its block's cursor) took 47 ms for the scatter alone.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -65,6 +71,14 @@ constexpr int kPartWaves = kPartThreads / 64;
 constexpr int kPartPerThread = 22;        // entries a thread holds in registers while its tile is ranked (24 spills)
 constexpr int kTileElems = kPartThreads * kPartPerThread;   // 22528 entries ranked together ...
 constexpr int kStageElems = 8192;         // ... and sorted through LDS 8192 positions at a time
+// queue form of the partition pass (round 3): only whole, aligned groups of kQueueGroup entries (128 B of values, 64 B
+// of row indices) leave for HBM; every block has a queue of one group in LDS, which takes the place of the stage
+constexpr int kQueueGroup = 16;
+constexpr int kQueueMinBlocks = 512;      // below: a tile's run per block is long enough for the staged form's plain write-out
+constexpr int kQueueMaxBlocks = 640;      // 232 B of LDS per block: queue, cursor, tile count, 16 packed counters
+constexpr int kQueuePerThread = 16;       // entries a thread holds per tile of the queue form (22 spill there: 81 registers)
+constexpr int kQueueTileElems = kPartThreads * kQueuePerThread;   // 16384: run length no longer matters, whole groups leave
+constexpr int kQueueCellPerTile = 96;     // a (block, supertile) cell above this many entries per tile of the supertile: staged form
 constexpr int kTilesPerSuper = 7;         // a workgroup's supertile: at most 157 696 entries
 constexpr size_t kCountTableMaxBytes = 64u << 20;
 constexpr int kAccThreads = 1024;         // accumulate workgroup: 15 wavefronts stage the entries, ONE adds them
@@ -156,16 +170,29 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
     e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, table_entries,
                                 rocprim::plus<int32_t>(), (hipStream_t)0);
     if (e != hipSuccess) return e;
+    // queue form of the partition pass (whole aligned groups of 16 entries only): every (block, supertile) region is
+    // padded to whole groups, so the regrouped copy has up to 15 slots more per region; kept to what 32-bit slots hold
+    static const bool queue_allowed = [] {   // RSP_ROWS_QUEUE=0: the round-2 write-out (A/B measurements)
+        const char* e = getenv("RSP_ROWS_QUEUE");
+        return !(e && atoi(e) == 0);
+    }();
+    const int64_t padded = nnz + (int64_t)(kQueueGroup - 1) * L->ncoarse * L->nsuper;
+    // (measured, 1e9 entries, queue against staged form: 611 blocks 7.3-7.4 against 8.2 ms on the slower devices of
+    // the pool, 9.32 against 9.57 ms per call on a faster one; 305 blocks 9.24 against 8.89 ms: with fewer blocks a
+    // tile's runs are long enough as they are, and the queues need more rounds)
+    L->aligned = queue_allowed && L->mode == 2 && !L->direct && L->ncoarse >= kQueueMinBlocks &&
+                 L->ncoarse <= kQueueMaxBlocks && padded <= 0x7fffffffll;
+    L->slots = L->aligned ? padded : nnz;
     if (!L->direct) {
-        L->vals_off = off;  off = align_up(off + (size_t)nnz * 8, 256);            // x grouped by row block
-        L->rows_off = off;  off = align_up(off + (size_t)nnz * 4, 256);            // their row indices
+        L->vals_off = off;  off = align_up(off + (size_t)L->slots * 8, 256);       // x grouped by row block
+        L->rows_off = off;  off = align_up(off + (size_t)L->slots * 4, 256);       // their row indices
     }
     L->boff_off = off;  off = align_up(off + ((size_t)L->ncoarse + 1) * 4, 256);   // first slot of every (coarse) block
     L->partial_off = off;                                                          // sums per (part, row)
     if (L->nsplit > 1) off = align_up(off + (size_t)L->nsplit * (size_t)(nrow > 0 ? nrow : 0) * 8, 256);
     L->persistent_bytes = off;
     off = 0;
-    L->table_off = off; off = align_up(off + table_entries * 4, 256);
+    L->table_off = off; off = align_up(off + (table_entries + 1) * 4, 256);   // (+ the clustered-rows flag of the queue form)
     L->temp_off = off;  off = align_up(off + temp, 256);
     L->temp_bytes = temp;
     if (L->mode == 3) {   // the intermediate copy (grouped by bucket) and the buckets' first slots
@@ -218,7 +245,7 @@ __device__ __forceinline__ void* uniform_ptr(const void* p) {
 __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
     const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift, int32_t nblocks,
     int64_t super_elems, int32_t nsuper, int32_t* __restrict__ table, const int32_t* __restrict__ seg,
-    int32_t row_base) {
+    int32_t row_base, int32_t group, int32_t* __restrict__ skew_flag, int32_t cell_limit) {
     extern __shared__ int32_t s_hist[];
     const int tid = threadIdx.x;
     const int s = blockIdx.x;
@@ -248,7 +275,13 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
             }
     }
     __syncthreads();
-    for (int b = tid; b < nblocks; b += kPartThreads) table[(size_t)b * nsuper + s] = s_hist[b];
+    // (queue form of the partition pass: every (block, supertile) region holds whole groups of `group` slots)
+    for (int b = tid; b < nblocks; b += kPartThreads) {
+        table[(size_t)b * nsuper + s] = (s_hist[b] + group - 1) / group * group;
+        // (queue form: a supertile that sends this many entries to ONE block could need dozens of queue rounds per tile
+        // -- rows sorted or clustered; the whole call then takes the staged form instead)
+        if (skew_flag && s_hist[b] > cell_limit) atomicOr(skew_flag, 1);
+    }
 }
 
 // 3. the partition pass.  A tile of 22528 entries (22 per thread, in registers) is ranked at once, so a
@@ -263,7 +296,11 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_histogram_kernel(
 __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift,
     int32_t nblocks, int64_t super_elems, int32_t nsuper, const int32_t* __restrict__ first_slot,
-    double* __restrict__ px, int32_t* __restrict__ pr, const int32_t* __restrict__ seg, int32_t row_base) {
+    double* __restrict__ px, int32_t* __restrict__ pr, const int32_t* __restrict__ seg, int32_t row_base,
+    const int32_t* __restrict__ run_if, int32_t pad_group) {
+    // (standing by for the queue form: runs only if the histogram pass found the row indices too clustered for it, and
+    // then fills every region up to whole groups with entries of no row, as the queue form's layout expects)
+    if (run_if && *run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double* stage_x = (double*)s_raw;                                   // kStageElems
     int32_t* stage_r = (int32_t*)(stage_x + kStageElems);               // kStageElems
@@ -389,6 +426,166 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
         for (; base + kStageElems < total; base += kStageElems) round(base, false);
         round(base, true);
         for (int b = tid; b < nblocks; b += kPartThreads) cursor[b] += tstart[b + 1] - tstart[b];
+    }
+    if (pad_group > 1) {
+        lds_barrier();
+        for (int b = tid; b < nblocks; b += kPartThreads) {
+            const int32_t cur = cursor[b];
+            const int over = cur & (pad_group - 1);
+            if (over)
+                for (int32_t d = cur; d < cur - over + pad_group; ++d) {
+                    px[d] = 0.0;
+                    pr[d] = -1;
+                }
+        }
+    }
+}
+
+// 3b. the QUEUE form of the partition pass (round 3; up to kQueueMaxBlocks blocks, one-level regrouping).
+//    What the pass above pays for is its write side (profiles/r03_rowsums_write_side.json: 7.45 ms as shipped in round
+//    2, 3.30 ms without its global stores, 4.73 ms with the same bytes stored contiguously; the same bytes as aligned
+//    pieces scattered over the array: 64-byte pieces 10.8 ms, 128-byte 6.7 ms, 256-byte 5.6 ms): unaligned runs of ~37
+//    entries into 1222 streams per workgroup.  Here only WHOLE, ALIGNED GROUPS of 16 entries leave for HBM (one full
+//    128-byte line of values, half a line of indices, each written exactly once): every block owns a queue of one group
+//    in LDS; a tile's entries are ranked per block as above (wave-private counters, two 16-bit halves per word), given
+//    their position in the block's stream, and go through the queues in rounds -- round r takes the entries whose
+//    stream position falls into the r-th group from the queue's start, then every full queue is written out by 16
+//    consecutive lanes; a trailing incomplete group simply stays queued for the next tile.  Regions of (block,
+//    supertile) are whole groups (the histogram pass pads its counts); what is queued at the end of the supertile goes
+//    out filled up with entries of no row (index -1), which the accumulate pass adds to nothing.  No stage: the
+//    queues are the sort.  An entry's slot is still a function of the data alone.
+__global__ __launch_bounds__(kPartThreads) void rows_tile_partition_queue_kernel(
+    const double* __restrict__ x, const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift,
+    int32_t nblocks, int64_t super_elems, int32_t nsuper, const int32_t* __restrict__ first_slot,
+    double* __restrict__ px, int32_t* __restrict__ pr, const int32_t* __restrict__ skew_flag) {
+    if (*skew_flag != 0) return;   // clustered row indices: the staged form (standing by on the same table) does the pass
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    double* qx = (double*)s_raw;                                        // nblocks x kQueueGroup
+    int32_t* qr = (int32_t*)(qx + (size_t)nblocks * kQueueGroup);       // nblocks x kQueueGroup
+    int32_t* cursor = qr + (size_t)nblocks * kQueueGroup;               // nblocks: next stream slot of this supertile
+    int32_t* tcount = cursor + nblocks;                                 // nblocks: this tile's entries per block
+    uint32_t* cnt = (uint32_t*)(tcount + nblocks);                      // (kPartWaves / 2) x nblocks, two wavefronts per word
+    int32_t* s_rounds = (int32_t*)(cnt + (size_t)(kPartWaves / 2) * nblocks);   // kPartWaves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x;
+    constexpr int G = kQueueGroup;
+    for (int b = tid; b < nblocks; b += kPartThreads) cursor[b] = first_slot[(size_t)b * nsuper + s];
+    int64_t e0 = (int64_t)s * super_elems;
+    e0 = e0 < nnz ? e0 : nnz;
+    const int64_t e1 = e0 + super_elems < nnz ? e0 + super_elems : nnz;
+    uint32_t* mycnt = cnt + (size_t)(wave >> 1) * nblocks;
+    const bool odd = wave & 1;
+    const int32_t len = __builtin_amdgcn_readfirstlane((int32_t)(e1 - e0));
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ri + e0), 0, len * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_x = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + e0), 0, len * 8, 0x00020000);
+    int32_t r[kQueuePerThread], pos[kQueuePerThread];
+    double v[kQueuePerThread];
+    auto fetch = [&](int32_t tile) {
+#pragma unroll
+        for (int k = 0; k < kQueuePerThread; ++k)
+            r[k] = __builtin_amdgcn_raw_buffer_load_b32(res_r, tid * 4, (tile + k * kPartThreads) * 4, 2);
+#pragma unroll
+        for (int k = 0; k < kQueuePerThread; ++k)
+            v[k] = __builtin_bit_cast(
+                double, __builtin_amdgcn_raw_buffer_load_b64(res_x, tid * 8, (tile + k * kPartThreads) * 8, 2));
+    };
+    fetch(0);
+    for (int32_t tile = 0; tile < len; tile += kQueueTileElems) {
+        for (int k = tid; k < (kPartWaves / 2) * nblocks; k += kPartThreads) cnt[k] = 0u;
+        if (tid < kPartWaves) s_rounds[tid] = 0;
+        lds_barrier();   // (also: cursors initialised / updated, the previous tile's last flush has read the queues)
+        // rank of every entry among the entries of the same block handled by the same wavefront
+#pragma unroll
+        for (int k = 0; k < kQueuePerThread; ++k) {
+            const bool ok = tile + k * kPartThreads + tid < len && (uint32_t)r[k] < (uint32_t)nrow;
+            r[k] = ok ? r[k] : -1;   // (a load past the end returned 0; rows outside [0, nrow) belong to no block)
+            if (ok) {
+                const uint32_t old = atomicAdd(&mycnt[(uint32_t)r[k] >> shift], odd ? 0x10000u : 1u);
+                pos[k] = (int32_t)(odd ? old >> 16 : old & 0xffffu);
+            } else {
+                pos[k] = -1;
+            }
+        }
+        lds_barrier();
+        // per block: exclusive prefix over the wavefronts (<= 22528: fits the 16-bit halves), the tile's count, and
+        // how many rounds the block needs = groups its queue passes through
+        {
+            int need = 0;
+            for (int b = tid; b < nblocks; b += kPartThreads) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < kPartWaves / 2; ++w2) {
+                    const uint32_t c = cnt[(size_t)w2 * nblocks + b];
+                    const uint32_t lo = run;
+                    run += c & 0xffffu;
+                    const uint32_t hi = run;
+                    run += c >> 16;
+                    cnt[(size_t)w2 * nblocks + b] = lo | (hi << 16);
+                }
+                tcount[b] = (int32_t)run;
+                const int nd = (int)(((cursor[b] & (G - 1)) + (int32_t)run + G - 1) / G);
+                need = nd > need ? nd : need;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int o = __shfl_xor(need, d, 64);
+                need = o > need ? o : need;
+            }
+            if (lane == 0) s_rounds[wave] = need;
+        }
+        lds_barrier();
+        // position of every entry in its block's stream, counted from the start of the group the queue holds
+#pragma unroll
+        for (int k = 0; k < kQueuePerThread; ++k)
+            if (pos[k] >= 0) {
+                const int b = (uint32_t)r[k] >> shift;
+                const uint32_t pre = mycnt[b];
+                const int32_t q = pos[k] + (int32_t)(odd ? pre >> 16 : pre & 0xffffu) + (cursor[b] & (G - 1));
+                pos[k] = ((q >> 4) << 14) | (b * G + (q & (G - 1)));   // (round, queue slot): b * 16 + 15 < 2^14
+            }
+        int rounds = 0;
+#pragma unroll
+        for (int w = 0; w < kPartWaves; ++w) rounds = s_rounds[w] > rounds ? s_rounds[w] : rounds;
+        rounds = __builtin_amdgcn_readfirstlane(rounds);
+        auto round = [&](int rr, bool last) {
+            // this round's entries into their queues ...
+#pragma unroll
+            for (int k = 0; k < kQueuePerThread; ++k)
+                if ((pos[k] >> 14) == rr) {   // (-1 >> 14 = -1: never a round)
+                    qx[pos[k] & 0x3fff] = v[k];
+                    qr[pos[k] & 0x3fff] = r[k];
+                }
+            if (last) fetch(tile + kQueueTileElems);   // (past the supertile: zeros, unused)
+            lds_barrier();
+            // ... and every queue that is full now goes out: 16 consecutive lanes, one aligned group
+            for (int item = tid; item < nblocks * G; item += kPartThreads) {
+                const int b = item >> 4, l = item & (G - 1);
+                const int32_t cur = cursor[b];
+                const int fill = cur & (G - 1);
+                if (fill + tcount[b] - rr * G >= G) {
+                    const int32_t dest = cur - fill + rr * G + l;
+                    px[dest] = qx[item];
+                    pr[dest] = qr[item];
+                }
+            }
+            lds_barrier();
+        };
+        int rr = 0;
+        for (; rr + 1 < rounds; ++rr) round(rr, false);
+        round(rr, true);   // (the last round is a separate copy of the code, like in the pass above; rounds == 0: nothing to place)
+        for (int b = tid; b < nblocks; b += kPartThreads) cursor[b] += tcount[b];
+    }
+    // what is still queued at the end of the supertile: out with it, the group filled up with entries of no row
+    lds_barrier();
+    for (int item = tid; item < nblocks * G; item += kPartThreads) {
+        const int b = item >> 4, l = item & (G - 1);
+        const int32_t cur = cursor[b];
+        const int fill = cur & (G - 1);
+        if (fill > 0) {
+            const int32_t dest = cur - fill + l;
+            px[dest] = l < fill ? qx[item] : 0.0;
+            pr[dest] = l < fill ? qr[item] : -1;
+        }
     }
 }
 
@@ -595,18 +792,24 @@ hipError_t launch_add_partials(const double* parts, int32_t nparts, int64_t stri
 static hipError_t partition_pass(const double* src_x, const int32_t* src_i, int64_t nnz, int32_t nrow_here, int32_t shift,
                                  int32_t nblocks, const RowSumsLayout& L, int32_t* table, void* temp, double* dst_x,
                                  int32_t* dst_i, int32_t* boff, const int32_t* seg, int32_t row_base, int32_t close,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, bool queue = false) {
     const size_t table_entries = (size_t)L.nsuper * (size_t)nblocks + 1;
-    hipError_t e = hipMemsetAsync(table + (table_entries - 1), 0, 4, stream);   // the slot that receives the total
+    hipError_t e = hipMemsetAsync(table + (table_entries - 1), 0, 8, stream);   // the slot that receives the total, and the flag behind it
     if (e != hipSuccess) return e;
-    const size_t part_lds = (size_t)kStageElems * 12 + ((size_t)nblocks * (2 + kPartWaves) + 1) * 4;
-    static DynamicLdsLimit part_limit;
+    auto queue_lds = [](size_t nb) { return nb * (kQueueGroup * 12 + 8 + (kPartWaves / 2) * 4) + kPartWaves * 4; };
+    const size_t stage_lds = (size_t)kStageElems * 12 + ((size_t)nblocks * (2 + kPartWaves) + 1) * 4;
+    const size_t part_lds = queue ? queue_lds((size_t)nblocks) : stage_lds;
+    int32_t* flag = table + table_entries;   // (queue form) "the row indices are too clustered for the queues"
+    static DynamicLdsLimit part_limit, queue_limit;
     e = part_limit.ensure((const void*)rows_tile_partition_kernel,
                           (int)((size_t)kStageElems * 12 + ((size_t)kPartMaxBlocks * (2 + kPartWaves) + 1) * 4));
+    if (e == hipSuccess) e = queue_limit.ensure((const void*)rows_tile_partition_queue_kernel, (int)queue_lds(kQueueMaxBlocks));
     if (e != hipSuccess) return e;
     if (L.nsuper > 0) {
         hipLaunchKernelGGL(rows_tile_histogram_kernel, dim3(L.nsuper), dim3(kPartThreads), (size_t)nblocks * 4, stream,
-                           src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, seg, row_base);
+                           src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, seg, row_base,
+                           queue ? kQueueGroup : 1, queue ? flag : (int32_t*)nullptr,
+                           (int32_t)(((L.super_elems + kQueueTileElems - 1) / kQueueTileElems) * kQueueCellPerTile));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -619,8 +822,18 @@ static hipError_t partition_pass(const double* src_x, const int32_t* src_i, int6
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (L.nsuper > 0) {
-        hipLaunchKernelGGL(rows_tile_partition_kernel, dim3(L.nsuper), dim3(kPartThreads), part_lds, stream, src_x, src_i,
-                           nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i, seg, row_base);
+        if (queue) {   // (one-level regrouping only: no segment, rows from 0); the staged form stands by for clustered rows
+            hipLaunchKernelGGL(rows_tile_partition_queue_kernel, dim3(L.nsuper), dim3(kPartThreads), part_lds, stream,
+                               src_x, src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i,
+                               flag);
+            hipLaunchKernelGGL(rows_tile_partition_kernel, dim3(L.nsuper), dim3(kPartThreads), stage_lds, stream, src_x,
+                               src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i, seg,
+                               row_base, flag, kQueueGroup);
+        } else {
+            hipLaunchKernelGGL(rows_tile_partition_kernel, dim3(L.nsuper), dim3(kPartThreads), part_lds, stream, src_x,
+                               src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i, seg,
+                               row_base, (const int32_t*)nullptr, 1);
+        }
         e = hipGetLastError();
     }
     return e;
@@ -637,7 +850,7 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
     void* temp = (char*)scratch + L.temp_off;
     if (L.mode == 2)
         return partition_pass(d_x, d_i, nnz, nrow, L.shift + L.sub, L.ncoarse, L, table, temp, px, pr, boff, nullptr, 0, 1,
-                              stream);
+                              stream, L.aligned);
     // two levels: by bucket into the intermediate copy, then every bucket by its blocks into the final one
     double* mx = (double*)((char*)scratch + L.mid_vals_off);
     int32_t* mr = (int32_t*)((char*)scratch + L.mid_rows_off);

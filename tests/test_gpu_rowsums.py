@@ -189,6 +189,49 @@ def test_row_sums_with_arrays_that_are_only_4_and_8_byte_aligned(torch_cuda):
             assert np.all(np.abs(got - ref) <= RTOL * scale), (nrow, off)
 
 
+@pytest.mark.parametrize("pattern", ["uniform", "one_row", "sorted", "edge_blocks", "one_block_dense", "all_invalid",
+                                     "first_tiles_invalid", "mostly_invalid"])
+@pytest.mark.parametrize("nrow", [8_400_000, 10_000_000, 10_485_760])
+def test_row_sums_queue_form_and_its_staged_stand_in(torch_cuda, pattern, nrow):
+    """512-640 row blocks: the partition pass's queue form (whole aligned groups of 16 entries through one LDS queue per
+    block; regions padded with entries of no row) on spread-out rows, and the staged form that stands by on the same
+    padded layout when a cell of the count table says the rows are clustered.  Enough entries for several tiles per
+    supertile and several supertiles; bit-stable, means through the parts' combine step."""
+    torch = torch_cuda
+    ncol, nnz = 500, 3_000_000
+    rng = np.random.default_rng(len(pattern) + nrow % 97)
+    x = rng.standard_normal(nnz)
+    if pattern == "uniform":
+        i = rng.integers(0, nrow, nnz)
+    elif pattern == "one_row":
+        i = np.full(nnz, nrow - 3)
+    elif pattern == "sorted":
+        i = np.sort(rng.integers(0, nrow, nnz))
+    elif pattern == "edge_blocks":
+        i = np.where(rng.random(nnz) < 0.5, rng.integers(0, 100, nnz), rng.integers(nrow - 100, nrow, nnz))
+    elif pattern == "one_block_dense":
+        i = rng.integers(300 * 16384, 301 * 16384, nnz)
+    elif pattern == "all_invalid":
+        i = np.full(nnz, -1)
+    elif pattern == "first_tiles_invalid":
+        i = rng.integers(0, nrow, nnz)
+        i[:50_000] = nrow + 7
+    else:
+        i = np.where(rng.random(nnz) < 0.9, rng.integers(-nrow, 0, nnz), rng.integers(0, nrow, nnz))
+    i = i.astype(np.int32)
+    xt, it = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda()
+    got = capi.row_sums_device(xt, it, nrow).cpu().numpy()
+    again = capi.row_sums_device(xt, it, nrow).cpu().numpy()
+    assert got.tobytes() == again.tobytes()
+    keep = (i >= 0) & (i < nrow)
+    ref = np.bincount(i[keep], weights=x[keep], minlength=nrow)
+    scale = np.bincount(i[keep], weights=np.abs(x[keep]), minlength=nrow)
+    assert np.all(np.abs(got - ref) <= RTOL * scale), float(np.max(np.abs(got - ref)))
+    assert not np.any(np.signbit(got[scale == 0]))
+    means = capi.row_sums_device(xt, it, nrow, ncol_for_means=ncol).cpu().numpy()
+    assert means.tobytes() == (got / ncol).tobytes()
+
+
 @pytest.mark.parametrize("pattern", ["one_row", "first_tiles_invalid", "edge_blocks", "one_block_dense", "all_invalid"])
 def test_row_sums_skewed_tiles(torch_cuda, pattern):
     """Shapes of a partition tile the uniform generator never makes: every entry of a tile in ONE block
