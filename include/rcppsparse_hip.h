@@ -234,8 +234,8 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
  * first regrouped by block of 16384 rows in ONE partition pass (up to 1.36e7 rows), by
  * coarse block of 2 / 4 / 8 such blocks (up to 1.09e8 rows; every row block then picks
  * its entries out of its coarse block's), or in two passes (more rows still), with a
- * workspace of 12 B/nnz (two passes: 24 B/nnz) + up to 64 B/row + a count table of at
- * most 64 MB.  The handle variants (the handle must have been uploaded with i[]) build
+ * workspace of 12 B/nnz (two passes: 24 B/nnz; up to 6 % more where the regrouped copy
+ * is padded to whole 16-entry groups) + up to 64 B/row + a count table of at most 64 MB.  The handle variants (the handle must have been uploaded with i[]) build
  * that regrouped copy on first use and keep it: repeated calls only accumulate
  * (12 B/nnz); the device variants regroup in the caller's workspace on every call.
  * Entries whose row index is outside [0, nrow) are left out, not added elsewhere.
