@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off checks of the "next" entry points at the 32-bit limit (nnz = 2^31 - 1), run by hand on one GPU
-(about 4 GPU-minutes, ~60 GB of HBM); not part of the test suite.
+(about 4 GPU-minutes, ~60 GB of HBM).  Since round 3 the same shapes are pinned inside the -m gpu suite against the
+ORACLE (tests/test_gpu_fullsize_next.py); this script keeps the torch-based whole-array comparisons.
 
   * rowSums in its direct, partition and block-sort forms against torch's index_add_ (1e-11 of the row's 1-norm),
     bit-stable run to run;
