@@ -159,7 +159,8 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
  * kernels (it then needs the workspace of rsp_column_sums_workspace_bytes).  Results are those of
  * rsp_column_sums_device within the same tolerance; the short-column paths are the same code, so columns of up
  * to 16 entries inside a group stay bit-identical to the reference loop.  A plan belongs to the p[] it was made
- * from (same ncol, nnz, offsets) and to the chunking in force when it was made.
+ * from (same ncol, nnz, offsets), to the chunking in force when it was made and to the device it was made on
+ * (a planned call from a thread whose current device is another one is RSP_ERR_BAD_ARG).
  * When in addition every column is short (at most 64 entries; BASELINE config 2) the plan takes the LEAN form:
  * the inspector rewrites the offsets a chunk needs as 16-bit column starts relative to the chunk, at a fixed
  * stride, so that a wavefront requests its rows of x, its header and its offsets in the same instant (2 B per

@@ -508,6 +508,13 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
 
 static int planned_enqueue(rsp_colsums_plan_t plan, const double* d_x, const int32_t* d_p, double* d_out,
                            void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+    if (plan->lean || plan->snapped) {   // the plan's records live in the HBM of the device it was made on
+        int cur = -1;
+        HIP_TRY(hipGetDevice(&cur));
+        if (cur != plan->device)
+            return fail(RSP_ERR_BAD_ARG, "this plan was made on device %d, the calling thread's current device is %d",
+                        plan->device, cur);
+    }
     if (plan->lean) {   // every column short: rows, header and 16-bit offsets of a chunk requested at once
         if (!d_out || !d_x) return fail(RSP_ERR_BAD_ARG, "null device pointer");
         if (((uintptr_t)d_x & 15) != 0) return fail(RSP_ERR_BAD_ARG, "d_x must be 16-byte aligned");
