@@ -242,3 +242,22 @@ def test_row_sums_eight_shards_reduce_in_rank_order(torch_cuda):
         assert torch.equal(res, parts[3] + 0.0)
     finally:
         comm.close()
+
+
+def test_bench_child_process_planned_c2(torch_cuda):
+    """`bench.py --workload c2 --planned`: BASELINE config 2 through the inspector-executor plan.  The plan takes the
+    lean form (every column of C2 is short), its cost is reported beside the calls (`config.planned.plan_ms`), the
+    kernel of the line is the one-launch lean kernel, and because a lean call adds every column in the reference's
+    order the whole-matrix parity figure is exactly zero."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--workload", "c2", "--planned", "--steps", "50", "--warmup", "5", "--no-cpu-baseline",
+                   "--latency-calls", "3")
+    pl = d["config"]["planned"]
+    assert pl["form"] == "lean" and pl["snapped"] is True and pl["plan_ms"] > 0 and pl["chunks"] > 10_000
+    assert d["roofline"]["kernel"].startswith("colsums_lean_kernel")
+    assert "ONE HIP event pair" in d["roofline"]["kernel_timing"]
+    par = d["parity"]
+    assert par["columns_checked"] == "all" and par["ncol"] == 1_000_000 and par["columns_out_of_tolerance"] == 0
+    assert par["max_abs_err_over_l1"] == 0.0
+    assert d["config"]["x_copies_rotated"] >= 5                      # every call reads from HBM, not the Infinity Cache
+    assert 0.3 < d["roofline"]["frac"] < 1.0
