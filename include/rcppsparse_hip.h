@@ -208,7 +208,26 @@ int rsp_column_reduce_device(const double *d_x, const int32_t *d_p, int32_t ncol
  * whose row i[j] is / is not in the row set.  The set is a bitmap of nrow bits
  * (row r = bit r % 32 of word r / 32; (nrow + 31) / 32 words in HBM).  Streams
  * x and i (12 B/nnz); d_i must be 8-byte aligned.
+ *
+ * Forms: up to 2^20 rows the bitmap is probed in L1 / LDS by the column-sum kernel.
+ * Above that, when the columns are long enough (nnz >= 32 * ncol * ceil(nrow / 2^20),
+ * ncol >= 32768), a slice-major kernel walks every column once per slice of 2^20 rows
+ * with that slice of the bitmap in LDS; it relies on the rows of a column ascending
+ * (dgCMatrix validity; the reference's restricted iterators merge on the same
+ * assumption) and needs the workspace of rsp_column_sums_in_rows_workspace_bytes.
+ * A device-side check hands matrices with giant columns back to the general kernel
+ * (probes served by L2), which is also what a workspace of only
+ * rsp_column_sums_workspace_bytes, rsp_set_row_slices(0) or RSP_ROW_SLICES=0 select.
+ * Both forms are deterministic and within 1e-12 * sum|x_col| of the reference's order.
  */
+size_t rsp_column_sums_in_rows_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz);
+int rsp_set_row_slices(int on);
+/* which form a call of these sizes with that much workspace takes (the slice form's device-side check aside) */
+#define RSP_IN_ROWS_FORM_L1     0   /* bitmap <= 16 KB: probed through L1                    */
+#define RSP_IN_ROWS_FORM_LDS    1   /* <= 128 KB: whole bitmap in LDS                        */
+#define RSP_IN_ROWS_FORM_L2     2   /* larger: general kernel, probes served by L2           */
+#define RSP_IN_ROWS_FORM_SLICES 3   /* larger, long columns: slice-major, bitmap slice in LDS */
+int rsp_column_sums_in_rows_form(int32_t nrow, int32_t ncol, int64_t nnz, size_t workspace_bytes);
 int rsp_column_sums_in_rows_device(const double *d_x, const int32_t *d_i,
                                    const int32_t *d_p, int32_t nrow, int32_t ncol,
                                    int64_t nnz, const uint32_t *d_row_bitmap,

@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
     "rsp_column_sums_plan_create", "rsp_column_sums_plan_create_device", "rsp_column_sums_plan_info",
     "rsp_column_sums_planned_device", "rsp_column_sums_plan_destroy", "rsp_set_lean",
+    "rsp_column_sums_in_rows_workspace_bytes", "rsp_set_row_slices", "rsp_column_sums_in_rows_form",
     "rsp_csc_crossprod", "rsp_crossprod_workspace_bytes", "rsp_crossprod_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
@@ -115,6 +116,10 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_planned_device.argtypes = [vp, vp, vp, i32, vp, vp, c.c_size_t, vp]
     L.rsp_column_sums_plan_destroy.argtypes = [vp]
     L.rsp_set_lean.argtypes = [c.c_int]
+    L.rsp_set_row_slices.argtypes = [c.c_int]
+    L.rsp_column_sums_in_rows_form.argtypes = [i32, i32, i64, c.c_size_t]
+    L.rsp_column_sums_in_rows_workspace_bytes.argtypes = [i32, i32, i64]
+    L.rsp_column_sums_in_rows_workspace_bytes.restype = c.c_size_t
     L.rsp_csc_crossprod.argtypes = [vp, dp]
     L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
     L.rsp_crossprod_workspace_bytes.argtypes = [i32, i32, i64]
@@ -408,6 +413,29 @@ def column_reduce_device(x_t, p_t, op: int, out_t=None, workspace=None, stream=N
     return out_t
 
 
+def in_rows_workspace_bytes(nrow: int, ncol: int, nnz: int) -> int:
+    """Workspace of the row-restricted sums: the column sums' plus the slice form's guard flag."""
+    return int(load().rsp_column_sums_in_rows_workspace_bytes(int(nrow), int(ncol), int(nnz)))
+
+
+IN_ROWS_FORMS = ("L1", "LDS", "L2", "slices")
+
+
+def in_rows_form(nrow: int, ncol: int, nnz: int, workspace_bytes: int | None = None) -> str:
+    """Which form rsp_column_sums_in_rows_device takes at these sizes (rsp_column_sums_in_rows_form)."""
+    if workspace_bytes is None:
+        workspace_bytes = in_rows_workspace_bytes(nrow, ncol, nnz)
+    f = int(load().rsp_column_sums_in_rows_form(int(nrow), int(ncol), int(nnz), int(workspace_bytes)))
+    if f < 0:
+        raise ValueError("sizes out of range")
+    return IN_ROWS_FORMS[f]
+
+
+def set_row_slices(on: bool) -> None:
+    """False: row-restricted sums over more than 2^20 rows always probe the bitmap in L2 (rsp_set_row_slices)."""
+    _check(load().rsp_set_row_slices(int(bool(on))))
+
+
 def row_set_bitmap(rows, nrow: int) -> np.ndarray:
     """Sorted row set (as the reference's restricted iterators take it) -> bitmap of nrow bits."""
     bits = np.zeros((int(nrow) + 31) // 32, dtype=np.uint32)
@@ -424,7 +452,7 @@ def column_sums_in_rows_device(x_t, i_t, p_t, nrow: int, bitmap_t, complement: b
     if out_t is None:
         out_t = torch.empty(ncol, dtype=torch.float64, device=x_t.device)
     if workspace is None:
-        workspace = alloc_workspace(ncol, nnz, x_t.device)
+        workspace = torch.empty(in_rows_workspace_bytes(nrow, ncol, nnz), dtype=torch.uint8, device=x_t.device)
     _check(load().rsp_column_sums_in_rows_device(x_t.data_ptr(), i_t.data_ptr(), p_t.data_ptr(), int(nrow),
                                                  ncol, nnz, bitmap_t.data_ptr(), int(bool(complement)),
                                                  out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),

@@ -79,6 +79,20 @@ bool lean_allowed() {
     return v != 0;
 }
 
+constexpr size_t kRowSlicesFlagBytes = 256;   // the slice form's guard flag, behind the general form's carries
+std::atomic<int> g_row_slices{-1};   // rsp_set_row_slices: 1 / 0; -1 = RSP_ROW_SLICES from the environment, else on
+bool row_slices_allowed() {
+    int v = g_row_slices.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static const int env = [] {
+            const char* s = getenv("RSP_ROW_SLICES");
+            return s ? (atoi(s) != 0 ? 1 : 0) : 1;
+        }();
+        v = env;
+    }
+    return v != 0;
+}
+
 // Rows of x per chunk of the lean form.  A chunk's columns are handed to the 64 lanes of its wavefront, so the chunk
 // should hold about 64 of them and rarely more: the largest of 2 / 3 / 4 / 5 / 6 / 8 / 12 / 16 rows that keeps the MEAN
 // number of columns per chunk at or below kLeanTargetColumns (C2, 10 per column: 4 rows = 51 columns, never more than
@@ -241,7 +255,7 @@ int require_device(int device) {
 int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out,
             void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream,
             int op = rsp::kOpSum, const int32_t* d_i = nullptr, const uint32_t* d_bitmap = nullptr,
-            int32_t bitmap_words = 0) {
+            int32_t bitmap_words = 0, const int32_t* d_run_if = nullptr) {
     if (int rc = check_sizes(ncol, nnz)) return rc;
     if (ncol == 0) return RSP_OK;
     if (!d_p || !d_out || (nnz > 0 && !d_x))
@@ -253,7 +267,7 @@ int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, do
     if (nnz > 0 && (!d_ws || ws_bytes < need))
         return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
     HIP_TRY(rsp::launch_column_sums(d_x, d_p, ncol, (int32_t)nnz, d_out, plan, d_ws, divisor, means,
-                                    stream, op, d_i, d_bitmap, bitmap_words));
+                                    stream, op, d_i, d_bitmap, bitmap_words, nullptr, d_run_if));
     return RSP_OK;
 }
 
@@ -564,8 +578,47 @@ int rsp_column_sums_in_rows_device(const double* d_x, const int32_t* d_i, const 
     if (nnz > 0 && (!d_i || !d_row_bitmap)) return fail(RSP_ERR_BAD_ARG, "row indices and row bitmap are required");
     if (((uintptr_t)d_i & 7) != 0) return fail(RSP_ERR_BAD_ARG, "d_i must be 8-byte aligned");
     const int32_t words = (int32_t)(((int64_t)nrow + 31) / 32);
-    return enqueue(d_x, d_p, ncol, nnz, d_out, d_workspace, workspace_bytes, 1.0, false, (hipStream_t)stream,
-                   complement ? rsp::kOpMaskedOut : rsp::kOpMaskedIn, d_i, d_row_bitmap, words);
+    const int op = complement ? rsp::kOpMaskedOut : rsp::kOpMaskedIn;
+    // More than 2^20 rows and tens of entries per column and slice: the slice-major form (bitmap probed in LDS),
+    // with the general form standing by for matrices its device-side guard turns away.  The guard's flag lives
+    // behind the general form's carries: a workspace of rsp_column_sums_in_rows_workspace_bytes has room for it,
+    // one sized by rsp_column_sums_workspace_bytes selects the general form alone.
+    rsp::RowSlicesPlan sp;
+    if (row_slices_allowed() && nnz > 0 && ncol > 0 && nnz <= INT32_MAX && d_x && d_p && d_out && d_workspace &&
+        rsp::rowslices_applicable(nrow, ncol, nnz, &sp)) {
+        const size_t general = rsp::workspace_bytes_for(make_plan(nnz).nchunks);
+        if (workspace_bytes >= general + kRowSlicesFlagBytes) {
+            int32_t* d_flag = (int32_t*)((char*)d_workspace + general);
+            HIP_TRY(rsp::launch_rowslices_guard(d_p, ncol, sp, d_flag, (hipStream_t)stream));
+            HIP_TRY(rsp::launch_column_sums_rowslices(d_x, d_i, d_p, ncol, (int32_t)nnz, d_row_bitmap, words,
+                                                      complement != 0, sp, d_out, d_flag, (hipStream_t)stream));
+            return enqueue(d_x, d_p, ncol, nnz, d_out, d_workspace, general, 1.0, false, (hipStream_t)stream, op,
+                           d_i, d_row_bitmap, words, d_flag);
+        }
+    }
+    return enqueue(d_x, d_p, ncol, nnz, d_out, d_workspace, workspace_bytes, 1.0, false, (hipStream_t)stream, op, d_i,
+                   d_row_bitmap, words);
+}
+
+size_t rsp_column_sums_in_rows_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz) {
+    (void)nrow;
+    return rsp_column_sums_workspace_bytes(ncol, nnz) + kRowSlicesFlagBytes;
+}
+
+int rsp_column_sums_in_rows_form(int32_t nrow, int32_t ncol, int64_t nnz, size_t workspace_bytes) {
+    if (nrow < 0 || ncol < 0 || nnz < 0 || nnz > INT32_MAX) return -1;
+    const size_t bitmap_bytes = (size_t)(((int64_t)nrow + 31) / 32) * 4;
+    if (bitmap_bytes <= rsp::kLdsBitmapMinBytes) return RSP_IN_ROWS_FORM_L1;
+    if (bitmap_bytes <= rsp::kLdsBitmapMaxBytes) return RSP_IN_ROWS_FORM_LDS;
+    if (row_slices_allowed() && nnz > 0 && ncol > 0 && rsp::rowslices_applicable(nrow, ncol, nnz, nullptr) &&
+        workspace_bytes >= rsp::workspace_bytes_for(make_plan(nnz).nchunks) + kRowSlicesFlagBytes)
+        return RSP_IN_ROWS_FORM_SLICES;
+    return RSP_IN_ROWS_FORM_L2;
+}
+
+int rsp_set_row_slices(int on) {
+    g_row_slices.store(on ? 1 : 0, std::memory_order_relaxed);
+    return RSP_OK;
 }
 
 int rsp_column_sums_device_timed(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,

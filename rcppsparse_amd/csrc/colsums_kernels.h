@@ -94,7 +94,30 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
                               double divisor, bool means, hipStream_t stream, int op = kOpSum,
                               const int32_t* rows_i = nullptr, const uint32_t* row_bitmap = nullptr,
-                              int32_t bitmap_words = 0, const int2* plan_rec = nullptr);
+                              int32_t bitmap_words = 0, const int2* plan_rec = nullptr,
+                              const int32_t* run_if = nullptr);
+
+// Row-restricted sums over more than 2^20 rows, slice-major form (colsums_rowslices.hip): a workgroup keeps ONE
+// slice of 2^20 rows of the bitmap in LDS and walks its group of columns slice by slice.
+constexpr int kSliceRowsShift = 20;        // rows per slice: 128 KB of bitmap
+constexpr int kSliceMaxGroup = 2048;       // columns per workgroup: a cursor (4 B) and a sum (8 B) each beside the bitmap
+constexpr int kSliceMinColumns = 32768;    // fewer columns do not fill 256 workgroups of 16 wavefronts x 8 columns
+constexpr int kSliceMinSegment = 32;       // mean entries per (column, slice) from which the form is selected
+constexpr int kSliceCus = 256;             // MI355X: one workgroup per CU, groups sized for whole rounds of them
+constexpr int kSliceMaxColumnFactor = 16;  // guard: a column longer than 16 x the mean (+ 4096) goes back to the general kernel
+struct RowSlicesPlan {
+    int32_t nslices, group, ngroups, max_col;
+    int64_t max_group;
+};
+bool rowslices_applicable(int32_t nrow, int32_t ncol, int64_t nnz, RowSlicesPlan* out);
+// zeroes *d_flag and sets it when the matrix has a column / column group the slice form should not take
+hipError_t launch_rowslices_guard(const int32_t* d_p, int32_t ncol, const RowSlicesPlan& sp, int32_t* d_flag,
+                                  hipStream_t stream);
+// runs unless *d_skip_if != 0 (d_skip_if may be null)
+hipError_t launch_column_sums_rowslices(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t ncol,
+                                        int32_t nnz, const uint32_t* d_bitmap, int32_t bitmap_words, bool complement,
+                                        const RowSlicesPlan& sp, double* d_out, const int32_t* d_skip_if,
+                                        hipStream_t stream);
 
 // hipFuncSetAttribute(..MaxDynamicSharedMemorySize..) once per (kernel, device): the attribute belongs to the
 // device's copy of the function, so a process that uses a second device has to raise it there as well.

@@ -565,10 +565,13 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     ChunkMap cmap, int32_t nchunks, double* __restrict__ out,
     double* __restrict__ carry_head, double* __restrict__ carry_tail,
     int4* __restrict__ carry_info, double divisor, const int32_t* __restrict__ rows_i,
-    const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words, const int2* __restrict__ plan_rec = nullptr) {
+    const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words, const int2* __restrict__ plan_rec = nullptr,
+    const int32_t* __restrict__ run_if = nullptr) {
     static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
     typedef Policy<MEANS, OP> P;
     constexpr bool MASKED = (OP == kOpMaskedIn || OP == kOpMaskedOut);
+    // row-restricted sums: the slice-major form (colsums_rowslices.hip) ran instead unless its guard said otherwise
+    if (MASKED && run_if != nullptr && *run_if == 0) return;
     __shared__ __attribute__((aligned(16))) double s_stage[WPG][kStageSlots];
     __shared__ __attribute__((aligned(16))) int32_t s_win[WPG][kPWin];
     static_assert(kHistPad * sizeof(int32_t) <= kStageSlots * sizeof(double), "the histogram lives in the staging area");
@@ -846,8 +849,10 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
 template <bool MEANS, int OP = kOpSum>
 __global__ __launch_bounds__(256) void colsums_fixup_kernel(
     int32_t ncol, int32_t nchunks, double* __restrict__ out, const double* __restrict__ carry_head,
-    const double* __restrict__ carry_tail, const int4* __restrict__ carry_info, double divisor) {
+    const double* __restrict__ carry_tail, const int4* __restrict__ carry_info, double divisor,
+    const int32_t* __restrict__ run_if = nullptr) {
     typedef Policy<MEANS, OP> P;
+    if (run_if != nullptr && *run_if == 0) return;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
@@ -959,7 +964,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
                               double divisor, bool means, hipStream_t stream, int op,
                               const int32_t* rows_i, const uint32_t* row_bitmap, int32_t bitmap_words,
-                              const int2* plan_rec) {
+                              const int2* plan_rec, const int32_t* run_if) {
     if (ncol <= 0) return hipSuccess;
     if (op == kOpCount) {   // nnz per column: offsets only, x is not read
         hipLaunchKernelGGL(colsums_count_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_p, d_out, ncol);
@@ -1023,7 +1028,8 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 #define RSP_LAUNCH_OP(OP_)                                                                             \
     hipLaunchKernelGGL((colsums_chunks_kernel<kBatchRows, false, kLoadAux, kWavesPerWG, OP_>), grid,   \
                        block, 0, stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out,   \
-                       carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words)
+                       carry_head, carry_tail, carry_info, divisor, rows_i, row_bitmap, bitmap_words,  \
+                       (const int2*)nullptr, run_if)
     // row-restricted sums with a bitmap of 16-128 KB (about 1e5-1e6 rows): bitmap in LDS, shared by as many
     // wavefronts as fit beside it (each brings 5.25 KB of its own): one workgroup of 16 / 8 / 6 / 4 per CU.
     // (With 4 the call is bound by its occupancy: 32 KB of loads in flight per CU, 4.7 TB/s at 1e6 rows.)
@@ -1094,7 +1100,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
     const dim3 fgrid((plan.nchunks + 255) / 256), fblock(256);   // one thread per chunk
 #define RSP_FIXUP(MEANS_, OP_)                                                                        \
     hipLaunchKernelGGL((colsums_fixup_kernel<MEANS_, OP_>), fgrid, fblock, 0, stream, ncol,            \
-                       plan.nchunks, d_out, carry_head, carry_tail, carry_info, divisor)
+                       plan.nchunks, d_out, carry_head, carry_tail, carry_info, divisor, run_if)
     if (op == kOpMax)
         RSP_FIXUP(false, kOpMax);
     else if (op == kOpMin)

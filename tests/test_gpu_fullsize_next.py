@@ -183,15 +183,17 @@ def test_crossprod_tall_form_at_the_int32_limit(torch_cuda):
 
 # ------------------------------------------------------------ row-restricted column sums
 MASKED_CASES = [
-    pytest.param(10_000_000, 1_000_000, 1_000_000_000, "c3", id="c3-bitmap-in-L2"),
-    pytest.param(3_000, 1_000_000, INT32_MAX, "equal", id="int32max-bitmap-in-L1"),
-    pytest.param(1_000_000, 1_000_000, INT32_MAX, "equal", id="int32max-bitmap-in-LDS"),
-    pytest.param(10_000_000, 500_000, INT32_MAX, "equal", id="int32max-bitmap-in-L2"),
+    pytest.param(10_000_000, 1_000_000, 1_000_000_000, "c3", "slices", id="c3-slice-major"),
+    pytest.param(10_000_000, 1_000_000, 1_000_000_000, "c3", "L2", id="c3-bitmap-in-L2"),
+    pytest.param(3_000, 1_000_000, INT32_MAX, "equal", "L1", id="int32max-bitmap-in-L1"),
+    pytest.param(1_000_000, 1_000_000, INT32_MAX, "equal", "LDS", id="int32max-bitmap-in-LDS"),
+    pytest.param(10_000_000, 500_000, INT32_MAX, "equal", "slices", id="int32max-slice-major"),
+    pytest.param(10_000_000, 500_000, INT32_MAX, "equal", "L2", id="int32max-bitmap-in-L2"),
 ]
 
 
-@pytest.mark.parametrize("nrow,ncol,nnz,structure", MASKED_CASES)
-def test_row_restricted_column_sums_full_size(torch_cuda, nrow, ncol, nnz, structure):
+@pytest.mark.parametrize("nrow,ncol,nnz,structure,form", MASKED_CASES)
+def test_row_restricted_column_sums_full_size(torch_cuda, nrow, ncol, nnz, structure, form):
     torch = torch_cuda
     need_hbm(torch, 60 if nnz == INT32_MAX else 30)
     seed = 42 if structure == "c3" else 9
@@ -200,7 +202,10 @@ def test_row_restricted_column_sums_full_size(torch_cuda, nrow, ncol, nnz, struc
     rows_in = np.flatnonzero(rng.random(nrow) < 0.5)
     bits = capi.row_set_bitmap(rows_in, nrow)
     bt = torch.from_numpy(bits).cuda()
-    ws = capi.alloc_workspace(ncol, nnz)
+    # the slice-major form needs the larger workspace (room for its guard's flag); the plain one selects the general form
+    ws = (capi.alloc_workspace(ncol, nnz) if form == "L2" else
+          torch.empty(capi.in_rows_workspace_bytes(nrow, ncol, nnz), dtype=torch.uint8, device="cuda"))
+    assert capi.in_rows_form(nrow, ncol, nnz, ws.numel()) == form
     res = {}
     for comp in (False, True):
         out = torch.empty(ncol, dtype=torch.float64, device="cuda")

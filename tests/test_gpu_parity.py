@@ -545,6 +545,103 @@ def test_column_sums_restricted_to_a_row_set(torch_cuda, nrow, ncol, density, co
     assert np.all(none == 0.0)
 
 
+def _matrix_over_row_slices(nrow, ncol, mean, seed, long_columns=(), extra_rows=()):
+    """CSC matrix with ascending, distinct rows per column: about `mean` uniformly drawn rows per column (some columns
+    empty), `long_columns` = {column: entries}, and `extra_rows` added to every 97th column (slice edges)."""
+    rng = np.random.default_rng(seed)
+    counts = rng.poisson(mean, size=ncol).astype(np.int64)
+    counts[rng.random(ncol) < 0.01] = 0
+    for c, k in dict(long_columns).items():
+        counts[c] = k
+    col = np.repeat(np.arange(ncol, dtype=np.int64), counts)
+    row = rng.integers(0, nrow, size=col.size, dtype=np.int64)
+    edge_cols = np.arange(0, ncol, 97, dtype=np.int64)
+    col = np.concatenate([col, np.repeat(edge_cols, len(extra_rows))])
+    row = np.concatenate([row, np.tile(np.asarray(extra_rows, dtype=np.int64), edge_cols.size)])
+    key = np.unique(col * nrow + row)                       # sorted by (column, row), duplicates dropped
+    col, row = key // nrow, key % nrow
+    p = np.zeros(ncol + 1, dtype=np.int64)
+    np.add.at(p, col + 1, 1)
+    p = np.cumsum(p).astype(np.int32)
+    x = synth.gen_values(int(p[-1]), seed=seed, kind=0)
+    return x, row.astype(np.int32), p
+
+
+@pytest.mark.parametrize("complement", [False, True])
+def test_row_restricted_sums_slice_major_form(torch_cuda, complement):
+    """More than 2^20 rows and long columns: the slice-major form (colsums_rowslices.hip; a workgroup walks its columns
+    once per slice of 2^20 rows with that slice of the bitmap in LDS).  Four slices with a partial last one, a column
+    count that is no multiple of anything, empty columns, entries on both sides of every slice edge, and two columns
+    whose segments take several rounds of 128 entries.  Against the oracle's restricted loop, the general form, a
+    second run; a matrix with one giant column and a workspace without the flag go back to the general form's bits."""
+    torch = torch_cuda
+    S = 1 << 20
+    nrow, ncol = 3 * S + 12_345, 40_001
+    edges = [0, S - 1, S, 2 * S - 1, 2 * S, 3 * S - 1, 3 * S, nrow - 1]
+    x, i, p = _matrix_over_row_slices(nrow, ncol, 140, seed=5, long_columns={7: 5_000, ncol - 1: 3_000},
+                                      extra_rows=edges)
+    nnz = len(x)
+    assert capi.in_rows_form(nrow, ncol, nnz) == "slices"
+    assert capi.in_rows_form(nrow, ncol, nnz, capi.workspace_bytes(ncol, nnz)) == "L2"
+    rng = np.random.default_rng(1)
+    s = np.sort(rng.choice(nrow, size=nrow // 3, replace=False))
+    s = np.union1d(s, [S - 1, 2 * S, nrow - 1])                # (and 0, S, 2S-1, 3S-1, 3S left to chance)
+    bits = capi.row_set_bitmap(s, nrow)
+    xt, it, pt, bt = (torch.from_numpy(a).cuda() for a in (x, i, p, bits))
+    ref = oracle.column_sums_in_rows(x, i, p, bits, complement)
+    keep = (((bits[i >> 5] >> (i & 31).astype(np.uint32)) & 1) == 1) != complement
+    scale = oracle.column_abs_sums(np.where(keep, x, 0.0), p)
+    got = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement)
+    assert np.all(np.abs(got.cpu().numpy() - ref) <= RTOL * scale)
+    assert np.all(got.cpu().numpy()[np.diff(p) == 0] == 0.0)
+    assert torch.equal(got, capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement))
+    capi.set_row_slices(False)
+    try:
+        general = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement)
+    finally:
+        capi.set_row_slices(True)
+    assert np.all(np.abs(general.cpu().numpy() - ref) <= RTOL * scale)
+    assert not torch.equal(got, general)                      # (two different summation trees really ran)
+    # a workspace sized for the plain column sums has no room for the guard's flag: the general form
+    small = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement, workspace=capi.alloc_workspace(ncol, nnz))
+    assert torch.equal(small, general)
+    # one giant column: the device-side guard turns the slice form away and the general kernel's bits come out
+    x2, i2, p2 = _matrix_over_row_slices(nrow, ncol, 140, seed=6, long_columns={123: 400_000})
+    assert capi.in_rows_form(nrow, ncol, len(x2)) == "slices"
+    x2t, i2t, p2t = (torch.from_numpy(a).cuda() for a in (x2, i2, p2))
+    got2 = capi.column_sums_in_rows_device(x2t, i2t, p2t, nrow, bt, complement)
+    capi.set_row_slices(False)
+    try:
+        general2 = capi.column_sums_in_rows_device(x2t, i2t, p2t, nrow, bt, complement)
+    finally:
+        capi.set_row_slices(True)
+    assert torch.equal(got2, general2)
+    ref2 = oracle.column_sums_in_rows(x2, i2, p2, bits, complement)
+    keep2 = (((bits[i2 >> 5] >> (i2 & 31).astype(np.uint32)) & 1) == 1) != complement
+    assert np.all(np.abs(got2.cpu().numpy() - ref2) <= RTOL * oracle.column_abs_sums(np.where(keep2, x2, 0.0), p2))
+
+
+def test_row_restricted_sums_slice_major_form_is_graph_capture_safe(torch_cuda):
+    """The slice form is a 4-byte memset and four launches on the caller's stream: capturable, replay reproduces the bits."""
+    torch = torch_cuda
+    nrow, ncol = (1 << 21) + 77, 33_000
+    x, i, p = _matrix_over_row_slices(nrow, ncol, 110, seed=8)
+    assert capi.in_rows_form(nrow, ncol, len(x)) == "slices"
+    bits = capi.row_set_bitmap(np.flatnonzero(np.random.default_rng(2).random(nrow) < 0.4), nrow)
+    xt, it, pt, bt = (torch.from_numpy(a).cuda() for a in (x, i, p, bits))
+    ws = torch.empty(capi.in_rows_workspace_bytes(nrow, ncol, len(x)), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(ncol, dtype=torch.float64, device="cuda")
+    eager = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, False, out.clone(), ws).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, False, out, ws)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+
+
 # ------------------------------------------------------------- maximum size, graph capture
 def test_maximum_nnz_int32_limit(torch_cuda):
     """nnz = 2^31 - 1, the largest matrix the reference's 32-bit p[] / iterator state can address

@@ -17,13 +17,21 @@ for grp in "TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_READ_sum TCC_HIT_sum" \
   timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/pmcm_${TAG}_$g -- \
     python3 /root/repo/tools/run_masked.py $WL $NROW 3 > $O/pmcm_${TAG}_$g.log 2>&1 || echo "pass $g failed"
 done
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/pmcm_${TAG}_trace -- \
+  python3 /root/repo/tools/run_masked.py $WL $NROW 5 > $O/pmcm_${TAG}_trace.log 2>&1 || echo "trace pass failed"
 python3 - <<PY
 import csv, glob, collections, json
-tot = collections.defaultdict(lambda: [0.0, 0])
+tot = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("$O/pmcm_${TAG}_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "colsums_chunks_kernel" in r["Kernel_Name"]:
-            t = tot[r["Counter_Name"]]; t[0] += float(r["Counter_Value"]); t[1] += 1
-out = {k: v / n for k, (v, n) in sorted(tot.items())}
-print(json.dumps({"tag": "$TAG", "workload": "$WL", "nrow": $NROW, "per_launch": out}))
+        for name in ("colsums_chunks_kernel", "colsums_rowslices_kernel"):   # (slice form: the general kernel is launched too and returns at once)
+            if name in r["Kernel_Name"]:
+                t = tot[name][r["Counter_Name"]]; t[0] += float(r["Counter_Value"]); t[1] += 1
+out = {name: {k: v / n for k, (v, n) in sorted(d.items())} for name, d in tot.items()}
+dur = collections.defaultdict(list)
+for f in glob.glob("$O/pmcm_${TAG}_trace/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        dur[r["Kernel_Name"].split("(")[0][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print(json.dumps({"tag": "$TAG", "workload": "$WL", "nrow": $NROW, "per_launch": out,
+                  "kernel_us_median": {k: sorted(v)[len(v) // 2] for k, v in dur.items() if "gen_" not in k}}))
 PY

@@ -23,7 +23,7 @@ it = torch.empty(nnz, dtype=torch.int32, device="cuda")
 capi.gen_values_device(xt, SEED, 0, 0)
 capi.gen_row_indices_device(it, pt, nrow, SEED)
 out = torch.empty(ncol, dtype=torch.float64, device="cuda")
-ws = capi.alloc_workspace(ncol, nnz)
+ws = torch.empty(capi.in_rows_workspace_bytes(nrow, ncol, nnz), dtype=torch.uint8, device="cuda")   # (RSP_ROW_SLICES=0: the general form)
 bits = torch.from_numpy(np.random.default_rng(0).integers(0, 2**32, size=(nrow + 31) // 32, dtype=np.uint32)).cuda()
 ts = []
 for _ in range(reps):
