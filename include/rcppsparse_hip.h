@@ -211,7 +211,7 @@ int rsp_column_reduce_device(const double *d_x, const int32_t *d_p, int32_t ncol
  *
  * Forms: up to 2^20 rows the bitmap is probed in L1 / LDS by the column-sum kernel.
  * Above that, when the columns are long enough (nnz >= 32 * ncol * ceil(nrow / 2^20),
- * ncol >= 32768), a slice-major kernel walks every column once per slice of 2^20 rows
+ * ncol >= 16384), a slice-major kernel walks every column once per slice of 2^20 rows
  * with that slice of the bitmap in LDS; it relies on the rows of a column ascending
  * (dgCMatrix validity; the reference's restricted iterators merge on the same
  * assumption) and needs the workspace of rsp_column_sums_in_rows_workspace_bytes.

@@ -101,7 +101,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 // slice of 2^20 rows of the bitmap in LDS and walks its group of columns slice by slice.
 constexpr int kSliceRowsShift = 20;        // rows per slice: 128 KB of bitmap
 constexpr int kSliceMaxGroup = 2048;       // columns per workgroup: a cursor (4 B) and a sum (8 B) each beside the bitmap
-constexpr int kSliceMinColumns = 32768;    // fewer columns do not fill 256 workgroups of 16 wavefronts x 8 columns
+constexpr int kSliceMinColumns = 16384;    // fewer columns leave wavefronts of the 256 workgroups without a batch (1e4 columns: 2.43 against 2.15 ms general; 2e4: 2.16 against 2.88)
 constexpr int kSliceMinSegment = 32;       // mean entries per (column, slice) from which the form is selected
 constexpr int kSliceCus = 256;             // MI355X: one workgroup per CU, groups sized for whole rounds of them
 constexpr int kSliceMaxColumnFactor = 16;  // guard: a column longer than 16 x the mean (+ 4096) goes back to the general kernel

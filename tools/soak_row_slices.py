@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the slice-major row-restricted sums (colsums_rowslices.hip) against the oracle's restricted loop:
-random row counts above 2^20 (2..7 slices, partial last slice), column counts from 32768, Poisson column lengths
+random row counts above 2^20 (2..7 slices, partial last slice), column counts from 16384, Poisson column lengths
 with empty and long columns (some beyond the device-side guard, which must hand the call to the general kernel),
 row sets from empty to full, both restrictions.  Prints one JSON line.
     python3 tools/soak_row_slices.py [cases] [seed]"""
@@ -20,7 +20,7 @@ for case in range(cases):
     rng = np.random.default_rng(seed0 * 100_000 + case)
     nsl = int(rng.integers(2, 8))
     nrow = (nsl - 1) * S + int(rng.integers(1, S + 1))
-    ncol = int(rng.integers(32_768, 50_000))
+    ncol = int(rng.integers(16_384, 50_000))
     mean = int(rng.integers(33, 60)) * nsl
     counts = rng.poisson(mean, size=ncol).astype(np.int64)
     counts[rng.random(ncol) < 0.02] = 0
