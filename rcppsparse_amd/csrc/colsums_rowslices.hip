@@ -28,6 +28,14 @@
 namespace rsp {
 namespace {
 
+#ifndef RSP_SLC_NT
+#define RSP_SLC_NT 3   // bit 0: row indices, bit 1: values loaded with the nontemporal hint
+#endif
+template <class T>
+__device__ __forceinline__ T slc_load_i(const T* q) { return (RSP_SLC_NT & 1) ? __builtin_nontemporal_load(q) : *q; }
+template <class T>
+__device__ __forceinline__ T slc_load_x(const T* q) { return (RSP_SLC_NT & 2) ? __builtin_nontemporal_load(q) : *q; }
+
 constexpr int kSlcWaves = 16;                 // one workgroup per CU: its LDS is the slice's bitmap
 constexpr int kSlcThreads = kSlcWaves * 64;
 constexpr int kSlcBatch = 8;                  // columns a wavefront has in flight
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(kSlcThreads) void colsums_rowslices_kernel(
             for (int j = 0; j < kSlcBatch; ++j) {
                 const uint32_t e0 = (uint32_t)b.cur[j] + (uint32_t)lane, e1 = e0 + 64u;   // (unsigned: a cursor may stand at 2^31 - 1)
                 b.r0[j] = b.r1[j] = 0x7fffffff;
-                if (e0 < (uint32_t)b.pend[j]) b.r0[j] = __builtin_nontemporal_load(ri + e0);
-                if (e1 < (uint32_t)b.pend[j]) b.r1[j] = __builtin_nontemporal_load(ri + e1);
+                if (e0 < (uint32_t)b.pend[j]) b.r0[j] = slc_load_i(ri + e0);
+                if (e1 < (uint32_t)b.pend[j]) b.r1[j] = slc_load_i(ri + e1);
             }
         };
         int k0 = wave * kSlcBatch;
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(kSlcThreads) void colsums_rowslices_kernel(
                     const bool v1 = ((more >> j) & 1) && (uint32_t)cb.r1[j] < row_end;
                     n[j] = __builtin_popcountll(__ballot(v0)) + __builtin_popcountll(__ballot(v1));
                     x0[j] = x1[j] = 0.0;
-                    if (v0) x0[j] = __builtin_nontemporal_load(x + e0);
-                    if (v1) x1[j] = __builtin_nontemporal_load(x + e1);
+                    if (v0) x0[j] = slc_load_x(x + e0);
+                    if (v1) x1[j] = slc_load_x(x + e1);
                 }
 #pragma unroll
                 for (int j = 0; j < kSlcBatch; ++j) {   // (an entry that was not taken has x = 0)
@@ -175,8 +183,8 @@ __global__ __launch_bounds__(kSlcThreads) void colsums_rowslices_kernel(
                     cb.r0[j] = cb.r1[j] = 0x7fffffff;
                     if ((more >> j) & 1) {
                         const uint32_t e0 = (uint32_t)cb.cur[j] + (uint32_t)lane, e1 = e0 + 64u;
-                        if (e0 < (uint32_t)cb.pend[j]) cb.r0[j] = __builtin_nontemporal_load(ri + e0);
-                        if (e1 < (uint32_t)cb.pend[j]) cb.r1[j] = __builtin_nontemporal_load(ri + e1);
+                        if (e0 < (uint32_t)cb.pend[j]) cb.r0[j] = slc_load_i(ri + e0);
+                        if (e1 < (uint32_t)cb.pend[j]) cb.r1[j] = slc_load_i(ri + e1);
                     }
                 }
             }
