@@ -211,13 +211,15 @@ int rsp_column_reduce_device(const double *d_x, const int32_t *d_p, int32_t ncol
  *
  * Forms: up to 2^20 rows the bitmap is probed in L1 / LDS by the column-sum kernel.
  * Above that, when the columns are long enough (nnz >= 32 * ncol * ceil(nrow / 2^20),
- * ncol >= 16384), a slice-major kernel walks every column once per slice of 2^20 rows
+ * ncol >= 16384, and a group of ncol / 256..512 columns holds >= 32768 entries per slice),
+ * a slice-major kernel walks every column once per slice of 2^20 rows
  * with that slice of the bitmap in LDS; it relies on the rows of a column ascending
  * (dgCMatrix validity; the reference's restricted iterators merge on the same
  * assumption) and needs the workspace of rsp_column_sums_in_rows_workspace_bytes.
  * A device-side check hands matrices with giant columns back to the general kernel
  * (probes served by L2), which is also what a workspace of only
- * rsp_column_sums_workspace_bytes, rsp_set_row_slices(0) or RSP_ROW_SLICES=0 select.
+ * rsp_column_sums_workspace_bytes, rsp_set_row_slices(0) or RSP_ROW_SLICES=0 select
+ * (2: the slice form wherever nrow > 2^20, whatever the shape -- tests).
  * Both forms are deterministic and within 1e-12 * sum|x_col| of the reference's order.
  */
 size_t rsp_column_sums_in_rows_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz);

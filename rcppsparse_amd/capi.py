@@ -431,9 +431,10 @@ def in_rows_form(nrow: int, ncol: int, nnz: int, workspace_bytes: int | None = N
     return IN_ROWS_FORMS[f]
 
 
-def set_row_slices(on: bool) -> None:
-    """False: row-restricted sums over more than 2^20 rows always probe the bitmap in L2 (rsp_set_row_slices)."""
-    _check(load().rsp_set_row_slices(int(bool(on))))
+def set_row_slices(on) -> None:
+    """0 / False: row-restricted sums over more than 2^20 rows always probe the bitmap in L2; 1 / True: the slice-major
+    form where it is the faster one (default); 2: wherever it is possible at all (tests) (rsp_set_row_slices)."""
+    _check(load().rsp_set_row_slices(int(on)))
 
 
 def row_set_bitmap(rows, nrow: int) -> np.ndarray:

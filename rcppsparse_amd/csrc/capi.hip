@@ -80,17 +80,19 @@ bool lean_allowed() {
 }
 
 constexpr size_t kRowSlicesFlagBytes = 256;   // the slice form's guard flag, behind the general form's carries
-std::atomic<int> g_row_slices{-1};   // rsp_set_row_slices: 1 / 0; -1 = RSP_ROW_SLICES from the environment, else on
-bool row_slices_allowed() {
+std::atomic<int> g_row_slices{-1};   // rsp_set_row_slices: 0 / 1 / 2; -1 = RSP_ROW_SLICES from the environment, else 1
+// 0: never the slice-major form of the row-restricted sums; 1: where it is the faster one; 2: wherever it is possible (tests)
+int row_slices_setting() {
     int v = g_row_slices.load(std::memory_order_relaxed);
     if (v < 0) {
         static const int env = [] {
             const char* s = getenv("RSP_ROW_SLICES");
-            return s ? (atoi(s) != 0 ? 1 : 0) : 1;
+            const int e = s ? atoi(s) : 1;
+            return e <= 0 ? 0 : (e >= 2 ? 2 : 1);
         }();
         v = env;
     }
-    return v != 0;
+    return v;
 }
 
 // Rows of x per chunk of the lean form.  A chunk's columns are handed to the 64 lanes of its wavefront, so the chunk
@@ -584,8 +586,8 @@ int rsp_column_sums_in_rows_device(const double* d_x, const int32_t* d_i, const 
     // behind the general form's carries: a workspace of rsp_column_sums_in_rows_workspace_bytes has room for it,
     // one sized by rsp_column_sums_workspace_bytes selects the general form alone.
     rsp::RowSlicesPlan sp;
-    if (row_slices_allowed() && nnz > 0 && ncol > 0 && nnz <= INT32_MAX && d_x && d_p && d_out && d_workspace &&
-        rsp::rowslices_applicable(nrow, ncol, nnz, &sp)) {
+    if (row_slices_setting() != 0 && nnz > 0 && ncol > 0 && nnz <= INT32_MAX && d_x && d_p && d_out && d_workspace &&
+        rsp::rowslices_applicable(nrow, ncol, nnz, row_slices_setting() == 2, &sp)) {
         const size_t general = rsp::workspace_bytes_for(make_plan(nnz).nchunks);
         if (workspace_bytes >= general + kRowSlicesFlagBytes) {
             int32_t* d_flag = (int32_t*)((char*)d_workspace + general);
@@ -610,14 +612,14 @@ int rsp_column_sums_in_rows_form(int32_t nrow, int32_t ncol, int64_t nnz, size_t
     const size_t bitmap_bytes = (size_t)(((int64_t)nrow + 31) / 32) * 4;
     if (bitmap_bytes <= rsp::kLdsBitmapMinBytes) return RSP_IN_ROWS_FORM_L1;
     if (bitmap_bytes <= rsp::kLdsBitmapMaxBytes) return RSP_IN_ROWS_FORM_LDS;
-    if (row_slices_allowed() && nnz > 0 && ncol > 0 && rsp::rowslices_applicable(nrow, ncol, nnz, nullptr) &&
+    if (row_slices_setting() != 0 && nnz > 0 && ncol > 0 && rsp::rowslices_applicable(nrow, ncol, nnz, row_slices_setting() == 2, nullptr) &&
         workspace_bytes >= rsp::workspace_bytes_for(make_plan(nnz).nchunks) + kRowSlicesFlagBytes)
         return RSP_IN_ROWS_FORM_SLICES;
     return RSP_IN_ROWS_FORM_L2;
 }
 
 int rsp_set_row_slices(int on) {
-    g_row_slices.store(on ? 1 : 0, std::memory_order_relaxed);
+    g_row_slices.store(on <= 0 ? 0 : (on >= 2 ? 2 : 1), std::memory_order_relaxed);
     return RSP_OK;
 }
 

@@ -103,13 +103,14 @@ constexpr int kSliceRowsShift = 20;        // rows per slice: 128 KB of bitmap
 constexpr int kSliceMaxGroup = 2048;       // columns per workgroup: a cursor (4 B) and a sum (8 B) each beside the bitmap
 constexpr int kSliceMinColumns = 16384;    // fewer columns leave wavefronts of the 256 workgroups without a batch (1e4 columns: 2.43 against 2.15 ms general; 2e4: 2.16 against 2.88)
 constexpr int kSliceMinSegment = 32;       // mean entries per (column, slice) from which the form is selected
+constexpr int kSliceMinEntriesPerPass = 32768;   // entries of a column group per slice (393 KB of x and i against the 128 KB of bitmap copied for them)
 constexpr int kSliceCus = 256;             // MI355X: one workgroup per CU, groups sized for whole rounds of them
 constexpr int kSliceMaxColumnFactor = 16;  // guard: a column longer than 16 x the mean (+ 4096) goes back to the general kernel
 struct RowSlicesPlan {
     int32_t nslices, group, ngroups, max_col;
     int64_t max_group;
 };
-bool rowslices_applicable(int32_t nrow, int32_t ncol, int64_t nnz, RowSlicesPlan* out);
+bool rowslices_applicable(int32_t nrow, int32_t ncol, int64_t nnz, bool force, RowSlicesPlan* out);
 // zeroes *d_flag and sets it when the matrix has a column / column group the slice form should not take
 hipError_t launch_rowslices_guard(const int32_t* d_p, int32_t ncol, const RowSlicesPlan& sp, int32_t* d_flag,
                                   hipStream_t stream);

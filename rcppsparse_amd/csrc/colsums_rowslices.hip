@@ -214,11 +214,13 @@ __global__ __launch_bounds__(256) void colsums_rowslices_guard_kernel(const int3
 
 }  // namespace
 
-bool rowslices_applicable(int32_t nrow, int32_t ncol, int64_t nnz, RowSlicesPlan* out) {
+bool rowslices_applicable(int32_t nrow, int32_t ncol, int64_t nnz, bool force, RowSlicesPlan* out) {
     if ((int64_t)nrow <= (int64_t)1 << kSliceRowsShift) return false;   // the bitmap fits in LDS: the LDS form of the general kernel
     const int32_t nslices = (int32_t)(((int64_t)nrow + ((int64_t)1 << kSliceRowsShift) - 1) >> kSliceRowsShift);
-    if (ncol < kSliceMinColumns) return false;
-    if (nnz < (int64_t)kSliceMinSegment * ncol * nslices) return false;
+    if (ncol < 1 || nnz < 1) return false;
+    // (force: tests take the form on matrices of any shape; what follows is about speed, not about correctness)
+    if (!force && ncol < kSliceMinColumns) return false;
+    if (!force && nnz < (int64_t)kSliceMinSegment * ncol * nslices) return false;
     // groups: a whole number of rounds of one workgroup per CU, at most kSliceMaxGroup columns each
     const int64_t per_round = (int64_t)kSliceCus * kSliceMaxGroup;
     const int64_t rounds = (ncol + per_round - 1) / per_round;
@@ -226,6 +228,8 @@ bool rowslices_applicable(int32_t nrow, int32_t ncol, int64_t nnz, RowSlicesPlan
     int32_t group = (int32_t)((ncol + units - 1) / units);
     group = (group + kSlcBatch - 1) / kSlcBatch * kSlcBatch;
     if (group > kSliceMaxGroup) group = kSliceMaxGroup;
+    // a workgroup copies 128 KB of bitmap per slice: its columns' entries in that slice should outweigh the copy
+    if (!force && nnz / ((int64_t)ncol * nslices) * group < kSliceMinEntriesPerPass) return false;
     if (out) {
         out->nslices = nslices;
         out->group = group;

@@ -581,6 +581,22 @@ def test_row_restricted_sums_slice_major_form(torch_cuda, complement):
     x, i, p = _matrix_over_row_slices(nrow, ncol, 140, seed=5, long_columns={7: 5_000, ncol - 1: 3_000},
                                       extra_rows=edges)
     nnz = len(x)
+    # selection at full size (host logic only): long columns over many rows take the form, short or few ones do not
+    assert capi.in_rows_form(10_000_000, 1_000_000, 1_000_000_000) == "slices"
+    assert capi.in_rows_form(10_000_000, 1_000_000, 1_000_000_000, capi.workspace_bytes(1_000_000, 1_000_000_000)) == "L2"
+    assert capi.in_rows_form(10_000_000, 4_000_000, 1_000_000_000) == "L2"          # 25 entries per column and slice
+    assert capi.in_rows_form(10_000_000, 10_000, 1_000_000_000) == "L2"             # too few columns for 256 workgroups
+    assert capi.in_rows_form(2**31 - 1, 16_384, 2**31 - 1) == "L2"                  # 2048 bitmap copies for 64 columns' entries
+    assert capi.in_rows_form(nrow, ncol, nnz) == "L2"                               # (this test's matrix is far too small)
+    capi.set_row_slices(2)                                                          # ... so the form is forced
+    try:
+        _check_slice_major_form(torch, x, i, p, nrow, ncol, complement, S)
+    finally:
+        capi.set_row_slices(1)
+
+
+def _check_slice_major_form(torch, x, i, p, nrow, ncol, complement, S):
+    nnz = len(x)
     assert capi.in_rows_form(nrow, ncol, nnz) == "slices"
     assert capi.in_rows_form(nrow, ncol, nnz, capi.workspace_bytes(ncol, nnz)) == "L2"
     rng = np.random.default_rng(1)
@@ -595,11 +611,9 @@ def test_row_restricted_sums_slice_major_form(torch_cuda, complement):
     assert np.all(np.abs(got.cpu().numpy() - ref) <= RTOL * scale)
     assert np.all(got.cpu().numpy()[np.diff(p) == 0] == 0.0)
     assert torch.equal(got, capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement))
-    capi.set_row_slices(False)
-    try:
-        general = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement)
-    finally:
-        capi.set_row_slices(True)
+    capi.set_row_slices(0)
+    general = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement)
+    capi.set_row_slices(2)
     assert np.all(np.abs(general.cpu().numpy() - ref) <= RTOL * scale)
     assert not torch.equal(got, general)                      # (two different summation trees really ran)
     # a workspace sized for the plain column sums has no room for the guard's flag: the general form
@@ -610,11 +624,9 @@ def test_row_restricted_sums_slice_major_form(torch_cuda, complement):
     assert capi.in_rows_form(nrow, ncol, len(x2)) == "slices"
     x2t, i2t, p2t = (torch.from_numpy(a).cuda() for a in (x2, i2, p2))
     got2 = capi.column_sums_in_rows_device(x2t, i2t, p2t, nrow, bt, complement)
-    capi.set_row_slices(False)
-    try:
-        general2 = capi.column_sums_in_rows_device(x2t, i2t, p2t, nrow, bt, complement)
-    finally:
-        capi.set_row_slices(True)
+    capi.set_row_slices(0)
+    general2 = capi.column_sums_in_rows_device(x2t, i2t, p2t, nrow, bt, complement)
+    capi.set_row_slices(2)
     assert torch.equal(got2, general2)
     ref2 = oracle.column_sums_in_rows(x2, i2, p2, bits, complement)
     keep2 = (((bits[i2 >> 5] >> (i2 & 31).astype(np.uint32)) & 1) == 1) != complement
@@ -626,20 +638,52 @@ def test_row_restricted_sums_slice_major_form_is_graph_capture_safe(torch_cuda):
     torch = torch_cuda
     nrow, ncol = (1 << 21) + 77, 33_000
     x, i, p = _matrix_over_row_slices(nrow, ncol, 110, seed=8)
-    assert capi.in_rows_form(nrow, ncol, len(x)) == "slices"
     bits = capi.row_set_bitmap(np.flatnonzero(np.random.default_rng(2).random(nrow) < 0.4), nrow)
     xt, it, pt, bt = (torch.from_numpy(a).cuda() for a in (x, i, p, bits))
     ws = torch.empty(capi.in_rows_workspace_bytes(nrow, ncol, len(x)), dtype=torch.uint8, device="cuda")
     out = torch.zeros(ncol, dtype=torch.float64, device="cuda")
-    eager = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, False, out.clone(), ws).clone()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, False, out, ws)
-    out.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(out, eager)
+    capi.set_row_slices(2)
+    try:
+        assert capi.in_rows_form(nrow, ncol, len(x)) == "slices"
+        eager = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, False, out.clone(), ws).clone()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, False, out, ws)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+    finally:
+        capi.set_row_slices(1)
+
+
+@pytest.mark.parametrize("ncol,mean", [(1, 5), (1, 700), (3, 0), (7, 40), (8, 300), (9, 129), (70, 64), (129, 128),
+                                       (2049, 3), (4100, 130)])
+def test_row_restricted_sums_slice_major_form_small_shapes(torch_cuda, ncol, mean):
+    """The slice form forced onto shapes it would never choose: one column, fewer columns than a batch of 8, a batch
+    and one more, more columns than one workgroup takes, empty matrices' worth of columns, pieces of exactly 128 and
+    129 entries -- against the oracle, both restrictions, with the row-set edges on the slice edges."""
+    torch = torch_cuda
+    S = 1 << 20
+    nrow = 2 * S + 5
+    x, i, p = _matrix_over_row_slices(nrow, ncol, mean, seed=ncol + mean, extra_rows=[0, S - 1, S, 2 * S - 1, 2 * S, nrow - 1])
+    if len(x) == 0:
+        x, i = np.array([1.5]), np.array([S], dtype=np.int32)
+        p = np.zeros(ncol + 1, dtype=np.int32)
+        p[1:] = 1
+    bits = capi.row_set_bitmap([0, S - 1, 2 * S, nrow - 1] + list(range(5, nrow, 3)), nrow)
+    xt, it, pt, bt = (torch.from_numpy(a).cuda() for a in (x, i, p, bits))
+    capi.set_row_slices(2)
+    try:
+        assert capi.in_rows_form(nrow, ncol, len(x)) == "slices"
+        for complement in (False, True):
+            got = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement).cpu().numpy()
+            ref = oracle.column_sums_in_rows(x, i, p, bits, complement)
+            keep = (((bits[i >> 5] >> (i & 31).astype(np.uint32)) & 1) == 1) != complement
+            assert np.all(np.abs(got - ref) <= RTOL * oracle.column_abs_sums(np.where(keep, x, 0.0), p)), complement
+    finally:
+        capi.set_row_slices(1)
 
 
 # ------------------------------------------------------------- maximum size, graph capture
