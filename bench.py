@@ -74,7 +74,7 @@ WORKLOADS = {
     "m100": (10_000_000, 10_000_000, 1_000_000_000, "uniform"),
     "m300": (10_000_000, 3_300_000, 1_000_000_000, "uniform"),
     "m10": (10_000_000, 100_000_000, 1_000_000_000, "uniform"),
-    # ~10 per column at sizes between C2 and 1e9 (where the lean planned form stops paying)
+    # ~10 per column at sizes between C2 and 1e9 (the lean planned form: profiles/r03_lean_sizes.jsonl)
     "m10_3e7": (3_000_000, 3_000_000, 30_000_000, "uniform"),
     "m10_1e8": (10_000_000, 10_000_000, 100_000_000, "uniform"),
     # small shapes for the -m gpu test that runs this file as a child process

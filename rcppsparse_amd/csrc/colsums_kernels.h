@@ -61,6 +61,7 @@ constexpr int kPlannedShortCallChunkRows = 8;   // inspector-executor form of su
 // no column is longer than kLeanMaxColumn entries or reaches more than one row past its chunk's grid end
 constexpr int kLeanTargetColumns = 52;                    // mean number of columns per chunk the row count aims at
 constexpr int kLeanMaxColumn = 64;
+constexpr int kLeanXcdRun = 16;                          // neighbouring workgroups that go to the same XCD (measured: 4 / 8 / 16 / 32)
 constexpr int kLeanMaxColumns = 1278;                     // + 1 closing offset + 1 pad = 1280 16-bit offsets
 constexpr int kLeanMaxOffsetDwords = 640;                 // = 10 x 64 lanes
 constexpr int kGuessWindow = 1024;   // offsets read around the guessed first column of a chunk (short calls)

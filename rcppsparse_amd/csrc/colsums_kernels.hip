@@ -63,6 +63,19 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 //   0x142 row_bcast:15 (lane 15 of a row -> every lane of the next row; row_mask 0xA = rows 1,3)
 //   0x143 row_bcast:31 (lane 31 -> rows 2,3; row_mask 0xC)
 //   0x138 wave_shr:1, 0x130 wave_shl:1 (whole-wave shift by one lane)
+// Workgroups are dealt to the 8 XCDs round-robin (b mod 8), so neighbouring chunks sit in different L2s, and a
+// 128-byte line of results that two chunks share is written back twice, as two partial lines.  Workgroup b of n ->
+// the position it takes when every XCD is to work on RUNS of G neighbouring positions (the runs themselves still go
+// round the XCDs, which keeps the reads spread over the address space).  Used by the lean planned kernel, whose chunks
+// write only ~3 lines each (kLeanXcdRun); the last, partial round of runs keeps its order.
+template <int G>
+__device__ __forceinline__ int xcd_runs(int b, int n) {
+    const int nfull = n / (8 * G) * (8 * G);
+    if (b >= nfull) return b;
+    const int k = b & 7, j = b >> 3;
+    return ((j / G) * 8 + k) * G + j % G;
+}
+
 template <int CTRL, int ROWMASK = 0xF, bool ZERO_FILL = true>
 __device__ __forceinline__ int dpp_i32(int v, int old = 0) {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWMASK, 0xF, ZERO_FILL);
@@ -1137,7 +1150,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
     extern __shared__ uint32_t s_offs[];   // kWavesPerWG x stride_dwords (as many offsets as the fullest chunk has)
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int w = blockIdx.x * kWavesPerWG + wave_in_wg;
+    // runs of kLeanXcdRun workgroups (64 chunks) per XCD: the result lines neighbouring chunks share meet in one L2
+    // (1e9 entries in columns of ~10: 1.86 -> 1.51 ms; of ~30: 1.63 -> 1.45; C2 16.6 -> 16.2 us; profiles/r03_c2.md)
+    const int w = xcd_runs<kLeanXcdRun>((int)blockIdx.x, (int)gridDim.x) * kWavesPerWG + wave_in_wg;
     if (w >= nchunks) return;
     const int32_t cs = w * (R * kRowElems);
     const int32_t left = nnz - cs;
