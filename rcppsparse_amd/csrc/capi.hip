@@ -703,6 +703,26 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
     h->ws_bytes = rsp_column_sums_workspace_bytes(ncol, nnz);
     // x is padded to a whole 16-byte pair so the device copy never ends mid-load
     const size_t xbytes = ((size_t)nnz * 8 + 15) & ~(size_t)15;
+    // p[] is in host memory right now: inspect it once, so that every columnSums on this handle is one launch
+    // without column search, carries or fix-up wherever the matrix allows (no column longer than a group across
+    // a chunk edge); a plan that does not apply costs nothing later.  The inspection is host work (1.6 ms for C2's
+    // 1e6 columns, 0.1-0.3 s for 1e8) and runs on a thread of its own beside the copies below, which keep this
+    // thread busy staging pageable memory; its own small upload goes over the null stream.
+    // (the one-shot host entry sums once: an inspection of 1e7 columns costs as much as uploading them)
+    rsp_colsums_plan* planned = nullptr;
+    std::thread inspector;
+    bool inspector_started = false;
+    if (with_plan) {
+        try {
+            inspector = std::thread([&planned, p, ncol, nnz, device] {
+                if (hipSetDevice(device) != hipSuccess) return;
+                if (plan_make(p, ncol, nnz, device, &planned) != RSP_OK) planned = nullptr;
+            });
+            inspector_started = true;
+        } catch (...) {
+            inspector_started = false;   // (no thread to be had: inspect afterwards, on this one)
+        }
+    }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_x, xbytes ? xbytes : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_p, ((size_t)ncol + 1) * 4);
@@ -716,15 +736,14 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
     if (e == hipSuccess && h->d_i)
         e = hipMemcpyAsync(h->d_i, i, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);   // host buffers are only borrowed
+    if (inspector_started) inspector.join();
     if (e != hipSuccess) {
+        if (planned) rsp_column_sums_plan_destroy(planned);
         rsp_csc_free(h);
         return fail(RSP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
-    // p[] is in host memory right now: inspect it once, so that every columnSums on this handle is one launch
-    // without column search, carries or fix-up wherever the matrix allows (no column longer than a group across
-    // a chunk edge); a plan that does not apply costs nothing later
-    // (the one-shot host entry sums once: an inspection of 1e7 columns costs as much as uploading them)
-    if (with_plan && plan_make(p, ncol, nnz, device, &h->plan) != RSP_OK) h->plan = nullptr;
+    if (with_plan && !inspector_started && plan_make(p, ncol, nnz, device, &planned) != RSP_OK) planned = nullptr;
+    h->plan = planned;
     *handle = h;
     return RSP_OK;
 }
