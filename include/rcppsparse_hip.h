@@ -264,9 +264,26 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
  * Ask for the workspace size with the device current that will run the call
  * (the plan looks at its CU count).
  * rsp_row_sums_workspace_bytes needs a usable device (it asks rocPRIM); 0 = error.
+ *
+ * Segments form (handles only -- it needs p[]): where the columns are long (a column has
+ * >= 128 entries per block of 16384 rows on average, more than 16384 rows, >= 30 columns)
+ * and the rows of every column ascend (dgCMatrix validity, checked once per handle on the
+ * device), nothing is regrouped: a table of every column's contiguous piece per row block
+ * is built on first use (4 B per column and block) and every call reads the uploaded x / i
+ * once, 12 B/nnz, also where the other forms would read them once per row block (2-4
+ * blocks) or keep a 12 B/nnz copy.  rsp_set_row_segments(0) / RSP_ROW_SEGMENTS=0 keeps
+ * handles on the other forms; 2 takes the segments form wherever it is possible (tests).
+ * rsp_csc_row_form tells which form a handle's row sums have taken.
  */
+#define RSP_ROW_FORM_NONE      0   /* not built yet (no row sums asked for so far)      */
+#define RSP_ROW_FORM_DIRECT    1   /* <= 65536 rows: straight from x / i, once per block */
+#define RSP_ROW_FORM_PARTITION 2   /* regrouped by (coarse) row block in one pass       */
+#define RSP_ROW_FORM_TWO_LEVEL 3   /* regrouped in two passes                            */
+#define RSP_ROW_FORM_SEGMENTS  4   /* table of column pieces per row block, no copy      */
 int rsp_csc_row_sums(rsp_csc_t handle, double *sums);     /* nrow doubles, host */
 int rsp_csc_row_means(rsp_csc_t handle, double *means);
+int rsp_csc_row_form(rsp_csc_t handle);
+int rsp_set_row_segments(int mode);
 size_t rsp_row_sums_workspace_bytes(int32_t nrow, int64_t nnz);
 int rsp_row_sums_device(const double *d_x, const int32_t *d_i, int32_t nrow,
                         int64_t nnz, double *d_sums, void *d_workspace,

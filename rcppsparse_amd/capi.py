@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_plan_create", "rsp_column_sums_plan_create_device", "rsp_column_sums_plan_info",
     "rsp_column_sums_planned_device", "rsp_column_sums_plan_destroy", "rsp_set_lean",
     "rsp_column_sums_in_rows_workspace_bytes", "rsp_set_row_slices", "rsp_column_sums_in_rows_form",
+    "rsp_csc_row_form", "rsp_set_row_segments",
     "rsp_csc_crossprod", "rsp_crossprod_workspace_bytes", "rsp_crossprod_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
@@ -117,6 +118,8 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_plan_destroy.argtypes = [vp]
     L.rsp_set_lean.argtypes = [c.c_int]
     L.rsp_set_row_slices.argtypes = [c.c_int]
+    L.rsp_set_row_segments.argtypes = [c.c_int]
+    L.rsp_csc_row_form.argtypes = [c.c_void_p]
     L.rsp_column_sums_in_rows_form.argtypes = [i32, i32, i64, c.c_size_t]
     L.rsp_column_sums_in_rows_workspace_bytes.argtypes = [i32, i32, i64]
     L.rsp_column_sums_in_rows_workspace_bytes.restype = c.c_size_t
@@ -324,6 +327,12 @@ class DeviceCSC:
         _check(load().rsp_csc_row_means(self._h, _dp(out)))
         return out
 
+    ROW_FORMS = ("none", "direct", "partition", "two-level", "segments")
+
+    def row_form(self) -> str:
+        """Which form this handle's row sums have taken (rsp_csc_row_form): "none" before the first call."""
+        return self.ROW_FORMS[int(load().rsp_csc_row_form(self._h))]
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             load().rsp_csc_free(self._h)
@@ -429,6 +438,12 @@ def in_rows_form(nrow: int, ncol: int, nnz: int, workspace_bytes: int | None = N
     if f < 0:
         raise ValueError("sizes out of range")
     return IN_ROWS_FORMS[f]
+
+
+def set_row_segments(mode) -> None:
+    """Handles' row sums: 0 never the segments form, 1 where it is the faster one (default), 2 wherever it is
+    possible (tests) (rsp_set_row_segments).  Looked at when a handle's row sums are asked for the first time."""
+    _check(load().rsp_set_row_segments(int(mode)))
 
 
 def set_row_slices(on) -> None:

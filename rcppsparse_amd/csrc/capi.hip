@@ -95,6 +95,21 @@ int row_slices_setting() {
     return v;
 }
 
+std::atomic<int> g_row_segments{-1};   // rsp_set_row_segments: 0 / 1 / 2; -1 = RSP_ROW_SEGMENTS from the environment, else 1
+// 0: a handle's row sums never take the segments form; 1: where it is the faster one; 2: wherever it is possible (tests)
+int row_segments_setting() {
+    int v = g_row_segments.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static const int env = [] {
+            const char* s = getenv("RSP_ROW_SEGMENTS");
+            const int e = s ? atoi(s) : 1;
+            return e <= 0 ? 0 : (e >= 2 ? 2 : 1);
+        }();
+        v = env;
+    }
+    return v;
+}
+
 // Rows of x per chunk of the lean form.  A chunk's columns are handed to the 64 lanes of its wavefront, so the chunk
 // should hold about 64 of them and rarely more: the largest of 2 / 3 / 4 / 5 / 6 / 8 / 12 / 16 rows that keeps the MEAN
 // number of columns per chunk at or below kLeanTargetColumns (C2, 10 per column: 4 rows = 51 columns, never more than
@@ -308,6 +323,8 @@ struct rsp_csc {
     void* d_row_persist;
     double* d_row_out;
     rsp::RowSumsLayout row_layout;
+    rsp::RowSegmentsLayout seg_layout;   // row_segments: the table of (block, column) pieces instead of a regrouped copy
+    bool row_segments;
     bool row_ready;
 };
 
@@ -828,7 +845,39 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
     if (h->nrow == 0) return RSP_OK;
     if (h->nnz > 0 && !h->d_i)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: rowSums needs the row indices");
-    if (!h->row_ready) {   // build the row-major form once; the scratch is released right after
+    if (!h->row_ready) {
+        // Long columns whose rows ascend (checked here, once, on the device): the segments form -- a table of every
+        // column's piece per row block, and the accumulate pass reads the uploaded x / i as they are (12 B/nnz, no
+        // regrouped copy).  Otherwise: the row-major form is built once; its scratch is released right after.
+        const int mode = row_segments_setting();
+        if (mode != 0 && h->d_i && h->d_p && rsp::row_segments_applicable(h->nrow, h->ncol, h->nnz, mode == 2)) {
+            hipError_t e = rsp::plan_row_segments(h->nrow, h->ncol, h->nnz, &h->seg_layout);
+            int32_t unsorted = 1;
+            if (e == hipSuccess && !h->d_row_persist) e = hipMalloc(&h->d_row_persist, h->seg_layout.bytes);
+            if (e == hipSuccess && !h->d_row_out) e = hipMalloc((void**)&h->d_row_out, (size_t)h->nrow * 8);
+            if (e == hipSuccess) {
+                int32_t* d_flag = (int32_t*)((char*)h->d_row_persist + h->seg_layout.flag_off);
+                e = rsp::launch_rows_sorted_check(h->d_i, h->d_p, h->ncol, h->nnz, d_flag, h->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(&unsorted, d_flag, 4, hipMemcpyDeviceToHost, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            }
+            if (e == hipSuccess && unsorted == 0) {
+                e = rsp::launch_row_segments_build(h->d_i, h->d_p, h->ncol, h->nnz, h->seg_layout, h->d_row_persist,
+                                                   h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                if (e == hipSuccess) {
+                    h->row_segments = true;
+                    h->row_ready = true;
+                }
+            }
+            if (!h->row_ready) {   // rows that do not ascend, or no memory for the table: the general forms below
+                if (h->d_row_persist) (void)hipFree(h->d_row_persist);
+                h->d_row_persist = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+    }
+    if (!h->row_ready) {
         if (int rc = row_plan(h->nrow, h->nnz, true, &h->row_layout)) return rc;
         void* scratch = nullptr;
         hipError_t e = hipSuccess;
@@ -848,16 +897,34 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
             (void)hipGetLastError();
             return fail(RSP_ERR_HIP, "building the row-major form failed: %s", hipGetErrorString(e));
         }
+        h->row_segments = false;
         h->row_ready = true;
     }
-    HIP_TRY(rsp::launch_row_reduce(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout, h->d_row_persist, h->d_row_out,
-                                   means ? (double)h->ncol : 1.0, means, make_plan(h->nnz), h->stream));
+    if (h->row_segments)
+        HIP_TRY(rsp::launch_row_segments_reduce(h->d_x, h->d_i, h->nrow, h->ncol, h->seg_layout, h->d_row_persist,
+                                                h->d_row_out, means ? (double)h->ncol : 1.0, means, h->stream));
+    else
+        HIP_TRY(rsp::launch_row_reduce(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout, h->d_row_persist, h->d_row_out,
+                                       means ? (double)h->ncol : 1.0, means, make_plan(h->nnz), h->stream));
     HIP_TRY(hipMemcpyAsync(host_out, h->d_row_out, (size_t)h->nrow * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return RSP_OK;
 }
 
 int rsp_csc_row_sums(rsp_csc_t h, double* sums) { return csc_rows(h, sums, false); }
+
+int rsp_csc_row_form(rsp_csc_t h) {
+    if (!h) return -1;
+    if (!h->row_ready) return RSP_ROW_FORM_NONE;
+    if (h->row_segments) return RSP_ROW_FORM_SEGMENTS;
+    if (h->row_layout.direct) return RSP_ROW_FORM_DIRECT;
+    return h->row_layout.mode == 3 ? RSP_ROW_FORM_TWO_LEVEL : RSP_ROW_FORM_PARTITION;
+}
+
+int rsp_set_row_segments(int mode) {
+    g_row_segments.store(mode <= 0 ? 0 : (mode >= 2 ? 2 : 1), std::memory_order_relaxed);
+    return RSP_OK;
+}
 int rsp_csc_row_means(rsp_csc_t h, double* means) { return csc_rows(h, means, true); }
 
 // ---- Matrix::crossprod (RcppSparse.h:159-194) -----------------------------------------------

@@ -159,6 +159,22 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
                              const RowSumsLayout& L, void* persist, double* d_out,
                              double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream);
 
+// Segments form of the row sums (rowsums.hip): behind a handle whose columns' rows ascend; no regrouped copy
+struct RowSegmentsLayout {
+    int32_t shift, nblocks, nsplit;
+    size_t table_off, cuts_off, flag_off, partial_off, bytes;
+};
+bool row_segments_applicable(int32_t nrow, int32_t ncol, int64_t nnz, bool force);
+hipError_t plan_row_segments(int32_t nrow, int32_t ncol, int64_t nnz, RowSegmentsLayout* L);
+// *d_flag = 1 if some column's rows do not ascend (0 otherwise)
+hipError_t launch_rows_sorted_check(const int32_t* d_i, const int32_t* d_p, int32_t ncol, int64_t nnz,
+                                    int32_t* d_flag, hipStream_t stream);
+hipError_t launch_row_segments_build(const int32_t* d_i, const int32_t* d_p, int32_t ncol, int64_t nnz,
+                                     const RowSegmentsLayout& L, void* persist, hipStream_t stream);
+hipError_t launch_row_segments_reduce(const double* d_x, const int32_t* d_i, int32_t nrow, int32_t ncol,
+                                      const RowSegmentsLayout& L, void* persist, double* d_out, double divisor,
+                                      bool means, hipStream_t stream);
+
 hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d_hdr, const uint32_t* d_offs,
                                    int32_t stride_dwords, int32_t nchunks, int32_t rows, double* d_out, double divisor,
                                    bool means, hipStream_t stream);

@@ -41,7 +41,8 @@
 //     copy, a second regroups every bucket by its blocks (the same kernels on the bucket's range): 21.2 ms for 1e9
 //     entries in 1.2e8 rows, workspace 24 B/nnz.
 //
-// A handle (rsp_csc_row_sums) keeps the regrouped copy and repeats steps 4 and 5 only (12 B/nnz per call).
+// A handle (rsp_csc_row_sums) keeps the regrouped copy and repeats steps 4 and 5 only (12 B/nnz per call) -- or, where
+// its columns are long and their rows ascend, regroups nothing at all (segments form, at the end of this file).
 // Rounds 1-2 sorted with rocPRIM here (by 4096-row block above 1.36e7 rows, fully by row behind the handle); the
 // only library call left is the exclusive scan of the count table.
 // All forms are deterministic and within the usual 1e-12 * sum|x| of the reference's order.
@@ -868,6 +869,29 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
     return e;
 }
 
+// out[row] = the parts' sums of that row, added in part order (+ 0.0, / divisor)
+static hipError_t launch_rows_combine(const double* parts, int32_t nrow, int32_t nsplit, double* d_out, double divisor,
+                                      bool means, hipStream_t stream) {
+    if (nsplit >= 16) {
+        const dim3 wgrid((unsigned)(((int64_t)nrow + 3) / 4));
+        if (means)
+            hipLaunchKernelGGL(rows_combine_many_parts_kernel<true>, wgrid, dim3(256), 0, stream, parts, nrow,
+                               nsplit, d_out, divisor);
+        else
+            hipLaunchKernelGGL(rows_combine_many_parts_kernel<false>, wgrid, dim3(256), 0, stream, parts, nrow,
+                               nsplit, d_out, divisor);
+        return hipGetLastError();
+    }
+    const dim3 cgrid((unsigned)(((int64_t)nrow + 255) / 256));
+    if (means)
+        hipLaunchKernelGGL(rows_combine_parts_kernel<true>, cgrid, dim3(256), 0, stream, parts, nrow, nsplit,
+                           d_out, divisor);
+    else
+        hipLaunchKernelGGL(rows_combine_parts_kernel<false>, cgrid, dim3(256), 0, stream, parts, nrow, nsplit,
+                           d_out, divisor);
+    return hipGetLastError();
+}
+
 // Row sums / means from the regrouped copy in `persist` (direct form: from the caller's x / i).
 hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow, int64_t nnz,
                              const RowSumsLayout& L, void* persist, double* d_out,
@@ -893,24 +917,275 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
                            boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor);
     e = hipGetLastError();
     if (e != hipSuccess || L.nsplit <= 1) return e;
-    if (L.nsplit >= 16) {
-        const dim3 wgrid((unsigned)(((int64_t)nrow + 3) / 4));
-        if (means)
-            hipLaunchKernelGGL(rows_combine_many_parts_kernel<true>, wgrid, dim3(256), 0, stream, parts, nrow,
-                               L.nsplit, d_out, divisor);
-        else
-            hipLaunchKernelGGL(rows_combine_many_parts_kernel<false>, wgrid, dim3(256), 0, stream, parts, nrow,
-                               L.nsplit, d_out, divisor);
-        return hipGetLastError();
+    return launch_rows_combine(parts, nrow, L.nsplit, d_out, divisor, means, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// segments form (round 3; behind a handle, which holds p[]): no regrouping when the columns are long
+// ---------------------------------------------------------------------------------------------
+// Inside a column of a dgCMatrix the rows ascend, so the entries of column c that belong to row block b are ONE
+// contiguous piece [T[b][c], T[b + 1][c]) of x / i.  With that table (a binary search per (block, column), built once
+// per handle; T[0] = p[c], T[nblocks] = p[c + 1]) the accumulate pass of every block reads exactly its own entries from
+// the caller's arrays: 12 B/nnz in total, where the direct form reads all entries once per block (2-4 blocks: 24-48
+// B/nnz) and the partition forms move ~40 B/nnz and keep a 12 B/nnz copy.  It pays when a (column, block) piece has
+// a hundred entries or more -- matrices of long columns over 16385 .. ~1e6 rows -- and needs rows that really ascend:
+// the handle checks that once on the device (rows_sorted_check_kernel) and keeps the other forms for matrices that fail.
+//   Work: `nsplit` workgroups per row block, each over a range of whole columns (cuts balanced by entries).  The 15
+//   staging wavefronts take the range's columns round-robin and walk their column's piece 64 entries per step; the
+//   sixteenth wavefront adds, exactly as in rows_tile_accumulate_kernel.  A row's terms are added in a fixed order
+//   (step, slot): bit-stable; within the usual 1e-12 * sum|x| of the reference's order.
+constexpr int kSegMinPiece = 128;         // mean entries per (column, block) piece from which the form is chosen
+constexpr int kSegMinColumnsPerPart = 30; // a workgroup's 15 staging wavefronts want two columns each at least
+
+__global__ __launch_bounds__(256) void rows_sorted_check_kernel(const int32_t* __restrict__ ri,
+                                                                const int32_t* __restrict__ p, int32_t ncol,
+                                                                int64_t nnz, int32_t* __restrict__ flag) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (e >= nnz) return;
+    if (ri[e] >= ri[e - 1]) return;
+    // a descent: fine only where a column starts (p[c] == e for the column c that holds entry e)
+    int32_t lo = 0, hi = ncol;   // invariant: p[lo] <= e < p[hi]
+    while (hi - lo > 1) {
+        const int32_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)p[mid] <= e) lo = mid; else hi = mid;
     }
-    const dim3 cgrid((unsigned)(((int64_t)nrow + 255) / 256));
-    if (means)
-        hipLaunchKernelGGL(rows_combine_parts_kernel<true>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
-                           d_out, divisor);
-    else
-        hipLaunchKernelGGL(rows_combine_parts_kernel<false>, cgrid, dim3(256), 0, stream, parts, nrow, L.nsplit,
-                           d_out, divisor);
+    if ((int64_t)p[lo] != e) *flag = 1;
+}
+
+// T[b][c] for b = 0 .. nblocks: first entry of column c whose row is >= b << shift (T[0] = p[c], T[nblocks] = p[c + 1])
+__global__ __launch_bounds__(256) void rows_segment_table_kernel(const int32_t* __restrict__ ri,
+                                                                 const int32_t* __restrict__ p, int32_t ncol,
+                                                                 int32_t nblocks, int32_t shift,
+                                                                 int32_t* __restrict__ table) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)(nblocks + 1) * ncol) return;
+    const int32_t b = (int32_t)(t / ncol), c = (int32_t)(t - (int64_t)b * ncol);
+    int32_t lo = p[c], hi = p[c + 1];
+    if (b == 0) {
+        table[t] = lo;
+    } else if (b == nblocks) {
+        table[t] = hi;
+    } else {
+        const int64_t first_row = (int64_t)b << shift;
+        while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if ((int64_t)ri[mid] < first_row) lo = mid + 1; else hi = mid;
+        }
+        table[t] = lo;
+    }
+}
+
+// cuts[k] = first column whose entries start at or after k * nnz / nsplit (cuts[0] = 0, cuts[nsplit] = ncol)
+__global__ void rows_column_cuts_kernel(const int32_t* __restrict__ p, int32_t ncol, int64_t nnz, int32_t nsplit,
+                                        int32_t* __restrict__ cuts) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nsplit) return;
+    if (k == 0 || k == nsplit) {
+        cuts[k] = k == 0 ? 0 : ncol;
+        return;
+    }
+    const int64_t target = nnz / nsplit * k + nnz % nsplit * k / nsplit;
+    int32_t lo = 0, hi = ncol;
+    while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)p[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    cuts[k] = lo;
+}
+
+template <bool MEANS>
+__global__ __launch_bounds__(kAccThreads) void rows_segments_accumulate_kernel(
+    const double* __restrict__ x, const int32_t* __restrict__ ri, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ cuts, int32_t ncol, int32_t nrow, int32_t shift, int32_t nsplit,
+    double* __restrict__ out, double* __restrict__ part_out, double divisor) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    double* sums = (double*)s_raw;                          // 1 << shift (+ 64 spare slots: where nothing-to-add goes)
+    double* st_x = sums + ((size_t)1 << shift) + 64;        // 2 x kAccStagers
+    int32_t* st_r = (int32_t*)(st_x + 2 * kAccStagers);     // 2 x kAccStagers: byte offsets into sums
+    __shared__ int32_t s_steps[kAccThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit;
+    const int rows_here = 1 << shift, mask = rows_here - 1;
+    for (int r = tid; r < rows_here; r += kAccThreads) sums[r] = 0.0;
+    const int32_t ca = cuts[part], cb = cuts[part + 1];
+    const int32_t* tb = table + (size_t)b * ncol;        // piece starts of this block ...
+    const int32_t* te = tb + ncol;                       // ... and ends (= the next block's starts)
+    constexpr int kStagerWaves = kAccStagers / 64;
+    // steps this staging wavefront needs: its columns' pieces, 64 entries per step
+    if (wave != 0) {
+        int32_t cnt = 0;
+        for (int64_t c = (int64_t)ca + (wave - 1) + (int64_t)kStagerWaves * lane; c < cb; c += (int64_t)kStagerWaves * 64) {
+            const int32_t len = te[c] - tb[c];
+            cnt += len > 0 ? (len + 63) >> 6 : 0;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if (lane == 0) s_steps[wave] = cnt;
+    } else if (lane == 0) {
+        s_steps[0] = 0;
+    }
+    __syncthreads();
+    int32_t nsteps = 0;
+#pragma unroll
+    for (int w = 0; w < kAccThreads / 64; ++w) nsteps = s_steps[w] > nsteps ? s_steps[w] : nsteps;
+    const int32_t nrounds = (nsteps + kAccDepth - 1) / kAccDepth;
+    if (wave != 0) {
+        const int stid = tid - 64;
+        // this wavefront's place in its column list: the piece [pos, end) of column c; the next column's piece is
+        // requested when this one is entered (all wave-uniform: scalar loads)
+        int32_t c = ca + (wave - 1);
+        int32_t pos = 0, end = 0, npos = 0, nend = 0;
+        if (c < cb) {
+            pos = tb[c];
+            end = te[c];
+        }
+        if (c + kStagerWaves < cb) {
+            npos = tb[c + kStagerWaves];
+            nend = te[c + kStagerWaves];
+        }
+        int32_t gr[kAccDepth];
+        double gv[kAccDepth];
+        auto fetch = [&](int d) {
+            while (pos >= end && c < cb) {   // (empty pieces, and the end of a piece: on to the wavefront's next column)
+                c += kStagerWaves;
+                pos = npos;
+                end = nend;
+                npos = nend = 0;
+                if (c + kStagerWaves < cb) {
+                    npos = tb[c + kStagerWaves];
+                    nend = te[c + kStagerWaves];
+                }
+                if (c >= cb) pos = end = 0;
+            }
+            const int32_t n = end - pos < 64 ? end - pos : 64;   // (0 once the columns are used up)
+            // unconditional loads from clamped addresses (exact wait counts); lanes past the piece stage "nothing"
+            const int32_t j = lane < n ? (int32_t)((uint32_t)pos + (uint32_t)lane) : (n > 0 ? pos : 0);
+            const int32_t t = __builtin_nontemporal_load(ri + j);
+            gv[d] = __builtin_nontemporal_load(x + j);
+            gr[d] = lane < n ? t : -1;
+            pos += n;
+        };
+        if (nrounds > 0) {
+#pragma unroll
+            for (int d = 0; d < kAccDepth; ++d) fetch(d);
+        }
+        for (int32_t q = 0; q < nrounds; ++q) {
+#pragma unroll
+            for (int d = 0; d < kAccDepth; ++d) {
+                const bool mine = (uint32_t)gr[d] < (uint32_t)nrow && (gr[d] >> shift) == b;
+                st_r[(d & 1) * kAccStagers + stid] = mine ? (gr[d] & mask) * 8 : (rows_here + (stid & 63)) * 8;
+                st_x[(d & 1) * kAccStagers + stid] = mine ? gv[d] : 0.0;
+                fetch(d);
+                lds_barrier();
+            }
+        }
+    } else {
+        for (int32_t q = 0; q < nrounds; ++q) {
+#pragma unroll
+            for (int d = 0; d < kAccDepth; ++d) {
+                lds_barrier();
+                const int32_t* br = st_r + (d & 1) * kAccStagers;
+                const double* bx = st_x + (d & 1) * kAccStagers;
+                int32_t off[kAccStagers / 64];
+                double xv[kAccStagers / 64];
+#pragma unroll
+                for (int u = 0; u < kAccStagers / 64; ++u) off[u] = br[u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < kAccStagers / 64; ++u) xv[u] = bx[u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < kAccStagers / 64; ++u) lds_add_f64((double*)((char*)sums + off[u]), xv[u]);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)b << shift;
+    for (int r = tid; r < rows_here; r += kAccThreads) {
+        const int64_t row = row0 + r;
+        if (row < nrow) {
+            if (nsplit > 1) {
+                part_out[(size_t)part * (size_t)nrow + (size_t)row] = sums[r];
+            } else {
+                double t = sums[r] + 0.0;
+                if (MEANS) t = t / divisor;
+                out[row] = t;
+            }
+        }
+    }
+}
+
+bool row_segments_applicable(int32_t nrow, int32_t ncol, int64_t nnz, bool force) {
+    const int64_t nblocks = ((int64_t)nrow + (1 << kPartShift) - 1) >> kPartShift;
+    if (nblocks < 2 || ncol < 1 || nnz < 1 || nnz > 0x7fffffffll) return false;
+    if ((nblocks + 1) * (int64_t)ncol > 0x7fffffffll) return false;   // (table entries)
+    if (force) return true;
+    return ncol >= kSegMinColumnsPerPart && nnz / ((int64_t)ncol * nblocks) >= kSegMinPiece;
+}
+
+hipError_t plan_row_segments(int32_t nrow, int32_t ncol, int64_t nnz, RowSegmentsLayout* L) {
+    memset(L, 0, sizeof(*L));
+    L->shift = kPartShift;
+    L->nblocks = (int32_t)(((int64_t)nrow + (1 << kPartShift) - 1) >> kPartShift);
+    int ns = accumulate_split(L->nblocks, nnz / L->nblocks, 1 << kPartShift);
+    const int by_columns = ncol / kSegMinColumnsPerPart;   // parts of at least 30 columns
+    if (ns > by_columns) ns = by_columns;
+    L->nsplit = ns < 1 ? 1 : ns;
+    size_t off = 0;
+    L->table_off = off;   off = align_up(off + (size_t)(L->nblocks + 1) * (size_t)ncol * 4, 256);
+    L->cuts_off = off;    off = align_up(off + ((size_t)L->nsplit + 1) * 4, 256);
+    L->flag_off = off;    off = align_up(off + 4, 256);
+    L->partial_off = off;
+    if (L->nsplit > 1) off = align_up(off + (size_t)L->nsplit * (size_t)nrow * 8, 256);
+    L->bytes = off;
+    return hipSuccess;
+}
+
+hipError_t launch_rows_sorted_check(const int32_t* d_i, const int32_t* d_p, int32_t ncol, int64_t nnz,
+                                    int32_t* d_flag, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_flag, 0, 4, stream);
+    if (e != hipSuccess || nnz < 2) return e;
+    hipLaunchKernelGGL(rows_sorted_check_kernel, dim3((unsigned)((nnz - 1 + 255) / 256)), dim3(256), 0, stream, d_i,
+                       d_p, ncol, nnz, d_flag);
     return hipGetLastError();
+}
+
+hipError_t launch_row_segments_build(const int32_t* d_i, const int32_t* d_p, int32_t ncol, int64_t nnz,
+                                     const RowSegmentsLayout& L, void* persist, hipStream_t stream) {
+    int32_t* table = (int32_t*)((char*)persist + L.table_off);
+    int32_t* cuts = (int32_t*)((char*)persist + L.cuts_off);
+    const int64_t cells = (int64_t)(L.nblocks + 1) * ncol;
+    hipLaunchKernelGGL(rows_segment_table_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, d_i,
+                       d_p, ncol, L.nblocks, L.shift, table);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rows_column_cuts_kernel, dim3((unsigned)((L.nsplit + 1 + 255) / 256)), dim3(256), 0, stream,
+                       d_p, ncol, nnz, L.nsplit, cuts);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_segments_reduce(const double* d_x, const int32_t* d_i, int32_t nrow, int32_t ncol,
+                                      const RowSegmentsLayout& L, void* persist, double* d_out, double divisor,
+                                      bool means, hipStream_t stream) {
+    if (nrow <= 0) return hipSuccess;
+    const int32_t* table = (const int32_t*)((char*)persist + L.table_off);
+    const int32_t* cuts = (const int32_t*)((char*)persist + L.cuts_off);
+    double* parts = (double*)((char*)persist + L.partial_off);
+    const size_t acc_lds = ((size_t)8 << L.shift) + 64 * 8 + (size_t)2 * kAccStagers * 12;
+    static DynamicLdsLimit lim_means, lim_sums;
+    hipError_t e = lim_means.ensure((const void*)rows_segments_accumulate_kernel<true>, (int)acc_lds);
+    if (e == hipSuccess) e = lim_sums.ensure((const void*)rows_segments_accumulate_kernel<false>, (int)acc_lds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)L.nblocks * (unsigned)L.nsplit);
+    if (means)
+        hipLaunchKernelGGL(rows_segments_accumulate_kernel<true>, grid, dim3(kAccThreads), acc_lds, stream, d_x, d_i,
+                           table, cuts, ncol, nrow, L.shift, L.nsplit, d_out, parts, divisor);
+    else
+        hipLaunchKernelGGL(rows_segments_accumulate_kernel<false>, grid, dim3(kAccThreads), acc_lds, stream, d_x, d_i,
+                           table, cuts, ncol, nrow, L.shift, L.nsplit, d_out, parts, divisor);
+    e = hipGetLastError();
+    if (e != hipSuccess || L.nsplit <= 1) return e;
+    return launch_rows_combine(parts, nrow, L.nsplit, d_out, divisor, means, stream);
 }
 
 }  // namespace rsp

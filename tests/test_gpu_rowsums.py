@@ -292,3 +292,97 @@ def test_fuzz_row_entries_and_masks(torch_cuda, seed):
         keep = np.isin(i, s) != comp
         scale = oracle.column_abs_sums(np.where(keep, x, 0.0), p)
         assert np.all(np.abs(got - ref) <= RTOL * scale)
+
+
+# ------------------------------------------------ the segments form behind a handle (no regrouped copy)
+def _sorted_columns_matrix(nrow, ncol, mean, seed, invalid=False, duplicates=False):
+    """CSC matrix whose columns' rows ascend: Poisson column lengths (some empty), uniformly drawn rows."""
+    rng = np.random.default_rng(seed)
+    counts = rng.poisson(mean, size=ncol).astype(np.int64)
+    counts[rng.random(ncol) < 0.05] = 0
+    col = np.repeat(np.arange(ncol, dtype=np.int64), counts)
+    row = rng.integers(0, nrow, size=col.size, dtype=np.int64)
+    if duplicates:
+        row[1::7] = row[0::7][:row[1::7].size]                   # the same row twice in a column now and then
+    if invalid:                                                  # rows outside [0, nrow): left out by every form
+        row[rng.random(row.size) < 0.03] = nrow + 5
+        row[rng.random(row.size) < 0.03] = -3
+    order = np.lexsort((row, col))
+    col, row = col[order], row[order]
+    p = np.zeros(ncol + 1, dtype=np.int64)
+    np.add.at(p, col + 1, 1)
+    p = np.cumsum(p).astype(np.int32)
+    x = synth.gen_values(int(p[-1]), seed=seed, kind=0)
+    return x, row.astype(np.int32), p
+
+
+def _handle_rows(x, i, p, nrow, ncol):
+    h = capi.DeviceCSC(x, p, (nrow, ncol), i=i)
+    assert h.row_form() == "none"
+    hs, hs2, hm = h.row_sums(), h.row_sums(), h.row_means()
+    form = h.row_form()
+    cs = h.column_sums()
+    h.close()
+    assert hs.tobytes() == hs2.tobytes() and hm.tobytes() == (hs / ncol).tobytes()
+    assert np.allclose(cs, oracle.column_sums(x, p), rtol=0, atol=1e-9)
+    return hs, form
+
+
+def test_handle_row_sums_take_the_segments_form_where_columns_are_long(torch_cuda):
+    """40 000 rows (3 blocks of 16384), 600 columns of ~2000 entries: a column has ~670 entries per row block, the
+    rows ascend -> no regrouping, a table of the columns' pieces per block (rsp_csc_row_form says "segments").
+    Against the oracle's scatter loop; against the form the handle takes otherwise; matrices whose rows do not ascend,
+    whose columns are short or which have a single row block keep the other forms."""
+    nrow, ncol = 40_000, 600
+    x, i, p = _sorted_columns_matrix(nrow, ncol, 2000, seed=3)
+    hs, form = _handle_rows(x, i, p, nrow, ncol)
+    assert form == "segments"
+    check(hs, x, i, p, nrow)
+    capi.set_row_segments(0)
+    try:
+        other, form0 = _handle_rows(x, i, p, nrow, ncol)
+    finally:
+        capi.set_row_segments(1)
+    assert form0 == "direct"
+    assert np.all(np.abs(hs - other) <= 2 * RTOL * row_l1(x, i, nrow))
+    # rows that do not ascend inside a column: found by the check on the device, the handle regroups as before
+    j0 = int(p[5]) + 10
+    i2 = i.copy()
+    i2[j0], i2[j0 + 1] = i[j0 + 1] + 1, i[j0]                      # (a descent in the middle of column 5)
+    assert i2[j0] > i2[j0 + 1]
+    hs2, form2 = _handle_rows(x, i2, p, nrow, ncol)
+    assert form2 == "direct"
+    check(hs2, x, i2, p, nrow)
+    # short columns / one row block: not chosen
+    xs, is_, ps = _sorted_columns_matrix(nrow, 5000, 40, seed=4)
+    assert _handle_rows(xs, is_, ps, nrow, 5000)[1] == "direct"
+    xb, ib, pb = _sorted_columns_matrix(16_384, 100, 3000, seed=5)
+    assert _handle_rows(xb, ib, pb, 16_384, 100)[1] == "direct"
+
+
+@pytest.mark.parametrize("nrow,ncol,mean,extra", [
+    (16_385, 1, 700, ""), (16_385, 40, 0, ""), (40_000, 7, 300, ""), (40_000, 31, 64, "duplicates"),
+    (70_001, 300, 500, "invalid"), (200_000, 90, 129, ""), (1_000_003, 64, 2000, ""), (1_000_003, 2000, 3, ""),
+    (32_768, 15, 1000, ""), (32_769, 16, 1000, "invalid"),
+])
+def test_handle_row_sums_segments_form_forced_onto_small_and_odd_shapes(torch_cuda, nrow, ncol, mean, extra):
+    """The segments form on shapes it would not choose (rsp_set_row_segments(2)): one column, fewer columns than
+    staging wavefronts, empty matrices' worth of columns, a last row block of one row, 62 blocks with three entries
+    per column, repeated rows, row indices outside [0, nrow) (left out, as in every form)."""
+    x, i, p = _sorted_columns_matrix(nrow, ncol, mean, seed=nrow % 1000 + ncol, invalid=extra == "invalid",
+                                     duplicates=extra == "duplicates")
+    if len(x) == 0:
+        x, i = np.array([2.5, -1.0]), np.array([3, nrow - 1], dtype=np.int32)
+        p = np.zeros(ncol + 1, dtype=np.int32)
+        p[1:] = 2
+    capi.set_row_segments(2)
+    try:
+        hs, form = _handle_rows(x, i, p, nrow, ncol)
+    finally:
+        capi.set_row_segments(1)
+    assert form == "segments"
+    keep = (i >= 0) & (i < nrow)
+    ref = oracle.row_sums(x[keep], i[keep], np.array([0, int(keep.sum())], dtype=np.int32), nrow)
+    scale = np.bincount(i[keep], weights=np.abs(x[keep]), minlength=nrow)
+    assert np.all(np.abs(hs - ref) <= RTOL * scale), float(np.max(np.abs(hs - ref) / np.maximum(scale, 1e-300)))
+    assert np.all(hs[scale == 0] == 0.0) and not np.any(np.signbit(hs[scale == 0]))
