@@ -597,7 +597,7 @@ def main(argv=None):
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
                 "planned": (None if plan is None else
-                            {"form": {2: "lean", 1: "snapped", 0: "general kernels"}[plan.form],
+                            {"form": {3: "columns", 2: "lean", 1: "snapped", 0: "general kernels"}[plan.form],
                              "snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
                              "entries_per_chunk": plan.chunk_elems, "max_skip": plan.max_skip,
                              "note": "inspection of p[] on the host, once, outside every timed region; a snapped "
@@ -616,7 +616,8 @@ def main(argv=None):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic[0], "traffic_source": traffic_source,
-                "kernel": ("colsums_lean_kernel (one launch)" if plan is not None and plan.lean else
+                "kernel": ("colsums_columns_kernel (one launch)" if plan is not None and plan.columns else
+                           "colsums_lean_kernel (one launch)" if plan is not None and plan.lean else
                            "colsums_chunks_kernel<PLANNED> (one launch)" if plan is not None and plan.snapped
                            else "colsums_chunks_kernel (+ colsums_fixup_kernel)"),
                 "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],

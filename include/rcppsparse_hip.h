@@ -167,8 +167,14 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
  * column, p[] itself is not read again), puts both into LDS and adds every column in storage order from +0.0:
  * every column then comes out BIT-IDENTICAL to the reference loop.  rsp_set_lean(0) / RSP_LEAN=0 keeps plans
  * out of that form (A/B measurements).
- * info4 = { form (0 general kernels, 1 snapped, 2 lean), chunks, entries per chunk, largest distance from a
- * chunk's grid start to its first column start (lean: most columns in one chunk) }; *inspect_ms = host time the
+ * When every column is LONG and of similar length (at least 2048 entries, none above four times the mean, at
+ * least 128 columns; the reference vignette's 100000 x 1000 benchmark matrix) the plan takes the COLUMNS form:
+ * nothing is recorded at all, a call is one launch of one workgroup per column that reads p[c], p[c + 1] itself
+ * (no column search per chunk, no carries, no fix-up launch, no workspace); results within the usual tolerance.
+ * RSP_COLUMNS_FORM=0 keeps plans out of it.
+ * info4 = { form (0 general kernels, 1 snapped, 2 lean, 3 columns), chunks (columns form: columns), entries per
+ * chunk (columns form: threads per column), largest distance from a chunk's grid start to its first column start
+ * (lean: most columns in one chunk; columns form: the longest column) }; *inspect_ms = host time the
  * inspection took (reported separately from the calls).
  * nrow_for_means > 0: colMeans (RcppSparse.h:145-150), 0: sums.
  */

@@ -539,10 +539,10 @@ class ColumnSumsPlan:
         info = np.zeros(4, dtype=np.int32)
         ms = ctypes.c_double(0)
         _check(L.rsp_column_sums_plan_info(self._h, _ip(info), ctypes.byref(ms)))
-        # form 2 = lean (all columns short: one launch, reference bits for every column), 1 = snapped (one launch),
-        # 0 = the general kernels behind the same entry
+        # form 3 = columns (all columns long: one workgroup per column), 2 = lean (all columns short: one launch,
+        # reference bits for every column), 1 = snapped (one launch), 0 = the general kernels behind the same entry
         self.form = int(info[0])
-        self.lean, self.snapped = self.form == 2, self.form >= 1
+        self.lean, self.columns, self.snapped = self.form == 2, self.form == 3, self.form >= 1
         self.nchunks, self.chunk_elems, self.max_skip = int(info[1]), int(info[2]), int(info[3])
         self.inspect_ms = float(ms.value)
 

@@ -110,6 +110,24 @@ int row_segments_setting() {
     return v;
 }
 
+// columns form of a plan (every column long): RSP_COLUMNS_FORM=0 keeps such matrices on the general kernels (A/B);
+// wavefronts per column: RSP_COLUMNS_WAVES = 4 / 8 / 16, else from the mean column length
+bool columns_allowed() {
+    static const int env = [] {
+        const char* s = getenv("RSP_COLUMNS_FORM");
+        return s ? (atoi(s) != 0 ? 1 : 0) : 1;
+    }();
+    return env != 0;
+}
+int columns_waves_setting(int32_t ncol, int64_t mean_len) {
+    static const int env = env_int("RSP_COLUMNS_WAVES");
+    if (env == 4 || env == 8 || env == 16) return env;
+    // 4 wavefronts per column wherever there are columns enough to fill the chip with them (1000 columns of 3e3 / 1e4 /
+    // 3e4 / 1e5 entries: 4 beats 8 and 16 by 1-6 %); fewer columns get more wavefronts each
+    (void)mean_len;
+    return ncol >= 512 ? 4 : (ncol >= 256 ? 8 : 16);
+}
+
 // Rows of x per chunk of the lean form.  A chunk's columns are handed to the 64 lanes of its wavefront, so the chunk
 // should hold about 64 of them and rarely more: the largest of 2 / 3 / 4 / 5 / 6 / 8 / 12 / 16 rows that keeps the MEAN
 // number of columns per chunk at or below kLeanTargetColumns (C2, 10 per column: 4 rows = 51 columns, never more than
@@ -305,6 +323,9 @@ struct rsp_colsums_plan {
     int32_t lean_chunks, lean_stride_dwords, lean_max_columns, lean_rows;
     int2* d_lean_hdr;
     uint32_t* d_lean_offs;
+    // columns form (every column long and of similar length): no records at all, one workgroup per column
+    bool columns;
+    int32_t columns_waves, columns_min, columns_max;
 };
 
 struct rsp_csc {
@@ -420,6 +441,8 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
     pl->lean = false;
     pl->d_lean_hdr = nullptr;
     pl->d_lean_offs = nullptr;
+    pl->columns = false;
+    pl->columns_waves = pl->columns_min = pl->columns_max = 0;
     try {
         if (lean_allowed()) {
             std::vector<uint32_t> image;
@@ -446,7 +469,24 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
             const rsp::inspect::Grid grid{pl->lp.chunk_elems, pl->lp.nbody, pl->lp.tail_elems, pl->lp.nchunks};
             rsp::inspect::inspect_offsets(p_host, ncol, nnz, grid, &rec, &pl->max_skip);
             pl->snapped = pl->max_skip <= rsp::kGroupElems;
-            if (pl->snapped) {
+            if (!pl->snapped && columns_allowed() && ncol >= rsp::kColumnsMinColumns) {
+                // every column long and of similar length: one workgroup per column, nothing to upload
+                int32_t mn = INT32_MAX, mx = 0;
+                for (int32_t c = 0; c < ncol; ++c) {
+                    const int32_t len = p_host[c + 1] - p_host[c];
+                    mn = len < mn ? len : mn;
+                    mx = len > mx ? len : mx;
+                }
+                const int64_t mean = nnz / ncol;
+                if (mn >= rsp::kColumnsMinLen && mx <= rsp::kColumnsMaxLen && (int64_t)mx <= rsp::kColumnsMaxOverMean * mean) {
+                    pl->columns = true;
+                    pl->snapped = true;   // (a planned, one-launch form too)
+                    pl->columns_min = mn;
+                    pl->columns_max = mx;
+                    pl->columns_waves = columns_waves_setting(ncol, mean);
+                }
+            }
+            if (pl->snapped && !pl->columns) {
                 hipError_t e = hipMalloc((void**)&pl->d_rec, rec.size() * sizeof(int2));
                 if (e == hipSuccess) e = hipMemcpy(pl->d_rec, rec.data(), rec.size() * sizeof(int2), hipMemcpyHostToDevice);
                 if (e != hipSuccess) {
@@ -520,10 +560,10 @@ int rsp_set_lean(int on) {
 
 int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t* info4, double* inspect_ms) {
     if (!plan || !info4) return fail(RSP_ERR_BAD_ARG, "null plan or output");
-    info4[0] = plan->lean ? 2 : (plan->snapped ? 1 : 0);
-    info4[1] = plan->lean ? plan->lean_chunks : plan->lp.nchunks;
-    info4[2] = plan->lean ? plan->lean_rows * rsp::kRowElems : plan->lp.chunk_elems;
-    info4[3] = plan->lean ? plan->lean_max_columns : plan->max_skip;
+    info4[0] = plan->columns ? 3 : (plan->lean ? 2 : (plan->snapped ? 1 : 0));
+    info4[1] = plan->columns ? plan->ncol : (plan->lean ? plan->lean_chunks : plan->lp.nchunks);
+    info4[2] = plan->columns ? plan->columns_waves * 64 : (plan->lean ? plan->lean_rows * rsp::kRowElems : plan->lp.chunk_elems);
+    info4[3] = plan->columns ? plan->columns_max : (plan->lean ? plan->lean_max_columns : plan->max_skip);
     if (inspect_ms) *inspect_ms = plan->inspect_ms;
     return RSP_OK;
 }
@@ -554,6 +594,11 @@ static int planned_enqueue(rsp_colsums_plan_t plan, const double* d_x, const int
         HIP_TRY(rsp::launch_column_sums_lean(d_x, (int32_t)plan->nnz, plan->d_lean_hdr, plan->d_lean_offs,
                                              plan->lean_stride_dwords, plan->lean_chunks, plan->lean_rows, d_out, divisor,
                                              means, stream));
+        return RSP_OK;
+    }
+    if (plan->columns) {   // every column long: one workgroup per column (no records; p[] is read by the kernel)
+        if (!d_p || !d_out || !d_x) return fail(RSP_ERR_BAD_ARG, "null device pointer");
+        HIP_TRY(rsp::launch_column_sums_columns(d_x, d_p, plan->ncol, plan->columns_waves, d_out, divisor, means, stream));
         return RSP_OK;
     }
     if (!plan->snapped)   // a column longer than a group crosses a chunk edge somewhere: the general kernels

@@ -159,6 +159,14 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
                              const RowSumsLayout& L, void* persist, double* d_out,
                              double divisor, bool means, const LaunchPlan& colsums_plan, hipStream_t stream);
 
+// columns planned form (every column long and of similar length): one workgroup of `waves` (4 / 8 / 16) wavefronts per column
+constexpr int kColumnsMinLen = 2048;       // shortest column the form takes (16 rows of 128 entries)
+constexpr int kColumnsMaxLen = 1 << 22;    // longest (its bytes stay far below a buffer descriptor's 2^31)
+constexpr int kColumnsMaxOverMean = 4;     // no column longer than this many times the mean (one workgroup walks it)
+constexpr int kColumnsMinColumns = 128;
+hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t waves,
+                                      double* d_out, double divisor, bool means, hipStream_t stream);
+
 // Segments form of the row sums (rowsums.hip): behind a handle whose columns' rows ascend; no regrouped copy
 struct RowSegmentsLayout {
     int32_t shift, nblocks, nsplit;

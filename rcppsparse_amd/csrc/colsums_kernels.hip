@@ -1234,6 +1234,77 @@ hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// columns planned kernel: every column long -- one workgroup per column
+// ---------------------------------------------------------------------------
+// Inspector-executor form for matrices whose columns are ALL long and of similar length (>= kColumnsMinLen entries,
+// none above four times the mean; the reference vignette's benchmark matrix: 1000 columns of ~1e4).  Such a matrix has
+// no planned form on the chunk grid (every column crosses chunk edges by more than a group), and in the general form a
+// call of its size pays a column search per chunk and a fix-up launch for ~1000 results.  Here the plan is only the
+// inspector's KNOWLEDGE of the column lengths: workgroup c reads p[c], p[c + 1] (scalar) and its WPG wavefronts stream
+// the column's rows of 128 entries round-robin, eight rows in flight each, through a buffer descriptor that ends
+// where the column ends (what lies beyond reads as +0.0, so there is no tail code); lane sums -> fixed wave tree ->
+// the wavefronts' sums added in wavefront order by one lane.  One launch, no workspace, no plan memory.
+// Deterministic; like the general kernel on long columns, within tolerance of the reference's order, not its bits.
+template <int WPG, bool MEANS>
+__global__ __launch_bounds__(WPG * 64) void colsums_columns_kernel(const double* __restrict__ x,
+                                                                   const int32_t* __restrict__ p, int32_t ncol,
+                                                                   double* __restrict__ out, double divisor) {
+    typedef Policy<MEANS, kOpSum> P;
+    __shared__ double s_part[WPG];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = blockIdx.x;
+    const int32_t lo = p[c], hi = p[c + 1];
+    const int32_t n = hi - lo;
+    const int32_t nrows = (int32_t)(((int64_t)n + kRowElems - 1) / kRowElems);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + lo), 0, n * 8, 0x00020000);
+    double a0 = 0.0, a1 = 0.0;
+    constexpr int kInFlight = 8;
+    for (int r0 = wave; r0 < nrows; r0 += WPG * kInFlight) {
+        d2 v[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u)   // (rows past the column's end lie outside the descriptor: they read as 0)
+            v[u] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16, (r0 + u * WPG) * 1024, kLoadAux));
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            a0 += v[u].x;
+            a1 += v[u].y;
+        }
+    }
+    const double s = wave_allreduce<P>(a0 + a1);
+    if (lane == 0) s_part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_part[0];
+#pragma unroll
+        for (int w = 1; w < WPG; ++w) t += s_part[w];
+        out[c] = P::finish(t, divisor);
+    }
+}
+
+hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t waves,
+                                      double* d_out, double divisor, bool means, hipStream_t stream) {
+    if (ncol <= 0) return hipSuccess;
+#define RSP_COLUMNS(W_)                                                                                          \
+    do {                                                                                                         \
+        if (means)                                                                                               \
+            hipLaunchKernelGGL((colsums_columns_kernel<W_, true>), dim3(ncol), dim3(W_ * 64), 0, stream, d_x, d_p, \
+                               ncol, d_out, divisor);                                                            \
+        else                                                                                                     \
+            hipLaunchKernelGGL((colsums_columns_kernel<W_, false>), dim3(ncol), dim3(W_ * 64), 0, stream, d_x, d_p, \
+                               ncol, d_out, divisor);                                                            \
+    } while (0)
+    switch (waves) {
+        case 4: RSP_COLUMNS(4); break;
+        case 8: RSP_COLUMNS(8); break;
+        case 16: RSP_COLUMNS(16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RSP_COLUMNS
+    return hipGetLastError();
+}
+
 hipError_t launch_gen_row_indices(int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,
                                   uint64_t seed, hipStream_t stream) {
     if (ncol <= 0) return hipSuccess;

@@ -82,7 +82,8 @@ def dev_colsums(torch, x, p, **kw):
             plan = capi.ColumnSumsPlan(np.ascontiguousarray(p, dtype=np.int32), nnz=int(x.size))
         else:
             plan = capi.ColumnSumsPlan(pt, nnz=int(x.size))
-        PLANS_SEEN[{2: "lean", 1: "snapped", 0: "general"}[plan.form]] = PLANS_SEEN.get({2: "lean", 1: "snapped", 0: "general"}[plan.form], 0) + 1
+        form = {3: "columns", 2: "lean", 1: "snapped", 0: "general"}[plan.form]
+        PLANS_SEEN[form] = PLANS_SEEN.get(form, 0) + 1
         out = plan.column_sums(xt, pt)
         torch.cuda.synchronize()
         again = plan.column_sums(xt, pt)                    # bit-stable, and the plan is reusable
@@ -1017,8 +1018,8 @@ def test_c2_full_size_planned_against_oracle(torch_cuda):
     plan_snapped.close()
 
 
-@pytest.mark.parametrize("shape,snaps", [("short", True), ("into512", True), ("into513", False), ("long", False),
-                                          ("zipf", False)])
+@pytest.mark.parametrize("shape,snaps", [("short", True), ("into512", True), ("into513", False), ("long", True),
+                                          ("long_few", False), ("zipf", False)])
 def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_cuda, shape, snaps):
     """The inspector's decision and both outcomes of the executor.  The chunk before an edge finishes the column
     that crosses it, the chunk after gives the identity to those entries -- inside its first group, so a column
@@ -1032,8 +1033,10 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
         # this size use 1024-entry chunks) and reaches 512 / 513 entries past it
         reach = 512 if shape == "into512" else 513
         counts = np.concatenate([np.full((7 * 1024 - 40) // 8, 8), [40 + reach], np.full(50_000, 8)]).astype(np.int64)
-    elif shape == "long":
+    elif shape == "long":                               # every column long: the columns form (one workgroup per column)
         counts = np.full(300, 10_000, dtype=np.int64)
+    elif shape == "long_few":                           # ... but too few of them for it: the general kernels
+        counts = np.full(100, 10_000, dtype=np.int64)
     else:
         counts = synth.zipf_counts(20_000, 3_000_000, seed=3, nrow=1_000_000)
     p = synth.offsets_from_counts(counts)
@@ -1044,10 +1047,60 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
         assert plan.chunk_elems == 1024 and plan.max_skip == reach
     assert plan.snapped is snaps, (shape, plan.max_skip)
     assert plan.lean is (shape == "short")            # only there is every column at most 64 entries long
+    assert plan.columns is (shape == "long")
     xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
     got = plan.column_sums(xt, pt).cpu().numpy()
     plan.close()
     assert_parity(got, x, p)
+
+
+@pytest.mark.parametrize("pattern", ["uniform_1e4", "min_2048", "min_2047", "max_4x_mean", "above_4x_mean",
+                                     "128_columns", "127_columns", "odd_lengths_300k", "one_empty"])
+def test_columns_plan_edges(torch_cuda, pattern):
+    """Where the columns form (every column long: one workgroup per column, p[] read by the kernel, no records) begins
+    and ends: the shortest column 2048 entries (taken) / 2047 (not), the longest four times the mean (taken) / beyond
+    (not), 128 columns (taken) / 127 (not), an empty column (not).  Parity against the oracle on every column, also
+    through the handle, whose upload makes the same plan, and with the division of the means fused."""
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    if pattern == "uniform_1e4":
+        counts, cols = rng.poisson(10_000, 1000), True
+    elif pattern in ("min_2048", "min_2047"):
+        counts = rng.integers(3000, 6000, 400)
+        counts[123] = 2048 if pattern == "min_2048" else 2047
+        cols = pattern == "min_2048"
+    elif pattern in ("max_4x_mean", "above_4x_mean"):
+        counts = np.full(500, 5000)
+        counts[77] = 20_120 if pattern == "max_4x_mean" else 40_000         # (499 x 5000 + 20120: mean 5030, 4 x mean = 20120)
+        cols = pattern == "max_4x_mean"
+    elif pattern in ("128_columns", "127_columns"):
+        counts = rng.integers(2048, 9000, 128 if pattern == "128_columns" else 127)
+        cols = pattern == "128_columns"
+    elif pattern == "odd_lengths_300k":
+        counts, cols = rng.integers(100_001, 300_000, 160) | 1, True        # (columns start at odd offsets: 8-byte aligned only)
+    else:
+        counts = rng.integers(3000, 6000, 400)
+        counts[5] = 0
+        cols = False
+    counts = np.asarray(counts, dtype=np.int64)
+    p = synth.offsets_from_counts(counts)
+    ncol, nnz = len(counts), int(p[-1])
+    x = synth.gen_values(nnz, seed=9, kind=0)
+    plan = capi.ColumnSumsPlan(p)
+    if pattern.endswith("4x_mean"):
+        assert (int(counts.max()) <= 4 * (nnz // ncol)) is cols, (int(counts.max()), nnz // ncol)
+    assert plan.columns is cols, (pattern, plan.form)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    got = plan.column_sums(xt, pt)
+    assert_parity(got.cpu().numpy(), x, p)
+    assert torch.equal(got, plan.column_sums(xt, pt))
+    means = plan.column_sums(xt, pt, nrow_for_means=777)
+    assert means.cpu().numpy().tobytes() == (got.cpu().numpy() / 777.0).tobytes()
+    plan.close()
+    h = capi.DeviceCSC(x, p, (1_000_000, ncol))
+    hs = h.column_sums()
+    h.close()
+    assert hs.tobytes() == got.cpu().numpy().tobytes()                      # the handle's own plan is the same one
 
 
 @pytest.mark.parametrize("pattern", ["len64", "len65", "all_ones", "many_empties_then_ones", "reach_one_row",

@@ -12,6 +12,7 @@ done
 timeout -k 10 200 python3 $R/bench.py --workload c2 --steps 300 --warmup 30 --no-cpu-baseline >> $O/bench_lines.jsonl 2>> $O/bench_lines.err
 timeout -k 10 200 python3 $R/bench.py --workload c2 --steps 300 --warmup 30 --no-cpu-baseline --planned >> $O/bench_lines.jsonl 2>> $O/bench_lines.err
 timeout -k 10 200 python3 $R/bench.py --workload c2 --steps 300 --warmup 30 --no-cpu-baseline --planned --no-lean >> $O/bench_lines.jsonl 2>> $O/bench_lines.err
+timeout -k 10 200 python3 $R/bench.py --workload vignette --steps 300 --warmup 30 --no-cpu-baseline --planned >> $O/bench_lines.jsonl 2>> $O/bench_lines.err
 echo "bench lines: $(wc -l < $O/bench_lines.jsonl)"
 timeout -k 10 500 bash $R/tools/profile_gpu.sh c3 --workload c3 || echo "profile c3 failed"
 timeout -k 10 500 bash $R/tools/profile_gpu.sh c5 --workload c5 || echo "profile c5 failed"
