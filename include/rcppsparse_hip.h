@@ -167,8 +167,8 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
  * column, p[] itself is not read again), puts both into LDS and adds every column in storage order from +0.0:
  * every column then comes out BIT-IDENTICAL to the reference loop.  rsp_set_lean(0) / RSP_LEAN=0 keeps plans
  * out of that form (A/B measurements).
- * When every column is LONG and of similar length (at least 2048 entries, none above four times the mean, at
- * least 128 columns; the reference vignette's 100000 x 1000 benchmark matrix) the plan takes the COLUMNS form:
+ * When every column is LONG and of similar length (at least 2048 entries -- 512 in matrices of up to 2.5e8
+ * entries --, none above four times the mean, at least 128 columns; the reference vignette's 100000 x 1000 benchmark matrix) the plan takes the COLUMNS form:
  * nothing is recorded at all, a call is one launch of one workgroup per column that reads p[c], p[c + 1] itself
  * (no column search per chunk, no carries, no fix-up launch, no workspace); results within the usual tolerance.
  * RSP_COLUMNS_FORM=0 keeps plans out of it.

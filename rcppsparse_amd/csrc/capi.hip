@@ -478,12 +478,18 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
                     mx = len > mx ? len : mx;
                 }
                 const int64_t mean = nnz / ncol;
-                if (mn >= rsp::kColumnsMinLen && mx <= rsp::kColumnsMaxLen && (int64_t)mx <= rsp::kColumnsMaxOverMean * mean) {
+                // columns of at least 2048 entries: 4 (8, 16) wavefronts each.  Shorter ones, from 512 entries: 2
+                // wavefronts each, and only up to 2.5e8 entries -- a C3 shard (1.25e8 entries in columns of ~1000)
+                // 159 -> 149 us, C3 itself 1.238 -> 1.260 ms (the general kernel's long streams win there).
+                const bool similar = mx <= rsp::kColumnsMaxLen && (int64_t)mx <= rsp::kColumnsMaxOverMean * mean;
+                const bool long_columns = mn >= rsp::kColumnsMinLen;
+                const bool mid_columns = mn >= rsp::kColumnsMinLenTwoWaves && nnz <= rsp::kColumnsTwoWavesMaxNnz;
+                if (similar && (long_columns || mid_columns)) {
                     pl->columns = true;
                     pl->snapped = true;   // (a planned, one-launch form too)
                     pl->columns_min = mn;
                     pl->columns_max = mx;
-                    pl->columns_waves = columns_waves_setting(ncol, mean);
+                    pl->columns_waves = long_columns ? columns_waves_setting(ncol, mean) : 2;
                 }
             }
             if (pl->snapped && !pl->columns) {

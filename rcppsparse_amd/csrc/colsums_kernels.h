@@ -161,6 +161,8 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
 
 // columns planned form (every column long and of similar length): one workgroup of `waves` (4 / 8 / 16) wavefronts per column
 constexpr int kColumnsMinLen = 2048;       // shortest column the form takes (16 rows of 128 entries)
+constexpr int kColumnsMinLenTwoWaves = 512;   // ... or, with two wavefronts per column, this short in matrices of up to
+constexpr int64_t kColumnsTwoWavesMaxNnz = 250000000;   // ... this many entries
 constexpr int kColumnsMaxLen = 1 << 22;    // longest (its bytes stay far below a buffer descriptor's 2^31)
 constexpr int kColumnsMaxOverMean = 4;     // no column longer than this many times the mean (one workgroup walks it)
 constexpr int kColumnsMinColumns = 128;

@@ -1296,6 +1296,7 @@ hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int
                                ncol, d_out, divisor);                                                            \
     } while (0)
     switch (waves) {
+        case 2: RSP_COLUMNS(2); break;
         case 4: RSP_COLUMNS(4); break;
         case 8: RSP_COLUMNS(8); break;
         case 16: RSP_COLUMNS(16); break;

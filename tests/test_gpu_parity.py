@@ -1054,21 +1054,22 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
     assert_parity(got, x, p)
 
 
-@pytest.mark.parametrize("pattern", ["uniform_1e4", "min_2048", "min_2047", "max_4x_mean", "above_4x_mean",
+@pytest.mark.parametrize("pattern", ["uniform_1e4", "min_2048", "min_2047", "min_512", "min_511", "max_4x_mean", "above_4x_mean",
                                      "128_columns", "127_columns", "odd_lengths_300k", "one_empty"])
 def test_columns_plan_edges(torch_cuda, pattern):
     """Where the columns form (every column long: one workgroup per column, p[] read by the kernel, no records) begins
-    and ends: the shortest column 2048 entries (taken) / 2047 (not), the longest four times the mean (taken) / beyond
-    (not), 128 columns (taken) / 127 (not), an empty column (not).  Parity against the oracle on every column, also
+    and ends: the shortest column 2048 entries (4 wavefronts per column) / 2047 and 512 (2 per column, in matrices of
+    up to 2.5e8 entries) / 511 (not taken), the longest four times the mean (taken) / beyond (not), 128 columns
+    (taken) / 127 (not), an empty column (not).  Parity against the oracle on every column, also
     through the handle, whose upload makes the same plan, and with the division of the means fused."""
     torch = torch_cuda
     rng = np.random.default_rng(17)
     if pattern == "uniform_1e4":
         counts, cols = rng.poisson(10_000, 1000), True
-    elif pattern in ("min_2048", "min_2047"):
+    elif pattern.startswith("min_"):
         counts = rng.integers(3000, 6000, 400)
-        counts[123] = 2048 if pattern == "min_2048" else 2047
-        cols = pattern == "min_2048"
+        counts[123] = int(pattern[4:])
+        cols = pattern != "min_511"
     elif pattern in ("max_4x_mean", "above_4x_mean"):
         counts = np.full(500, 5000)
         counts[77] = 20_120 if pattern == "max_4x_mean" else 40_000         # (499 x 5000 + 20120: mean 5030, 4 x mean = 20120)
