@@ -261,3 +261,19 @@ def test_bench_child_process_planned_c2(torch_cuda):
     assert par["max_abs_err_over_l1"] == 0.0
     assert d["config"]["x_copies_rotated"] >= 5                      # every call reads from HBM, not the Infinity Cache
     assert 0.3 < d["roofline"]["frac"] < 1.0
+
+
+def test_bench_child_process_planned_vignette(torch_cuda):
+    """`bench.py --workload vignette --planned`: the shape of the reference's own benchmark (100000 x 1000, 1000 columns
+    of ~1e4 entries, Documentation.Rmd:425) through the plan's columns form -- one workgroup per column, one launch, no
+    records -- with every column of the result checked against the oracle."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--workload", "vignette", "--planned", "--steps", "50", "--warmup", "5", "--no-cpu-baseline",
+                   "--latency-calls", "3")
+    pl = d["config"]["planned"]
+    assert pl["form"] == "columns" and pl["snapped"] is True and pl["chunks"] == 1000
+    assert d["roofline"]["kernel"].startswith("colsums_columns_kernel")
+    par = d["parity"]
+    assert par["columns_checked"] == "all" and par["ncol"] == 1000 and par["columns_out_of_tolerance"] == 0
+    assert par["max_abs_err_over_l1"] <= 1e-12
+    assert 0.3 < d["roofline"]["frac"] < 1.0
