@@ -25,7 +25,7 @@ def kernel_avgs(path):
     if not os.path.exists(path):
         return None, None
     for r in csv.DictReader(open(path)):
-        if "colsums_chunks_kernel" in r["Name"] or "colsums_lean_kernel" in r["Name"]:
+        if "colsums_chunks_kernel" in r["Name"] or "colsums_lean_kernel" in r["Name"] or "colsums_columns_kernel" in r["Name"]:
             main = float(r["AverageNs"]) / 1e3
         if "colsums_fixup_kernel" in r["Name"]:
             fix = float(r["AverageNs"]) / 1e3
@@ -72,7 +72,7 @@ def main():
     for d in lines:
         tag = d["config"]["workload"].split(":")[0]
         form = (d["config"].get("planned") or {}).get("form")
-        ptag = tag + ("planned" if form in ("lean", "snapped") else "")
+        ptag = tag + ("planned" if form in ("lean", "snapped", "columns") else "")
         label = tag if form is None else f"{tag} `--planned` ({form} form)"
         if form == "snapped" and any((x["config"].get("planned") or {}).get("form") == "lean" and
                                      x["config"]["workload"].split(":")[0] == tag for x in lines):

@@ -58,7 +58,7 @@ def main():
     for (k, c), v in sorted({**fetch, **write}.items()):
         rows.append({"kernel": k, "counter": c, "launches": len(v), "mean_KiB": sum(v) / len(v),
                      "min_KiB": min(v), "max_KiB": max(v)})
-        if "colsums_chunks_kernel" in k or "colsums_lean_kernel" in k:   # (one of them per profiled command)
+        if "colsums_chunks_kernel" in k or "colsums_lean_kernel" in k or "colsums_columns_kernel" in k:   # (one of them per profiled command)
             main_kernel = k
     with open(os.path.join(dst, base + "_pmc_summary.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0]))
