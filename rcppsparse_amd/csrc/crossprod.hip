@@ -400,6 +400,9 @@ typedef double xp_v4f64 __attribute__((ext_vector_type(4)));
 #ifndef RSP_TALL_SPLIT12
 #define RSP_TALL_SPLIT12 1
 #endif
+#ifndef RSP_TALL_XCD_PAIRS
+#define RSP_TALL_XCD_PAIRS 1
+#endif
 constexpr int kTallSplit16 = RSP_TALL_SPLIT16, kTallSplit12 = RSP_TALL_SPLIT12;   // workgroups sharing a row range at 16 / 12 column tiles
 
 // workgroup barrier for LDS hand-offs only (__syncthreads() would also wait for the loads just issued for the
@@ -451,7 +454,18 @@ void crossprod_tall_kernel(
     int ti[MAXP], tj[MAXP];
     xp_v4f64 acc[MAXP];
     // this wavefront's tile pairs: q = (s * NW + wave) * SPLIT + half
-    const int group = blockIdx.x / SPLIT, half = blockIdx.x - group * SPLIT;
+    // SPLIT workgroups share a range of rows and read the same pieces of x / i.  Workgroups are dealt to the 8 XCDs
+    // round-robin, so blocks b and b + 8 meet in the same L2: in every run of 8 * SPLIT blocks, block 8 h + k is part h
+    // of the run's k-th range -- the second reader of a piece finds it in its XCD's L2 instead of fetching it again.
+    // (the last, incomplete run keeps neighbours together)
+    int group = blockIdx.x / SPLIT, half = blockIdx.x - group * SPLIT;
+    if (SPLIT > 1 && RSP_TALL_XCD_PAIRS) {
+        const int run = blockIdx.x / (8 * SPLIT), in_run = blockIdx.x - run * (8 * SPLIT);
+        if ((run + 1) * (8 * SPLIT) <= (int)gridDim.x) {
+            group = run * 8 + (in_run & 7);
+            half = in_run >> 3;
+        }
+    }
     auto pair_of = [&](int s) { return (s * NW + wave) * SPLIT + half; };
 #pragma unroll
     for (int s = 0; s < MAXP; ++s) {
