@@ -86,6 +86,10 @@ constexpr int kAccThreads = 1024;         // accumulate workgroup: 15 wavefronts
 constexpr int kAccStagers = kAccThreads - 64;
 constexpr int kAccDepth = 8;              // steps of entries a staging thread has in flight (8 x 11.5 KB per CU)
 constexpr int kAccMaxSplit = 1024;        // workgroups that may share one row block
+#ifndef RSP_DIRECT_XCD_RUNS
+#define RSP_DIRECT_XCD_RUNS 1
+#endif
+constexpr bool kDirectXcdRuns = RSP_DIRECT_XCD_RUNS != 0;   // direct form: the readers of a part run together on one XCD
 constexpr int kDirectMaxBlocks = 4;       // up to here the accumulate pass scans the caller's x / i once per block instead
 
 // ---------------------------------------------------------------------------------------------
@@ -624,7 +628,26 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     double* st_x = sums + ((size_t)1 << shift) + 64;        // 2 x kAccStagers  (64 spare slots behind the sums: where nothing-to-add goes)
     int32_t* st_r = (int32_t*)(st_x + 2 * kAccStagers);     // 2 x kAccStagers: byte offsets into sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit;
+    int b = blockIdx.x / nsplit, part = blockIdx.x - b * nsplit;
+    // Direct form with several row blocks: the workgroups (block 0..nb-1, part k) scan the SAME entries.  Dealt out
+    // block-major they would run rounds apart and each fetch its part from HBM again (4 blocks: 48 B/nnz); dealt out so
+    // that they are 8 apart in the grid they run together AND on the same XCD (workgroups go round the 8 XCDs), and the
+    // second to fourth reader of a part find it in that XCD's L2.  Runs of 8 parts x nb blocks; the last, incomplete run
+    // of the grid is dealt part-major (together, if not on one XCD).
+    if (kDirectXcdRuns && direct_nnz >= 0) {
+        const int nb = gridDim.x / nsplit;
+        if (nb > 1) {
+            const int per_run = 8 * nb, run = blockIdx.x / per_run, in_run = blockIdx.x - run * per_run;
+            if ((run + 1) * 8 <= nsplit) {
+                part = run * 8 + (in_run & 7);
+                b = in_run >> 3;
+            } else {
+                const int left = nsplit - run * 8;   // parts in the incomplete run (1..7)
+                part = run * 8 + in_run % left;
+                b = in_run / left;
+            }
+        }
+    }
     const int rows_here = 1 << shift, mask = rows_here - 1;
     for (int r = tid; r < rows_here; r += kAccThreads) sums[r] = 0.0;
     // this workgroup's part of the block: whole steps, the same for every run
