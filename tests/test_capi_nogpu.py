@@ -233,3 +233,31 @@ def test_row_reduce_workspace_arithmetic_and_argument_checks():
     assert L.rsp_add_partials_device(None, 2, 0, 0, 0, None, None) == capi.RSP_OK               # nothing to add
     assert L.rsp_mcsc_row_sums(None, None) == capi.RSP_ERR_BAD_ARG
     assert L.rsp_mcsc_column_means(None, None) == capi.RSP_ERR_BAD_ARG
+
+
+def test_row_restricted_form_selection_is_host_logic():
+    """rsp_column_sums_in_rows_form: which form a call takes follows from its sizes and workspace alone (the slice-major
+    form's device-side guard aside) -- no device needed.  Bitmap <= 16 KB: L1; <= 128 KB: LDS; above: slices when the
+    columns are long enough, there are enough of them, a column group outweighs its bitmap copies and the workspace has
+    room for the guard's flag; L2 otherwise."""
+    capi.load()
+    big = dict(nrow=10_000_000, ncol=1_000_000, nnz=1_000_000_000)
+    assert capi.in_rows_form(131_072, 10, 100) == "L1" and capi.in_rows_form(131_073, 10, 100) == "LDS"
+    assert capi.in_rows_form(1_048_576, 10, 100) == "LDS" and capi.in_rows_form(1_048_577, 10, 100) == "L2"
+    assert capi.in_rows_form(**big) == "slices"
+    assert capi.in_rows_form(**big, workspace_bytes=capi.workspace_bytes(big["ncol"], big["nnz"])) == "L2"
+    assert capi.in_rows_form(**big, workspace_bytes=capi.in_rows_workspace_bytes(**big) - 1) == "L2"
+    assert capi.in_rows_form(10_000_000, 4_000_000, 1_000_000_000) == "L2"      # 25 entries per column and slice
+    assert capi.in_rows_form(30_000_000, 1_000_000, 1_000_000_000) == "slices"   # 34
+    assert capi.in_rows_form(10_000_000, 16_383, 1_000_000_000) == "L2"         # one column too few
+    assert capi.in_rows_form(10_000_000, 16_384, 1_000_000_000) == "slices"
+    assert capi.in_rows_form(2**31 - 1, 16_384, 2**31 - 1) == "L2"              # 2048 bitmap copies per 64 columns
+    capi.set_row_slices(0)
+    try:
+        assert capi.in_rows_form(**big) == "L2"
+        capi.set_row_slices(2)
+        assert capi.in_rows_form(1_048_577, 3, 100) == "slices" and capi.in_rows_form(1_048_576, 3, 100) == "LDS"
+    finally:
+        capi.set_row_slices(1)
+    with pytest.raises(ValueError):
+        capi.in_rows_form(-1, 1, 1)
