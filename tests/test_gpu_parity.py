@@ -732,6 +732,36 @@ def test_device_entry_is_graph_capture_safe(torch_cuda):
     assert torch.equal(out, eager * 2.0)
 
 
+@pytest.mark.parametrize("form", ["lean", "snapped", "columns"])
+def test_planned_entry_is_graph_capture_safe(torch_cuda, form):
+    """rsp_column_sums_planned_device is one kernel launch in every planned form (no allocation, no synchronisation, no
+    workspace): capturable into a HIP graph; a replay reproduces the bits, also with new values in the same buffers."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4)
+    counts = {"lean": rng.integers(0, 30, 40_000), "snapped": rng.integers(70, 200, 6_000),
+              "columns": rng.integers(3_000, 9_000, 200)}[form].astype(np.int64)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=6, kind=0)
+    plan = capi.ColumnSumsPlan(p)
+    assert {2: "lean", 1: "snapped", 3: "columns"}[plan.form] == form
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.zeros(len(counts), dtype=torch.float64, device="cuda")
+    eager = plan.column_sums(xt, pt, out.clone()).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.column_sums(xt, pt, out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    xt.mul_(2.0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager * 2.0)
+    plan.close()
+
+
 def test_handles_do_not_leak_device_memory(torch_cuda):
     torch = torch_cuda
     m = synth.rsparsematrix(20_000, 3_000, density=0.01, seed=3)
