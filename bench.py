@@ -117,6 +117,15 @@ def parse_args(argv=None):
                     help="--rendezvous gloo only: also take the C-ABI communicator through its multi-rank "
                          "bootstrap (unique id from rank 0, rsp_comm_init on every rank).  With ranks sharing a "
                          "device RCCL must refuse it; the refusal is recorded in config.comm_init_rehearsal")
+    ap.add_argument("--also", default="auto",
+                    help="N = 1: more single-GPU workloads measured after the headline one, OUTSIDE its timed region, "
+                         "as compact sub-records under the key `also` (never part of `value`).  auto = every other "
+                         "single-GPU BASELINE configuration and its planned form when the headline workload is c3 "
+                         "(c2, c2:planned, c5, c4shard, c4shard:planned, vignette:planned), nothing otherwise; or a "
+                         "comma-separated list of workload[:planned]")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` records (profiling runs)")
+    ap.add_argument("--ceiling-reps", type=int, default=5,
+                    help="launches of the read-only kernel timed for roofline.read_ceiling (0 = skip)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: still create the RCCL communicator and run the gatherv in every "
                          "call (rehearsal of the N>1 code path on a 1-GPU box)")
@@ -267,6 +276,97 @@ def traffic_from_profiles(workload):
         except Exception:
             pass
     return best, src
+
+
+ALSO_AUTO = ("c2", "c2:planned", "c5", "c4shard", "c4shard:planned", "vignette:planned")
+PLAN_FORMS = {3: "columns", 2: "lean", 1: "snapped", 0: "general kernels"}
+
+
+def read_ceiling(capi, x_t, reps):
+    """roofline.read_ceiling: a hand-written read-only kernel with the access shape of the column-sum kernel
+    (same chunk grid, same 1 KiB nt loads, same register pipeline; no p[], no stores) over the SAME x on the
+    SAME device in the SAME run -- the practical ceiling SURVEY.md 8(d) asks for beside the spec peak."""
+    ms = capi.read_ceiling_device(x_t, reps=reps)
+    nbytes = 8 * x_t.numel()
+    return {"GBps": nbytes / (ms * 1e-3) / 1e9, "ms_per_launch": ms, "reps": reps, "bytes_per_launch": nbytes,
+            "of_spec_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "kernel": "read_ceiling_kernel (rsp_debug_read_ceiling_device): the chunk grid, buffer descriptors, "
+                      "nt loads and register pipeline of colsums_chunks_kernel without any column work",
+            "timing": f"one untimed launch, then {reps} launches between two HIP events on the launch stream"}
+
+
+def also_record(torch, capi, spec, args, dev, dev_index, stream):
+    """One more single-GPU workload, measured like the headline one (inputs resident in HBM, rotated copies of x
+    where the workload would fit the Infinity Cache, K calls back to back on one stream, HIP events on that
+    stream, every column against the oracle) and reported as a compact record."""
+    name, _, mode = spec.partition(":")
+    planned = mode == "planned"
+    nrow, ncol, nnz, shape, p = build_offsets(name, 0)
+    small = nnz < 200_000_000
+    steps = args.steps * 10 if small else args.steps      # a 20 us call wants more than 20 of them in the region
+    ncopies = max(1, -(-400_000_000 // max(1, 8 * nnz)))
+    xs = []
+    for k in range(ncopies):
+        xk = torch.empty(nnz, dtype=torch.float64, device=dev)
+        capi.gen_values_device(xk, SEED + k, 0, args.kind)
+        xs.append(xk)
+    pt = torch.from_numpy(p).to(dev)
+    out = torch.empty(ncol, dtype=torch.float64, device=dev)
+    ws = capi.alloc_workspace(ncol, nnz, dev)
+    plan = capi.ColumnSumsPlan(p, nnz=nnz, device=dev_index) if planned else None
+    launches = [(plan.prepared(xk, pt, out, ws, stream=stream) if plan is not None else
+                 capi.prepared_column_sums(xk, pt, out, ws, stream=stream)) for xk in xs]
+    for k in range(max(args.warmup, ncopies)):
+        launches[k % ncopies]()
+    mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    torch.cuda.synchronize()
+    if small:      # one event pair around the region (an event pair per call would idle the queue)
+        e0, e1 = mk(), mk()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for k in range(steps):
+            launches[k % ncopies]()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kernel_ms = e0.elapsed_time(e1) / steps
+    else:          # an event pair around the kernels of every call
+        evs = [(mk(), mk()) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            evs[k][0].record(stream)
+            launches[k % ncopies]()
+            evs[k][1].record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+    launches[0]()          # copy 0 (seed SEED) for the parity check
+    torch.cuda.synchronize()
+    par = parity_whole_matrix(out.cpu().numpy(), p, args.kind)
+    if par["columns_out_of_tolerance"] or not par["empty_columns_exactly_plus_zero"]:
+        raise SystemExit(f"parity check failed on also:{spec}: {json.dumps(par)}")
+    algo = 8 * nnz + 4 * (ncol + 1) + 8 * ncol
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    one_launch = plan is not None and plan.snapped
+    traffic = traffic_from_profiles(name + ("planned" if one_launch else ""))
+    rec = {"workload": spec, "shape": f"{nrow}x{ncol}, nnz={nnz}, {shape}",
+           "form": "general kernels" if plan is None else PLAN_FORMS[plan.form],
+           "launches_per_call": 1 if one_launch else 2,
+           "plan_ms": None if plan is None else plan.inspect_ms,
+           "steps": steps, "x_copies_rotated": ncopies,
+           "ms_per_call": wall / steps * 1e3, "kernel_ms": kernel_ms,
+           "nnz_per_s": nnz * steps / wall,
+           "algorithmic_bytes_per_launch": algo, "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBPS,
+           "traffic": traffic[0], "traffic_source": traffic[1],
+           "parity": {"max_abs_err_over_l1": par["max_abs_err_over_l1"],
+                      "columns_out_of_tolerance": par["columns_out_of_tolerance"],
+                      "columns_checked": "all", "ncol": ncol,
+                      "empty_columns_exactly_plus_zero": par["empty_columns_exactly_plus_zero"]}}
+    if plan is not None:
+        plan.close()
+    del xs, launches, out, ws, pt
+    torch.cuda.empty_cache()
+    return rec
 
 
 def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev, shard, counts, displs,
@@ -597,7 +697,7 @@ def main(argv=None):
                 "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
                 "chunk_rows": args.chunk_rows,
                 "planned": (None if plan is None else
-                            {"form": {3: "columns", 2: "lean", 1: "snapped", 0: "general kernels"}[plan.form],
+                            {"form": PLAN_FORMS[plan.form],
                              "snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
                              "entries_per_chunk": plan.chunk_elems, "max_skip": plan.max_skip,
                              "note": "inspection of p[] on the host, once, outside every timed region; a snapped "
@@ -637,6 +737,25 @@ def main(argv=None):
             },
             "parity": parity,
         }
+        if world == 1 and args.ceiling_reps > 0:
+            # the same x (copy 0), the same device, the same run; after every timed region
+            rc = read_ceiling(capi, xs[0], args.ceiling_reps)
+            rc["frac_of_ceiling"] = achieved / rc["GBps"]
+            rc["note"] = ("frac_of_ceiling = roofline.achieved (algorithmic bytes: x, p and the sums) / the GB/s of "
+                          "the read-only kernel (x alone)")
+            result["roofline"]["read_ceiling"] = rc
+        if world == 1 and not args.no_also:
+            specs = (ALSO_AUTO if args.workload == "c3" and not args.planned else ()) if args.also == "auto" else \
+                tuple(t for t in args.also.split(",") if t)
+            if specs:
+                t_also = time.perf_counter()
+                recs = [also_record(torch, capi, spec, args, dev, dev_index, s_main) for spec in specs]
+                result["also"] = {"records": recs, "seconds": time.perf_counter() - t_also,
+                                  "note": "more single-GPU workloads measured after the headline one, outside its "
+                                          "timed region, by the same protocol; never part of `value`"}
+                # (the driver's record keeps `roofline` whole and only the NAMES of other extra keys: the same
+                # records travel there as well)
+                result["roofline"]["also"] = recs
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(p, args.kind)
         elif world == 1:

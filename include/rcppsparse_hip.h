@@ -251,6 +251,18 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
                                  void *d_workspace, size_t workspace_bytes,
                                  void *stream, int reps, float *ms_per_call);
 
+/*
+ * Measurement helper ("also record a measured read-only bandwidth on the box as the
+ * practical ceiling"): a kernel with the ACCESS SHAPE of rsp_column_sums_device over the same x -- the same
+ * chunk grid, one wavefront per chunk, the same 1 KiB nt loads in the same register pipeline, two adds per
+ * lane and row -- and none of its column work: p[] is not read, nothing is stored (d_sink: one double, only
+ * there so that the loads cannot be optimised away).  The reference reads x once (RcppSparse.h:226); this is
+ * how fast this device lets that be done.  One untimed launch, then `reps` launches between two HIP events
+ * on `stream`; returns the mean milliseconds per launch (8 * nnz bytes each).  Synchronises `stream`.
+ */
+int rsp_debug_read_ceiling_device(const double *d_x, int64_t nnz, double *d_sink, void *stream,
+                                  int reps, float *ms_per_launch);
+
 /* ---- row-wise "next" entries: Matrix::rowSums / rowMeans ----------------- */
 /*
  * Reference RcppSparse.h:138-144 / :151-156: sums[i[j]] += x[j] over all stored

@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = (
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
     "rsp_comm_reduce_rows_workspace_bytes", "rsp_comm_reduce_rows", "rsp_add_partials_device",
     "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe", "rsp_set_crossprod_exact",
-    "rsp_set_experiment",
+    "rsp_set_experiment", "rsp_debug_read_ceiling_device",
 )
 
 
@@ -150,6 +150,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_set_taper.argtypes = [c.c_int, c.c_int]
     L.rsp_set_crossprod_exact.argtypes = [c.c_int]
     L.rsp_plan_describe.argtypes = [i64, ip]
+    L.rsp_debug_read_ceiling_device.argtypes = [vp, i64, vp, vp, c.c_int, c.POINTER(c.c_float)]
     _lib = L
     return L
 
@@ -593,6 +594,17 @@ def column_sums_device_timed(x_t, p_t, out_t, workspace, reps: int, stream=None)
                                                out_t.data_ptr(), workspace.data_ptr(),
                                                workspace.numel(), _stream_ptr(stream), int(reps),
                                                ctypes.byref(ms)))
+    return float(ms.value)
+
+
+def read_ceiling_device(x_t, reps: int = 5, stream=None) -> float:
+    """Mean ms per launch of the read-only kernel with the column sums' access shape over x_t
+    (rsp_debug_read_ceiling_device): the practical ceiling of this device for this stream."""
+    import torch
+    sink = torch.zeros(1, dtype=torch.float64, device=x_t.device)
+    ms = ctypes.c_float(0)
+    _check(load().rsp_debug_read_ceiling_device(x_t.data_ptr(), x_t.numel(), sink.data_ptr(), _stream_ptr(stream),
+                                                int(reps), ctypes.byref(ms)))
     return float(ms.value)
 
 

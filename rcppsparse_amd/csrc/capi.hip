@@ -717,6 +717,31 @@ int rsp_column_sums_device_timed(const double* d_x, const int32_t* d_p, int32_t 
     return RSP_OK;
 }
 
+int rsp_debug_read_ceiling_device(const double* d_x, int64_t nnz, double* d_sink, void* stream, int reps,
+                                  float* ms_per_launch) {
+    if (int rc = check_sizes(0, nnz)) return rc;
+    if (reps <= 0 || !ms_per_launch) return fail(RSP_ERR_BAD_ARG, "reps <= 0 or null result");
+    if (!d_sink || (nnz > 0 && !d_x)) return fail(RSP_ERR_BAD_ARG, "null device pointer");
+    if (((uintptr_t)d_x & 15) != 0) return fail(RSP_ERR_BAD_ARG, "d_x must be 16-byte aligned");
+    const rsp::LaunchPlan plan = make_plan(nnz);   // the chunk grid rsp_column_sums_device would use
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipError_t he = rsp::launch_read_ceiling(d_x, (int32_t)nnz, plan, d_sink, s);   // one untimed launch first
+    if (he == hipSuccess) he = hipEventRecord(e0, s);
+    for (int r = 0; r < reps && he == hipSuccess; ++r) he = rsp::launch_read_ceiling(d_x, (int32_t)nnz, plan, d_sink, s);
+    if (he == hipSuccess) he = hipEventRecord(e1, s);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return fail(RSP_ERR_HIP, "read ceiling failed: %s", hipGetErrorString(he));
+    *ms_per_launch = ms / (float)reps;
+    return RSP_OK;
+}
+
 int rsp_gen_values_device(double* d_x, int64_t n, uint64_t seed, uint64_t first_idx, int kind,
                           void* stream) {
     if (n < 0 || (n > 0 && !d_x)) return fail(RSP_ERR_BAD_ARG, "bad buffer");

@@ -98,6 +98,10 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               int32_t bitmap_words = 0, const int2* plan_rec = nullptr,
                               const int32_t* run_if = nullptr);
 
+// the main kernel's access shape without any column work (rsp_debug_read_ceiling_device)
+hipError_t launch_read_ceiling(const double* d_x, int32_t nnz, const LaunchPlan& plan, double* d_sink,
+                               hipStream_t stream);
+
 // Row-restricted sums over more than 2^20 rows, slice-major form (colsums_rowslices.hip): a workgroup keeps ONE
 // slice of 2^20 rows of the bitmap in LDS and walks its group of columns slice by slice.
 constexpr int kSliceRowsShift = 20;        // rows per slice: 128 KB of bitmap

@@ -911,6 +911,59 @@ __global__ __launch_bounds__(256) void colsums_fixup_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// read-only ceiling (measurement helper behind rsp_debug_read_ceiling_device)
+// ---------------------------------------------------------------------------
+// What the memory system delivers to the main kernel's ACCESS SHAPE with all column work taken away: the same
+// chunk grid (ChunkMap, one wavefront per chunk, 4 wavefronts per workgroup), the same buffer descriptor per
+// chunk, the same 1 KiB `nt` loads in the same rolling register pipeline, two adds per lane and row -- no p[],
+// no column ends, no result stores.  bench.py times it over the same x in the same run: the practical ceiling
+// SURVEY.md 8(d) asks for next to the 8 TB/s spec peak.
+template <int BATCH_ROWS>
+__global__ __launch_bounds__(kWavesPerWG * 64) void read_ceiling_kernel(const double* __restrict__ x, int32_t nnz,
+                                                                        ChunkMap cmap, int32_t nchunks,
+                                                                        double* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * kWavesPerWG + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w >= nchunks) return;
+    const int32_t cs = (int32_t)cmap.start(w);
+    const int64_t ce64 = (int64_t)cs + cmap.elems(w);
+    const int32_t ce = ce64 < (int64_t)nnz ? (int32_t)ce64 : nnz;
+    const int32_t nrows = (int32_t)(((int64_t)ce - cs + 127) >> 7);
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(x + cs), 0, (int)((uint32_t)(ce - cs) * 8u), 0x00020000);
+    const int voff = lane * 16;
+    d2 v[BATCH_ROWS];
+#pragma unroll
+    for (int r = 0; r < BATCH_ROWS; ++r)
+        v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, r * 1024, kLoadAux));
+    double a0 = 0.0, a1 = 0.0;
+    for (int b = 0; b < nrows; b += BATCH_ROWS) {
+#pragma unroll
+        for (int r = 0; r < BATCH_ROWS; ++r) {
+            a0 += v[r].x;
+            a1 += v[r].y;
+            v[r] = __builtin_bit_cast(
+                d2, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (b + r + BATCH_ROWS) * 1024, kLoadAux));
+        }
+    }
+    // keeps the loads alive; a lane whose sum is exactly this value (it will not be) stores it
+    if (a0 + a1 == -0x1.23456789abcdep+1000) sink[0] = a0 + a1;
+}
+
+hipError_t launch_read_ceiling(const double* d_x, int32_t nnz, const LaunchPlan& plan, double* d_sink,
+                               hipStream_t stream) {
+    if (nnz <= 0) return hipSuccess;
+    const ChunkMap cmap{plan.chunk_elems, plan.nbody, plan.tail_elems};
+    const dim3 grid((plan.nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
+    if (plan.short_pipeline)
+        hipLaunchKernelGGL((read_ceiling_kernel<4>), grid, block, 0, stream, d_x, nnz, cmap, plan.nchunks, d_sink);
+    else
+        hipLaunchKernelGGL((read_ceiling_kernel<kBatchRows>), grid, block, 0, stream, d_x, nnz, cmap, plan.nchunks,
+                           d_sink);
+    return hipGetLastError();
+}
+
 // nnz == 0: every column is empty (0 for sums, -inf / +inf for max / min)
 __global__ void colsums_fill_kernel(double* __restrict__ out, int32_t ncol, double value) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

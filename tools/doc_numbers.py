@@ -54,9 +54,15 @@ def row_of(d, label, m=None, f=None, tr=None):
     pipe = d.get("pipelined") or {}
     gather = f" (+ gatherv {r['gather_ms'] * 1e3:.1f} us)" if r.get("gather_ms") else ""
     prof = "-" if m is None else (f"{m:.1f} + {f:.1f}" if f is not None else f"{m:.1f} (one launch)")
+    # (the driver's record keeps the contract keys, `config`, `roofline` and `cpu_baseline` of the line; the rest only by name)
+    lat = f"{d['latency_ms_per_call']:.4f}" if "latency_ms_per_call" in d else "-"
+    ovl = f"{pipe['ms_per_step']:.4f}" if "ms_per_step" in pipe else "-"
+    par = f"{d['parity']['max_abs_err_over_l1']:.1e}" if "parity" in d else "checked in the run (exit 0)"
+    if tr is None and r.get("traffic"):
+        tr = r["traffic"] / r["algorithmic_bytes_per_launch"]
     return (f"| {label} | {d['ms_per_step']:.4f} | {r['kernel_ms']:.4f}{gather} | {d['value']:.3e} | {r['achieved']:.0f} | "
-            f"{100 * r['frac']:.1f} % | {d['latency_ms_per_call']:.4f} | {pipe.get('ms_per_step', float('nan')):.4f} | "
-            f"{prof} | {'-' if tr is None else f'{tr:.3f}'} | {d['parity']['max_abs_err_over_l1']:.1e} |")
+            f"{100 * r['frac']:.1f} % | {lat} | {ovl} | "
+            f"{prof} | {'-' if tr is None else f'{tr:.3f}'} | {par} |")
 
 
 def main():
