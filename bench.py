@@ -52,6 +52,9 @@ sys.path.insert(0, ROOT)
 # "hipIpcGetMemHandle: invalid argument".  It has to be in the environment before the HIP runtime
 # starts, i.e. before torch is imported.  An explicit setting wins.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Nothing this file measures may come from the Rcpp layer's host loop (columnsums_impl.hpp answers on the CPU when
+# a machine has no GPU): a GPU is required in this process and in every child it starts.
+os.environ["RCPPSPARSE_REQUIRE_GPU"] = "1"
 
 HBM_PEAK_GBPS = 8000.0     # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 SEED = 42

@@ -105,6 +105,13 @@ int rsp_mcsc_upload_csc(const double *x, const int32_t *i, const int32_t *p, int
                         rsp_mcsc_t *handle);
 int rsp_mcsc_row_sums(rsp_mcsc_t handle, double *sums);
 int rsp_mcsc_row_means(rsp_mcsc_t handle, double *means);
+/* Dim[0], Dim[1] and the number of shards, from the handle itself (any output may be NULL). */
+int rsp_mcsc_dims(rsp_mcsc_t handle, int32_t *nrow, int32_t *ncol, int32_t *nshards);
+/* info4 = { first column, one past the last column, column-sum form (rsp_csc_column_form), entries } of a shard */
+int rsp_mcsc_shard_info(rsp_mcsc_t handle, int32_t shard, int32_t *info4);
+/* Memory and threads: the row-wise entries take nshards * nrow doubles of HOST memory for the duration of a
+ * call (8 shards x 1e7 rows: 640 MB; nothing is kept between calls).  Calls on one handle must not overlap
+ * (as for rsp_csc_t); different handles may be used from different threads. */
 int rsp_mcsc_free(rsp_mcsc_t handle);
 
 /* ---- device-resident dgCMatrix handle (upload once, sum many) ---------- */
@@ -123,6 +130,15 @@ int rsp_csc_upload(const double *x, const int32_t *i, const int32_t *p,
 int rsp_csc_column_sums(rsp_csc_t handle, double *sums);
 /* Matrix::colMeans (RcppSparse.h:145-150): column sums divided by Dim[0]. */
 int rsp_csc_column_means(rsp_csc_t handle, double *means);
+/* Dim[0], Dim[1], length(x) of the resident copy (any output may be NULL). */
+int rsp_csc_dims(rsp_csc_t handle, int32_t *nrow, int32_t *ncol, int64_t *nnz);
+/* The upload inspects p[] once (beside the copies) and freezes the result in the handle: which form the
+ * handle's column sums take -- 0 general kernels, 1 snapped, 2 lean, 3 columns (rsp_column_sums_plan_info).
+ * The settings in force AT UPLOAD decide (rsp_set_lean / RSP_LEAN, RSP_COLUMNS_FORM, the chunking knobs);
+ * changing them later does not touch existing handles.  rsp_csc_set_planned(h, 0) sends the handle's
+ * column sums through the general kernels whatever the plan says (A/B measurements), 1 switches back. */
+int rsp_csc_column_form(rsp_csc_t handle);
+int rsp_csc_set_planned(rsp_csc_t handle, int on);
 int rsp_csc_free(rsp_csc_t handle);
 
 /* ---- device-pointer path (inputs already in HBM) ----------------------- */
@@ -185,8 +201,12 @@ int rsp_column_sums_plan_create(const int32_t *p, int32_t ncol, int64_t nnz, int
 int rsp_column_sums_plan_create_device(const int32_t *d_p, int32_t ncol, int64_t nnz,
                                        void *stream, rsp_colsums_plan_t *plan);
 int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t *info4, double *inspect_ms);
+/* ncol, nnz: the sizes of the matrix behind d_x / d_p; they must be the plan's (RSP_ERR_BAD_ARG otherwise:
+ * the lean form never reads d_p and would run over a shorter x).  The offsets themselves are the caller's
+ * word: a plan belongs to the p[] it was made from. */
 int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double *d_x,
-                                   const int32_t *d_p, int32_t nrow_for_means, double *d_sums,
+                                   const int32_t *d_p, int32_t ncol, int64_t nnz,
+                                   int32_t nrow_for_means, double *d_sums,
                                    void *d_workspace, size_t workspace_bytes, void *stream);
 int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan);
 int rsp_set_lean(int on);

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "rsp_comm_reduce_rows_workspace_bytes", "rsp_comm_reduce_rows", "rsp_add_partials_device",
     "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe", "rsp_set_crossprod_exact",
     "rsp_set_experiment", "rsp_debug_read_ceiling_device",
+    "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
 )
 
 
@@ -114,7 +115,12 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_plan_create.argtypes = [ip, i32, i64, c.c_int, c.POINTER(vp)]
     L.rsp_column_sums_plan_create_device.argtypes = [vp, i32, i64, vp, c.POINTER(vp)]
     L.rsp_column_sums_plan_info.argtypes = [vp, ip, c.POINTER(c.c_double)]
-    L.rsp_column_sums_planned_device.argtypes = [vp, vp, vp, i32, vp, vp, c.c_size_t, vp]
+    L.rsp_column_sums_planned_device.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, c.c_size_t, vp]
+    L.rsp_csc_dims.argtypes = [vp, ip, ip, c.POINTER(i64)]
+    L.rsp_csc_column_form.argtypes = [vp]
+    L.rsp_csc_set_planned.argtypes = [vp, c.c_int]
+    L.rsp_mcsc_dims.argtypes = [vp, ip, ip, ip]
+    L.rsp_mcsc_shard_info.argtypes = [vp, i32, ip]
     L.rsp_column_sums_plan_destroy.argtypes = [vp]
     L.rsp_set_lean.argtypes = [c.c_int]
     L.rsp_set_row_slices.argtypes = [c.c_int]
@@ -277,6 +283,18 @@ class MultiDeviceCSC:
     def row_means(self) -> np.ndarray:
         return self._out(load().rsp_mcsc_row_means, self.nrow)
 
+    def dims(self):
+        """(nrow, ncol, shards) as the native handle knows them (rsp_mcsc_dims)."""
+        a, b, g = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(load().rsp_mcsc_dims(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(g)))
+        return a.value, b.value, g.value
+
+    def shard_info(self, k: int) -> dict:
+        """Column range, column-sum form and entries of shard k (rsp_mcsc_shard_info)."""
+        out = np.zeros(4, dtype=np.int32)
+        _check(load().rsp_mcsc_shard_info(self._h, int(k), _ip(out)))
+        return {"c0": int(out[0]), "c1": int(out[1]), "form": DeviceCSC.COLUMN_FORMS[int(out[2])], "nnz": int(out[3])}
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             load().rsp_mcsc_free(self._h)
@@ -327,6 +345,21 @@ class DeviceCSC:
         out = np.empty(self.nrow, dtype=np.float64)
         _check(load().rsp_csc_row_means(self._h, _dp(out)))
         return out
+
+    COLUMN_FORMS = ("general kernels", "snapped", "lean", "columns")
+
+    def column_form(self) -> str:
+        """Which form this handle's column sums take (rsp_csc_column_form): decided at upload."""
+        return self.COLUMN_FORMS[int(load().rsp_csc_column_form(self._h))]
+
+    def set_planned(self, on: bool) -> None:
+        """False: the general kernels whatever the upload's plan says (rsp_csc_set_planned; A/B)."""
+        _check(load().rsp_csc_set_planned(self._h, int(bool(on))))
+
+    def dims(self):
+        nr, nc, nz = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+        _check(load().rsp_csc_dims(self._h, ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(nz)))
+        return nr.value, nc.value, nz.value
 
     ROW_FORMS = ("none", "direct", "partition", "two-level", "segments")
 
@@ -555,7 +588,7 @@ class ColumnSumsPlan:
         if workspace is None and not self.snapped:
             workspace = alloc_workspace(self.ncol, self.nnz, x_t.device)
         _check(load().rsp_column_sums_planned_device(
-            self._h, x_t.data_ptr(), p_t.data_ptr(), int(nrow_for_means), out_t.data_ptr(),
+            self._h, x_t.data_ptr(), p_t.data_ptr(), self.ncol, self.nnz, int(nrow_for_means), out_t.data_ptr(),
             workspace.data_ptr() if workspace is not None else None,
             workspace.numel() if workspace is not None else 0, _stream_ptr(stream)))
         return out_t
@@ -563,7 +596,8 @@ class ColumnSumsPlan:
     def prepared(self, x_t, p_t, out_t, workspace=None, stream=None):
         """Pre-bound launcher for hot loops (bench): one foreign call per launch."""
         fn = load().rsp_column_sums_planned_device
-        args = (self._h, ctypes.c_void_p(x_t.data_ptr()), ctypes.c_void_p(p_t.data_ptr()), ctypes.c_int32(0),
+        args = (self._h, ctypes.c_void_p(x_t.data_ptr()), ctypes.c_void_p(p_t.data_ptr()),
+                ctypes.c_int32(p_t.numel() - 1), ctypes.c_int64(x_t.numel()), ctypes.c_int32(0),
                 ctypes.c_void_p(out_t.data_ptr()),
                 ctypes.c_void_p(workspace.data_ptr() if workspace is not None else None),
                 ctypes.c_size_t(workspace.numel() if workspace is not None else 0), _stream_ptr(stream))

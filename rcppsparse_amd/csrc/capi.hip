@@ -349,6 +349,7 @@ struct rsp_csc {
     bool rows_checked;       // the upload has looked at i[]: rows_unsorted says whether some column's rows do not ascend
     int32_t rows_unsorted;
     bool row_ready;
+    bool plan_bypass;        // rsp_csc_set_planned(h, 0): the general kernels also where the upload's plan applies (A/B)
 };
 
 extern "C" {
@@ -428,6 +429,18 @@ int rsp_column_means_device(const double* d_x, const int32_t* d_p, int32_t nrow,
                    (hipStream_t)stream);
 }
 
+// A plan's image goes to the device over a non-blocking stream of its own: a copy on the legacy null stream would
+// wait for -- and hold up -- every blocking stream of the process (a host program's, torch's) for the upload.
+static hipError_t upload_plan_image(void* dst, const void* src, size_t bytes) {
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    const hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    return e != hipSuccess ? e : e2;
+}
+
 // ---- inspector-executor: plan once (p[] seen by the host), then one launch per call -------------------
 static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int device, rsp_colsums_plan** out) {
     *out = nullptr;
@@ -454,7 +467,7 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
                                            &pl->lean_stride_dwords, &pl->lean_max_columns)) {
                 // headers and offsets in ONE device allocation and ONE copy
                 hipError_t e = hipMalloc((void**)&pl->d_lean_hdr, image.size() * 4);
-                if (e == hipSuccess) e = hipMemcpy(pl->d_lean_hdr, image.data(), image.size() * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = upload_plan_image(pl->d_lean_hdr, image.data(), image.size() * 4);
                 if (e != hipSuccess) {
                     rsp_column_sums_plan_destroy(pl);
                     return fail(RSP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
@@ -496,7 +509,7 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
             }
             if (pl->snapped && !pl->columns) {
                 hipError_t e = hipMalloc((void**)&pl->d_rec, rec.size() * sizeof(int2));
-                if (e == hipSuccess) e = hipMemcpy(pl->d_rec, rec.data(), rec.size() * sizeof(int2), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = upload_plan_image(pl->d_rec, rec.data(), rec.size() * sizeof(int2));
                 if (e != hipSuccess) {
                     rsp_column_sums_plan_destroy(pl);
                     return fail(RSP_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
@@ -619,9 +632,14 @@ static int planned_enqueue(rsp_colsums_plan_t plan, const double* d_x, const int
 }
 
 int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double* d_x, const int32_t* d_p,
-                                   int32_t nrow_for_means, double* d_sums, void* d_workspace,
-                                   size_t workspace_bytes, void* stream) {
+                                   int32_t ncol, int64_t nnz, int32_t nrow_for_means, double* d_sums,
+                                   void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!plan || nrow_for_means < 0) return fail(RSP_ERR_BAD_ARG, "null plan or negative nrow_for_means");
+    // a plan belongs to the matrix it was made from: the lean form never reads d_p and trusts the plan's sizes,
+    // so a matrix of another shape must not get as far as a launch
+    if (ncol != plan->ncol || nnz != plan->nnz)
+        return fail(RSP_ERR_BAD_ARG, "this plan was made for ncol = %d, nnz = %lld; the call passes ncol = %d, nnz = %lld",
+                    plan->ncol, (long long)plan->nnz, ncol, (long long)nnz);
     return planned_enqueue(plan, d_x, d_p, d_sums, d_workspace, workspace_bytes,
                            nrow_for_means > 0 ? (double)nrow_for_means : 1.0, nrow_for_means > 0,
                            (hipStream_t)stream);
@@ -862,7 +880,7 @@ static int csc_run(rsp_csc_t h, double* host_out, bool means) {
     DeviceGuard on(h->device);
     HIP_TRY(on.error());
     if (h->ncol == 0) return RSP_OK;
-    if (h->plan && h->plan->snapped) {
+    if (h->plan && h->plan->snapped && !h->plan_bypass) {
         if (int rc = planned_enqueue(h->plan, h->d_x, h->d_p, h->d_out, h->d_ws, h->ws_bytes,
                                      means ? (double)h->nrow : 1.0, means, h->stream))
             return rc;
@@ -875,6 +893,26 @@ static int csc_run(rsp_csc_t h, double* host_out, bool means) {
 }
 
 int rsp_csc_column_sums(rsp_csc_t h, double* sums) { return csc_run(h, sums, false); }
+
+int rsp_csc_dims(rsp_csc_t h, int32_t* nrow, int32_t* ncol, int64_t* nnz) {
+    if (!h) return fail(RSP_ERR_BAD_ARG, "null handle");
+    if (nrow) *nrow = h->nrow;
+    if (ncol) *ncol = h->ncol;
+    if (nnz) *nnz = h->nnz;
+    return RSP_OK;
+}
+
+int rsp_csc_column_form(rsp_csc_t h) {
+    if (!h) return -1;
+    if (!h->plan || !h->plan->snapped || h->plan_bypass) return 0;
+    return h->plan->columns ? 3 : (h->plan->lean ? 2 : 1);
+}
+
+int rsp_csc_set_planned(rsp_csc_t h, int on) {
+    if (!h) return fail(RSP_ERR_BAD_ARG, "null handle");
+    h->plan_bypass = on == 0;
+    return RSP_OK;
+}
 int rsp_csc_column_means(rsp_csc_t h, double* means) { return csc_run(h, means, true); }
 
 // ---- row-wise "next" entries (Matrix::rowSums / rowMeans, RcppSparse.h:138-156) ----------

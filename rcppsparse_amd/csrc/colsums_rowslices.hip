@@ -81,6 +81,7 @@ __device__ __forceinline__ double reduce8(const double (&t)[kSlcBatch], int lane
 struct Batch {   // 8 columns of one wavefront: cursors and column ends (wave-uniform), the piece's row indices (2 per lane)
     int cur[kSlcBatch], pend[kSlcBatch];
     int r0[kSlcBatch], r1[kSlcBatch];
+    uint32_t have0, have1;   // bit j: this lane has loaded r0[j] / r1[j] (no sentinel row value: every 32-bit pattern is data)
 };
 
 template <bool COMPLEMENT>
@@ -113,7 +114,10 @@ __global__ __launch_bounds__(kSlcThreads) void colsums_rowslices_kernel(
         }
         __syncthreads();
         const uint32_t row_base = (uint32_t)s << kSliceRowsShift;
-        const uint32_t row_end = row_base + (1u << kSliceRowsShift);   // (<= 2^31: rows are below it)
+        const uint32_t row_end = row_base + (1u << kSliceRowsShift);   // (<= 2^31; the last slice may end exactly there)
+        // The last slice takes whatever is left of a column, also rows at or beyond nrow (not a valid dgCMatrix): their
+        // bits lie outside the bitmap and read as "not in the set", which is what the general kernel makes of them.
+        const bool last_slice = s == nslices - 1;
 
         // A wavefront takes its batches of 8 columns in order.  Software pipeline: the row indices of the NEXT
         // batch's first pieces (and the column ends of the one after) are requested before the current batch's
@@ -128,12 +132,13 @@ __global__ __launch_bounds__(kSlcThreads) void colsums_rowslices_kernel(
                 b.cur[j] = __builtin_amdgcn_readfirstlane(k0 + j < c_n ? s_cur[k0 + j] : 0);
                 b.pend[j] = __builtin_amdgcn_readlane(pe, j);
             }
+            b.have0 = b.have1 = 0u;
 #pragma unroll
             for (int j = 0; j < kSlcBatch; ++j) {
                 const uint32_t e0 = (uint32_t)b.cur[j] + (uint32_t)lane, e1 = e0 + 64u;   // (unsigned: a cursor may stand at 2^31 - 1)
-                b.r0[j] = b.r1[j] = 0x7fffffff;
-                if (e0 < (uint32_t)b.pend[j]) b.r0[j] = slc_load_i(ri + e0);
-                if (e1 < (uint32_t)b.pend[j]) b.r1[j] = slc_load_i(ri + e1);
+                b.r0[j] = b.r1[j] = 0;
+                if (e0 < (uint32_t)b.pend[j]) { b.r0[j] = slc_load_i(ri + e0); b.have0 |= 1u << j; }
+                if (e1 < (uint32_t)b.pend[j]) { b.r1[j] = slc_load_i(ri + e1); b.have1 |= 1u << j; }
             }
         };
         int k0 = wave * kSlcBatch;
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(kSlcThreads) void colsums_rowslices_kernel(
 #pragma unroll
                 for (int j = 0; j < kSlcBatch; ++j) {   // the piece's entries inside the slice are a prefix (rows ascend)
                     const uint32_t e0 = (uint32_t)cb.cur[j] + (uint32_t)lane, e1 = e0 + 64u;
-                    const bool v0 = ((more >> j) & 1) && (uint32_t)cb.r0[j] < row_end;   // (not loaded: 0x7fffffff)
-                    const bool v1 = ((more >> j) & 1) && (uint32_t)cb.r1[j] < row_end;
+                    const bool v0 = ((more & cb.have0) >> j & 1) && (last_slice || (uint32_t)cb.r0[j] < row_end);
+                    const bool v1 = ((more & cb.have1) >> j & 1) && (last_slice || (uint32_t)cb.r1[j] < row_end);
                     n[j] = __builtin_popcountll(__ballot(v0)) + __builtin_popcountll(__ballot(v1));
                     x0[j] = x1[j] = 0.0;
                     if (v0) x0[j] = slc_load_x(x + e0);
@@ -178,13 +183,14 @@ __global__ __launch_bounds__(kSlcThreads) void colsums_rowslices_kernel(
                 }
                 more = again;
                 if (more == 0) break;
+                cb.have0 = cb.have1 = 0u;
 #pragma unroll
                 for (int j = 0; j < kSlcBatch; ++j) {   // (long segments: the next piece of the columns that go on)
-                    cb.r0[j] = cb.r1[j] = 0x7fffffff;
+                    cb.r0[j] = cb.r1[j] = 0;
                     if ((more >> j) & 1) {
                         const uint32_t e0 = (uint32_t)cb.cur[j] + (uint32_t)lane, e1 = e0 + 64u;
-                        if (e0 < (uint32_t)cb.pend[j]) cb.r0[j] = slc_load_i(ri + e0);
-                        if (e1 < (uint32_t)cb.pend[j]) cb.r1[j] = slc_load_i(ri + e1);
+                        if (e0 < (uint32_t)cb.pend[j]) { cb.r0[j] = slc_load_i(ri + e0); cb.have0 |= 1u << j; }
+                        if (e1 < (uint32_t)cb.pend[j]) { cb.r1[j] = slc_load_i(ri + e1); cb.have1 |= 1u << j; }
                     }
                 }
             }

@@ -192,7 +192,6 @@ struct rsp_mcsc {
     std::vector<int32_t> bounds;   // column range of shard k: [bounds[k], bounds[k+1])
     int32_t nrow, ncol;
     bool has_rows;                 // uploaded with i[]: the row-wise entries are available
-    std::vector<double> row_partials;   // shards x nrow: where the shards' partial row sums land (kept between calls)
 };
 
 int rsp_mcsc_free(rsp_mcsc_t h) {
@@ -314,8 +313,9 @@ static int mcsc_rows(rsp_mcsc_t h, double* out, bool means) try {
     const int G = (int)h->shards.size();
     const size_t nrow = (size_t)h->nrow;
     if (nrow == 0) return RSP_OK;
-    if (h->row_partials.size() != (size_t)G * nrow) h->row_partials.assign((size_t)G * nrow, 0.0);
-    std::vector<double>& partial = h->row_partials;
+    // shards x nrow doubles for the duration of this call only (8 shards x 1e7 rows: 640 MB), so that the handle
+    // holds no host memory between calls and two threads asking the same handle for row sums do not share a buffer
+    std::vector<double> partial((size_t)G * nrow);
     std::vector<int> status((size_t)G, RSP_OK);
     std::vector<std::string> message((size_t)G);
     auto work = [&](int k) noexcept {
@@ -335,19 +335,46 @@ static int mcsc_rows(rsp_mcsc_t h, double* out, bool means) try {
     if (!run_shards(G, work)) return fail(RSP_ERR_ALLOC, "out of host memory or threads while summing the shards");
     for (int k = 0; k < G; ++k)
         if (status[k] != RSP_OK) return fail(status[k], "shard %d: %s", k, message[k].c_str());
+    // the add: rows are independent, so ranges of rows go to host threads; per row the order stays shard 0, 1, ...
     const double divisor = (double)h->ncol;
-    for (size_t r = 0; r < nrow; ++r) {
-        double t = partial[r];
-        for (int k = 1; k < G; ++k) t += partial[(size_t)k * nrow + r];
-        t += 0.0;
-        out[r] = means ? t / divisor : t;   // RcppSparse.h:153-154
-    }
+    const int nthreads = nrow >= ((size_t)1 << 18) ? 8 : 1;
+    auto add = [&](int t) noexcept {
+        const size_t r0 = nrow * (size_t)t / (size_t)nthreads, r1 = nrow * (size_t)(t + 1) / (size_t)nthreads;
+        for (size_t r = r0; r < r1; ++r) {
+            double v = partial[r];
+            for (int k = 1; k < G; ++k) v += partial[(size_t)k * nrow + r];
+            v += 0.0;
+            out[r] = means ? v / divisor : v;   // RcppSparse.h:153-154
+        }
+    };
+    if (nthreads == 1 || !run_shards(nthreads, add))
+        for (int t = 0; t < nthreads; ++t) add(t);   // (no threads to be had: the same ranges on this one)
     return RSP_OK;
 } catch (...) {
     return fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_row_sums");
 }
 
 int rsp_mcsc_row_sums(rsp_mcsc_t h, double* sums) { return mcsc_rows(h, sums, false); }
+
+int rsp_mcsc_dims(rsp_mcsc_t h, int32_t* nrow, int32_t* ncol, int32_t* nshards) {
+    if (!h) return fail(RSP_ERR_BAD_ARG, "null handle");
+    if (nrow) *nrow = h->nrow;
+    if (ncol) *ncol = h->ncol;
+    if (nshards) *nshards = (int32_t)h->shards.size();
+    return RSP_OK;
+}
+
+int rsp_mcsc_shard_info(rsp_mcsc_t h, int32_t shard, int32_t* info4) {
+    if (!h || !info4) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    if (shard < 0 || shard >= (int32_t)h->shards.size()) return fail(RSP_ERR_BAD_ARG, "shard %d out of range", shard);
+    info4[0] = h->bounds[shard];
+    info4[1] = h->bounds[shard + 1];
+    info4[2] = rsp_csc_column_form(h->shards[shard]);
+    int64_t nnz = 0;
+    (void)rsp_csc_dims(h->shards[shard], nullptr, nullptr, &nnz);
+    info4[3] = (int32_t)nnz;
+    return RSP_OK;
+}
 int rsp_mcsc_row_means(rsp_mcsc_t h, double* means) { return mcsc_rows(h, means, true); }
 
 int rsp_comm_unique_id(void* id_bytes) {

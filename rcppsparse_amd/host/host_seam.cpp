@@ -153,6 +153,21 @@ int seam_columnSums(const double* x, const int* i, const int* p, const int* dim,
     });
 }
 
+// columnSums(A) with the R-level option twin spelled out: require_gpu = 1 / 0, or -1 = the environment decides
+int seam_columnSums_opt(const double* x, const int* i, const int* p, const int* dim, int nnz, int require_gpu,
+                        double* out) {
+    return guarded([&] {
+        Matrix A = view(x, i, p, dim, nnz);
+        NumericVector s = rcppsparse_core::column_sums_via_hip<Matrix, Traits>(A, require_gpu);
+        for (std::size_t k = 0; k < s.size(); ++k) out[k] = s[k];
+    });
+}
+
+// 0 none, 1 hip, 2 cpu: the path the most recent columnSums took (last != 0) / a call would take now
+int seam_backend(int last, int require_gpu) {
+    return last ? rcppsparse_core::last_backend() : rcppsparse_core::choose_backend(require_gpu);
+}
+
 // the reference loop over the mirror's InnerIterator (CPU; tests iterator semantics)
 int seam_columnSums_by_iterator(const double* x, const int* i, const int* p, const int* dim, int nnz,
                                 double* out) {

@@ -10,6 +10,18 @@ columnSums <- function(A) {
     else .Call(`_RcppSparse_columnSums`, A)
 }
 
+#' Which path answers columnSums()
+#'
+#' \code{columnSums()} on a \code{dgCMatrix} runs on the GPU whenever one is visible.  On a machine without
+#' any GPU it answers with the same column loop on the host, like the CPU original -- unless
+#' \code{options(RcppSparse.require_gpu = TRUE)} (or \code{RCPPSPARSE_REQUIRE_GPU=1} in the environment) is
+#' set, in which case it is an error.
+#' @param last \code{FALSE}: the path a call would take now; \code{TRUE}: the path that answered the most
+#'   recent call
+#' @return \code{"hip"}, \code{"cpu"} or \code{"none"}
+#' @export
+columnSumsBackend <- function(last = FALSE) .Call(`_RcppSparse_columnSumsBackend`, as.integer(isTRUE(last)))
+
 #' Keep a sparse matrix in GPU memory
 #'
 #' Uploads a \code{dgCMatrix} once; \code{columnSums()}, \code{gpuColMeans()}, \code{gpuRowSums()},

@@ -9,6 +9,6 @@ sed -i 's#"../../include/rcppsparse_hip.h"#"rcppsparse_hip.h"#' "$here/inst/incl
 # the package namespace: native routines are registered (see src/rcpp_glue.cpp), the only
 # exported R function is columnSums, Rcpp and Matrix are imported like in the reference
 printf '%s\n' 'useDynLib(RcppSparse, .registration=TRUE)' 'import(Rcpp)' 'import(Matrix)' \
-    'export(columnSums)' 'export(gpuMatrix)' 'export(gpuFree)' 'export(gpuColMeans)' 'export(gpuRowSums)' \
+    'export(columnSums)' 'export(columnSumsBackend)' 'export(gpuMatrix)' 'export(gpuFree)' 'export(gpuColMeans)' 'export(gpuRowSums)' \
     'export(gpuRowMeans)' 'export(gpuCrossprod)' 'S3method(dim, gpuMatrix)' 'S3method(dim, gpuMatrixMulti)' > "$here/NAMESPACE"
 echo "assembled: $(ls $here/inst/include | tr '\n' ' ')"

@@ -24,11 +24,31 @@ void release_gpu_matrix(rsp_csc* h) { rsp_csc_free(h); }   // rsp_csc_free(NULL)
 
 typedef Rcpp::XPtr<rsp_csc, Rcpp::PreserveStorage, release_gpu_matrix, true> GpuMatrixPtr;
 
+// The two kinds of handle are told apart by the external pointer's TAG (a symbol set here, which R code cannot
+// change), not by the class attribute (which it can): a "gpuMatrixMulti" reaching a single-GPU routine, or the
+// reverse -- through class<- or a direct .Call -- is an R error instead of one struct read as the other.
+SEXP single_tag() { return Rf_install("rsp_csc"); }
+SEXP multi_tag() { return Rf_install("rsp_mcsc"); }
+
+void check_tag(SEXP handle, SEXP want, const char* what) {
+    if (R_ExternalPtrTag(handle) != want) throw std::invalid_argument(std::string("not a ") + what + " handle");
+}
+
 rsp_csc* resident(SEXP handle) {
     GpuMatrixPtr ptr(handle);
+    check_tag(handle, single_tag(), "gpuMatrix");
     rsp_csc* h = ptr.get();
     if (!h) throw std::invalid_argument("this gpuMatrix handle has been released");
     return h;
+}
+
+// Dim[0] / Dim[1] come from the native handle, not from the (mutable) "Dim" attribute: an edited attribute must
+// not decide how long an output vector is
+void native_dims(rsp_csc* h, int* nrow, int* ncol) {
+    int32_t r = 0, c = 0;
+    if (rsp_csc_dims(h, &r, &c, 0) != RSP_OK) throw std::runtime_error(rsp_last_error());
+    *nrow = r;
+    *ncol = c;
 }
 
 }  // namespace
@@ -49,7 +69,7 @@ SEXP gpuMatrix(RcppSparse::Matrix& A, int device) {
     const int rc = rsp_csc_upload(nnz ? &A.x[0] : (const double*)0, nnz ? &A.i[0] : (const int*)0, &A.p[0],
                                   (int)A.rows(), (int)A.cols(), nnz, device, &h);
     if (rc != RSP_OK) throw std::runtime_error(std::string("RcppSparse gpuMatrix (HIP): ") + rsp_last_error());
-    GpuMatrixPtr ptr(h, true);                       // R now owns the device copy
+    GpuMatrixPtr ptr(h, true, single_tag());        // R now owns the device copy
     ptr.attr("class") = "gpuMatrix";
     ptr.attr("Dim") = Rcpp::IntegerVector::create((int)A.rows(), (int)A.cols());
     return ptr;
@@ -61,9 +81,10 @@ SEXP gpuMatrix(RcppSparse::Matrix& A, int device) {
 //[[Rcpp::export]]
 Rcpp::NumericVector gpuColumnSums(SEXP handle) {
     rsp_csc* h = resident(handle);
-    Rcpp::IntegerVector dim = GpuMatrixPtr(handle).attr("Dim");
-    Rcpp::NumericVector sums(dim[1]);                // allocated by R, on the R main thread
-    if (dim[1] == 0) return sums;
+    int nrow = 0, ncol = 0;
+    native_dims(h, &nrow, &ncol);
+    Rcpp::NumericVector sums(ncol);                  // allocated by R, on the R main thread
+    if (ncol == 0) return sums;
     if (rsp_csc_column_sums(h, &sums[0]) != RSP_OK)
         throw std::runtime_error(std::string("RcppSparse columnSums (HIP): ") + rsp_last_error());
     return sums;
@@ -80,8 +101,9 @@ Rcpp::NumericVector gpuColumnSums(SEXP handle) {
 Rcpp::NumericVector gpuReduce(SEXP handle, int what) {
     rsp_csc* h = resident(handle);
     if (what < 0 || what > 3) throw std::invalid_argument("what must be 0 (colSums), 1 (colMeans), 2 (rowSums) or 3 (rowMeans)");
-    Rcpp::IntegerVector dim = GpuMatrixPtr(handle).attr("Dim");
-    const int n = what < 2 ? dim[1] : dim[0];
+    int nrow = 0, ncol = 0;
+    native_dims(h, &nrow, &ncol);
+    const int n = what < 2 ? ncol : nrow;
     Rcpp::NumericVector out(n);                      // allocated by R, on the R main thread
     if (n == 0) return out;
     const int rc = what == 0 ? rsp_csc_column_sums(h, &out[0]) : what == 1 ? rsp_csc_column_means(h, &out[0])
@@ -99,8 +121,8 @@ Rcpp::NumericVector gpuReduce(SEXP handle, int what) {
 //[[Rcpp::export]]
 Rcpp::NumericMatrix gpuCrossprod(SEXP handle) {
     rsp_csc* h = resident(handle);
-    Rcpp::IntegerVector dim = GpuMatrixPtr(handle).attr("Dim");
-    const int n = dim[1];
+    int nrow = 0, n = 0;
+    native_dims(h, &nrow, &n);
     Rcpp::NumericMatrix out(n, n);
     if (n == 0) return out;
     if (rsp_csc_crossprod(h, &out(0, 0)) != RSP_OK)
@@ -132,7 +154,7 @@ SEXP gpuMatrixMulti(RcppSparse::Matrix& A, Rcpp::IntegerVector devices) {
     const int rc = rsp_mcsc_upload_csc(nnz ? &A.x[0] : (const double*)0, nnz ? &A.i[0] : (const int*)0, &A.p[0],
                                        (int)A.rows(), (int)A.cols(), nnz, &devices[0], (int)devices.size(), &h);
     if (rc != RSP_OK) throw std::runtime_error(std::string("RcppSparse gpuMatrix (HIP): ") + rsp_last_error());
-    GpuMatrixMultiPtr ptr(h, true);
+    GpuMatrixMultiPtr ptr(h, true, multi_tag());
     ptr.attr("class") = "gpuMatrixMulti";
     ptr.attr("Dim") = Rcpp::IntegerVector::create((int)A.rows(), (int)A.cols());
     return ptr;
@@ -144,11 +166,13 @@ SEXP gpuMatrixMulti(RcppSparse::Matrix& A, Rcpp::IntegerVector devices) {
 //[[Rcpp::export]]
 Rcpp::NumericVector gpuMultiReduce(SEXP handle, int what) {
     GpuMatrixMultiPtr ptr(handle);
+    check_tag(handle, multi_tag(), "gpuMatrixMulti");
     rsp_mcsc* h = ptr.get();
     if (!h) throw std::invalid_argument("this gpuMatrix handle has been released");
     if (what < 0 || what > 3) throw std::invalid_argument("what must be 0 (colSums), 1 (colMeans), 2 (rowSums) or 3 (rowMeans)");
-    Rcpp::IntegerVector dim = ptr.attr("Dim");
-    const int n = what < 2 ? dim[1] : dim[0];
+    int32_t nrow = 0, ncol = 0;
+    if (rsp_mcsc_dims(h, &nrow, &ncol, 0) != RSP_OK) throw std::runtime_error(rsp_last_error());
+    const int n = what < 2 ? ncol : nrow;
     Rcpp::NumericVector out(n);
     if (n == 0) return out;
     const int rc = what == 0 ? rsp_mcsc_column_sums(h, &out[0]) : what == 1 ? rsp_mcsc_column_means(h, &out[0])
@@ -162,6 +186,7 @@ Rcpp::NumericVector gpuMultiReduce(SEXP handle, int what) {
 //[[Rcpp::export]]
 void gpuFreeMulti(SEXP handle) {
     GpuMatrixMultiPtr ptr(handle);
+    check_tag(handle, multi_tag(), "gpuMatrixMulti");
     ptr.release();
 }
 
@@ -170,5 +195,6 @@ void gpuFreeMulti(SEXP handle) {
 //[[Rcpp::export]]
 void gpuFree(SEXP handle) {
     GpuMatrixPtr ptr(handle);
+    check_tag(handle, single_tag(), "gpuMatrix");
     ptr.release();                                   // runs the finalizer once and clears the pointer
 }

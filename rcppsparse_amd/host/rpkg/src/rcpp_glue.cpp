@@ -11,7 +11,8 @@
 // Rcpp::compileAttributes() can regenerate an equivalent file from the [[Rcpp::export]]
 // attributes in columnSums.cpp / gpuMatrix.cpp; delete this one if you do.  Nothing here touches
 // HIP: loading the package must stay cheap and must succeed on a machine without a GPU (the
-// device is first touched inside columnSums() / gpuMatrix()).
+// device is first touched inside columnSums() / gpuMatrix(); without one columnSums() answers on the
+// host, see columnsums_impl.hpp).
 #include "../inst/include/RcppSparse.h"
 #include <Rcpp.h>
 
@@ -32,6 +33,7 @@ Rcpp::NumericMatrix gpuCrossprod(SEXP handle);
 SEXP gpuMatrixMulti(RcppSparse::Matrix& A, Rcpp::IntegerVector devices);
 Rcpp::NumericVector gpuMultiReduce(SEXP handle, int what);
 void gpuFreeMulti(SEXP handle);
+SEXP columnSumsBackend(int last);
 
 namespace {
 
@@ -124,6 +126,15 @@ SEXP call_gpuFreeMulti(SEXP handle) {
     END_RCPP
 }
 
+SEXP call_columnSumsBackend(SEXP last) {
+    BEGIN_RCPP
+    Rcpp::RObject result;
+    Rcpp::RNGScope rng_state;
+    result = columnSumsBackend(Rcpp::as<int>(last));
+    return result;
+    END_RCPP
+}
+
 }  // namespace
 
 extern "C" {
@@ -137,6 +148,7 @@ SEXP _RcppSparse_gpuCrossprod(SEXP handle) { return call_gpuCrossprod(handle); }
 SEXP _RcppSparse_gpuMatrixMulti(SEXP A, SEXP devices) { return call_gpuMatrixMulti(A, devices); }
 SEXP _RcppSparse_gpuMultiReduce(SEXP handle, SEXP what) { return call_gpuMultiReduce(handle, what); }
 SEXP _RcppSparse_gpuFreeMulti(SEXP handle) { return call_gpuFreeMulti(handle); }
+SEXP _RcppSparse_columnSumsBackend(SEXP last) { return call_columnSumsBackend(last); }
 
 void R_init_RcppSparse(DllInfo* dll) {
     static const R_CallMethodDef routines[] = {
@@ -149,6 +161,7 @@ void R_init_RcppSparse(DllInfo* dll) {
         {"_RcppSparse_gpuMatrixMulti", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuMatrixMulti), 2},
         {"_RcppSparse_gpuMultiReduce", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuMultiReduce), 2},
         {"_RcppSparse_gpuFreeMulti", reinterpret_cast<DL_FUNC>(&_RcppSparse_gpuFreeMulti), 1},
+        {"_RcppSparse_columnSumsBackend", reinterpret_cast<DL_FUNC>(&_RcppSparse_columnSumsBackend), 1},
         {NULL, NULL, 0}};
     R_registerRoutines(dll, /*.C*/ NULL, /*.Call*/ routines, /*.Fortran*/ NULL, /*.External*/ NULL);
     R_useDynamicSymbols(dll, FALSE);   // only registered names resolve

@@ -60,6 +60,24 @@ def columnSums(m) -> np.ndarray:
     return out
 
 
+def columnSums_opt(m, require_gpu: int = -1) -> np.ndarray:
+    """The same exported function with the R option twin spelled out: 1 = a GPU is required, 0 = the host loop
+    may answer when the machine has no GPU, -1 = RCPPSPARSE_REQUIRE_GPU in the environment decides."""
+    x, i, p, d = _slots(m)
+    out = np.empty(int(d[1]), dtype=np.float64)
+    _check(load().seam_columnSums_opt(*_args(x, i, p, d), ctypes.c_int(int(require_gpu)),
+                                      out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+BACKENDS = ("none", "hip", "cpu")
+
+
+def backend(last: bool = False, require_gpu: int = -1) -> str:
+    """Which path answers columnSums: now (last=False) or in the most recent call (last=True)."""
+    return BACKENDS[int(load().seam_backend(int(bool(last)), int(require_gpu)))]
+
+
 def columnSums_by_iterator(m) -> np.ndarray:
     x, i, p, d = _slots(m)
     out = np.empty(int(d[1]), dtype=np.float64)

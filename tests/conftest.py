@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# The Rcpp layer's columnSums() answers on the host when the machine has no GPU at all (columnsums_impl.hpp).
+# Nothing this suite checks on a GPU box may ever come from that loop: a GPU is REQUIRED in every process the
+# tests start, and the tests of the host answer itself take the requirement away explicitly.
+os.environ["RCPPSPARSE_REQUIRE_GPU"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -23,6 +23,7 @@ struct SEXPREC {
     void (*finalizer)(SEXP) = 0;
     std::map<std::string, SEXP> attrs;
     std::string str;
+    SEXP tag = 0;          // R_ExternalPtrTag
 };
 
 namespace Rcpp {
@@ -176,9 +177,11 @@ public:
     explicit XPtr(SEXP s) : s_(s) {
         if (!s || !s->is_extptr) throw std::invalid_argument("Expecting an external pointer");
     }
-    explicit XPtr(T* p, bool set_delete_finalizer = true) : s_(mock_new()) {
+    explicit XPtr(T* p, bool set_delete_finalizer = true, SEXP tag = 0, SEXP prot = 0) : s_(mock_new()) {
+        (void)prot;
         s_->is_extptr = true;
         s_->extptr = p;
+        s_->tag = tag;
         if (set_delete_finalizer) s_->finalizer = &finalize;
     }
     T* get() const { return static_cast<T*>(s_->extptr); }
@@ -247,6 +250,22 @@ inline int R_registerRoutines(DllInfo* dll, const void*, const R_CallMethodDef* 
 }
 inline int R_useDynamicSymbols(DllInfo* dll, Rboolean v) { dll->dynamic_symbols = (v != FALSE); return 1; }
 #define R_NilValue (Rcpp::mock_nil())
+// the few C-level R entry points the package uses: symbols, options(), external pointer tags
+namespace Rcpp {
+inline std::map<std::string, SEXP>& mock_options() { static std::map<std::string, SEXP> o; return o; }
+inline std::map<std::string, SEXP>& mock_symbols() { static std::map<std::string, SEXP> o; return o; }
+}
+inline SEXP Rf_install(const char* name) {          // symbols are unique per name, like R's symbol table
+    SEXP& s = Rcpp::mock_symbols()[name];
+    if (!s) { s = Rcpp::mock_new(); s->str = name; }
+    return s;
+}
+inline SEXP Rf_GetOption1(SEXP sym) {
+    std::map<std::string, SEXP>::const_iterator it = Rcpp::mock_options().find(sym->str);
+    return it == Rcpp::mock_options().end() ? R_NilValue : it->second;
+}
+inline int Rf_asLogical(SEXP s) { return (s && s->integer && !s->integer->empty() && (*s->integer)[0] != 0) ? TRUE : FALSE; }
+inline SEXP R_ExternalPtrTag(SEXP s) { return (s && s->tag) ? s->tag : R_NilValue; }
 #ifndef NULL
 #define NULL 0
 #endif

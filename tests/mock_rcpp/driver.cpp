@@ -6,6 +6,10 @@
 //   driver kat                 -> Documentation.Rmd:213-216 matrix through .Call (needs a GPU)
 //   driver handle              -> gpuMatrix(A) external pointer: resident sums, copy semantics, finalizer (GPU)
 //   driver handle_nogpu        -> gpuMatrix(A) on a machine without a GPU must be an R error
+//   driver kat_cpu             -> the same matrix on a machine WITHOUT a GPU: the host loop answers (reference bits),
+//                                 columnSumsBackend() says "cpu"; with options(RcppSparse.require_gpu = TRUE) an R error
+//   driver backend             -> prints columnSumsBackend() / columnSumsBackend(last = TRUE) before any call
+//   driver handle_swap         -> a "gpuMatrixMulti" handed to a single-GPU routine (and the reverse), an edited Dim (GPU)
 //   driver handle_methods      -> colMeans / rowSums / rowMeans / crossprod on the handle, and the same matrix
 //                                 spread over three shards (gpuMatrix(A, devices = c(0, 0, 0))) (GPU)
 #include "../../rcppsparse_amd/host/RcppSparse.h"
@@ -143,6 +147,70 @@ int main(int argc, char** argv) {
         if (!multi_free(m)->error.empty()) return 63;
         if (Rcpp::RNGScope::live() != 0) return 64;
         std::printf("gpuMatrix methods ok\n");
+        return 0;
+    }
+    if (mode == "kat_cpu" || mode == "backend") {
+        call1 backend = 0;
+        for (int k = 0; dll.registered[k].name; ++k)
+            if (std::string(dll.registered[k].name) == "_RcppSparse_columnSumsBackend") backend = (call1)dll.registered[k].fun;
+        if (!backend) return 70;
+        SEXP now = Rcpp::wrap(Rcpp::IntegerVector::create(0, 0)), last = Rcpp::wrap(Rcpp::IntegerVector::create(1, 0));
+        if (mode == "backend") {
+            std::printf("%s %s\n", backend(now)->str.c_str(), backend(last)->str.c_str());
+            return 0;
+        }
+        if (backend(last)->str != "none") return 71;              // nothing has been summed yet
+        SEXP r = fn(dgc(true));
+        if (!r->error.empty()) { std::printf("R error: %s\n", r->error.c_str()); return 72; }
+        const double want[5] = {0.0, 0.41, 0.35, 0.84 + 0.37, 0.26};
+        if (r->num->size() != 5 || std::memcmp(&(*r->num)[0], want, sizeof want) != 0) return 73;
+        if (!r->attrs.empty() || !r->klass.empty()) return 74;    // a plain numeric vector, no attributes
+        for (int k = 0; k < 5; ++k) std::printf("%a%c", (*r->num)[k], k == 4 ? '\n' : ' ');
+        std::printf("backend now=%s last=%s\n", backend(now)->str.c_str(), backend(last)->str.c_str());
+        // options(RcppSparse.require_gpu = TRUE): the same call is an R error, and it says why
+        Rcpp::mock_options()["RcppSparse.require_gpu"] = Rcpp::wrap(Rcpp::IntegerVector::create(1, 0));
+        SEXP e = fn(dgc(true));
+        std::printf("required: %s | now=%s\n", e->error.c_str(), backend(now)->str.c_str());
+        if (e->error.find("no HIP device") == std::string::npos) return 75;
+        // options(RcppSparse.require_gpu = FALSE) wins over the environment variable
+        Rcpp::mock_options()["RcppSparse.require_gpu"] = Rcpp::wrap(Rcpp::IntegerVector::create(0, 0));
+        if (!fn(dgc(true))->error.empty()) return 76;
+        return 0;
+    }
+    if (mode == "handle_swap") {
+        call2 gpu_matrix = 0, gpu_reduce = 0, gpu_multi = 0, multi_reduce = 0;
+        call1 gpu_sums = 0, gpu_free = 0, multi_free = 0;
+        for (int k = 0; dll.registered[k].name; ++k) {
+            const std::string nm = dll.registered[k].name;
+            if (nm == "_RcppSparse_gpuMatrix") gpu_matrix = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuReduce") gpu_reduce = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuColumnSums") gpu_sums = (call1)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuFree") gpu_free = (call1)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuMatrixMulti") gpu_multi = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuMultiReduce") multi_reduce = (call2)dll.registered[k].fun;
+            if (nm == "_RcppSparse_gpuFreeMulti") multi_free = (call1)dll.registered[k].fun;
+        }
+        SEXP A = dgc(true);
+        SEXP h = gpu_matrix(A, Rcpp::wrap(Rcpp::IntegerVector::create(0, 0)));
+        const int two[2] = {0, 0};
+        SEXP m = gpu_multi(A, Rcpp::wrap(Rcpp::IntegerVector(two, two + 2)));
+        if (!h->error.empty() || !m->error.empty()) return 80;
+        SEXP zero = Rcpp::wrap(Rcpp::IntegerVector::create(0, 0));
+        // class(m) <- "gpuMatrix"; columnSums(m): the tag, not the class, decides -- an R error, not a crash
+        if (gpu_sums(m)->error.find("not a gpuMatrix handle") == std::string::npos) return 81;
+        if (gpu_reduce(m, zero)->error.find("not a gpuMatrix handle") == std::string::npos) return 82;
+        if (multi_reduce(h, zero)->error.find("not a gpuMatrixMulti handle") == std::string::npos) return 83;
+        if (gpu_free(m)->error.find("not a gpuMatrix handle") == std::string::npos) return 84;
+        if (multi_free(h)->error.find("not a gpuMatrixMulti handle") == std::string::npos) return 85;
+        // attr(h, "Dim") <- c(5L, 5000L): the output length comes from the native handle
+        (*h->attrs.at("Dim")->integer)[1] = 5000;
+        (*m->attrs.at("Dim")->integer)[0] = 7000;
+        SEXP r = gpu_sums(h);
+        if (!r->error.empty() || r->num->size() != 5) return 86;
+        r = multi_reduce(m, Rcpp::wrap(Rcpp::IntegerVector::create(2, 0)));
+        if (!r->error.empty() || r->num->size() != 5) return 87;
+        if (!gpu_free(h)->error.empty() || !multi_free(m)->error.empty()) return 88;
+        std::printf("handle swap ok\n");
         return 0;
     }
     if (mode == "missing_slot") {

@@ -207,7 +207,7 @@ def test_plan_entries_validate_arguments_and_do_not_answer_without_a_device():
     L = capi.load()
     assert L.rsp_column_sums_plan_destroy(None) == capi.RSP_OK           # destroying nothing is fine
     assert L.rsp_column_sums_plan_info(None, None, None) == capi.RSP_ERR_BAD_ARG
-    assert L.rsp_column_sums_planned_device(None, None, None, 0, None, None, 0, None) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_column_sums_planned_device(None, None, None, 0, 0, 0, None, None, 0, None) == capi.RSP_ERR_BAD_ARG
     if _no_gpu():
         with pytest.raises(capi.RspError) as e:
             capi.ColumnSumsPlan(good)

@@ -634,6 +634,60 @@ def _check_slice_major_form(torch, x, i, p, nrow, ncol, complement, S):
     assert np.all(np.abs(got2.cpu().numpy() - ref2) <= RTOL * oracle.column_abs_sums(np.where(keep2, x2, 0.0), p2))
 
 
+@pytest.mark.parametrize("complement", [False, True])
+def test_row_restricted_sums_slice_major_form_at_the_last_possible_slice(torch_cuda, complement):
+    """with nrow above 2^31 - 2^20 the last of the 2048 slices ends at 2^31 and the old "not loaded"
+    marker (row 0x7fffffff) counted as a row of that slice: the piece never ended (a hang).  Validity is an
+    explicit per-lane predicate now.  nrow = 2^31 - 1, the form forced: a few hundred columns with entries in the
+    first slice, in the middle, and in the last slice up to row 2^31 - 2, against the oracle's restricted loop and
+    the general form; then the same matrix with rows at and beyond nrow put in (not a valid dgCMatrix): both forms
+    treat them as "not in the set" and neither hangs."""
+    torch = torch_cuda
+    nrow, ncol = 2**31 - 1, 300
+    rng = np.random.default_rng(11)
+    cols = []
+    for c in range(ncol):
+        k = int(rng.integers(0, 260))
+        r = np.unique(np.concatenate([rng.integers(0, 1 << 20, size=k // 3), rng.integers(1 << 29, 1 << 30, size=k // 3),
+                                      rng.integers(nrow - (1 << 20), nrow, size=k - 2 * (k // 3))]))
+        cols.append(r)
+    cols[5] = np.union1d(cols[5], [nrow - 1, nrow - 2, (2047 << 20) - 1, 2047 << 20])
+    p = np.zeros(ncol + 1, dtype=np.int32)
+    p[1:] = np.cumsum([len(r) for r in cols])
+    i = np.concatenate(cols).astype(np.int32)
+    x = synth.gen_values(len(i), seed=11, kind=0)
+    s = np.unique(np.concatenate([rng.integers(0, 1 << 20, size=400_000), rng.integers(1 << 29, 1 << 30, size=400_000),
+                                  rng.integers(nrow - (1 << 20), nrow, size=400_000), [nrow - 1]]))
+    bits = capi.row_set_bitmap(s, nrow)
+    xt, it, pt, bt = (torch.from_numpy(a).cuda() for a in (x, i, p, bits))
+    ref = oracle.column_sums_in_rows(x, i, p, bits, complement)
+    keep = (((bits[i >> 5] >> (i & 31).astype(np.uint32)) & 1) == 1) != complement
+    scale = oracle.column_abs_sums(np.where(keep, x, 0.0), p)
+    capi.set_row_slices(2)
+    try:
+        assert capi.in_rows_form(nrow, ncol, len(x)) == "slices"
+        got = capi.column_sums_in_rows_device(xt, it, pt, nrow, bt, complement).cpu().numpy()
+        assert np.all(np.abs(got - ref) <= RTOL * scale)
+        # rows at / beyond nrow and negative ones at the END of some columns (rows still ascending as unsigned numbers)
+        bad = i.copy()
+        for c in (3, 77, 210):
+            if p[c + 1] - p[c] >= 2:
+                bad[p[c + 1] - 1] = -5                       # 0xfffffffb
+                bad[p[c + 1] - 2] = 2**31 - 1                # == nrow
+        badt = torch.from_numpy(bad).cuda()
+        sl = capi.column_sums_in_rows_device(xt, badt, pt, nrow, bt, complement).cpu().numpy()
+        capi.set_row_slices(0)
+        ge = capi.column_sums_in_rows_device(xt, badt, pt, nrow, bt, complement).cpu().numpy()
+        torch.cuda.synchronize()
+        inside = (bad >= 0) & (bad < nrow)
+        keep_b = np.where(inside, (((bits[np.where(inside, bad, 0) >> 5] >> (np.where(inside, bad, 0) & 31).astype(np.uint32)) & 1) == 1), False) != complement
+        want = oracle.column_sums(np.where(keep_b, x, 0.0), p)
+        tol = RTOL * oracle.column_abs_sums(x, p) + 1e-300
+        assert np.all(np.abs(sl - want) <= tol) and np.all(np.abs(ge - want) <= tol)
+    finally:
+        capi.set_row_slices(1)
+
+
 def test_row_restricted_sums_slice_major_form_is_graph_capture_safe(torch_cuda):
     """The slice form is a 4-byte memset and four launches on the caller's stream: capturable, replay reproduces the bits."""
     torch = torch_cuda

@@ -132,6 +132,40 @@ def test_by_reference_semantics():
     assert hostseam.shares_storage()
 
 
+@pytest.mark.parametrize("name", golden_names())
+def test_exported_columnSums_answers_on_the_host_when_the_machine_has_no_gpu(name):
+    """with zero HIP devices the exported columnSums(Matrix&) runs the reference's loop
+    (example.cpp:28-30) over the mirror's own InnerIterator into the vector it has already allocated -- the
+    reference's bits on every golden fixture -- and says so; with a GPU required (this suite's default, set in
+    conftest.py) the same call stays the error it was."""
+    from rcppsparse_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present: the host loop is never selected")
+    g = load_golden(name)
+    ncol = int(g["Dim"][1])
+    if ncol > 0:                                     # (a matrix without columns has nothing to ask a device for)
+        with pytest.raises(hostseam.SeamError) as e:
+            hostseam.columnSums(g)                   # RCPPSPARSE_REQUIRE_GPU=1 from conftest
+        assert "no HIP device" in str(e.value)
+    assert hostseam.backend() == "none"
+    got = hostseam.columnSums_opt(g, require_gpu=0)
+    assert hostseam.backend(last=True) == "cpu" and hostseam.backend(require_gpu=0) == "cpu"
+    assert got.tobytes() == np.asarray(g["sums"], dtype=np.float64).tobytes()
+    if ncol > 0:
+        with pytest.raises(hostseam.SeamError):
+            hostseam.columnSums_opt(g, require_gpu=1)
+        assert hostseam.backend(last=True) == "none"    # the failed call answered nothing
+
+
+@pytest.mark.gpu
+def test_with_a_gpu_present_the_host_loop_is_never_selected():
+    g = load_golden(golden_names()[0])
+    for req in (-1, 0, 1):
+        assert hostseam.backend(require_gpu=req) == "hip"
+        hostseam.columnSums_opt(g, require_gpu=req)
+        assert hostseam.backend(last=True) == "hip"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", golden_names())
 def test_exported_columnSums_through_the_hip_shim(name):

@@ -5,7 +5,8 @@ scaffolding; neither R nor Rcpp exists in this image) and drives it the way R do
 init, routine table, `.Call` with a dgCMatrix-like S4 object.  What the boundary must keep
 (reference src/RcppExports.cpp:16-34, inst/include/RcppSparse.h:33-42, :398-423): the two C
 symbols, arity-1 registration with dynamic lookup off, zero-copy S4 -> Matrix, the missing-slot
-message, C++ exceptions surfacing as R errors, and no CPU fallback."""
+message, C++ exceptions surfacing as R errors; on a machine without any GPU the host loop answers (above the
+C ABI, which itself never falls back) unless a GPU is required."""
 import os
 import subprocess
 
@@ -31,8 +32,12 @@ def driver(tmp_path_factory):
     return exe
 
 
-def run(exe, mode):
-    return subprocess.run([exe, mode], capture_output=True, text=True, timeout=120)
+def run(exe, mode, require_gpu="1"):
+    env = dict(os.environ)
+    env.pop("RCPPSPARSE_REQUIRE_GPU", None)
+    if require_gpu is not None:
+        env["RCPPSPARSE_REQUIRE_GPU"] = require_gpu
+    return subprocess.run([exe, mode], capture_output=True, text=True, timeout=120, env=env)
 
 
 def test_package_registers_the_reference_routine_first(driver):
@@ -45,7 +50,8 @@ def test_package_registers_the_reference_routine_first(driver):
     assert rows[1:] == [["_RcppSparse_gpuMatrix", "2"], ["_RcppSparse_gpuColumnSums", "1"],
                         ["_RcppSparse_gpuFree", "1"], ["_RcppSparse_gpuReduce", "2"],
                         ["_RcppSparse_gpuCrossprod", "1"], ["_RcppSparse_gpuMatrixMulti", "2"],
-                        ["_RcppSparse_gpuMultiReduce", "2"], ["_RcppSparse_gpuFreeMulti", "1"]]
+                        ["_RcppSparse_gpuMultiReduce", "2"], ["_RcppSparse_gpuFreeMulti", "1"],
+                        ["_RcppSparse_columnSumsBackend", "1"]]
 
 
 def test_glue_also_builds_with_global_rostream(tmp_path):
@@ -73,12 +79,96 @@ def test_missing_slot_becomes_an_r_error_with_the_reference_message(driver):
     assert r.stdout.strip() == "Cannot construct RcppSparse::Matrix from this S4 object"
 
 
-def test_without_a_gpu_columnSums_is_an_r_error_not_a_cpu_answer(driver):
+def test_without_a_gpu_and_a_gpu_required_columnSums_is_an_r_error(driver):
+    """RCPPSPARSE_REQUIRE_GPU=1 (what this suite, bench.py and smoke() run under): no CPU answer."""
     from rcppsparse_amd import capi
     if capi.device_count() > 0:
         pytest.skip("a GPU is present")
-    r = run(driver, "kat")
+    r = run(driver, "kat", require_gpu="1")
     assert r.returncode == 16 and "no HIP device" in r.stdout
+    r = run(driver, "backend", require_gpu="1")
+    assert r.stdout.split() == ["none", "none"]
+
+
+KAT_HEX = ["0x0p+0", "0x1.a3d70a3d70a3dp-2", "0x1.6666666666666p-2", "0x1.35c28f5c28f5cp+0", "0x1.0a3d70a3d70a4p-2"]
+
+
+def test_without_a_gpu_columnSums_answers_on_the_host_like_the_reference(driver):
+    """SURVEY.md 8b "CPU fallback selected when no device": the reference's columnSums always answers
+    (src/example.cpp:26-32).  Through .Call on a machine without a GPU: the five sums of the vignette's matrix
+    (Documentation.Rmd:213-216) bit for bit, a plain vector without attributes, columnSumsBackend() = "cpu";
+    options(RcppSparse.require_gpu = TRUE) turns the same call into the R error, FALSE overrides the environment."""
+    from rcppsparse_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present: the host loop is never selected")
+    r = run(driver, "kat_cpu", require_gpu=None)
+    assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
+    lines = r.stdout.splitlines()
+    assert lines[0].split() == KAT_HEX
+    assert lines[1] == "backend now=cpu last=cpu"
+    assert lines[2].startswith("required: RcppSparse columnSums (HIP): no HIP device") and lines[2].endswith("now=none")
+    for off in ("0", ""):
+        assert run(driver, "kat_cpu", require_gpu=off).returncode == 0      # "0" and empty do not require a GPU
+    r = run(driver, "kat_cpu", require_gpu="1")                             # the environment requires one ...
+    assert r.returncode == 72 and "no HIP device" in r.stdout               # ... and the first call is the R error
+
+
+def test_host_only_build_of_the_package_without_the_hip_library(tmp_path):
+    """./configure's second branch (no librcppsparse_hip.so on the machine): the package's sources plus
+    src/nohip_stubs.c, NOT linked against the library.  It behaves like the GPU build on a box without a GPU:
+    columnSums answers on the host with the reference's bits, gpuMatrix is an R error."""
+    rpkg = os.path.join(ROOT, "rcppsparse_amd", "host", "rpkg")
+    subprocess.run(["bash", os.path.join(rpkg, "assemble.sh")], check=True, stdout=subprocess.DEVNULL)
+    mock = os.path.join(ROOT, "tests", "mock_rcpp")
+    stubs = tmp_path / "stubs.o"
+    subprocess.run(["gcc", "-c", "-O1", "-Wall", "-o", str(stubs), os.path.join(rpkg, "src", "nohip_stubs.c")], check=True)
+    exe = str(tmp_path / "driver_nohip")
+    subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-I", mock, "-o", exe, os.path.join(mock, "driver.cpp"),
+                    os.path.join(rpkg, "src", "columnSums.cpp"), os.path.join(rpkg, "src", "gpuMatrix.cpp"),
+                    os.path.join(rpkg, "src", "rcpp_glue.cpp"), str(stubs)], check=True)
+    libs = subprocess.run(["ldd", exe], capture_output=True, text=True, check=True).stdout
+    assert "rcppsparse_hip" not in libs and "amdhip" not in libs
+    r = run(exe, "kat_cpu", require_gpu=None)
+    assert r.returncode == 0 and r.stdout.splitlines()[0].split() == KAT_HEX
+    r = run(exe, "handle_nogpu")
+    assert r.returncode == 0 and "no HIP device" in r.stdout
+    # the configure script picks that branch by itself when the library is not where it looks
+    work = tmp_path / "pkg"
+    subprocess.run(["cp", "-r", rpkg, str(work)], check=True)
+    env = dict(os.environ, RCPPSPARSE_HIP_LIB=str(tmp_path / "nowhere"))
+    out = subprocess.run(["sh", "./configure"], cwd=str(work), env=env, capture_output=True, text=True, check=True).stdout
+    def makevars():
+        return dict(ln.split(" = ", 1) for ln in (work / "src" / "Makevars").read_text().splitlines()
+                    if " = " in ln and not ln.startswith("#"))
+    mk = makevars()
+    assert "host-only build" in out and "nohip_stubs.o" in mk["OBJECTS"] and "-lrcppsparse_hip" not in mk["PKG_LIBS"]
+    env["RCPPSPARSE_HIP_LIB"] = os.path.join(ROOT, "rcppsparse_amd")
+    subprocess.run(["sh", "./configure"], cwd=str(work), env=env, check=True, stdout=subprocess.DEVNULL)
+    mk = makevars()
+    assert "-lrcppsparse_hip" in mk["PKG_LIBS"] and "nohip_stubs.o" not in mk["OBJECTS"]
+
+
+def test_nothing_in_the_product_tree_touches_the_oracle():
+    """The host answer is the product's own loop over its own InnerIterator -- not the oracle.  No file under
+    rcppsparse_amd/ includes, imports, loads or links anything of oracle/ (comments may name it)."""
+    import re
+    pat = re.compile(r'#\s*include\s*[<"][^>"]*oracle|import\s+oracle|from\s+oracle|liboracle|oracle/|oracle\.(build|column_sums|gen_)')
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "rcppsparse_amd")):
+        if "__pycache__" in base or os.sep + "build" in base:
+            continue
+        for f in files:
+            if f.endswith((".so", ".o", ".pyc")):
+                continue
+            path = os.path.join(base, f)
+            for n, line in enumerate(open(path, errors="replace"), 1):
+                code = line.split("//")[0].split("#")[0] if not line.lstrip().startswith(("#include", "# include")) else line
+                if pat.search(code):
+                    bad.append(f"{os.path.relpath(path, ROOT)}:{n}: {line.strip()}")
+    assert not bad, bad
+    for lib in ("librcppsparse_hip.so", "librcppsparse_host.so"):
+        libs = subprocess.run(["ldd", os.path.join(ROOT, "rcppsparse_amd", lib)], capture_output=True, text=True).stdout
+        assert "oracle" not in libs
 
 
 def test_without_a_gpu_gpuMatrix_is_an_r_error(driver):
@@ -116,3 +206,16 @@ def test_dot_call_columnSums_on_the_gpu(driver):
     r = run(driver, "kat")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "columnSums via .Call ok" in r.stdout
+    # with a GPU present the host loop is never selected, whatever the requirement says
+    assert run(driver, "backend", require_gpu=None).stdout.split() == ["hip", "none"]
+    r = run(driver, "kat_cpu", require_gpu=None)
+    assert "backend now=hip last=hip" in r.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_matrix_handles_are_told_apart_by_tag_and_sized_by_the_native_handle(driver):
+    """dispatch relied on the R-level class attribute and the output length on the mutable Dim
+    attribute.  Now the external pointer's tag decides and the native handle gives the sizes."""
+    r = run(driver, "handle_swap")
+    assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
+    assert "handle swap ok" in r.stdout
