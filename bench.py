@@ -281,7 +281,7 @@ def traffic_from_profiles(workload):
     return best, src
 
 
-ALSO_AUTO = ("c2", "c2:planned", "c5", "c4shard", "c4shard:planned", "vignette:planned")
+ALSO_AUTO = ("c2", "c2:planned", "c2:planned-device", "c5", "c4shard", "c4shard:planned", "vignette:planned")
 PLAN_FORMS = {3: "columns", 2: "lean", 1: "snapped", 0: "general kernels"}
 
 
@@ -303,7 +303,7 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
     where the workload would fit the Infinity Cache, K calls back to back on one stream, HIP events on that
     stream, every column against the oracle) and reported as a compact record."""
     name, _, mode = spec.partition(":")
-    planned = mode == "planned"
+    planned = mode in ("planned", "planned-device")
     nrow, ncol, nnz, shape, p = build_offsets(name, 0)
     small = nnz < 200_000_000
     steps = args.steps * 10 if small else args.steps      # a 20 us call wants more than 20 of them in the region
@@ -316,9 +316,25 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
     pt = torch.from_numpy(p).to(dev)
     out = torch.empty(ncol, dtype=torch.float64, device=dev)
     ws = capi.alloc_workspace(ncol, nnz, dev)
-    plan = capi.ColumnSumsPlan(p, nnz=nnz, device=dev_index) if planned else None
-    launches = [(plan.prepared(xk, pt, out, ws, stream=stream) if plan is not None else
-                 capi.prepared_column_sums(xk, pt, out, ws, stream=stream)) for xk in xs]
+    early = None
+    if mode == "planned-device":
+        # p[] is never shown to the host: the inspection runs as kernels on the launch stream, nothing waits for it, and
+        # the calls issued meanwhile are answered by the general kernels (counted here) until the host has seen the result
+        torch.cuda.synchronize()
+        t_enq = time.perf_counter()
+        plan = capi.ColumnSumsPlan(pt, nnz=nnz, stream=stream)
+        enqueue_ms = (time.perf_counter() - t_enq) * 1e3
+        launches = [plan.prepared(xk, pt, out, ws, stream=stream) for xk in xs]
+        early = 0
+        while not plan.ready() and early < 10_000:
+            launches[early % ncopies]()
+            early += 1
+        early = {"calls_answered_by_the_general_kernels_before_the_plan_was_known": early,
+                 "plan_enqueue_ms_host": enqueue_ms}
+    else:
+        plan = capi.ColumnSumsPlan(p, nnz=nnz, device=dev_index) if planned else None
+        launches = [(plan.prepared(xk, pt, out, ws, stream=stream) if plan is not None else
+                     capi.prepared_column_sums(xk, pt, out, ws, stream=stream)) for xk in xs]
     for k in range(max(args.warmup, ncopies)):
         launches[k % ncopies]()
     mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
@@ -356,6 +372,10 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
            "form": "general kernels" if plan is None else PLAN_FORMS[plan.form],
            "launches_per_call": 1 if one_launch else 2,
            "plan_ms": None if plan is None else plan.inspect_ms,
+           "plan_made": None if plan is None else ("on the device, on the launch stream (rsp_column_sums_plan_create_device); "
+                                                   "plan_ms = device time of the inspection kernels" if plan.device_made else
+                                                   "on the host from a host copy of p[] (rsp_column_sums_plan_create)"),
+           "plan_device": early,
            "steps": steps, "x_copies_rotated": ncopies,
            "ms_per_call": wall / steps * 1e3, "kernel_ms": kernel_ms,
            "nnz_per_s": nnz * steps / wall,

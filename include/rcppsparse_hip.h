@@ -197,9 +197,31 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
 typedef struct rsp_colsums_plan *rsp_colsums_plan_t;
 int rsp_column_sums_plan_create(const int32_t *p, int32_t ncol, int64_t nnz, int device,
                                 rsp_colsums_plan_t *plan);
-/* The same for offsets that live in HBM: copies them to the host once (synchronises `stream`). */
+/*
+ * The same for offsets that live in HBM, WITHOUT showing them to the host: the inspection runs as three small
+ * kernels on `stream` (one pass over p[] with a thread per column: validity of p[], column lengths, the snapped
+ * records, the lean grid's first columns; then the lean chunks' widths; then the lean image), a few tens of
+ * microseconds for 1e6 columns, and nothing synchronises.  The images equal those of rsp_column_sums_plan_create
+ * bit for bit (tests/test_gpu_parity.py); the few statistics the choice of form rests on travel to a page-locked
+ * host record behind the kernels.  Until the host has seen them, rsp_column_sums_planned_device answers with the
+ * general kernels (right for any matrix; pass their workspace), from then on with the form they select -- it looks
+ * (hipEventQuery, no waiting) at every call, so a caller that plans and then sums in a loop gets the planned form
+ * from the second call or so on, and never blocks.  rsp_column_sums_plan_ready looks without calling;
+ * rsp_column_sums_plan_wait blocks until the inspection is done (a caller about to CAPTURE planned calls into a
+ * HIP graph waits first: a capture records whatever form is known at that moment, and looks at nothing itself);
+ * rsp_column_sums_plan_info waits too, and its *inspect_ms is then the device time of the inspection.
+ * Offsets that are not a dgCMatrix's (p[0] != 0, decreasing, p[ncol] != nnz) are noticed by the inspection: such a
+ * plan stays on the general kernels.  Differences from the host-made plan: the lean image is sized before the
+ * offsets are seen, for 3 x the mean number of columns per chunk + 16 (at least 126): a matrix with a denser
+ * chunk takes the snapped or general form here.  The plan owns its device memory; destroy it after the stream's work.
+ */
 int rsp_column_sums_plan_create_device(const int32_t *d_p, int32_t ncol, int64_t nnz,
                                        void *stream, rsp_colsums_plan_t *plan);
+int rsp_column_sums_plan_ready(rsp_colsums_plan_t plan);   /* 1: the form is known (always, for host-made plans), 0: not yet */
+int rsp_column_sums_plan_wait(rsp_colsums_plan_t plan);
+/* Test helper: copies a plan's image to the host -- what = 0: the snapped form's (chunks + 1) records, 1: the lean
+ * form's headers and 16-bit offsets.  *bytes = its size (0: this plan has no such image); host may be NULL. */
+int rsp_debug_plan_image(rsp_colsums_plan_t plan, int what, void *host, size_t capacity, size_t *bytes);
 int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t *info4, double *inspect_ms);
 /* ncol, nnz: the sizes of the matrix behind d_x / d_p; they must be the plan's (RSP_ERR_BAD_ARG otherwise:
  * the lean form never reads d_p and would run over a shorter x).  The offsets themselves are the caller's

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "rsp_comm_reduce_rows_workspace_bytes", "rsp_comm_reduce_rows", "rsp_add_partials_device",
     "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe", "rsp_set_crossprod_exact",
     "rsp_set_experiment", "rsp_debug_read_ceiling_device",
+    "rsp_column_sums_plan_ready", "rsp_column_sums_plan_wait", "rsp_debug_plan_image",
     "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
 )
 
@@ -122,6 +123,9 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_mcsc_dims.argtypes = [vp, ip, ip, ip]
     L.rsp_mcsc_shard_info.argtypes = [vp, i32, ip]
     L.rsp_column_sums_plan_destroy.argtypes = [vp]
+    L.rsp_column_sums_plan_ready.argtypes = [vp]
+    L.rsp_column_sums_plan_wait.argtypes = [vp]
+    L.rsp_debug_plan_image.argtypes = [vp, c.c_int, vp, c.c_size_t, c.POINTER(c.c_size_t)]
     L.rsp_set_lean.argtypes = [c.c_int]
     L.rsp_set_row_slices.argtypes = [c.c_int]
     L.rsp_set_row_segments.argtypes = [c.c_int]
@@ -550,42 +554,80 @@ def prepared_column_sums(x_t, p_t, out_t, workspace, stream=None):
 
 
 class ColumnSumsPlan:
-    """Inspector-executor plan of a column-sum call (rsp_column_sums_plan_*): made once from p[] (a host
-    array, or a device tensor that is copied to the host once), then every call is one launch without
-    column search, carries or fix-up -- where the matrix allows it (``snapped``); otherwise the executor
-    runs the general kernels and needs their workspace."""
+    """Inspector-executor plan of a column-sum call (rsp_column_sums_plan_*): made once from p[], then every call is
+    one launch without column search, carries or fix-up -- where the matrix allows it (``snapped``); otherwise the
+    executor runs the general kernels and needs their workspace.
+    p a host array: inspected on the host (rsp_column_sums_plan_create).  p a device tensor: inspected ON THE DEVICE, on
+    ``stream``, without any synchronisation (rsp_column_sums_plan_create_device); until the host has seen the result
+    (``ready()``; ``wait()`` blocks) calls run the general kernels, and the attributes ``form`` / ``lean`` / ``snapped``
+    / ``columns`` / ``inspect_ms`` ... wait for it when they are read."""
+
+    _INFO = ("form", "lean", "columns", "snapped", "nchunks", "chunk_elems", "max_skip", "inspect_ms")
 
     def __init__(self, p, nnz: int = None, device: int = 0, stream=None):
         L = load()
         self._h = ctypes.c_void_p()
+        self._info = None
         if isinstance(p, np.ndarray):
             p = np.ascontiguousarray(p, dtype=np.int32)
             self.ncol = len(p) - 1
             self.nnz = int(p[-1]) if nnz is None else int(nnz)
+            self.device_made = False
             _check(L.rsp_column_sums_plan_create(_ip(p), self.ncol, self.nnz, int(device), ctypes.byref(self._h)))
+            self._load_info()
         else:   # a device tensor of offsets
             self.ncol = p.numel() - 1
             if nnz is None:
                 raise ValueError("nnz is needed with device offsets")
             self.nnz = int(nnz)
+            self.device_made = True
             _check(L.rsp_column_sums_plan_create_device(p.data_ptr(), self.ncol, self.nnz, _stream_ptr(stream),
                                                         ctypes.byref(self._h)))
+
+    def _load_info(self):
         info = np.zeros(4, dtype=np.int32)
         ms = ctypes.c_double(0)
-        _check(L.rsp_column_sums_plan_info(self._h, _ip(info), ctypes.byref(ms)))
+        _check(load().rsp_column_sums_plan_info(self._h, _ip(info), ctypes.byref(ms)))   # (waits for a device-made plan)
         # form 3 = columns (all columns long: one workgroup per column), 2 = lean (all columns short: one launch,
         # reference bits for every column), 1 = snapped (one launch), 0 = the general kernels behind the same entry
-        self.form = int(info[0])
-        self.lean, self.columns, self.snapped = self.form == 2, self.form == 3, self.form >= 1
-        self.nchunks, self.chunk_elems, self.max_skip = int(info[1]), int(info[2]), int(info[3])
-        self.inspect_ms = float(ms.value)
+        form = int(info[0])
+        self._info = {"form": form, "lean": form == 2, "columns": form == 3, "snapped": form >= 1,
+                      "nchunks": int(info[1]), "chunk_elems": int(info[2]), "max_skip": int(info[3]),
+                      "inspect_ms": float(ms.value)}
+
+    def __getattr__(self, name):
+        if name in ColumnSumsPlan._INFO:
+            if self.__dict__.get("_info") is None:
+                self._load_info()
+            return self.__dict__["_info"][name]
+        raise AttributeError(name)
+
+    def ready(self) -> bool:
+        """Has the host seen the inspection's result (always True for a host-made plan)?  Never blocks."""
+        return int(load().rsp_column_sums_plan_ready(self._h)) == 1
+
+    def wait(self) -> "ColumnSumsPlan":
+        _check(load().rsp_column_sums_plan_wait(self._h))
+        return self
+
+    def image(self, what: int) -> np.ndarray:
+        """The plan's image as the device holds it (rsp_debug_plan_image): what = 0 the snapped records, 1 the lean
+        headers + 16-bit offsets; uint32 words, empty when the plan has no such image."""
+        n = ctypes.c_size_t(0)
+        _check(load().rsp_debug_plan_image(self._h, int(what), None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value // 4, dtype=np.uint32)
+        if n.value:
+            _check(load().rsp_debug_plan_image(self._h, int(what), out.ctypes.data, out.nbytes, ctypes.byref(n)))
+        return out
 
     def column_sums(self, x_t, p_t, out_t=None, workspace=None, stream=None, nrow_for_means: int = 0):
         import torch
         assert x_t.numel() == self.nnz and p_t.numel() == self.ncol + 1
         if out_t is None:
             out_t = torch.empty(self.ncol, dtype=torch.float64, device=x_t.device)
-        if workspace is None and not self.snapped:
+        # (a device-made plan whose result has not been looked at yet may still answer with the general kernels)
+        info = self.__dict__.get("_info")
+        if workspace is None and (info is None or not info["snapped"]):
             workspace = alloc_workspace(self.ncol, self.nnz, x_t.device)
         _check(load().rsp_column_sums_planned_device(
             self._h, x_t.data_ptr(), p_t.data_ptr(), self.ncol, self.nnz, int(nrow_for_means), out_t.data_ptr(),

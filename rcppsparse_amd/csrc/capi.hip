@@ -326,6 +326,14 @@ struct rsp_colsums_plan {
     // columns form (every column long and of similar length): no records at all, one workgroup per column
     bool columns;
     int32_t columns_waves, columns_min, columns_max;
+    // device-made plan (rsp_column_sums_plan_create_device): the inspection runs as kernels on the caller's stream and
+    // its statistics land in a page-locked host record; until the host has SEEN them (`known`) calls take the general
+    // kernels, afterwards the form they select.  d_rec / d_lean_hdr then point into d_mem.
+    bool device_built, known;
+    void* d_mem;
+    rsp::DeviceInspectLayout dl;
+    rsp::PlanStats* h_stats;
+    hipEvent_t ev_begin, ev_end;
 };
 
 struct rsp_csc {
@@ -556,6 +564,99 @@ int rsp_column_sums_plan_create(const int32_t* p, int32_t ncol, int64_t nnz, int
     return RSP_OK;
 }
 
+// ---- the same plans for offsets that live in HBM: inspected ON THE DEVICE, on the caller's stream ----------------
+// Sizes of the plan memory depend on ncol, nnz and the settings only (never on the offsets' values): the records of
+// the planned chunk grid, and -- when the mean column length leaves the lean form possible at all -- the lean grid's
+// first columns and an image with room for `capacity` columns per chunk (three times the mean + 16, at least 126;
+// a matrix with a denser chunk than that keeps the other forms).
+static rsp::DeviceInspectLayout device_plan_layout(int32_t ncol, int64_t nnz, const rsp::LaunchPlan& lp) {
+    rsp::DeviceInspectLayout L{};
+    size_t off = 0;
+    auto take = [&off](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    L.stats_off = take(sizeof(rsp::PlanStats));
+    L.rec_off = take(((size_t)lp.nchunks + 1) * sizeof(int2));
+    L.try_lean = lean_allowed() && nnz <= (int64_t)ncol * rsp::kLeanMaxColumn;
+    if (L.try_lean) {
+        L.lean_rows = lean_rows_setting(ncol, nnz);
+        const int64_t chunk = (int64_t)L.lean_rows * rsp::kRowElems;
+        const int64_t nchunks = (nnz + chunk - 1) / chunk;
+        if (nchunks <= 0 || nchunks > INT32_MAX / 4) {
+            L.try_lean = false;
+        } else {
+            L.lean_chunks = (int32_t)nchunks;
+            const int64_t mean = ((int64_t)ncol + nchunks - 1) / nchunks;
+            int64_t cap = 3 * mean + 16;
+            cap = cap < 126 ? 126 : (cap > rsp::kLeanMaxColumns ? rsp::kLeanMaxColumns : cap);
+            L.lean_capacity = (int32_t)cap;
+            L.lean_capacity_stride = rsp::inspect::lean_stride_dwords(L.lean_capacity);
+            L.first_off = take(((size_t)nchunks + 1) * 4);
+            L.hdr_off = take((size_t)nchunks * sizeof(int2) + (size_t)nchunks * (size_t)L.lean_capacity_stride * 4);
+        }
+    }
+    L.bytes = off;
+    return L;
+}
+
+// The statistics have arrived: choose the form exactly as plan_make does from a host copy of p[].
+static void plan_finalize(rsp_colsums_plan* pl) {
+    const rsp::PlanStats& st = *pl->h_stats;
+    pl->known = true;
+    pl->snapped = pl->lean = pl->columns = false;
+    pl->max_skip = st.max_skip;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pl->ev_begin, pl->ev_end) == hipSuccess) pl->inspect_ms = (double)ms;   // device time of the inspection
+    else (void)hipGetLastError();
+    if (st.invalid) return;   // not a dgCMatrix's offsets: the general kernels (in bounds for any p[]) stay
+    const int32_t min_len = INT32_MAX - st.inv_min_len, max_len = st.max_len;
+    if (pl->dl.try_lean && !st.lean_bad && max_len <= rsp::kLeanMaxColumn && st.lean_widest <= rsp::kLeanMaxColumns) {
+        pl->lean = pl->snapped = true;
+        pl->max_skip = 0;
+        pl->lean_rows = pl->dl.lean_rows;
+        pl->lean_chunks = pl->dl.lean_chunks;
+        pl->lean_max_columns = st.lean_widest;
+        pl->lean_stride_dwords = rsp::inspect::lean_stride_dwords(st.lean_widest);
+        pl->d_lean_hdr = (int2*)((char*)pl->d_mem + pl->dl.hdr_off);
+        pl->d_lean_offs = (uint32_t*)(pl->d_lean_hdr + pl->lean_chunks);
+        return;
+    }
+    pl->snapped = st.max_skip <= rsp::kGroupElems;
+    if (!pl->snapped && columns_allowed() && pl->ncol >= rsp::kColumnsMinColumns) {
+        const int64_t mean = pl->nnz / pl->ncol;
+        const bool similar = max_len <= rsp::kColumnsMaxLen && (int64_t)max_len <= rsp::kColumnsMaxOverMean * mean;
+        const bool long_columns = min_len >= rsp::kColumnsMinLen;
+        const bool mid_columns = min_len >= rsp::kColumnsMinLenTwoWaves && pl->nnz <= rsp::kColumnsTwoWavesMaxNnz;
+        if (similar && (long_columns || mid_columns)) {
+            pl->columns = pl->snapped = true;
+            pl->columns_min = min_len;
+            pl->columns_max = max_len;
+            pl->columns_waves = long_columns ? columns_waves_setting(pl->ncol, mean) : 2;
+        }
+    }
+    if (pl->snapped && !pl->columns) pl->d_rec = (int2*)((char*)pl->d_mem + pl->dl.rec_off);
+}
+
+// Non-blocking look at a device-made plan's statistics (block: wait for them).  Never called on a capturing stream's
+// behalf with anything but a query the capture cannot see: while `stream` is being captured the look is skipped.
+static int plan_poll(rsp_colsums_plan* pl, hipStream_t stream, bool block) {
+    if (!pl->device_built || pl->known) return RSP_OK;
+    if (!block) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+        if (cs != hipStreamCaptureStatusNone) return RSP_OK;
+        const hipError_t q = hipEventQuery(pl->ev_end);
+        if (q == hipErrorNotReady) return RSP_OK;
+        if (q != hipSuccess) return fail(RSP_ERR_HIP, "plan inspection failed: %s", hipGetErrorString(q));
+    } else {
+        HIP_TRY(hipEventSynchronize(pl->ev_end));
+    }
+    plan_finalize(pl);
+    return RSP_OK;
+}
+
 int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t nnz, void* stream,
                                        rsp_colsums_plan_t* plan) {
     if (!plan) return fail(RSP_ERR_BAD_ARG, "plan is null");
@@ -564,14 +665,73 @@ int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t
     if (!d_p) return fail(RSP_ERR_BAD_ARG, "d_p is null");
     int device = 0;
     HIP_TRY(hipGetDevice(&device));
-    try {
-        std::vector<int32_t> host((size_t)ncol + 1);
-        HIP_TRY(hipMemcpyAsync(host.data(), d_p, host.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        return rsp_column_sums_plan_create(host.data(), ncol, nnz, device, plan);
-    } catch (...) {
-        return fail(RSP_ERR_ALLOC, "out of host memory while planning");
+    rsp_colsums_plan* pl = new (std::nothrow) rsp_colsums_plan();
+    if (!pl) return fail(RSP_ERR_ALLOC, "out of host memory");
+    pl->device = device;
+    pl->ncol = ncol;
+    pl->nnz = nnz;
+    if (ncol <= 0 || nnz <= 0) {   // nothing to plan: the general entry handles these shapes
+        pl->lp = make_plan(nnz);
+        *plan = pl;
+        return RSP_OK;
     }
+    const auto t0 = std::chrono::steady_clock::now();
+    pl->lp = make_plan(nnz, true);
+    pl->device_built = true;
+    pl->dl = device_plan_layout(ncol, nnz, pl->lp);
+    hipError_t e = hipMalloc(&pl->d_mem, pl->dl.bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&pl->h_stats, sizeof(rsp::PlanStats), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev_end);
+    hipStream_t s = (hipStream_t)stream;
+    if (e == hipSuccess) e = hipEventRecord(pl->ev_begin, s);
+    if (e == hipSuccess) e = rsp::launch_inspect_device(d_p, ncol, (int32_t)nnz, pl->lp, pl->dl, pl->d_mem, s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(pl->h_stats, (char*)pl->d_mem + pl->dl.stats_off, sizeof(rsp::PlanStats), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipEventRecord(pl->ev_end, s);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (pl->ev_end) (void)hipStreamSynchronize(s);   // (whatever was enqueued has to be done before its memory goes)
+        rsp_column_sums_plan_destroy(pl);
+        return fail(RSP_ERR_HIP, "device-side inspection could not be enqueued: %s", hipGetErrorString(e));
+    }
+    // (until the statistics have been seen: the host time of the enqueue; afterwards the device time of the kernels)
+    pl->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *plan = pl;
+    return RSP_OK;
+}
+
+int rsp_column_sums_plan_ready(rsp_colsums_plan_t plan) {
+    if (!plan) return -1;
+    if (plan->device_built && !plan->known) (void)plan_poll(plan, nullptr, false);
+    return (!plan->device_built || plan->known) ? 1 : 0;
+}
+
+int rsp_column_sums_plan_wait(rsp_colsums_plan_t plan) {
+    if (!plan) return fail(RSP_ERR_BAD_ARG, "null plan");
+    return plan_poll(plan, nullptr, true);
+}
+
+int rsp_debug_plan_image(rsp_colsums_plan_t plan, int what, void* host, size_t capacity, size_t* bytes) {
+    if (!plan || !bytes) return fail(RSP_ERR_BAD_ARG, "null plan or size");
+    if (int rc = plan_poll(plan, nullptr, true)) return rc;
+    const void* src = nullptr;
+    size_t n = 0;
+    if (what == 0 && plan->snapped && !plan->lean && !plan->columns && plan->d_rec) {
+        src = plan->d_rec;
+        n = ((size_t)plan->lp.nchunks + 1) * sizeof(int2);
+    } else if (what == 1 && plan->lean && plan->d_lean_hdr) {
+        src = plan->d_lean_hdr;
+        n = (size_t)plan->lean_chunks * sizeof(int2) + (size_t)plan->lean_chunks * (size_t)plan->lean_stride_dwords * 4;
+    }
+    *bytes = n;
+    if (n == 0 || !host) return RSP_OK;   // (this plan has no such image / the caller only asked for the size)
+    if (capacity < n) return fail(RSP_ERR_BAD_ARG, "buffer too small: %zu < %zu bytes", capacity, n);
+    DeviceGuard on(plan->device);
+    HIP_TRY(on.error());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, src, n, hipMemcpyDeviceToHost));
+    return RSP_OK;
 }
 
 int rsp_set_lean(int on) {
@@ -581,6 +741,7 @@ int rsp_set_lean(int on) {
 
 int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t* info4, double* inspect_ms) {
     if (!plan || !info4) return fail(RSP_ERR_BAD_ARG, "null plan or output");
+    if (int rc = plan_poll(plan, nullptr, true)) return rc;   // (a device-made plan: wait for its inspection)
     info4[0] = plan->columns ? 3 : (plan->lean ? 2 : (plan->snapped ? 1 : 0));
     info4[1] = plan->columns ? plan->ncol : (plan->lean ? plan->lean_chunks : plan->lp.nchunks);
     info4[2] = plan->columns ? plan->columns_waves * 64 : (plan->lean ? plan->lean_rows * rsp::kRowElems : plan->lp.chunk_elems);
@@ -591,7 +752,14 @@ int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t* info4, double* i
 
 int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
     if (!plan) return RSP_OK;
-    if (plan->d_rec || plan->d_lean_hdr) {
+    if (plan->device_built) {   // (records and images live inside d_mem)
+        DeviceGuard on(plan->device);
+        if (plan->ev_end) (void)hipEventSynchronize(plan->ev_end);   // the inspection may still be writing
+        if (plan->d_mem) (void)hipFree(plan->d_mem);
+        if (plan->h_stats) (void)hipHostFree(plan->h_stats);
+        if (plan->ev_begin) (void)hipEventDestroy(plan->ev_begin);
+        if (plan->ev_end) (void)hipEventDestroy(plan->ev_end);
+    } else if (plan->d_rec || plan->d_lean_hdr) {
         DeviceGuard on(plan->device);
         if (plan->d_rec) (void)hipFree(plan->d_rec);
         if (plan->d_lean_hdr) (void)hipFree(plan->d_lean_hdr);   // (the offsets live behind the headers in the same allocation)
@@ -602,6 +770,12 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
 
 static int planned_enqueue(rsp_colsums_plan_t plan, const double* d_x, const int32_t* d_p, double* d_out,
                            void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+    if (plan->device_built && !plan->known) {
+        // a device-made plan whose inspection the host has not seen yet: look (no waiting); still unknown -> the
+        // general kernels answer this call (right for any matrix), the planned form takes over once it is known
+        if (int rc = plan_poll(plan, stream, false)) return rc;
+        if (!plan->known) return enqueue(d_x, d_p, plan->ncol, plan->nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
+    }
     if (plan->lean || plan->snapped) {   // the plan's records live in the HBM of the device it was made on
         int cur = -1;
         HIP_TRY(hipGetDevice(&cur));

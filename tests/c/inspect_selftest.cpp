@@ -140,6 +140,44 @@ static void check_lean(const std::vector<int32_t>& p, int32_t ncol, int32_t rows
     }
 }
 
+// The one-pass formulation (inspect_by_columns: what the device-side inspector's three kernels compute, executed index
+// by index on the host) against the two search-based inspectors: the same records wherever the plan is snapped (and the
+// same max_skip always), the same lean image / stride / widest wherever the lean form applies within the capacity, and
+// the same verdicts otherwise; an offsets array that is no dgCMatrix's is flagged.
+static void check_by_columns(const std::vector<int32_t>& p, int32_t ncol, const Grid& grid, int32_t rows,
+                             const LeanLimits& lim, int32_t capacity) {
+    const int64_t nnz = p[ncol];
+    std::vector<Rec> want_rec, rec;
+    int32_t want_skip = -1;
+    inspect_offsets(p.data(), ncol, nnz, grid, &want_rec, &want_skip);
+    std::vector<uint32_t> want_image, image;
+    int32_t want_chunks = -1, want_stride = -1, want_widest = -1, chunks = -1;
+    const bool want_lean = inspect_lean(p.data(), ncol, nnz, rows, lim, &want_image, &want_chunks, &want_stride, &want_widest);
+    Stats st;
+    inspect_by_columns(p.data(), ncol, nnz, grid, &rec, rows, lim, capacity, &image, &chunks, &st);
+    CHECK(st.invalid == 0, "a valid offsets array was flagged invalid");
+    CHECK(st.max_skip == want_skip, "one-pass max_skip %d, searches %d", st.max_skip, want_skip);
+    int32_t mx = 0, mn = INT_MAX;
+    for (int32_t c = 0; c < ncol; ++c) {
+        mx = std::max(mx, p[c + 1] - p[c]);
+        mn = std::min(mn, p[c + 1] - p[c]);
+    }
+    CHECK(st.max_len == mx && INT_MAX - st.inv_min_len == mn, "column lengths %d..%d, want %d..%d", INT_MAX - st.inv_min_len, st.max_len, mn, mx);
+    if (want_skip <= 512) {   // a snapped plan: its records are used, so they have to be the searches' records
+        CHECK(rec.size() == want_rec.size(), "record count");
+        for (size_t w = 0; w < rec.size() && w < want_rec.size(); ++w)
+            CHECK(rec[w].a == want_rec[w].a && rec[w].b == want_rec[w].b, "record %zu: {%d, %d}, want {%d, %d}", w, rec[w].a,
+                  rec[w].b, want_rec[w].a, want_rec[w].b);
+    }
+    const bool lean = !st.lean_bad && st.max_len <= lim.max_column && st.lean_widest <= lim.max_columns;
+    const bool within = want_lean && want_widest <= capacity;
+    CHECK(lean == within, "one-pass lean verdict %d, searches %d (widest %d, capacity %d)", (int)lean, (int)want_lean, want_widest, capacity);
+    if (lean && within) {
+        CHECK(chunks == want_chunks && st.lean_widest == want_widest, "lean chunks %d / widest %d, want %d / %d", chunks, st.lean_widest, want_chunks, want_widest);
+        CHECK(image == want_image, "lean image differs (%zu words, want %zu)", image.size(), want_image.size());
+    }
+}
+
 int main(int argc, char** argv) {
     const int cases = argc > 1 ? std::atoi(argv[1]) : 1500;
     std::mt19937_64 g(12345);
@@ -166,6 +204,24 @@ int main(int argc, char** argv) {
         check_snapped(p, ncol, grid);
         static const int rows_choices[] = {2, 3, 4, 5, 6, 8, 12, 16};
         check_lean(p, ncol, rows_choices[g() % 8], lim, x);
+        {
+            static const int caps[] = {126, 200, 1278, 8, 40};
+            check_by_columns(p, ncol, grid, rows_choices[g() % 8], lim, caps[g() % 5]);
+            // the same array made invalid in one place: the one-pass inspector has to notice
+            if (ncol >= 3 && k % 7 == 0) {
+                std::vector<int32_t> q = p;
+                const int kind = (int)(g() % 3);
+                if (kind == 0) q[0] = 1;
+                else if (kind == 1) q[ncol] = q[ncol] + 1;
+                else { const size_t at = 1 + (size_t)(g() % (uint64_t)(ncol - 1)); q[at] = q[at + 1] + 1 + (int32_t)(g() % 5); }
+                std::vector<Rec> r2;
+                std::vector<uint32_t> im2;
+                int32_t ch2 = 0;
+                Stats st2;
+                inspect_by_columns(q.data(), ncol, nnz, grid, &r2, 4, lim, 126, &im2, &ch2, &st2);
+                CHECK(st2.invalid == 1, "an invalid offsets array (kind %d) was not flagged", kind);
+            }
+        }
         // a chunk holding exactly max_columns column starts, and one more
         if (k % 50 == 0) {
             for (int extra = 0; extra < 2; ++extra) {
@@ -175,6 +231,9 @@ int main(int argc, char** argv) {
                 for (int c = 0; c < 300; ++c) q.push_back(q.back() + 3);
                 std::vector<double> y((size_t)q.back(), 0.5);
                 check_lean(q, (int32_t)q.size() - 1, 8, lim, y);
+                const int32_t qn = (int32_t)q.size() - 1;
+                const Grid qg{1024, (q.back() + 1023) / 1024, 1024, (q.back() + 1023) / 1024};
+                check_by_columns(q, qn, qg, 8, lim, lim.max_columns);
             }
         }
     }

@@ -816,6 +816,180 @@ def test_planned_entry_is_graph_capture_safe(torch_cuda, form):
     plan.close()
 
 
+# ------------------------------------------------------------- device-side inspector
+def _plan_shapes():
+    rng = np.random.default_rng(21)
+    shapes = {
+        "c2_like": rng.poisson(10, 200_000),
+        "short_with_empties": np.where(rng.random(150_000) < 0.3, 0, rng.integers(1, 40, 150_000)),
+        "runs_of_empties": np.concatenate([np.zeros(5_000), rng.integers(1, 12, 30_000), np.zeros(70_000), rng.integers(1, 12, 30_000),
+                                           np.zeros(3_000)]),
+        "all_ones": np.ones(300_000),
+        "len_64_exactly": np.full(20_000, 64),
+        "one_column_of_65": np.concatenate([np.full(9_000, 20), [65], np.full(9_000, 20)]),
+        "medium_snapped": rng.integers(70, 200, 30_000),
+        "into_512": np.full(3_000, 1024 + 512),
+        "long_unsnapped": rng.integers(600, 5_000, 3_000),
+        "vignette_like": rng.integers(9_000, 11_000, 1_000),
+        "mid_columns_two_waves": rng.integers(520, 1_900, 20_000),
+        "zipf": synth.zipf_counts(40_000, 3_000_000, seed=5, nrow=1_000_000),
+        "dense_chunk_beyond_capacity": np.concatenate([np.full(40_000, 12), np.zeros(900), np.full(40_000, 12)]),
+        "single_column": np.array([700_001]),
+        "two_entries": np.array([1, 1]),
+    }
+    return {k: np.asarray(v, dtype=np.int64) for k, v in shapes.items()}
+
+
+PLAN_SHAPES = _plan_shapes()
+
+
+@pytest.mark.parametrize("shape", sorted(PLAN_SHAPES))
+@pytest.mark.parametrize("chunk_rows", [0, 3])
+def test_device_made_plan_equals_the_host_made_plan_bit_for_bit(torch_cuda, shape, chunk_rows):
+    """rsp_column_sums_plan_create_device inspects p[] with kernels on the caller's stream (inspect_device.hip: one pass
+    with a thread per column instead of a search per chunk) and never shows it to the host.  Same form, same sizes,
+    same max_skip, and the same IMAGE in HBM -- the snapped records, or the lean headers + 16-bit offsets at the same
+    stride -- as the host inspector (inspect.hpp) makes from a host copy, bit for bit; then the same sums.  The one
+    documented difference: a chunk with more columns than the device-made image has room for (sized before p[] is
+    seen) keeps that plan out of the lean form."""
+    torch = torch_cuda
+    capi.set_tuning(chunk_rows)
+    try:
+        counts = PLAN_SHAPES[shape]
+        p = synth.offsets_from_counts(counts)
+        nnz = int(p[-1])
+        x = synth.gen_values(nnz, seed=9, kind=0)
+        xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+        host = capi.ColumnSumsPlan(p, nnz=nnz)
+        dev = capi.ColumnSumsPlan(pt, nnz=nnz)
+        assert dev.device_made and not host.device_made
+        dev.wait()
+        assert dev.ready()
+        if shape == "dense_chunk_beyond_capacity":
+            assert host.lean and not dev.lean and dev.snapped           # 900 empty columns in one chunk > 3 x mean + 16
+        else:
+            assert (dev.form, dev.nchunks, dev.chunk_elems, dev.max_skip) == (host.form, host.nchunks, host.chunk_elems, host.max_skip), shape
+            for what in (0, 1):
+                a, b = host.image(what), dev.image(what)
+                assert a.shape == b.shape and a.tobytes() == b.tobytes(), (shape, what)
+            assert (host.image(0).size > 0) == (host.form == 1) and (host.image(1).size > 0) == (host.form == 2)
+        got_h = host.column_sums(xt, pt).cpu().numpy()
+        got_d = dev.column_sums(xt, pt).cpu().numpy()
+        if shape != "dense_chunk_beyond_capacity":
+            assert got_h.tobytes() == got_d.tobytes()
+        assert_parity(got_d, x, p)
+        assert dev.inspect_ms < 5.0                                     # device time of the inspection (kernels only)
+        host.close()
+        dev.close()
+    finally:
+        capi.set_tuning(0)
+
+
+def test_device_made_plan_never_blocks_and_is_right_before_it_is_known(torch_cuda):
+    """Nothing in plan_create_device or in a planned call waits for the inspection.  With the stream kept busy (16 GB of
+    values generated ahead of the inspection) the plan is provably not known when the first calls are enqueued: they
+    answer with the general kernels (bit-identical to rsp_column_sums_device); once the host has seen the statistics the
+    same entry runs the lean form (reference bits)."""
+    torch = torch_cuda
+    counts = np.random.default_rng(3).poisson(9, 400_000)
+    p = synth.offsets_from_counts(counts)
+    nnz = int(p[-1])
+    x = synth.gen_values(nnz, seed=4, kind=0)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    general = capi.column_sums_device(xt, pt).cpu().numpy()
+    ballast = torch.empty(2_000_000_000, dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        capi.gen_values_device(ballast, seed=1, stream=s)              # milliseconds of work ahead of the inspection
+        plan = capi.ColumnSumsPlan(pt, nnz=nnz, stream=s)
+        early_ready = plan.ready()
+        ws = capi.alloc_workspace(len(counts), nnz)
+        first = plan.column_sums(xt, pt, workspace=ws, stream=s).clone()
+    assert not early_ready                                             # (the host got here long before the device did)
+    s.synchronize()
+    assert plan.ready() and plan.lean
+    assert first.cpu().numpy().tobytes() == general.tobytes()           # the general kernels answered the early call
+    with torch.cuda.stream(s):
+        later = plan.column_sums(xt, pt, workspace=ws, stream=s)
+    s.synchronize()
+    assert later.cpu().numpy().tobytes() == oracle.column_sums(x, p).tobytes()   # lean form: the reference's bits
+    plan.close()
+    del ballast
+
+
+@pytest.mark.parametrize("form", ["lean", "snapped", "columns"])
+def test_device_made_plan_is_graph_capture_safe_once_known(torch_cuda, form):
+    """A capture records the form known at that moment and looks at nothing itself (no event query inside a capture):
+    wait() first, then the captured planned call is ONE launch, and a replay reproduces the bits."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4)
+    counts = {"lean": rng.integers(0, 30, 40_000), "snapped": rng.integers(70, 200, 6_000),
+              "columns": rng.integers(3_000, 9_000, 200)}[form].astype(np.int64)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=6, kind=0)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    plan = capi.ColumnSumsPlan(pt, nnz=int(p[-1])).wait()
+    assert {2: "lean", 1: "snapped", 3: "columns"}[plan.form] == form
+    out = torch.zeros(len(counts), dtype=torch.float64, device="cuda")
+    eager = plan.column_sums(xt, pt, out.clone()).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.column_sums(xt, pt, out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    assert_parity(out.cpu().numpy(), x, p)
+    plan.close()
+
+
+def test_device_made_plan_notices_offsets_that_are_not_a_dgcmatrix(torch_cuda):
+    """The host entry rejects such a p[] (RSP_ERR_BAD_ARG); the device inspection cannot return a status, so it flags
+    the plan instead: it stays on the general kernels, whose reads and writes are in bounds for any p[]."""
+    torch = torch_cuda
+    counts = np.random.default_rng(8).poisson(9, 50_000)
+    p = synth.offsets_from_counts(counts)
+    nnz = int(p[-1])
+    xt = torch.from_numpy(synth.gen_values(nnz, seed=2, kind=0)).cuda()
+    for kind in ("first_not_zero", "decreasing", "last_not_nnz"):
+        q = p.copy()
+        if kind == "first_not_zero":
+            q[0] = 3
+        elif kind == "decreasing":
+            q[20_000] = q[20_001] + 7
+        else:
+            q[-1] -= 2
+        with pytest.raises(capi.RspError):
+            capi.ColumnSumsPlan(q, nnz=nnz)
+        qt = torch.from_numpy(q).cuda()
+        plan = capi.ColumnSumsPlan(qt, nnz=nnz).wait()
+        assert plan.form == 0, kind
+        out = plan.column_sums(xt, qt)
+        torch.cuda.synchronize()
+        assert out.shape == (len(counts),)
+        plan.close()
+
+
+def test_planned_entry_checks_the_sizes_it_is_called_with(torch_cuda):
+    """the lean form never reads d_p and trusts the plan's sizes; a matrix of another shape now fails
+    with RSP_ERR_BAD_ARG before anything is launched."""
+    torch = torch_cuda
+    import ctypes
+    p = synth.offsets_from_counts(np.full(10_000, 9, dtype=np.int64))
+    plan = capi.ColumnSumsPlan(p)
+    assert plan.lean
+    xt = torch.zeros(int(p[-1]), dtype=torch.float64, device="cuda")
+    pt = torch.from_numpy(p).cuda()
+    out = torch.zeros(10_000, dtype=torch.float64, device="cuda")
+    L = capi.load()
+    for ncol, nnz in ((9_999, int(p[-1])), (10_000, int(p[-1]) - 8), (10_000, int(p[-1]) + 1)):
+        rc = L.rsp_column_sums_planned_device(plan._h, xt.data_ptr(), pt.data_ptr(), ncol, nnz, 0, out.data_ptr(), None, 0,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == capi.RSP_ERR_BAD_ARG and b"this plan was made for" in L.rsp_last_error()
+    plan.close()
+
+
 def test_handles_do_not_leak_device_memory(torch_cuda):
     torch = torch_cuda
     m = synth.rsparsematrix(20_000, 3_000, density=0.01, seed=3)
