@@ -577,7 +577,8 @@ static rsp::DeviceInspectLayout device_plan_layout(int32_t ncol, int64_t nnz, co
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    L.stats_off = take(sizeof(rsp::PlanStats));
+    L.part1_off = take(rsp::kInspectMaxBlocksColumns * sizeof(int4));
+    L.part2_off = take(rsp::kInspectMaxBlocksChunks * sizeof(int2));
     L.rec_off = take(((size_t)lp.nchunks + 1) * sizeof(int2));
     L.try_lean = lean_allowed() && nnz <= (int64_t)ncol * rsp::kLeanMaxColumn;
     if (L.try_lean) {
@@ -685,9 +686,8 @@ int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t
     if (e == hipSuccess) e = hipEventCreate(&pl->ev_end);
     hipStream_t s = (hipStream_t)stream;
     if (e == hipSuccess) e = hipEventRecord(pl->ev_begin, s);
-    if (e == hipSuccess) e = rsp::launch_inspect_device(d_p, ncol, (int32_t)nnz, pl->lp, pl->dl, pl->d_mem, s);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(pl->h_stats, (char*)pl->d_mem + pl->dl.stats_off, sizeof(rsp::PlanStats), hipMemcpyDeviceToHost, s);
+    // (the last kernel writes the statistics straight into the page-locked host record: no copy, no memset)
+    if (e == hipSuccess) e = rsp::launch_inspect_device(d_p, ncol, (int32_t)nnz, pl->lp, pl->dl, pl->d_mem, pl->h_stats, s);
     if (e == hipSuccess) e = hipEventRecord(pl->ev_end, s);
     if (e != hipSuccess) {
         (void)hipGetLastError();

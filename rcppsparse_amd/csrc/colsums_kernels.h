@@ -101,15 +101,17 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               const int32_t* run_if = nullptr);
 
 // ---- device-side inspector (inspect_device.hip): the plans of inspect.hpp for offsets that live in HBM ----
+constexpr int kInspectMaxBlocksColumns = 1024;   // blocks of the pass over p[] (grid-stride): one partial record each
+constexpr int kInspectMaxBlocksChunks = 256;     // blocks of the pass over the lean chunks
 typedef inspect::Stats PlanStats;   // (inspect.hpp: shared with the host restatement of the same pass)
 struct DeviceInspectLayout {   // the plan memory of a device-made plan (byte offsets, 256-aligned); sizes depend on ncol, nnz and the settings only
-    size_t stats_off, rec_off, first_off, hdr_off, bytes;
+    size_t part1_off, part2_off, rec_off, first_off, hdr_off, bytes;   // part1 / part2: the blocks' partial statistics
     bool try_lean;             // mean column length <= kLeanMaxColumn: otherwise some column is too long for the lean form
     int32_t lean_rows, lean_chunks;
     int32_t lean_capacity, lean_capacity_stride;   // columns per chunk the image has room for, and that stride in dwords
 };
 hipError_t launch_inspect_device(const int32_t* d_p, int32_t ncol, int32_t nnz, const LaunchPlan& grid,
-                                 const DeviceInspectLayout& L, void* d_mem, hipStream_t stream);
+                                 const DeviceInspectLayout& L, void* d_mem, PlanStats* stats_out, hipStream_t stream);
 
 // the main kernel's access shape without any column work (rsp_debug_read_ceiling_device)
 hipError_t launch_read_ceiling(const double* d_x, int32_t nnz, const LaunchPlan& plan, double* d_sink,
