@@ -120,6 +120,14 @@ def parse_args(argv=None):
                     help="--rendezvous gloo only: also take the C-ABI communicator through its multi-rank "
                          "bootstrap (unique id from rank 0, rsp_comm_init on every rank).  With ranks sharing a "
                          "device RCCL must refuse it; the refusal is recorded in config.comm_init_rehearsal")
+    ap.add_argument("--op", default="colsums", choices=["colsums", "rowsums"],
+                    help="colsums (default): the headline path.  rowsums: Matrix::rowSums (reference RcppSparse.h:138-144) over "
+                         "the same column-range shards -- every rank sums the rows of ITS columns (rsp_row_sums_device) and "
+                         "the partial vectors of nrow doubles are reduced in rank order to rank 0 (rsp_comm_reduce_rows over "
+                         "RCCL; over gloo in the rehearsal).  Its line carries metric 'rowSums nnz/s ...': a next-row figure, "
+                         "never the headline")
+    ap.add_argument("--no-planned-shards", action="store_true", help="N > 1: skip the separate planned_shards figure")
+    ap.add_argument("--no-direct-gather", action="store_true", help="N > 1: skip the separate direct_gather figure")
     ap.add_argument("--also", default="auto",
                     help="N = 1: more single-GPU workloads measured after the headline one, OUTSIDE its timed region, "
                          "as compact sub-records under the key `also` (never part of `value`).  auto = every other "
@@ -392,6 +400,296 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
     return rec
 
 
+def timed_steps(torch, dist, world, stat_dev, fence, steps, step_fn):
+    """K calls of step_fn back to back between two fences; the MAX over ranks of the wall time."""
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    fence()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=stat_dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el[0])
+
+
+def planned_shards_figure(ctx):
+    """N > 1, separate key: every rank inspects ITS shard's offsets once (a ColumnSumsPlan on p_local: at C4 shard
+    size the columns form, one launch per call instead of main kernel + fix-up) and the same protocol as `value` runs
+    again -- planned launch, then that call's gather, in order on one stream.  Never feeds `value`."""
+    torch, dist, capi, sharded = ctx["torch"], ctx["dist"], ctx["capi"], ctx["sharded"]
+    args, shard, world, rank = ctx["args"], ctx["shard"], ctx["world"], ctx["rank"]
+    plan = capi.ColumnSumsPlan(shard.p_local, nnz=shard.nnz, device=ctx["dev_index"])
+    xs, pt, out, ws, s_main = ctx["xs"], ctx["pt"], ctx["out_main"], ctx["ws_main"], ctx["s_main"]
+    launches = [plan.prepared(xk, pt, out, ws, stream=s_main) for xk in xs]
+    n = [0]
+
+    def compute(_shard):
+        launches[n[0] % len(launches)]()
+        n[0] += 1
+        return out
+    driver = sharded.ShardedColumnSums(shard, compute, ctx["new_gather"](s_main))
+    recv = ctx["recv"]
+    for _ in range(args.warmup):
+        driver.step(recv)
+    elapsed = timed_steps(torch, dist, world, ctx["stat_dev"], ctx["fence"], args.steps, lambda: driver.step(recv))
+    n[0] = 0
+    driver.step(recv)
+    ctx["fence"]()
+    forms = [None] * world
+    mine = PLAN_FORMS[plan.form]
+    if world > 1:
+        dist.all_gather_object(forms, mine)
+    else:
+        forms = [mine]
+    fig = None
+    if rank == 0:
+        full = (recv if ctx["use_comm"] else out).cpu().numpy()
+        par = parity_whole_matrix(full, ctx["p"], args.kind)
+        fig = {"value": ctx["nnz"] * args.steps / elapsed, "unit": "nnz/s", "ms_per_step": elapsed / args.steps * 1e3,
+               "forms_by_rank": forms, "plan_ms_rank0": plan.inspect_ms,
+               "parity": {"max_abs_err_over_l1": par["max_abs_err_over_l1"],
+                          "columns_out_of_tolerance": par["columns_out_of_tolerance"], "columns_checked": "all"},
+               "protocol": "the protocol of `value` with every rank's launches going through a plan of its own shard "
+                           "(inspected once, outside the timed region); NOT `value`"}
+    plan.close()
+    return fig
+
+
+def direct_gather_figure(ctx):
+    """N > 1, separate key: the direct-write comparator of the gatherv.  Rank 0 exports its result
+    buffer (rsp_shared_result_alloc: hipIpcGetMemHandle), the other rank processes map it, and every rank's kernels take
+    `mapped + displacement` as their output pointer: the exchange is the kernels' own result stores over xGMI plus one
+    fence per call (every rank waits for its stream, then the ranks cross a shared-memory barrier).  Never `value`."""
+    torch, dist, capi = ctx["torch"], ctx["dist"], ctx["capi"]
+    args, shard, world, rank = ctx["args"], ctx["shard"], ctx["world"], ctx["rank"]
+    ncol, displs, s_main = ctx["ncol"], ctx["displs"], ctx["s_main"]
+    note = None
+    try:
+        box = [None, None]
+        if rank == 0:
+            shared = capi.SharedResult(ncol)
+            box = [shared.handle, f"/rsp_bench_{os.getpid()}"]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        if rank != 0:
+            shared = capi.SharedResult(ncol, handle=box[0])
+        barrier = capi.HostBarrier(box[1], world, rank)
+    except Exception as e:                      # e.g. IPC not offered by this host: say so, measure nothing
+        note = f"not measured: {e}"
+        ok = torch.tensor([0.0], device=ctx["stat_dev"])
+    else:
+        ok = torch.tensor([1.0], device=ctx["stat_dev"])
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok[0]) == 0.0:
+        notes = [None] * world
+        if world > 1:
+            dist.all_gather_object(notes, note)
+        return {"value": None, "note": [n for n in notes if n] or [note]} if rank == 0 else None
+
+    class Out:                                   # what the prepared launcher needs of an output tensor
+        def __init__(self, ptr):
+            self._p = ptr
+
+        def data_ptr(self):
+            return self._p
+    out = Out(shared.ptr + 8 * int(displs[rank]))
+    launches = [capi.prepared_column_sums(xk, ctx["pt"], out, ctx["ws_main"], stream=s_main) for xk in ctx["xs"]]
+    n = [0]
+
+    def step():
+        launches[n[0] % len(launches)]()
+        n[0] += 1
+        s_main.synchronize()                      # this rank's slice is complete in the root's memory ...
+        barrier.wait()                            # ... and after the barrier every rank's is
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_steps(torch, dist, world, ctx["stat_dev"], ctx["fence"], args.steps, step)
+    n[0] = 0
+    step()
+    fig = None
+    if rank == 0:
+        par = parity_whole_matrix(shared.read(stream=s_main), ctx["p"], args.kind)
+        fig = {"value": ctx["nnz"] * args.steps / elapsed, "unit": "nnz/s", "ms_per_step": elapsed / args.steps * 1e3,
+               "parity": {"max_abs_err_over_l1": par["max_abs_err_over_l1"],
+                          "columns_out_of_tolerance": par["columns_out_of_tolerance"], "columns_checked": "all"},
+               "protocol": "every rank's kernels store into rank 0's result buffer (mapped with hipIpcOpenMemHandle) at the "
+                           "rank's displacement; per call: launch, wait for the own stream, cross a shared-memory barrier; "
+                           "NOT the protocol of `value` (its calls are never waited for by the host)"}
+    barrier.wait()
+    barrier.close()
+    if rank != 0:
+        shared.close()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        shared.close()
+    return fig
+
+
+def main_rowsums(args):
+    """bench.py --op rowsums: Matrix::rowSums (reference RcppSparse.h:138-144) over column-range shards.  A step = every rank
+    sums the rows of its own columns (rsp_row_sums_device: nrow doubles) and the partial vectors are reduced IN RANK ORDER to
+    rank 0 (rsp_comm_reduce_rows: all-to-all of row slices over xGMI, one add kernel, gatherv).  Same timing protocol as the
+    headline path; parity = every row against the oracle's scatter loop over the whole matrix."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rcppsparse_amd import capi, sharded
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    rehearsal = args.rendezvous == "gloo"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    stat_dev = torch.device("cpu") if rehearsal else dev
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo") if rehearsal else dist.init_process_group("nccl", device_id=dev)
+    capi.load()
+    nrow, ncol, nnz, shape, p = build_offsets(args.workload, args.nnz)
+    shard = sharded.make_shard(p, rank, world, balance=args.partition)
+    # this rank's slices of x and i, generated in HBM (the row generator hashes the GLOBAL element index, so the rows are
+    # those of the whole matrix: they are made from the global offsets and the shard's part is kept)
+    x = torch.empty(shard.nnz, dtype=torch.float64, device=dev)
+    capi.gen_values_device(x, SEED, shard.x0, args.kind)
+    pg = torch.from_numpy(np.ascontiguousarray(p)).to(dev)
+    i_all = torch.empty(nnz, dtype=torch.int32, device=dev)
+    capi.gen_row_indices_device(i_all, pg, nrow, SEED)
+    i_loc = i_all[shard.x0:shard.x1].clone()
+    del i_all, pg
+    torch.cuda.empty_cache()
+    partial = torch.empty(nrow, dtype=torch.float64, device=dev)
+    result = torch.empty(nrow, dtype=torch.float64, device=dev) if rank == 0 else None
+    nbytes = int(capi.load().rsp_row_sums_workspace_bytes(nrow, shard.nnz))
+    if nbytes == 0:
+        raise SystemExit("rsp_row_sums_workspace_bytes failed")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    s_main = torch.cuda.Stream()
+    torch.cuda.set_stream(s_main)
+    comm = None
+    if world > 1 and not rehearsal:
+        uid = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+        reduce = sharded.RcclReduceRows(comm, nrow, dev, 0, stream=s_main)
+    elif world > 1:
+        reduce = sharded.GlooReduceRows(dist, rank, world, 0)
+    else:
+        reduce = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def compute(_shard):
+        return capi.row_sums_device(x, i_loc, nrow, out_t=(partial if reduce is not None else result), workspace=ws,
+                                    stream=s_main)
+    mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    evs = []
+
+    def step(record=False):
+        e = (mk(), mk(), mk()) if record else None
+        if e:
+            e[0].record(s_main)
+        part = compute(shard)
+        if e:
+            e[1].record(s_main)
+        if reduce is not None:
+            reduce(part, result, 0)
+        if e:
+            e[2].record(s_main)
+            evs.append(e)
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_steps(torch, dist, world, stat_dev, fence, args.steps, step)
+    for _ in range(args.steps):                  # the kernel / reduce split, outside the timed region
+        step(record=True)
+    fence()
+    kernel_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
+    reduce_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)
+    mine = torch.tensor([shard.c0, shard.c1, shard.nnz, kernel_ms, reduce_ms], dtype=torch.float64, device=stat_dev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    out = None
+    if rank == 0:
+        got = result.cpu().numpy()
+        # the oracle's scatter loop over the whole matrix, column slab after column slab in storage order
+        import oracle
+        ref, scale = np.zeros(nrow), np.zeros(nrow)
+        p64 = np.asarray(p, dtype=np.int64)
+        c0 = 0
+        while c0 < ncol:
+            c1 = int(np.searchsorted(p64, p64[c0] + 40_000_000, side="right")) - 1
+            c1 = min(ncol, max(c1, c0 + 1))
+            lo, hi = int(p64[c0]), int(p64[c1])
+            if hi > lo:
+                xv = oracle.gen_values_threads(hi - lo, SEED, lo, args.kind, max(1, usable_cores()))
+                iv = oracle.gen_row_indices(p, nrow, SEED, c0, c1)
+                oracle.row_sums_accumulate(xv, iv, ref, scale)
+            c0 = c1
+        err = np.abs(got - ref)
+        nbad = int(np.count_nonzero(~(err <= 1e-12 * scale)))
+        nz = scale > 0
+        worst = float(np.max(err[nz] / scale[nz])) if nz.any() else 0.0
+        if nbad:
+            raise SystemExit(f"rowSums parity check failed: {nbad} rows out of tolerance (worst {worst:.3e})")
+        # one rank's launch: reads its x and i (12 B per entry), writes nrow sums
+        algo = 12 * shard.nnz + 8 * nrow
+        achieved = algo / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "rowSums nnz/s (next row f1: Matrix::rowSums over column-range shards, rank-ordered reduce)",
+            "value": nnz * args.steps / elapsed, "unit": "nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, rows "
+                                   f"ascending and distinct per column (stratified), values kind {args.kind}, seed {SEED}",
+                       "op": "rowsums",
+                       "parallelism": ("single GPU" if world == 1 else
+                                       f"REHEARSAL on {torch.cuda.device_count()} device(s): {world} ranks share them; the "
+                                       "partial vectors travel as host copies over gloo and are added in rank order on rank 0"
+                                       if rehearsal else
+                                       f"{world} nnz-balanced column ranges; partial row sums reduced in rank order "
+                                       "(rsp_comm_reduce_rows: all-to-all of row slices, add, gatherv) to rank 0"),
+                       "reduce": None if reduce is None else reduce.name,
+                       "rendezvous": args.rendezvous if world > 1 else None,
+                       "shards": [{"rank": r, "c0": int(t[0]), "c1": int(t[1]), "nnz": int(t[2]), "kernel_ms": float(t[3]),
+                                   "reduce_ms": float(t[4]) if world > 1 else None} for r, t in enumerate(per_rank)],
+                       "protocol": "K calls back to back; each call in order on one stream per rank: the row-sum kernels "
+                                   "of the shard, then (N > 1) that call's reduce"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "rsp_row_sums_device (histogram + partition + accumulate + combine) of rank 0's shard",
+                         "kernel_ms": kernel_ms, "reduce_ms": reduce_ms if world > 1 else None,
+                         "reduce_bytes_per_rank": None if world == 1 else 8 * nrow,
+                         "algorithmic_bytes_per_launch": algo,
+                         "kernel_timing": f"HIP events on the launch stream around the kernels (and the reduce) of each of "
+                                          f"{len(evs)} calls issued again right after the timed region"},
+            "parity": {"max_abs_err_over_l1": worst, "tolerance": 1e-12, "rows_checked": "all", "nrow": nrow,
+                       "rows_out_of_tolerance": nbad},
+        }
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
 def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev, shard, counts, displs,
                       recv):
     """The C-ABI communicator (rsp_comm_*), checked with a trial gatherv of a known pattern.  If it
@@ -466,6 +764,8 @@ def main(argv=None):
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
+    if args.op == "rowsums":
+        return main_rowsums(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -659,6 +959,17 @@ def main(argv=None):
                             "NOT the protocol of `value`"}
         del prepared, launches, outs, wss
 
+    # ------------------------------------------------------------------ N > 1: two more separate figures
+    ctx = {"torch": torch, "dist": dist, "capi": capi, "sharded": sharded, "args": args, "rank": rank, "world": world,
+           "dev": dev, "dev_index": dev_index, "stat_dev": stat_dev, "shard": shard, "counts": counts, "displs": displs,
+           "xs": xs, "pt": pt, "s_main": s_main, "fence": fence, "nnz": nnz, "ncol": ncol, "p": p, "recv": recv,
+           "use_comm": use_comm, "out_main": out_main, "ws_main": ws_main, "new_gather": new_gather}
+    planned_shards = direct_gather = None
+    if world > 1 and plan is None and not args.no_planned_shards:
+        planned_shards = planned_shards_figure(ctx)
+    if world > 1 and not args.no_direct_gather:
+        direct_gather = direct_gather_figure(ctx)
+
     stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=stat_dev)
     # what every rank owned and measured (rank order), so the line shows the whole partition
     mine = torch.tensor([shard.c0, shard.c1, shard.x0, shard.x1, kernel_ms, gather_ms, dev_index],
@@ -735,6 +1046,8 @@ def main(argv=None):
                         "protocol": "one call at a time: barrier, then host launch -> kernels -> gatherv -> stream "
                                     "synchronize on rank 0 (the gathered result is complete and the host has seen it)"},
             "pipelined": pipe,
+            "planned_shards": planned_shards,
+            "direct_gather": direct_gather,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,

@@ -440,6 +440,29 @@ int rsp_add_partials_device(const double *d_parts, int32_t nparts, int64_t strid
                             int32_t ncol_for_means, double *d_out, void *stream);
 int rsp_comm_destroy(rsp_comm_t comm);
 
+/* ---- direct-write gather (one process per GPU, one node): a comparator beside the RCCL gatherv ---------- */
+/*
+ * The root allocates its result buffer with rsp_shared_result_alloc and hands the 64-byte handle to the other rank
+ * processes (any channel: a torch.distributed broadcast, a file); they map it with rsp_shared_result_open and
+ * pass `mapped + displs[rank]` as d_sums to rsp_column_sums_device: their results are stored straight into the
+ * root's memory, over xGMI, as the kernels produce them -- no send / receive pair, no staging.  What remains of the
+ * exchange is one fence per call: every rank waits for its own stream, then the ranks cross a barrier
+ * (rsp_host_barrier_*: a page of POSIX shared memory, a microsecond or two); after it the root owns a complete
+ * vector.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment on hosts that offer dmabuf IPC only.
+ * rsp_shared_result_close: owner != 0 frees the root's allocation, 0 unmaps a rank's view.
+ */
+#define RSP_IPC_HANDLE_BYTES 64
+int rsp_shared_result_alloc(size_t bytes, void **d_ptr, void *handle_bytes);
+int rsp_shared_result_open(const void *handle_bytes, void **d_ptr);
+/* the gathered vector (or a part of it) into host memory -- the one D2H copy into the NumericVector; waits for `stream` */
+int rsp_shared_result_read(const void *d_ptr, size_t offset_bytes, void *host, size_t bytes, void *stream);
+int rsp_shared_result_close(void *d_ptr, int owner);
+typedef struct rsp_host_barrier *rsp_host_barrier_t;
+/* name: a POSIX shared-memory name ("/something", the same on every rank); rank 0 creates it, the others wait for it */
+int rsp_host_barrier_create(const char *name, int nranks, int rank, rsp_host_barrier_t *barrier);
+int rsp_host_barrier_wait(rsp_host_barrier_t barrier, double timeout_seconds);
+int rsp_host_barrier_destroy(rsp_host_barrier_t barrier);
+
 /* ---- synthetic inputs (bench / tests) ---------------------------------- */
 /*
  * d_x[k] = value(seed, first_idx + k) for k in [0, n): a counter-based

@@ -88,6 +88,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_crossprod.restype = None
         L.oracle_gen_row_indices.argtypes = [ip, ip, i32, i32, i32, u64]
         L.oracle_gen_row_indices.restype = None
+        L.oracle_row_sums_accumulate.argtypes = [dp, ip, ctypes.c_int64, dp, dp]
+        L.oracle_row_sums_accumulate.restype = None
         L.oracle_gen_value.argtypes = [u64, u64, ctypes.c_int]
         L.oracle_gen_value.restype = ctypes.c_double
         for f in ("oracle_column_sums", "oracle_col_sums", "oracle_col_means",
@@ -186,6 +188,16 @@ def row_sums(x, i, p, nrow, ncol=None) -> np.ndarray:
     out = np.empty(int(nrow), dtype=np.float64)
     lib().oracle_row_sums(_dp(x), _ip(i), _ip(p), int(nrow), ncol, _dp(out))
     return out
+
+
+def row_sums_accumulate(x, i, sums, abs_sums=None) -> None:
+    """sums[i[j]] += x[j] over a further slab of stored entries (RcppSparse.h:141-143 continued in storage order);
+    abs_sums likewise with |x[j]| (the tolerance's scale)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    i = np.ascontiguousarray(i, dtype=np.int32)
+    assert sums.dtype == np.float64 and sums.flags.c_contiguous and x.size == i.size
+    lib().oracle_row_sums_accumulate(_dp(x), _ip(i), int(x.size), _dp(sums),
+                                     _dp(abs_sums) if abs_sums is not None else ctypes.POINTER(ctypes.c_double)())
 
 
 def row_means(x, i, p, nrow, ncol=None) -> np.ndarray:

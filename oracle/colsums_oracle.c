@@ -95,6 +95,16 @@ void oracle_row_sums(const double *x, const int32_t *i, const int32_t *p,
             sums[i[j]] += x[j];
 }
 
+/* The same scatter loop (RcppSparse.h:141-143) continued over a further run of n stored entries, in storage order:
+ * calling it on consecutive slabs of x / i is the whole-matrix loop term for term.  abs_sums (may be NULL)
+ * collects Sum|x| per row, the scale of the parity tolerance. */
+void oracle_row_sums_accumulate(const double *x, const int32_t *i, int64_t n, double *sums, double *abs_sums) {
+    for (int64_t j = 0; j < n; ++j) {
+        sums[i[j]] += x[j];
+        if (abs_sums) abs_sums[i[j]] += x[j] < 0 ? -x[j] : x[j];
+    }
+}
+
 /* RcppSparse.h:151-156 -- rowSums() then divide each by Dim[1]. */
 void oracle_row_means(const double *x, const int32_t *i, const int32_t *p,
                       int32_t nrow, int32_t ncol, double *means) {

@@ -48,6 +48,8 @@ EXPORTED_SYMBOLS = (
     "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe", "rsp_set_crossprod_exact",
     "rsp_set_experiment", "rsp_debug_read_ceiling_device",
     "rsp_column_sums_plan_ready", "rsp_column_sums_plan_wait", "rsp_debug_plan_image",
+    "rsp_shared_result_alloc", "rsp_shared_result_open", "rsp_shared_result_close", "rsp_shared_result_read",
+    "rsp_host_barrier_create", "rsp_host_barrier_wait", "rsp_host_barrier_destroy",
     "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
 )
 
@@ -153,6 +155,13 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_comm_reduce_rows_workspace_bytes.restype = c.c_size_t
     L.rsp_comm_reduce_rows.argtypes = [vp, vp, i32, i32, vp, vp, c.c_size_t, c.c_int, vp]
     L.rsp_add_partials_device.argtypes = [vp, i32, i64, i64, i32, vp, vp]
+    L.rsp_shared_result_alloc.argtypes = [c.c_size_t, c.POINTER(vp), vp]
+    L.rsp_shared_result_open.argtypes = [vp, c.POINTER(vp)]
+    L.rsp_shared_result_close.argtypes = [vp, c.c_int]
+    L.rsp_shared_result_read.argtypes = [vp, c.c_size_t, vp, c.c_size_t, vp]
+    L.rsp_host_barrier_create.argtypes = [c.c_char_p, c.c_int, c.c_int, c.POINTER(vp)]
+    L.rsp_host_barrier_wait.argtypes = [vp, c.c_double]
+    L.rsp_host_barrier_destroy.argtypes = [vp]
     L.rsp_gen_values_device.argtypes = [vp, i64, u64, u64, c.c_int, vp]
     L.rsp_gen_row_indices_device.argtypes = [vp, vp, i32, i32, u64, vp]
     L.rsp_set_tuning.argtypes = [c.c_int]
@@ -769,6 +778,63 @@ class Comm:
     def close(self) -> None:
         if self._h:
             load().rsp_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+IPC_HANDLE_BYTES = 64
+
+
+class SharedResult:
+    """The root's result buffer of the direct-write gather (rsp_shared_result_*): rank `root` allocates it and
+    exports a 64-byte handle, the other rank processes map it; ``tensor()`` is a float64 view of n doubles
+    (torch only wraps the pointer: the memory belongs to this object)."""
+
+    def __init__(self, n: int, handle: bytes = None):
+        import torch   # noqa: F401
+        self.n, self.owner = int(n), handle is None
+        self._p = ctypes.c_void_p()
+        if self.owner:
+            buf = ctypes.create_string_buffer(IPC_HANDLE_BYTES)
+            _check(load().rsp_shared_result_alloc(self.n * 8, ctypes.byref(self._p), buf))
+            self.handle = buf.raw
+        else:
+            assert len(handle) == IPC_HANDLE_BYTES
+            self.handle = bytes(handle)
+            buf = ctypes.create_string_buffer(self.handle, IPC_HANDLE_BYTES)
+            _check(load().rsp_shared_result_open(buf, ctypes.byref(self._p)))
+
+    @property
+    def ptr(self) -> int:
+        return int(self._p.value)
+
+    def read(self, stream=None) -> np.ndarray:
+        """The n doubles as a host array (rsp_shared_result_read; waits for `stream`)."""
+        out = np.empty(self.n, dtype=np.float64)
+        _check(load().rsp_shared_result_read(self._p, 0, out.ctypes.data, out.nbytes, _stream_ptr(stream)))
+        return out
+
+    def close(self) -> None:
+        if self._p:
+            load().rsp_shared_result_close(self._p, int(self.owner))
+            self._p = ctypes.c_void_p()
+
+
+class HostBarrier:
+    """Barrier between the rank processes of one node through POSIX shared memory (rsp_host_barrier_*)."""
+
+    def __init__(self, name: str, nranks: int, rank: int):
+        self._h = ctypes.c_void_p()
+        _check(load().rsp_host_barrier_create(name.encode(), int(nranks), int(rank), ctypes.byref(self._h)))
+        self._wait = load().rsp_host_barrier_wait
+
+    def wait(self, timeout: float = 60.0) -> None:
+        rc = self._wait(self._h, timeout)
+        if rc != RSP_OK:
+            _check(rc)
+
+    def close(self) -> None:
+        if self._h:
+            load().rsp_host_barrier_destroy(self._h)
             self._h = ctypes.c_void_p()
 
 

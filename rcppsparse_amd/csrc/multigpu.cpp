@@ -6,6 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -530,6 +537,148 @@ int rsp_comm_reduce_rows(rsp_comm_t c, const double* d_partial, int32_t nrow, in
         pd[k] = first(k);
     }
     return rsp_comm_gatherv(c, reduced, count(me), d_result, pc, pd, root, stream);
+}
+
+// ---- direct-write gather: the root's result buffer mapped into every rank's address space ------------------
+// The gatherv above moves every rank's slice with a send / receive pair.  On one node the root can instead hand its
+// result buffer to the other rank processes (hipIpcGetMemHandle / hipIpcOpenMemHandle): a rank's column-sum kernels
+// then take `mapped + displacement` as their output pointer and the "gather" is their own result stores, travelling
+// over xGMI as they are made; what is left of the exchange is one fence (every rank's kernels done, then a barrier
+// between the rank processes).  SURVEY.md section 5 calls this a legitimate comparator beside RCCL; bench.py reports
+// it as `direct_gather`, never as `value`.
+static_assert(RSP_IPC_HANDLE_BYTES >= sizeof(hipIpcMemHandle_t), "ipc handle size");
+
+int rsp_shared_result_alloc(size_t bytes, void** d_ptr, void* handle_bytes) {
+    if (!d_ptr || !handle_bytes || bytes == 0) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_shared_result_alloc");
+    *d_ptr = nullptr;
+    void* q = nullptr;
+    // fine-grained: stores arriving from other devices are coherent with this device's later reads without relying on
+    // where the home L2 keeps its lines (the buffer is a few MB of results, not a stream)
+    hipError_t e = hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(&q, bytes);
+    }
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "allocating the shared result failed: %s", hipGetErrorString(e));
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, q);
+    if (e != hipSuccess) {
+        (void)hipFree(q);
+        return fail(RSP_ERR_HIP, "hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set before the runtime started?)",
+                    hipGetErrorString(e));
+    }
+    memset(handle_bytes, 0, RSP_IPC_HANDLE_BYTES);
+    memcpy(handle_bytes, &h, sizeof(h));
+    *d_ptr = q;
+    return RSP_OK;
+}
+
+int rsp_shared_result_open(const void* handle_bytes, void** d_ptr) {
+    if (!d_ptr || !handle_bytes) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_shared_result_open");
+    *d_ptr = nullptr;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle_bytes, sizeof(h));
+    void* q = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    *d_ptr = q;
+    return RSP_OK;
+}
+
+int rsp_shared_result_read(const void* d_ptr, size_t offset_bytes, void* host, size_t bytes, void* stream) {
+    if (!d_ptr || (bytes > 0 && !host)) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_shared_result_read");
+    hipError_t e = hipMemcpyAsync(host, (const char*)d_ptr + offset_bytes, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "reading the shared result failed: %s", hipGetErrorString(e));
+    return RSP_OK;
+}
+
+int rsp_shared_result_close(void* d_ptr, int owner) {
+    if (!d_ptr) return RSP_OK;
+    hipError_t e = owner ? hipFree(d_ptr) : hipIpcCloseMemHandle(d_ptr);
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "releasing the shared result failed: %s", hipGetErrorString(e));
+    return RSP_OK;
+}
+
+// A barrier between the rank PROCESSES of one node through a page of POSIX shared memory: sense-reversing, spinning
+// on the host (the ranks are about to consume each other's results: they have nothing else to do), a microsecond or
+// two per crossing, with a timeout instead of a hang when a rank has died.
+struct rsp_host_barrier {
+    struct Page {
+        std::atomic<int32_t> arrived;
+        std::atomic<int32_t> generation;
+    };
+    Page* page;
+    int nranks, rank;
+    std::string name;
+};
+
+int rsp_host_barrier_create(const char* name, int nranks, int rank, rsp_host_barrier_t* out) {
+    if (!name || name[0] != '/' || !out || nranks <= 0 || rank < 0 || rank >= nranks)
+        return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_host_barrier_create (name must start with '/')");
+    *out = nullptr;
+    int fd = -1;
+    if (rank == 0) {   // rank 0 creates and sizes the page; the others wait for it to appear with its size
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, 4096) != 0) {
+            close(fd);
+            (void)shm_unlink(name);
+            fd = -1;
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && st.st_size >= 4096) break;
+            if (fd >= 0) close(fd);
+            fd = -1;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    if (fd < 0) return fail(RSP_ERR_ALLOC, "shared memory %s could not be %s", name, rank == 0 ? "created" : "opened");
+    void* m = mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(RSP_ERR_ALLOC, "mmap of %s failed", name);
+    rsp_host_barrier* b = new (std::nothrow) rsp_host_barrier();
+    if (!b) {
+        munmap(m, 4096);
+        return fail(RSP_ERR_ALLOC, "out of host memory");
+    }
+    b->page = (rsp_host_barrier::Page*)m;   // (a fresh page of shared memory is zero-filled: both counters start at 0)
+    b->nranks = nranks;
+    b->rank = rank;
+    b->name = name;
+    *out = b;
+    return RSP_OK;
+}
+
+int rsp_host_barrier_wait(rsp_host_barrier_t b, double timeout_seconds) {
+    if (!b) return fail(RSP_ERR_BAD_ARG, "null barrier");
+    const int32_t gen = b->page->generation.load(std::memory_order_acquire);
+    if (b->page->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == b->nranks) {
+        b->page->arrived.store(0, std::memory_order_relaxed);
+        b->page->generation.store(gen + 1, std::memory_order_release);   // releases the others
+        return RSP_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (b->page->generation.load(std::memory_order_acquire) == gen) {
+        if ((++spins & 1023u) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
+            return fail(RSP_ERR_RCCL, "host barrier timed out after %.1f s (a rank is missing)", timeout_seconds);
+    }
+    return RSP_OK;
+}
+
+int rsp_host_barrier_destroy(rsp_host_barrier_t b) {
+    if (!b) return RSP_OK;
+    munmap((void*)b->page, 4096);
+    if (b->rank == 0) (void)shm_unlink(b->name.c_str());
+    delete b;
+    return RSP_OK;
 }
 
 int rsp_comm_destroy(rsp_comm_t c) {

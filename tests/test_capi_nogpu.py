@@ -261,3 +261,43 @@ def test_row_restricted_form_selection_is_host_logic():
         capi.set_row_slices(1)
     with pytest.raises(ValueError):
         capi.in_rows_form(-1, 1, 1)
+
+
+def test_host_barrier_between_processes(tmp_path):
+    """rsp_host_barrier_* (the fence of the direct-write gather): three processes cross the same barrier 3000 times;
+    between two crossings each adds its rank's increment to a shared file-backed counter array, and after every
+    crossing every process sees all the increments of the round before.  A barrier one rank never reaches times out
+    with an error instead of hanging."""
+    import subprocess
+    import sys
+    name = f"/rsp_nogpu_{os.getpid()}"
+    counters = tmp_path / "counters.bin"
+    counters.write_bytes(bytes(3 * 8))
+    code = f"""
+import sys, mmap, struct
+sys.path.insert(0, {ROOT!r})
+from rcppsparse_amd import capi
+capi.load(build=False)
+rank = int(sys.argv[1])
+b = capi.HostBarrier({name!r}, 3, rank)
+f = open({str(counters)!r}, "r+b"); m = mmap.mmap(f.fileno(), 24)
+for k in range(3000):
+    struct.pack_into("q", m, 8 * rank, k + 1)
+    b.wait(30.0)
+    seen = struct.unpack_from("3q", m, 0)
+    assert min(seen) >= k + 1, (rank, k, seen)
+    b.wait(30.0)
+b.close()
+print("ok", rank)
+"""
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(3)]
+    for r, pr in enumerate(procs):
+        out, err = pr.communicate(timeout=180)
+        assert pr.returncode == 0 and f"ok {r}" in out, err[-1500:]
+    # a missing rank: the wait comes back with an error after its timeout
+    b = capi.HostBarrier(name + "_lonely", 2, 0)
+    with pytest.raises(capi.RspError) as e:
+        b.wait(0.3)
+    assert "timed out" in str(e.value)
+    b.close()

@@ -132,6 +132,16 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     assert roof["kernel_ms_max_over_ranks"] >= max(s["kernel_ms"] for s in shards) * (1 - 1e-9)
     assert roof["algorithmic_bytes_per_launch"] == 8 * shards[0]["nnz"] + 4 * (shards[0]["c1"] + 1) + 8 * shards[0]["c1"]
     assert "cpu_baseline" not in d                                       # rank 0 at N = 1 only
+    # round 4: the two further figures of an N > 1 line, each with its own whole-matrix parity, neither feeding `value`
+    ps = d["planned_shards"]
+    assert ps["value"] > 0 and len(ps["forms_by_rank"]) == world and "NOT `value`" in ps["protocol"]
+    assert ps["parity"]["columns_out_of_tolerance"] == 0 and ps["parity"]["max_abs_err_over_l1"] <= RTOL
+    if workload == "c4shard":
+        assert ps["forms_by_rank"] == ["columns"] * world            # columns of ~1000 entries in shards of <= 2.5e8
+    dg = d["direct_gather"]
+    assert dg["value"] is not None, dg                                # the ranks mapped rank 0's buffer (hipIpc) ...
+    assert dg["parity"]["columns_out_of_tolerance"] == 0 and dg["parity"]["max_abs_err_over_l1"] <= RTOL   # ... and wrote into it
+    assert "NOT the protocol of `value`" in dg["protocol"]
     # --try-comm: the C-ABI communicator's multi-rank bootstrap ran between the rank processes (unique id
     # from rank 0, rsp_comm_init everywhere) and RCCL refused the shared device on EVERY rank, cleanly
     seen = cfg["comm_init_rehearsal"]
@@ -197,6 +207,157 @@ def test_c4_c5_eight_shards_at_full_size_on_one_gpu(torch_cuda, shape):
     l1 = capi.column_reduce_device(xt, pt, capi.OP_SUM_ABS)
     assert bool(torch.all((whole - full).abs() <= 2 * RTOL * l1))
     assert [int(d) for d in displs] == [sh.c0 for sh in shards]     # slices land at their columns
+
+
+@pytest.mark.parametrize("shape", ["uniform", "zipf"])
+def test_c4_c5_multi_device_handle_at_full_size(torch_cuda, shape):
+    """BASELINE configs 4 and 5 through the form a multi-GPU HANDLE actually runs: the 1e9-entry
+    matrices uploaded once as 8 resident shards (MultiDeviceCSC, rsp_mcsc_*; all on this box's one device), every shard
+    inspected at upload.  The uniform matrix's shards (1.25e8 entries in columns of ~1000) must have taken the COLUMNS
+    form -- two wavefronts per column, one launch -- which until now was only tested on small shapes; the Zipf shards
+    keep the general kernels.  Checks: the shards tile the columns, the oracle on both edges of every shard, every
+    column against the plan-free device entry, identical bits on a second call."""
+    torch = torch_cuda
+    nrow, ncol, nnz, G = 10_000_000, 1_000_000, 1_000_000_000, 8
+    if torch.cuda.get_device_properties(0).total_memory < 40 * 2**30:
+        pytest.skip("needs >= 40 GB of HBM")
+    try:
+        free_host = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        free_host = 0
+    if free_host < 14 * 2**30:
+        pytest.skip("needs >= 14 GB of free host memory for x")
+    torch.cuda.empty_cache()
+    counts_col = (synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow) if shape == "uniform"
+                  else synth.zipf_counts(ncol, nnz, seed=42, nrow=nrow))
+    p = synth.offsets_from_counts(counts_col)
+    x = oracle.gen_values_threads(nnz, 42, 0, 0, max(1, min(16, len(os.sched_getaffinity(0)))))
+    h = capi.MultiDeviceCSC(x, p, (nrow, ncol), devices=[0] * G)
+    try:
+        assert h.dims() == (nrow, ncol, G)
+        info = [h.shard_info(k) for k in range(G)]
+        assert info[0]["c0"] == 0 and info[-1]["c1"] == ncol
+        assert all(a["c1"] == b["c0"] for a, b in zip(info, info[1:]))
+        assert sum(s["nnz"] for s in info) == nnz
+        assert [s["c0"] for s in info] + [ncol] == [int(b) for b in capi.partition_columns(p, G)]
+        if shape == "uniform":
+            assert [s["form"] for s in info] == ["columns"] * G, info
+        else:
+            assert all(s["form"] in ("general kernels", "snapped") for s in info), info
+        got = h.column_sums()
+        assert got.tobytes() == h.column_sums().tobytes()                       # run-to-run bits
+        for s in info:                                                          # the oracle next to every cut
+            for a, b in ((s["c0"], min(s["c0"] + 300, s["c1"])), (max(s["c0"], s["c1"] - 300), s["c1"])):
+                lo, hi = int(p[a]), int(p[b])
+                pl = (p[a:b + 1] - lo).astype(np.int32)
+                ref = oracle.column_sums(x[lo:hi], pl)
+                scale = oracle.column_abs_sums(x[lo:hi], pl)
+                assert np.all(np.abs(got[a:b] - ref) <= RTOL * scale), (shape, s, a)
+        empty = np.diff(p) == 0
+        assert np.all(got[empty] == 0.0) and not np.any(np.signbit(got[empty]))
+        means = h.column_means()
+        assert means.tobytes() == (got / nrow).tobytes()
+    finally:
+        h.close()
+    # every column against one plan-free launch over the whole matrix
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    capi.gen_values_device(xt, seed=42, kind=0)
+    pt = torch.from_numpy(p).cuda()
+    whole = capi.column_sums_device(xt, pt)
+    l1 = capi.column_reduce_device(xt, pt, capi.OP_SUM_ABS)
+    assert bool(torch.all((whole - torch.from_numpy(got).cuda()).abs() <= 2 * RTOL * l1))
+
+
+@pytest.mark.parametrize("world,workload,nrow,nnz", [(1, "tiny", 200_000, 4_000_000), (2, "tiny", 200_000, 4_000_000),
+                                                     (3, "m10_3e7", 3_000_000, 30_000_000)])
+def test_bench_rowsums_over_column_range_shards(torch_cuda, world, workload, nrow, nnz):
+    """`bench.py --op rowsums` (missing 5): every rank sums the rows of ITS column range
+    (rsp_row_sums_device on its x / i slices), the partial vectors of nrow doubles are reduced in rank order to rank 0
+    (here over gloo: the ranks share the GPU; on the driver's node rsp_comm_reduce_rows over RCCL) and rank 0 checks every
+    row against the oracle's scatter loop over the whole matrix."""
+    torch_cuda.cuda.empty_cache()
+    flags = ["--op", "rowsums", "--workload", workload, "--steps", "4", "--warmup", "1"]
+    if world > 1:
+        flags += ["--gpus", str(world), "--rendezvous", "gloo"]
+    d = _run_bench(*flags)
+    assert d["metric"].startswith("rowSums nnz/s") and d["config"]["op"] == "rowsums"
+    assert d["n_gpus"] == world and d["steps"] == 4 and d["unit"] == "nnz/s" and d["dtype"] == "f64"
+    assert d["value"] == pytest.approx(nnz * 4 / (d["ms_per_step"] * 4e-3), rel=1e-9)
+    par = d["parity"]
+    assert par["rows_checked"] == "all" and par["nrow"] == nrow and par["rows_out_of_tolerance"] == 0
+    assert par["max_abs_err_over_l1"] <= RTOL
+    shards = d["config"]["shards"]
+    assert len(shards) == world and sum(s["nnz"] for s in shards) == nnz and all(s["kernel_ms"] > 0 for s in shards)
+    roof = d["roofline"]
+    assert roof["algorithmic_bytes_per_launch"] == 12 * shards[0]["nnz"] + 8 * nrow and 0 < roof["frac"] < 1
+    if world > 1:
+        assert d["config"]["reduce"] == sharded.GlooReduceRows.name and "REHEARSAL" in d["config"]["parallelism"]
+        assert roof["reduce_ms"] > 0 and roof["reduce_bytes_per_rank"] == 8 * nrow
+    else:
+        assert d["config"]["reduce"] is None and roof["reduce_ms"] is None
+
+
+def test_direct_write_gather_between_two_processes_sharing_the_gpu(torch_cuda, tmp_path):
+    """The pieces of the direct-write gather on their own (rsp_shared_result_* + rsp_host_barrier_*): a child process maps
+    this process's result buffer through its IPC handle and its column-sum kernels write their slice straight into it; a
+    barrier between the two processes orders the parent's read behind the child's kernels."""
+    torch = torch_cuda
+    ncol, split = 30_000, 17_123
+    counts = synth.uniform_counts(ncol, 2_000_000, seed=7, nrow=None)
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=7, kind=0)
+    shared = capi.SharedResult(ncol)
+    name = f"/rsp_test_{os.getpid()}"
+    child = tmp_path / "child.py"
+    child.write_text(f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np, torch
+from rcppsparse_amd import capi, synth
+capi.load()
+handle = bytes.fromhex(sys.argv[1])
+bar = capi.HostBarrier({name!r}, 2, 1)
+view = capi.SharedResult({ncol}, handle=handle)
+p = synth.offsets_from_counts(synth.uniform_counts({ncol}, 2_000_000, seed=7, nrow=None))
+x = synth.gen_values(int(p[-1]), seed=7, kind=0)
+c0 = {split}
+pl = (p[c0:] - p[c0]).astype(np.int32)
+xt, pt = torch.from_numpy(x[p[c0]:]).cuda(), torch.from_numpy(pl).cuda()
+class Out:
+    def data_ptr(self): return view.ptr + 8 * c0
+ws = capi.alloc_workspace(len(pl) - 1, xt.numel())
+capi.prepared_column_sums(xt, pt, Out(), ws)()
+torch.cuda.synchronize()
+bar.wait()          # the parent may read now
+bar.wait()          # ... and has read
+view.close(); bar.close()
+""")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.Popen([sys.executable, str(child), shared.handle.hex()], env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True)
+    try:
+        bar = capi.HostBarrier(name, 2, 0)
+        # this process sums the first columns into the same buffer meanwhile
+        pl = p[:split + 1].copy()
+        xt, pt = torch.from_numpy(x[:p[split]]).cuda(), torch.from_numpy(pl).cuda()
+
+        class Out:
+            def data_ptr(self):
+                return shared.ptr
+        ws = capi.alloc_workspace(split, xt.numel())
+        capi.prepared_column_sums(xt, pt, Out(), ws)()
+        torch.cuda.synchronize()
+        bar.wait(timeout=120.0)
+        got = shared.read()
+        bar.wait(timeout=120.0)
+        bar.close()
+    finally:
+        out, err = proc.communicate(timeout=120)
+    assert proc.returncode == 0, err[-2000:]
+    ref = oracle.column_sums(x, p)
+    assert np.all(np.abs(got - ref) <= RTOL * oracle.column_abs_sums(x, p))
+    shared.close()
 
 
 # ------------------------------------------------------------------ rowSums over column-range shards
