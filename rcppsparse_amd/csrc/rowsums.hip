@@ -145,6 +145,15 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
     // by block took 19).  Beyond 8 (1.09e8 rows) the two-level form takes over.
     L->sub = 0;
     while (L->sub < kPartMaxSub && ((L->nblocks + (1 << L->sub) - 1) >> L->sub) > kPartMaxBlocks) ++L->sub;
+    // RSP_ROWS_SUB=1 / 2 / 3: regroup by coarse blocks of at least 2 / 4 / 8 row blocks also where one pass could separate
+    // the row blocks themselves (round 4's last structural attempt on the one-shot call at C3: fewer, longer output
+    // streams in the partition pass against 2 / 4 / 8 x the accumulate pass's reads; profiles/r04_rowsums.md)
+    static const int forced_sub = [] {
+        const char* e = getenv("RSP_ROWS_SUB");
+        const int v = e ? atoi(e) : 0;
+        return v < 0 ? 0 : (v > kPartMaxSub ? kPartMaxSub : v);
+    }();
+    if (forced_sub > L->sub && L->nblocks > kDirectMaxBlocks) L->sub = forced_sub;
     L->ncoarse = (L->nblocks + (1 << L->sub) - 1) >> L->sub;
     L->mode = L->ncoarse <= kPartMaxBlocks ? 2 : 3;
     if (L->mode == 3) {
