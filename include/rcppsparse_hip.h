@@ -181,8 +181,9 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
  * the inspector rewrites the offsets a chunk needs as 16-bit column starts relative to the chunk, at a fixed
  * stride, so that a wavefront requests its rows of x, its header and its offsets in the same instant (2 B per
  * column, p[] itself is not read again), puts both into LDS and adds every column in storage order from +0.0:
- * every column then comes out BIT-IDENTICAL to the reference loop.  rsp_set_lean(0) / RSP_LEAN=0 keeps plans
- * out of that form (A/B measurements).
+ * every column then comes out BIT-IDENTICAL to the reference loop.  It is selected up to a mean column length of 60
+ * (longer columns leave a chunk's 64 lanes too few columns: tools/edge_sweep.py); rsp_set_lean(0) / RSP_LEAN=0 keeps
+ * plans out of that form, 2 takes it wherever every column is <= 64 entries (A/B measurements, tests).
  * When every column is LONG and of similar length (at least 2048 entries -- 512 in matrices of up to 2.5e8
  * entries --, none above four times the mean, at least 128 columns; the reference vignette's 100000 x 1000 benchmark matrix) the plan takes the COLUMNS form:
  * nothing is recorded at all, a call is one launch of one workgroup per column that reads p[c], p[c + 1] itself
@@ -232,6 +233,10 @@ int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double *d_x,
                                    void *d_workspace, size_t workspace_bytes, void *stream);
 int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan);
 int rsp_set_lean(int on);
+/* Plans made from now on: 0 never take the columns form, 1 where it is the faster one (default; RSP_COLUMNS_FORM),
+ * 2 on every matrix whose longest column the kernel can take, whatever the lengths (measurements on both sides of
+ * the thresholds, tools/edge_sweep.py; results stay within the documented tolerance). */
+int rsp_set_columns_form(int mode);
 /*
  * Generic column reduction ("next" row f3): the same column-iteration loop with a
  * different per-element body, out[c] = sum_j f(x[j]) over column c's stored entries --
@@ -377,7 +382,13 @@ int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
  * a NaN or an infinity the bit-identical kernel does the work instead (a structural zero must not
  * meet a non-finite value).  rsp_set_crossprod_exact(1), or RSP_CROSSPROD_EXACT=1 in the
  * environment, keeps the bit-identical forms everywhere; set it before asking for the workspace size.
+ * The matrix-core form is taken where a cost model says it pays (its time is that of a DENSE rank update, nrow x
+ * ncol^2, however sparse the matrix: 256 columns of 4096 entries over 1e6 rows stay with the exact form, the same
+ * columns over 1e5 rows or with 20000 entries each do not); rsp_crossprod_form tells which form sizes select.
  */
+#define RSP_CROSSPROD_FORM_EXACT 0   /* reference order, bit-identical */
+#define RSP_CROSSPROD_FORM_TALL  1   /* matrix cores, within 1e-12 * sum|x1 x2| */
+int rsp_crossprod_form(int32_t nrow, int32_t ncol, int64_t nnz);   /* with a workspace; -1 = sizes out of range / no device */
 int rsp_set_crossprod_exact(int exact);
 int rsp_csc_crossprod(rsp_csc_t handle, double *out);        /* host, ncol*ncol */
 size_t rsp_crossprod_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz);

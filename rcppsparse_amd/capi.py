@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_plan_ready", "rsp_column_sums_plan_wait", "rsp_debug_plan_image",
     "rsp_shared_result_alloc", "rsp_shared_result_open", "rsp_shared_result_close", "rsp_shared_result_read",
     "rsp_host_barrier_create", "rsp_host_barrier_wait", "rsp_host_barrier_destroy",
+    "rsp_set_columns_form", "rsp_crossprod_form",
     "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
 )
 
@@ -129,6 +130,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_plan_wait.argtypes = [vp]
     L.rsp_debug_plan_image.argtypes = [vp, c.c_int, vp, c.c_size_t, c.POINTER(c.c_size_t)]
     L.rsp_set_lean.argtypes = [c.c_int]
+    L.rsp_set_columns_form.argtypes = [c.c_int]
     L.rsp_set_row_slices.argtypes = [c.c_int]
     L.rsp_set_row_segments.argtypes = [c.c_int]
     L.rsp_csc_row_form.argtypes = [c.c_void_p]
@@ -137,6 +139,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_in_rows_workspace_bytes.restype = c.c_size_t
     L.rsp_csc_crossprod.argtypes = [vp, dp]
     L.rsp_crossprod_device.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp, c.c_size_t, vp]
+    L.rsp_crossprod_form.argtypes = [i32, i32, i64]
     L.rsp_crossprod_workspace_bytes.argtypes = [i32, i32, i64]
     L.rsp_crossprod_workspace_bytes.restype = c.c_size_t
     L.rsp_csc_row_sums.argtypes = [vp, dp]
@@ -221,9 +224,16 @@ def plan_describe(nnz: int) -> dict:
     return {"body_elems": int(out[0]), "nbody": int(out[1]), "tail_elems": int(out[2]), "nchunks": int(out[3])}
 
 
-def set_lean(on: bool = True) -> None:
-    """False: plans made from now on never take the lean form (rsp_set_lean; A/B measurements, tests)."""
-    _check(load().rsp_set_lean(int(bool(on))))
+def set_lean(on=True) -> None:
+    """Plans made from now on: 0 / False never take the lean form, 1 / True where it is the faster one (default: every
+    column <= 64 entries and a mean of at most 60), 2 wherever it applies at all (rsp_set_lean; A/B measurements, tests)."""
+    _check(load().rsp_set_lean(int(on)))
+
+
+def set_columns_form(mode: int = 1) -> None:
+    """Plans made from now on: 0 never the columns form, 1 where it is the faster one (default), 2 wherever the
+    kernel can run at all (rsp_set_columns_form; edge measurements)."""
+    _check(load().rsp_set_columns_form(int(mode)))
 
 
 def set_experiment(variant: int = 0) -> None:
@@ -521,6 +531,14 @@ def column_sums_in_rows_device(x_t, i_t, p_t, nrow: int, bitmap_t, complement: b
                                                  out_t.data_ptr(), workspace.data_ptr(), workspace.numel(),
                                                  _stream_ptr(stream)))
     return out_t
+
+
+def crossprod_form(nrow: int, ncol: int, nnz: int) -> str:
+    """Which form rsp_crossprod_device (with a workspace) takes at these sizes: "tall" (matrix cores) or "exact"."""
+    f = int(load().rsp_crossprod_form(int(nrow), int(ncol), int(nnz)))
+    if f < 0:
+        raise RspError(RSP_ERR_HIP, load().rsp_last_error().decode())
+    return ("exact", "tall")[f]
 
 
 def crossprod_device(x_t, i_t, p_t, nrow, out_t=None, workspace=None, stream=None, tiles=False):

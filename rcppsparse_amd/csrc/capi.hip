@@ -66,17 +66,27 @@ using rsp::fail;
                         __FILE__, __LINE__);                                               \
     } while (0)
 
-std::atomic<int> g_lean{-1};   // rsp_set_lean: 1 / 0; -1 = RSP_LEAN from the environment, else on
-bool lean_allowed() {
+std::atomic<int> g_lean{-1};   // rsp_set_lean: 0 / 1 / 2; -1 = RSP_LEAN from the environment, else 1
+// 0: plans never take the lean form; 1: where it is the faster one (every column <= 64 entries AND a mean of at most
+// kLeanMaxMeanLen = 60: with longer columns a chunk of 16 rows holds too few of them for its 64 lanes -- columns of exactly
+// 64: 33.0 us against 19.6 snapped; means of 20..56 at 1e7 / 1e8 entries: lean within 0.85..1.05 of snapped, with the
+// reference's bits; profiles/r04_form_edges.json); 2: wherever it applies at all (tests, edge sweeps)
+int lean_setting() {
     int v = g_lean.load(std::memory_order_relaxed);
     if (v < 0) {
         static const int env = [] {
             const char* s = getenv("RSP_LEAN");
-            return s ? (atoi(s) != 0 ? 1 : 0) : 1;
+            const int e = s ? atoi(s) : 1;
+            return e <= 0 ? 0 : (e >= 2 ? 2 : 1);
         }();
         v = env;
     }
-    return v != 0;
+    return v;
+}
+bool lean_allowed(int32_t ncol, int64_t nnz) {
+    const int mode = lean_setting();
+    if (mode == 0) return false;
+    return mode == 2 || nnz <= (int64_t)rsp::kLeanMaxMeanLen * (int64_t)ncol;
 }
 
 constexpr size_t kRowSlicesFlagBytes = 256;   // the slice form's guard flag, behind the general form's carries
@@ -112,13 +122,22 @@ int row_segments_setting() {
 
 // columns form of a plan (every column long): RSP_COLUMNS_FORM=0 keeps such matrices on the general kernels (A/B);
 // wavefronts per column: RSP_COLUMNS_WAVES = 4 / 8 / 16, else from the mean column length
-bool columns_allowed() {
-    static const int env = [] {
-        const char* s = getenv("RSP_COLUMNS_FORM");
-        return s ? (atoi(s) != 0 ? 1 : 0) : 1;
-    }();
-    return env != 0;
+std::atomic<int> g_columns_form{-1};   // rsp_set_columns_form: 0 / 1 / 2; -1 = RSP_COLUMNS_FORM from the environment, else 1
+// 0: never; 1: where it is the faster form (the thresholds below); 2: on every matrix the kernel can take at all (a
+// workgroup per column whatever its length: measurements on both sides of the thresholds, tools/edge_sweep.py)
+int columns_form_setting() {
+    int v = g_columns_form.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static const int env = [] {
+            const char* s = getenv("RSP_COLUMNS_FORM");
+            const int e = s ? atoi(s) : 1;
+            return e <= 0 ? 0 : (e >= 2 ? 2 : 1);
+        }();
+        v = env;
+    }
+    return v;
 }
+bool columns_allowed() { return columns_form_setting() != 0; }
 int columns_waves_setting(int32_t ncol, int64_t mean_len) {
     static const int env = env_int("RSP_COLUMNS_WAVES");
     if (env == 4 || env == 8 || env == 16) return env;
@@ -467,7 +486,7 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
     pl->columns = false;
     pl->columns_waves = pl->columns_min = pl->columns_max = 0;
     try {
-        if (lean_allowed()) {
+        if (lean_allowed(ncol, nnz)) {
             std::vector<uint32_t> image;
             pl->lean_rows = lean_rows_setting(ncol, nnz);
             const rsp::inspect::LeanLimits lim{rsp::kRowElems, rsp::kLeanMaxColumn, rsp::kLeanMaxColumns};
@@ -492,7 +511,8 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
             const rsp::inspect::Grid grid{pl->lp.chunk_elems, pl->lp.nbody, pl->lp.tail_elems, pl->lp.nchunks};
             rsp::inspect::inspect_offsets(p_host, ncol, nnz, grid, &rec, &pl->max_skip);
             pl->snapped = pl->max_skip <= rsp::kGroupElems;
-            if (!pl->snapped && columns_allowed() && ncol >= rsp::kColumnsMinColumns) {
+            const bool forced_columns = columns_form_setting() == 2;
+            if ((!pl->snapped && columns_allowed()) || forced_columns) {
                 // every column long and of similar length: one workgroup per column, nothing to upload
                 int32_t mn = INT32_MAX, mx = 0;
                 for (int32_t c = 0; c < ncol; ++c) {
@@ -507,7 +527,9 @@ static int plan_make(const int32_t* p_host, int32_t ncol, int64_t nnz, int devic
                 const bool similar = mx <= rsp::kColumnsMaxLen && (int64_t)mx <= rsp::kColumnsMaxOverMean * mean;
                 const bool long_columns = mn >= rsp::kColumnsMinLen;
                 const bool mid_columns = mn >= rsp::kColumnsMinLenTwoWaves && nnz <= rsp::kColumnsTwoWavesMaxNnz;
-                if (similar && (long_columns || mid_columns)) {
+                // (fewer than 128 columns: only while a column is short enough for ONE workgroup to stream it in a few microseconds)
+                const bool enough = ncol >= rsp::kColumnsMinColumns || (int64_t)mx <= rsp::kColumnsFewMaxLen + nnz / 192;
+                if ((similar && enough && (long_columns || mid_columns)) || (forced_columns && mx <= rsp::kColumnsMaxLen)) {
                     pl->columns = true;
                     pl->snapped = true;   // (a planned, one-launch form too)
                     pl->columns_min = mn;
@@ -580,7 +602,7 @@ static rsp::DeviceInspectLayout device_plan_layout(int32_t ncol, int64_t nnz, co
     L.part1_off = take(rsp::kInspectMaxBlocksColumns * sizeof(int4));
     L.part2_off = take(rsp::kInspectMaxBlocksChunks * sizeof(int2));
     L.rec_off = take(((size_t)lp.nchunks + 1) * sizeof(int2));
-    L.try_lean = lean_allowed() && nnz <= (int64_t)ncol * rsp::kLeanMaxColumn;
+    L.try_lean = lean_allowed(ncol, nnz) && nnz <= (int64_t)ncol * rsp::kLeanMaxColumn;
     if (L.try_lean) {
         L.lean_rows = lean_rows_setting(ncol, nnz);
         const int64_t chunk = (int64_t)L.lean_rows * rsp::kRowElems;
@@ -625,12 +647,14 @@ static void plan_finalize(rsp_colsums_plan* pl) {
         return;
     }
     pl->snapped = st.max_skip <= rsp::kGroupElems;
-    if (!pl->snapped && columns_allowed() && pl->ncol >= rsp::kColumnsMinColumns) {
+    const bool forced_columns = columns_form_setting() == 2;
+    if ((!pl->snapped && columns_allowed()) || forced_columns) {
         const int64_t mean = pl->nnz / pl->ncol;
         const bool similar = max_len <= rsp::kColumnsMaxLen && (int64_t)max_len <= rsp::kColumnsMaxOverMean * mean;
         const bool long_columns = min_len >= rsp::kColumnsMinLen;
         const bool mid_columns = min_len >= rsp::kColumnsMinLenTwoWaves && pl->nnz <= rsp::kColumnsTwoWavesMaxNnz;
-        if (similar && (long_columns || mid_columns)) {
+        const bool enough = pl->ncol >= rsp::kColumnsMinColumns || (int64_t)max_len <= rsp::kColumnsFewMaxLen + pl->nnz / 192;
+        if ((similar && enough && (long_columns || mid_columns)) || (forced_columns && max_len <= rsp::kColumnsMaxLen)) {
             pl->columns = pl->snapped = true;
             pl->columns_min = min_len;
             pl->columns_max = max_len;
@@ -735,7 +759,12 @@ int rsp_debug_plan_image(rsp_colsums_plan_t plan, int what, void* host, size_t c
 }
 
 int rsp_set_lean(int on) {
-    g_lean.store(on ? 1 : 0, std::memory_order_relaxed);
+    g_lean.store(on <= 0 ? 0 : (on >= 2 ? 2 : 1), std::memory_order_relaxed);
+    return RSP_OK;
+}
+
+int rsp_set_columns_form(int mode) {
+    g_columns_form.store(mode <= 0 ? 0 : (mode >= 2 ? 2 : 1), std::memory_order_relaxed);
     return RSP_OK;
 }
 
@@ -1258,6 +1287,12 @@ size_t rsp_crossprod_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz) {
     rsp::CrossprodLayout L;
     if (xp_plan(nrow, ncol, nnz, &L) != RSP_OK) return 0;
     return L.total_bytes;
+}
+
+int rsp_crossprod_form(int32_t nrow, int32_t ncol, int64_t nnz) {
+    rsp::CrossprodLayout L;
+    if (xp_plan(nrow, ncol, nnz, &L) != RSP_OK) return -1;
+    return L.tall ? RSP_CROSSPROD_FORM_TALL : RSP_CROSSPROD_FORM_EXACT;
 }
 
 int rsp_crossprod_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol,

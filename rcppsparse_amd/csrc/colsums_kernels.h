@@ -63,6 +63,7 @@ constexpr int kPlannedShortCallChunkRows = 8;   // inspector-executor form of su
 // no column is longer than kLeanMaxColumn entries or reaches more than one row past its chunk's grid end
 constexpr int kLeanTargetColumns = 52;                    // mean number of columns per chunk the row count aims at
 constexpr int kLeanMaxColumn = 64;
+constexpr int kLeanMaxMeanLen = 60;                       // mean column length up to which the form is selected (rsp_set_lean(2): any)
 constexpr int kLeanXcdRun = 16;                          // neighbouring workgroups that go to the same XCD (measured: 4 / 8 / 16 / 32)
 constexpr int kLeanMaxColumns = 1278;                     // + 1 closing offset + 1 pad = 1280 16-bit offsets
 constexpr int kLeanMaxOffsetDwords = 640;                 // = 10 x 64 lanes
@@ -121,7 +122,7 @@ hipError_t launch_read_ceiling(const double* d_x, int32_t nnz, const LaunchPlan&
 // slice of 2^20 rows of the bitmap in LDS and walks its group of columns slice by slice.
 constexpr int kSliceRowsShift = 20;        // rows per slice: 128 KB of bitmap
 constexpr int kSliceMaxGroup = 2048;       // columns per workgroup: a cursor (4 B) and a sum (8 B) each beside the bitmap
-constexpr int kSliceMinColumns = 16384;    // fewer columns leave wavefronts of the 256 workgroups without a batch (1e4 columns: 2.43 against 2.15 ms general; 2e4: 2.16 against 2.88)
+constexpr int kSliceMinColumns = 13312;    // fewer columns leave wavefronts of the 256 workgroups without a batch (1e9 entries over 1e7 rows, slices against L2 probes: 1e4 columns 2.68 / 2.18 ms, 1.6e4 2.29 / 2.62, 2e4 2.16 / 2.88; round 4's edge sweep moved this from 16384)
 constexpr int kSliceMinSegment = 32;       // mean entries per (column, slice) from which the form is selected
 constexpr int kSliceMinEntriesPerPass = 32768;   // entries of a column group per slice (393 KB of x and i against the 128 KB of bitmap copied for them)
 constexpr int kSliceCus = 256;             // MI355X: one workgroup per CU, groups sized for whole rounds of them
@@ -185,6 +186,7 @@ constexpr int64_t kColumnsTwoWavesMaxNnz = 250000000;   // ... this many entries
 constexpr int kColumnsMaxLen = 1 << 22;    // longest (its bytes stay far below a buffer descriptor's 2^31)
 constexpr int kColumnsMaxOverMean = 4;     // no column longer than this many times the mean (one workgroup walks it)
 constexpr int kColumnsMinColumns = 128;
+constexpr int kColumnsFewMaxLen = 49152;   // fewer columns than that take the form too while the longest column has at most this many entries + nnz / 192: one workgroup streams a column alone (3.3 us + 0.14 us per 1000 entries) against the general kernels' 8.5 us + 1.1 us per 1e6 entries of the whole call (8..127 columns of 3e3..3e5 entries, profiles/r04_form_edges.json)
 hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t waves,
                                       double* d_out, double divisor, bool means, hipStream_t stream);
 

@@ -700,10 +700,30 @@ static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiat
     return nt <= 4 ? (nt < 1 ? 1 : nt) : (nt <= 6 ? 6 : (nt <= 8 ? 8 : (nt <= 12 ? 12 : 16)));
 }
 
+// Does the matrix-core form pay?  Its time does not depend on how sparse the matrix is -- every 64-row panel is a dense
+// rank-64 update of ncol x ncol (padded to whole tiles) -- while the exact forms pay per PRODUCT and per entry of a
+// column's serial walk.  A model in milliseconds, calibrated on round 4's edge sweep (1e6 rows, columns of exactly 4096
+// entries: 256 columns tall 1.76 against exact 0.45 ms; 64 columns 0.23 against 0.41; profiles/r04_form_edges.json):
+//   exact: 0.04 + 1e-4 per entry of a column (the walk) + products / 4e8 per ms, products ~ nnz^2 / nrow for rows alike
+//   tall : 0.13 + nrow * width^2 / 3.8e10 per ms (the panels' multiply-adds) + 12 B per entry at 3.9 TB/s
+// Rounds 2-3 asked for columns of >= 4096 entries only, which sent sparse wide matrices (256 columns, 0.4 % dense) to a
+// form four times slower.
+static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
+    const char* always = getenv("RSP_CROSSPROD_TALL_ALWAYS");   // (edge measurements: the round 2-3 rule, columns of >= 4096 entries)
+    if (always && always[0] == '1') return true;
+    const double len = (double)nnz / (double)ncol;
+    const double rows = nrow > 0 ? (double)nrow : 1.0;
+    const double products = (double)nnz * (double)nnz / rows + (double)nnz;
+    const double t_exact = 0.04 + len * 1.0e-4 + products / 4.0e8;
+    const double width = 16.0 * tall_tiles(ncol);
+    const double t_tall = 0.13 + rows * width * width / 3.8e10 + 12.0 * (double)nnz / 3.9e9;
+    return t_tall <= t_exact;
+}
+
 hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, CrossprodLayout* L) {
     memset(L, 0, sizeof(*L));
     crossprod_split(nrow, ncol > 0 ? ncol : 1, nnz, &L->nsplit, &L->width);
-    L->tall = !exact && ncol >= 1 && ncol <= kTallMaxCols && nnz / ncol >= kTallMinColumnLength;
+    L->tall = !exact && ncol >= 1 && ncol <= kTallMaxCols && nnz / ncol >= kTallMinColumnLength && tall_pays(nrow, ncol, nnz);
     if (L->tall) {   // one row-major form, unsliced, shared with the exact kernel that stands by
         L->nsplit = 1;
         L->width = ncol;

@@ -164,7 +164,7 @@ def test_crossprod_tall_form_within_tolerance_and_deterministic(torch_cuda, nrow
     torch = torch_cuda
     m = synth.rsparsematrix(nrow, ncol, density=density, seed=nrow % 97 + ncol, kind=0)
     x, i, p = m["x"], m["i"], m["p"]
-    assert x.size // ncol >= 4096                                    # (the shape does select the tall form)
+    assert x.size // ncol >= 4096 and capi.crossprod_form(nrow, ncol, x.size) == "tall"   # (the shape does select the tall form)
     ref = oracle.crossprod(x, i, p)
     scale = oracle.crossprod(np.abs(x), i, p)
     xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()

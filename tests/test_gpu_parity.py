@@ -9,6 +9,9 @@ Bar (BASELINE.json north_star / SURVEY.md 8d):
     all-positive variant plain |gpu - ref| <= 1e-12 * |ref|;
   * bit-identical run to run (no float atomics).
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +20,8 @@ from conftest import golden_names, load_golden
 from rcppsparse_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RTOL = 1e-12   # the tolerance north_star states, relative to the column's 1-norm
 
@@ -64,9 +69,9 @@ def launch_mode(request):
     launch when no long column crosses a chunk edge, the general kernels behind the same entry otherwise)."""
     _MODE["launch"] = request.param
     capi.load()
-    capi.set_lean(request.param != "planned_no_lean")   # (the lean form would otherwise take every short-column case)
+    capi.set_lean(2 if request.param != "planned_no_lean" else 0)   # (2: the lean form wherever it applies -- it would otherwise take only means <= 60)
     yield request.param
-    capi.set_lean(True)
+    capi.set_lean(1)
     _MODE["launch"] = "general"
 
 
@@ -1391,8 +1396,15 @@ def test_lean_plan_edges(torch_cuda, pattern):
     p = synth.offsets_from_counts(counts)
     nnz = int(p[-1])
     x = synth.gen_values(nnz, seed=8, kind=0)
-    plan = capi.ColumnSumsPlan(p)
+    capi.set_lean(2)          # where the form APPLIES (the default additionally asks for a mean of at most 60: below)
+    try:
+        plan = capi.ColumnSumsPlan(p)
+    finally:
+        capi.set_lean(1)
     assert plan.lean is lean, (pattern, plan.form, plan.max_skip)
+    auto = capi.ColumnSumsPlan(p)
+    assert auto.lean is (lean and nnz <= 60 * len(counts)), pattern      # round 4: selected up to a mean length of 60
+    auto.close()
     xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
     got = plan.column_sums(xt, pt).cpu().numpy()
     means = plan.column_sums(xt, pt, nrow_for_means=977).cpu().numpy()
@@ -1401,3 +1413,19 @@ def test_lean_plan_edges(torch_cuda, pattern):
     assert means.tobytes() == (got / 977).tobytes()
     if lean:
         assert got.tobytes() == oracle.column_sums(x, p).tobytes()
+
+
+def test_form_edges_smoke(torch_cuda):
+    """tools/edge_sweep.py --quick: at the selection thresholds that have a forcing knob, the
+    chosen form and its neighbour are both timed on the same small matrix just beside the threshold.  The full sweep
+    (profiles/r04_form_edges*.json, limit 1.10) found four thresholds that sent matrices to the slower form and moved them;
+    this smoke keeps a coarse watch (limit 1.30: small calls, shared test box) on the column-sum forms."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "edge_sweep.py"), "--quick", "--limit", "1.30",
+                        "--only", "lean,snapped,columns"], capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    edges = [ln for ln in lines if "edge" in ln]
+    assert len(edges) >= 20, r.stdout[-1500:] + r.stderr[-1500:]
+    bad = [(e["edge"], e["side"], e["shape"], e["chosen_over_neighbour"]) for e in edges if not e["ok"]]
+    assert r.returncode == 0 and not bad, bad
