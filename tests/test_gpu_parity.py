@@ -1282,7 +1282,7 @@ def test_c2_full_size_planned_against_oracle(torch_cuda):
 
 
 @pytest.mark.parametrize("shape,snaps", [("short", True), ("into512", True), ("into513", False), ("long", True),
-                                          ("long_few", False), ("zipf", False)])
+                                          ("long_few", True), ("very_long_few", False), ("zipf", False)])
 def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_cuda, shape, snaps):
     """The inspector's decision and both outcomes of the executor.  The chunk before an edge finishes the column
     that crosses it, the chunk after gives the identity to those entries -- inside its first group, so a column
@@ -1298,8 +1298,10 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
         counts = np.concatenate([np.full((7 * 1024 - 40) // 8, 8), [40 + reach], np.full(50_000, 8)]).astype(np.int64)
     elif shape == "long":                               # every column long: the columns form (one workgroup per column)
         counts = np.full(300, 10_000, dtype=np.int64)
-    elif shape == "long_few":                           # ... but too few of them for it: the general kernels
+    elif shape == "long_few":                           # (round 4: also fewer than 128 columns, while one workgroup can stream a column)
         counts = np.full(100, 10_000, dtype=np.int64)
+    elif shape == "very_long_few":                      # ... but few columns of 3e5 entries each: the general kernels
+        counts = np.full(40, 300_000, dtype=np.int64)
     else:
         counts = synth.zipf_counts(20_000, 3_000_000, seed=3, nrow=1_000_000)
     p = synth.offsets_from_counts(counts)
@@ -1310,7 +1312,7 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
         assert plan.chunk_elems == 1024 and plan.max_skip == reach
     assert plan.snapped is snaps, (shape, plan.max_skip)
     assert plan.lean is (shape == "short")            # only there is every column at most 64 entries long
-    assert plan.columns is (shape == "long")
+    assert plan.columns is (shape in ("long", "long_few"))
     xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
     got = plan.column_sums(xt, pt).cpu().numpy()
     plan.close()
@@ -1318,12 +1320,13 @@ def test_plan_snaps_exactly_when_no_column_reaches_far_past_a_chunk_edge(torch_c
 
 
 @pytest.mark.parametrize("pattern", ["uniform_1e4", "min_2048", "min_2047", "min_512", "min_511", "max_4x_mean", "above_4x_mean",
-                                     "128_columns", "127_columns", "odd_lengths_300k", "one_empty"])
+                                     "128_columns", "127_columns", "60_columns_of_2e5", "odd_lengths_300k", "one_empty"])
 def test_columns_plan_edges(torch_cuda, pattern):
     """Where the columns form (every column long: one workgroup per column, p[] read by the kernel, no records) begins
     and ends: the shortest column 2048 entries (4 wavefronts per column) / 2047 and 512 (2 per column, in matrices of
     up to 2.5e8 entries) / 511 (not taken), the longest four times the mean (taken) / beyond (not), 128 columns
-    (taken) / 127 (not), an empty column (not).  Parity against the oracle on every column, also
+    (taken) / 127 short ones (taken since round 4: a workgroup streams such a column in microseconds) / 60 columns of
+    2e5 entries (not: the longest column may have 49152 entries + nnz / 192 below 128 columns), an empty column (not).  Parity against the oracle on every column, also
     through the handle, whose upload makes the same plan, and with the division of the means fused."""
     torch = torch_cuda
     rng = np.random.default_rng(17)
@@ -1339,7 +1342,9 @@ def test_columns_plan_edges(torch_cuda, pattern):
         cols = pattern == "max_4x_mean"
     elif pattern in ("128_columns", "127_columns"):
         counts = rng.integers(2048, 9000, 128 if pattern == "128_columns" else 127)
-        cols = pattern == "128_columns"
+        cols = True
+    elif pattern == "60_columns_of_2e5":
+        counts, cols = rng.integers(190_000, 210_000, 60), False
     elif pattern == "odd_lengths_300k":
         counts, cols = rng.integers(100_001, 300_000, 160) | 1, True        # (columns start at odd offsets: 8-byte aligned only)
     else:
