@@ -562,7 +562,47 @@ void crossprod_tall_kernel(
     // 0.11 / 0.22 / 0.30 / 0.46 ms (the refill inside the panel is an exposed wait that several resident workgroups used to
     // hide), 128 / 192 / 256 columns 0.71 / 1.15 / 2.42 against 0.69 / 1.13 / 2.30 ms: the batch form from 8 tiles on.
     constexpr bool kBatch = NT >= 8;
-    if (kBatch) {
+    // Round 4, 16 column tiles (one workgroup per CU: nobody else hides a wait): the batch is a RING.  Lane l of
+    // column k always holds the entry e = l (mod 64) of the window [cur, cur + 64) of the column; the lanes a panel has
+    // consumed at once request the entries 64 further on -- into their own registers, nothing new stays live -- and nobody
+    // looks at them before the next panel's take, one MFMA phase later.  A window is full at the start of every take and a
+    // 64-row panel takes at most 64 of a column's (distinct, ascending) rows, so there is never a second take inside a panel:
+    // round 3's refill-and-take-again (an exposed memory round trip in about every other panel at 50 % density) is gone.
+    // 1e6 x 256 / 200 / 192: profiles/r04_crossprod.json.
+    constexpr bool kRing = NT >= 16;   // (12 tiles: 1.13 ms without the ring, 1.29 with it: its per-lane addresses cost more than its waits there)
+    auto ring_load = [&](int k) {   // the first window of column k
+        const int32_t e = cur[k] + ((lane - cur[k]) & 63);
+        const bool in = e < end[k];
+        row[k] = in ? ri[e] : 0x7fffffff;
+        val[k] = in ? x[e] : 0.0;
+    };
+    auto take_ring = [&](int k, int64_t r0_, int32_t& pending) {
+        const bool below = (int64_t)row[k] < r0_ + kTallRows;
+        const uint32_t local = (uint32_t)((int64_t)row[k] - r0_);
+        if (below) bad |= ((uint32_t)__double2hiint(val[k]) & 0x7ff00000u) == 0x7ff00000u;
+        if (below && local < (uint32_t)kTallRows) panel[local][wave * CPW + k] = val[k];
+        const int n = __popcll(__ballot(below));   // (also steps over rows below r0: an unsorted, invalid column)
+        // what this column still has to deliver: its oldest entry not taken; if the whole window went, the next panel may hold more
+        const int32_t left = below ? 0x7fffffff : row[k];
+        pending = left < pending ? left : pending;
+        if (n == 64 && (int64_t)cur[k] + 64 < end[k]) {
+            const int64_t np = r0_ + kTallRows;
+            pending = np < (int64_t)pending ? (int32_t)np : pending;
+        }
+        // the consumed lanes' next entries (64 further on); past the column's end: INT_MAX, never below a panel's limit
+        const int32_t e = cur[k] + ((lane - cur[k]) & 63) + 64;
+        const bool more = below && e < end[k] && e > 0;   // (e > 0: no wrap at 2^31)
+        if (below) row[k] = 0x7fffffff;
+        if (more) {
+            row[k] = ri[e];
+            val[k] = x[e];
+        }
+        cur[k] += n;
+    };
+    if (kRing) {
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) ring_load(k);
+    } else if (kBatch) {
 #pragma unroll
         for (int k = 0; k < CPW; ++k) refill(k);
     } else {
@@ -571,7 +611,12 @@ void crossprod_tall_kernel(
     int64_t r0 = R0;
     while (r0 < R1) {
         int32_t pending = 0x7fffffff;   // smallest row this wavefront's columns still have to deliver
-        if (kBatch) {
+        if (kRing) {
+            for (int k = tid; k < kTallRows * (W + 1); k += NW * 64) (&panel[0][0])[k] = 0.0;
+            xp_lds_barrier();
+#pragma unroll
+            for (int k = 0; k < CPW; ++k) take_ring(k, r0, pending);
+        } else if (kBatch) {
             for (int k = tid; k < kTallRows * (W + 1); k += NW * 64) (&panel[0][0])[k] = 0.0;
             xp_lds_barrier();
             uint32_t again = 0;   // columns refilled inside this panel (wave-uniform)
