@@ -72,6 +72,7 @@ WORKLOADS = {
     # (no column ends inside the stream: the ceiling of the streaming fast path)
     "c4shard": (10_000_000, 125_000, 125_000_000, "uniform"),
     "stream": (2_000_000_000, 1, 1_000_000_000, "uniform"),
+    "fewcols": (10_000_000, 10_000, 1_000_000_000, "uniform"),   # 1e4 columns of 1e5 entries (row-restricted sums: profiles/r04_masked.md)
     # column-length regimes between C2 (10 per column) and C3 (1000 per column), all 1e9 nnz
     "m30": (10_000_000, 33_000_000, 1_000_000_000, "uniform"),
     "m100": (10_000_000, 10_000_000, 1_000_000_000, "uniform"),
