@@ -93,6 +93,36 @@ def test_bench_child_process_default_protocol_small(torch_cuda):
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
+def test_bench_line_measures_its_own_ceiling_traffic_and_more_workloads(torch_cuda):
+    """Round 4: the N = 1 line carries, measured in the same run on the same device,
+    `roofline.read_ceiling` (a read-only kernel with the column sums' access shape over the same x), `roofline.traffic`
+    from two rocprofv3 counter passes run as child processes (not a constant from an earlier round), and `also`: more
+    workloads by the same protocol, each with whole-matrix parity -- here a C4 shard as the headline and C2 three ways."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--workload", "c4shard", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--traffic-pass", "on",
+                   "--also", "c2,c2:planned,c2:planned-device")
+    roof = d["roofline"]
+    rc = roof["read_ceiling"]
+    assert 3000 < rc["GBps"] < 8000 and rc["bytes_per_launch"] == 8 * 125_000_000 and rc["reps"] == 5
+    assert 0.5 < rc["frac_of_ceiling"] < 1.05 and rc["frac_of_ceiling"] == pytest.approx(roof["achieved"] / rc["GBps"], rel=1e-9)
+    assert roof["traffic_source"].startswith("measured in this run"), roof.get("traffic_detail")
+    assert 0.98 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.10       # 1 GB of x: past every cache
+    assert roof["traffic_detail"]["read_bytes"] > 100 * roof["traffic_detail"]["write_bytes"]
+    recs = {r["workload"]: r for r in d["also"]["records"]}
+    assert set(recs) == {"c2", "c2:planned", "c2:planned-device"} and roof["also"] == d["also"]["records"]
+    for r in recs.values():
+        assert r["parity"]["columns_out_of_tolerance"] == 0 and r["parity"]["columns_checked"] == "all"
+        assert r["x_copies_rotated"] >= 5 and 0.2 < r["frac"] < 1.0
+    assert recs["c2"]["form"] == "general kernels" and recs["c2"]["launches_per_call"] == 2
+    for k in ("c2:planned", "c2:planned-device"):
+        assert recs[k]["form"] == "lean" and recs[k]["launches_per_call"] == 1
+        assert recs[k]["parity"]["max_abs_err_over_l1"] == 0.0                          # the reference's bits
+        assert recs[k]["kernel_ms"] < recs["c2"]["kernel_ms"]
+    dev = recs["c2:planned-device"]
+    assert "on the device" in dev["plan_made"] and dev["plan_ms"] < 1.0                 # device time of the inspection kernels
+    assert dev["plan_device"]["calls_answered_by_the_general_kernels_before_the_plan_was_known"] >= 0
+
+
 @pytest.mark.parametrize("workload,world,nnz,ncol", [("c4shard", 2, 125_000_000, 125_000),
                                                      ("tiny", 3, 4_000_000, 40_000)])
 def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload, world, nnz, ncol):
