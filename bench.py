@@ -400,6 +400,7 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
     if mode == "planned-device":
         # p[] is never shown to the host: the inspection runs as kernels on the launch stream, nothing waits for it, and
         # the calls issued meanwhile are answered by the general kernels (counted here) until the host has seen the result
+        capi.ColumnSumsPlan(pt, nnz=nnz, stream=stream).wait().close()   # (first use loads the inspector's kernels: not what plan_ms is about)
         torch.cuda.synchronize()
         t_enq = time.perf_counter()
         plan = capi.ColumnSumsPlan(pt, nnz=nnz, stream=stream)

@@ -49,7 +49,7 @@ def driver_record(rnd):
     return best
 
 
-def row_of(d, label, m=None, f=None, tr=None):
+def row_of(d, label, m=None, f=None, tr=None, own_traffic=False):
     r = d["roofline"]
     pipe = d.get("pipelined") or {}
     gather = f" (+ gatherv {r['gather_ms'] * 1e3:.1f} us)" if r.get("gather_ms") else ""
@@ -58,7 +58,7 @@ def row_of(d, label, m=None, f=None, tr=None):
     lat = f"{d['latency_ms_per_call']:.4f}" if "latency_ms_per_call" in d else "-"
     ovl = f"{pipe['ms_per_step']:.4f}" if "ms_per_step" in pipe else "-"
     par = f"{d['parity']['max_abs_err_over_l1']:.1e}" if "parity" in d else "checked in the run (exit 0)"
-    if tr is None and r.get("traffic"):
+    if tr is None and own_traffic and r.get("traffic"):
         tr = r["traffic"] / r["algorithmic_bytes_per_launch"]
     return (f"| {label} | {d['ms_per_step']:.4f} | {r['kernel_ms']:.4f}{gather} | {d['value']:.3e} | {r['achieved']:.0f} | "
             f"{100 * r['frac']:.1f} % | {lat} | {ovl} | "
@@ -74,7 +74,7 @@ def main():
            "|---|---|---|---|---|---|---|---|---|---|---|"]
     drv = driver_record(rnd)
     if drv and drv[0] == rnd:     # the driver's own run of this round's code is the headline
-        out.append(row_of(drv[1], f"c3 -- the driver's run (`BENCH_{rnd}.json`)"))
+        out.append(row_of(drv[1], f"c3 -- the driver's run (`BENCH_{rnd}.json`)", own_traffic=True))
     for d in lines:
         tag = d["config"]["workload"].split(":")[0]
         form = (d["config"].get("planned") or {}).get("form")
@@ -98,6 +98,27 @@ def main():
                    f"c3 {p['ms_per_step']:.4f} ms per call, kernels {p['roofline']['kernel_ms']:.4f} ms = "
                    f"{100 * p['roofline']['frac']:.1f} % of 8 TB/s.  The rows above are the builder's runs of THIS round's code on "
                    f"the devices `gpurun` handed out (c3 on them: 1.19-1.24 ms, 81-85 %, device to device).")
+    # what the default line measures beside the headline figure (round 4): the read-only ceiling, its own traffic, more workloads
+    full = next((d for d in ([drv[1]] if drv and drv[0] == rnd else []) + lines if (d["roofline"].get("read_ceiling"))), None)
+    if full:
+        r = full["roofline"]
+        rc = r["read_ceiling"]
+        src = "the driver's run" if (drv and drv[0] == rnd and full is drv[1]) else "the builder's default run (`bench.py`, no flags)"
+        out.append("")
+        out.append(f"In the same run as the c3 line ({src}): a read-only kernel with the column sums' access shape over the same 8 GB of x "
+                   f"reaches **{rc['GBps']:.0f} GB/s** ({100 * rc['of_spec_peak']:.1f} % of the 8 TB/s spec peak) -- the c3 call is at "
+                   f"**{100 * rc['frac_of_ceiling']:.1f} % of that measured ceiling**"
+                   + (f"; HBM traffic of one call from two rocprofv3 counter passes run by the bench itself: {r['traffic'] / 1e9:.4f} GB = "
+                      f"{r['traffic'] / r['algorithmic_bytes_per_launch']:.4f} x the algorithmic bytes" if str(r.get("traffic_source", "")).startswith("measured in this run") else "") + ".")
+        also = r.get("also") or (full.get("also") or {}).get("records")
+        if also:
+            out.append("")
+            out.append("| `also` record of that line | form | launches per call | ms per call | kernels, HIP events (ms) | of 8 TB/s | plan (ms) | parity: max err / column 1-norm |")
+            out.append("|---|---|---|---|---|---|---|---|")
+            for a in also:
+                plan = "-" if a.get("plan_ms") is None else f"{a['plan_ms']:.3f}" + (" (device time; made on the device)" if "on the device" in str(a.get("plan_made")) else " (host)")
+                out.append(f"| {a['workload']} | {a['form']} | {a['launches_per_call']} | {a['ms_per_call']:.4f} | {a['kernel_ms']:.4f} | "
+                           f"{100 * a['frac']:.1f} % | {plan} | {a['parity']['max_abs_err_over_l1']:.1e} |")
     cpu = [d for d in lines if d.get("cpu_baseline")]
     if cpu:
         c = cpu[0]["cpu_baseline"]

@@ -11,9 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 O=/root/repo/gpurun_out
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- \
-    python3 /root/repo/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipelined --latency-calls 1 "$@" > $O/prof_${TAG}_stats.log 2>&1
+    python3 /root/repo/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipelined --latency-calls 1 --no-also --traffic-pass off "$@" > $O/prof_${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_fetch -- \
-    python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --latency-calls 1 "$@" > $O/prof_${TAG}_fetch.log 2>&1
+    python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --latency-calls 1 --no-also --traffic-pass off "$@" > $O/prof_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_write -- \
-    python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --latency-calls 1 "$@" > $O/prof_${TAG}_write.log 2>&1
+    python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --latency-calls 1 --no-also --traffic-pass off "$@" > $O/prof_${TAG}_write.log 2>&1
 grep '"metric"' $O/prof_${TAG}_stats.log | cut -c1-300
