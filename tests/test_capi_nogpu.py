@@ -249,7 +249,8 @@ def test_row_restricted_form_selection_is_host_logic():
     assert capi.in_rows_form(**big, workspace_bytes=capi.in_rows_workspace_bytes(**big) - 1) == "L2"
     assert capi.in_rows_form(10_000_000, 4_000_000, 1_000_000_000) == "L2"      # 25 entries per column and slice
     assert capi.in_rows_form(30_000_000, 1_000_000, 1_000_000_000) == "slices"   # 34
-    assert capi.in_rows_form(10_000_000, 16_383, 1_000_000_000) == "L2"         # one column too few
+    assert capi.in_rows_form(10_000_000, 13_311, 1_000_000_000) == "L2"         # one column too few (round 4: 13312, was 16384)
+    assert capi.in_rows_form(10_000_000, 13_312, 1_000_000_000) == "slices"
     assert capi.in_rows_form(10_000_000, 16_384, 1_000_000_000) == "slices"
     assert capi.in_rows_form(2**31 - 1, 16_384, 2**31 - 1) == "L2"              # 2048 bitmap copies per 64 columns
     capi.set_row_slices(0)
