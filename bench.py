@@ -128,7 +128,12 @@ def parse_args(argv=None):
                          "RCCL; over gloo in the rehearsal).  Its line carries metric 'rowSums nnz/s ...': a next-row figure, "
                          "never the headline")
     ap.add_argument("--no-planned-shards", action="store_true", help="N > 1: skip the separate planned_shards figure")
-    ap.add_argument("--no-direct-gather", action="store_true", help="N > 1: skip the separate direct_gather figure")
+    ap.add_argument("--direct-gather", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: the separate direct_gather figure (the ranks' kernels store into rank 0's result buffer, mapped "
+                         "with hipIpc).  auto = in the --rendezvous gloo rehearsal only: between DIFFERENT devices a kernel that "
+                         "writes through a mapping the driver does not honour faults, and a fault ends the whole job -- on a "
+                         "real multi-GPU node the figure is asked for explicitly (--direct-gather on), the line with `value` is not "
+                         "put at its mercy")
     ap.add_argument("--also", default="auto",
                     help="N = 1: more single-GPU workloads measured after the headline one, OUTSIDE its timed region, "
                          "as compact sub-records under the key `also` (never part of `value`).  auto = every other "
@@ -492,7 +497,18 @@ def planned_shards_figure(ctx):
     again -- planned launch, then that call's gather, in order on one stream.  Never feeds `value`."""
     torch, dist, capi, sharded = ctx["torch"], ctx["dist"], ctx["capi"], ctx["sharded"]
     args, shard, world, rank = ctx["args"], ctx["shard"], ctx["world"], ctx["rank"]
-    plan = capi.ColumnSumsPlan(shard.p_local, nnz=shard.nnz, device=ctx["dev_index"])
+    plan, err = None, None
+    try:
+        plan = capi.ColumnSumsPlan(shard.p_local, nnz=shard.nnz, device=ctx["dev_index"])
+    except Exception as e:            # (a rank that cannot plan must not leave the others alone in the collectives below)
+        err = str(e)
+    ok = torch.tensor([0.0 if plan is None else 1.0], device=ctx["stat_dev"])
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok[0]) == 0.0:
+        if plan is not None:
+            plan.close()
+        return {"value": None, "note": f"not measured: a rank could not make its plan ({err})"} if rank == 0 else None
     xs, pt, out, ws, s_main = ctx["xs"], ctx["pt"], ctx["out_main"], ctx["ws_main"], ctx["s_main"]
     launches = [plan.prepared(xk, pt, out, ws, stream=s_main) for xk in xs]
     n = [0]
@@ -1042,8 +1058,11 @@ def main(argv=None):
     planned_shards = direct_gather = None
     if world > 1 and plan is None and not args.no_planned_shards:
         planned_shards = planned_shards_figure(ctx)
-    if world > 1 and not args.no_direct_gather:
+    if world > 1 and (args.direct_gather == "on" or (args.direct_gather == "auto" and rehearsal)):
         direct_gather = direct_gather_figure(ctx)
+    elif world > 1:
+        direct_gather = {"value": None, "note": "not run: --direct-gather auto measures it in the --rendezvous gloo rehearsal only; "
+                                                "ask for it with --direct-gather on"} if rank == 0 else None
 
     stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=stat_dev)
     # what every rank owned and measured (rank order), so the line shows the whole partition
