@@ -307,6 +307,9 @@ int rsp_column_sums_device_timed(const double *d_x, const int32_t *d_p,
  * how fast this device lets that be done.  One untimed launch, then `reps` launches between two HIP events
  * on `stream`; returns the mean milliseconds per launch (8 * nnz bytes each).  Synchronises `stream`.
  */
+/* Test helper: the hand-written exclusive prefix sum of 32-bit counts the regrouping passes use on their count tables
+ * (csrc/scan.hip): d_out[k] = d_in[0] + ... + d_in[k - 1]; d_out may be d_in.  Allocates its scratch, waits for `stream`. */
+int rsp_debug_exclusive_scan_device(const int32_t *d_in, int32_t *d_out, int64_t n, void *stream);
 int rsp_debug_read_ceiling_device(const double *d_x, int64_t nnz, double *d_sink, void *stream,
                                   int reps, float *ms_per_launch);
 
@@ -328,7 +331,7 @@ int rsp_debug_read_ceiling_device(const double *d_x, int64_t nnz, double *d_sink
  * Entries whose row index is outside [0, nrow) are left out, not added elsewhere.
  * Ask for the workspace size with the device current that will run the call
  * (the plan looks at its CU count).
- * rsp_row_sums_workspace_bytes needs a usable device (it asks rocPRIM); 0 = error.
+ * rsp_row_sums_workspace_bytes: 0 = error (sizes out of range).
  *
  * Segments form (handles only -- it needs p[]): where the columns are long (a column has
  * >= 128 entries per block of 16384 rows on average, more than 16384 rows, >= 30 columns)
@@ -371,7 +374,7 @@ int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
  * by walking the rows its column touches (work = sum over rows of nnz(row)^2 products);
  * with d_workspace == NULL a scratch-free 64 x 64 tile kernel is used instead (slower on
  * sparse data).  Both give the same bits.  rsp_crossprod_workspace_bytes needs a usable
- * device (it asks rocPRIM); 0 = error.
+ * device; 0 = error.
  *
  * One exception to "same bits": for ncol <= 256 and columns of >= 4096 stored entries on
  * average (the tall matrices crossprod is meant for), the workspace form sums in a different

@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_plan_ready", "rsp_column_sums_plan_wait", "rsp_debug_plan_image",
     "rsp_shared_result_alloc", "rsp_shared_result_open", "rsp_shared_result_close", "rsp_shared_result_read",
     "rsp_host_barrier_create", "rsp_host_barrier_wait", "rsp_host_barrier_destroy",
-    "rsp_set_columns_form", "rsp_crossprod_form",
+    "rsp_set_columns_form", "rsp_crossprod_form", "rsp_debug_exclusive_scan_device",
     "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
 )
 
@@ -172,6 +172,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_set_taper.argtypes = [c.c_int, c.c_int]
     L.rsp_set_crossprod_exact.argtypes = [c.c_int]
     L.rsp_plan_describe.argtypes = [i64, ip]
+    L.rsp_debug_exclusive_scan_device.argtypes = [vp, vp, i64, vp]
     L.rsp_debug_read_ceiling_device.argtypes = [vp, i64, vp, vp, c.c_int, c.POINTER(c.c_float)]
     _lib = L
     return L
@@ -698,6 +699,16 @@ def column_sums_device_timed(x_t, p_t, out_t, workspace, reps: int, stream=None)
                                                workspace.numel(), _stream_ptr(stream), int(reps),
                                                ctypes.byref(ms)))
     return float(ms.value)
+
+
+def exclusive_scan_device(in_t, out_t=None, stream=None):
+    """Exclusive prefix sum of an int32 tensor through the library's hand-written scan (rsp_debug_exclusive_scan_device)."""
+    import torch
+    assert in_t.dtype == torch.int32 and in_t.is_contiguous()
+    if out_t is None:
+        out_t = torch.empty_like(in_t)
+    _check(load().rsp_debug_exclusive_scan_device(in_t.data_ptr(), out_t.data_ptr(), in_t.numel(), _stream_ptr(stream)))
+    return out_t
 
 
 def read_ceiling_device(x_t, reps: int = 5, stream=None) -> float:

@@ -938,6 +938,19 @@ int rsp_column_sums_device_timed(const double* d_x, const int32_t* d_p, int32_t 
     return RSP_OK;
 }
 
+int rsp_debug_exclusive_scan_device(const int32_t* d_in, int32_t* d_out, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!d_in || !d_out))) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_debug_exclusive_scan_device");
+    if (n == 0) return RSP_OK;
+    const size_t bytes = rsp::exclusive_scan_temp_bytes(n);
+    void* temp = nullptr;
+    HIP_TRY(hipMalloc(&temp, bytes));
+    hipError_t e = rsp::launch_exclusive_scan_i32(d_in, d_out, n, 0, temp, bytes, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(temp);
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "exclusive scan failed: %s", hipGetErrorString(e));
+    return RSP_OK;
+}
+
 int rsp_debug_read_ceiling_device(const double* d_x, int64_t nnz, double* d_sink, void* stream, int reps,
                                   float* ms_per_launch) {
     if (int rc = check_sizes(0, nnz)) return rc;

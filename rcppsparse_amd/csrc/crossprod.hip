@@ -34,7 +34,6 @@
 // zero.
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 
 #include "colsums_kernels.h"
@@ -571,8 +570,8 @@ void crossprod_tall_kernel(
     // 1e6 x 256 / 200 / 192: profiles/r04_crossprod.json.
     constexpr bool kRing = NT >= 16;   // (12 tiles: 1.13 ms without the ring, 1.29 with it: its per-lane addresses cost more than its waits there)
     auto ring_load = [&](int k) {   // the first window of column k
-        const int32_t e = cur[k] + ((lane - cur[k]) & 63);
-        const bool in = e < end[k];
+        const uint32_t e = (uint32_t)cur[k] + (uint32_t)((lane - cur[k]) & 63);   // (unsigned: a cursor may stand just below 2^31)
+        const bool in = e < (uint32_t)end[k];
         row[k] = in ? ri[e] : 0x7fffffff;
         val[k] = in ? x[e] : 0.0;
     };
@@ -590,8 +589,8 @@ void crossprod_tall_kernel(
             pending = np < (int64_t)pending ? (int32_t)np : pending;
         }
         // the consumed lanes' next entries (64 further on); past the column's end: INT_MAX, never below a panel's limit
-        const int32_t e = cur[k] + ((lane - cur[k]) & 63) + 64;
-        const bool more = below && e < end[k] && e > 0;   // (e > 0: no wrap at 2^31)
+        const uint32_t e = (uint32_t)cur[k] + (uint32_t)((lane - cur[k]) & 63) + 64u;   // (unsigned: no wrap below 2^32)
+        const bool more = below && e < (uint32_t)end[k];
         if (below) row[k] = 0x7fffffff;
         if (more) {
             row[k] = ri[e];
@@ -788,10 +787,7 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
     }
     const size_t nv1 = (size_t)nrow * (size_t)L->nsplit + 1;   // virtual rows + 1
     if (nv1 > 0x7fffffffull) return hipErrorInvalidValue;
-    size_t temp = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, nv1,
-                                           rocprim::plus<int32_t>(), (hipStream_t)0);
-    if (e != hipSuccess) return e;
+    const size_t temp = exclusive_scan_temp_bytes((int64_t)nv1);   // (scan.hip: hand-written since round 4)
     size_t off = 0;
     L->rp_off = off;     off = xp_align(off + nv1 * 4);
     L->cursor_off = off; off = xp_align(off + nv1 * 4);
@@ -862,9 +858,7 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     if (nnz > 0)
         hipLaunchKernelGGL(xp_count_rows_kernel, cgrid, dim3(256), 0, stream, d_i, d_p, nrow, ncol, nsplit, width,
                            cursor, run_if);
-    size_t temp_bytes = L.temp_bytes;
-    e = rocprim::exclusive_scan((char*)ws + L.temp_off, temp_bytes, (const int32_t*)cursor, rp, 0, nv1,
-                                rocprim::plus<int32_t>(), stream);
+    e = launch_exclusive_scan_i32(cursor, rp, (int64_t)nv1, 0, (char*)ws + L.temp_off, L.temp_bytes, stream);
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(cursor, rp, nv1 * 4, hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) return e;

@@ -12,7 +12,7 @@
 //   tile partition (5 to 832 row blocks = up to 1.36e7 rows): the entries are regrouped by ROW BLOCK in ONE pass,
 //     then added up block by block.
 //       1. rows_tile_histogram_kernel   entries per (block, supertile)              reads  4 B/nnz
-//       2. one exclusive scan over that table (rocPRIM; a few MB) = first output slot of every pair
+//       2. one exclusive scan over that table (scan.hip; a few MB) = first output slot of every pair
 //       3. rows_tile_partition_kernel   a workgroup walks its supertile in tiles of 22528 entries (22
 //          per thread, in registers): ranks them per block with wave-private LDS counters, SORTS THE
 //          TILE BY BLOCK THROUGH LDS (8192 positions per round), and writes every block's run to its
@@ -44,14 +44,13 @@
 // A handle (rsp_csc_row_sums) keeps the regrouped copy and repeats steps 4 and 5 only (12 B/nnz per call) -- or, where
 // its columns are long and their rows ascend, regroups nothing at all (segments form, at the end of this file).
 // Rounds 1-2 sorted with rocPRIM here (by 4096-row block above 1.36e7 rows, fully by row behind the handle); the
-// only library call left is the exclusive scan of the count table.
+// exclusive scan of the count table was the last library call (round 4: scan.hip).
 // All forms are deterministic and within the usual 1e-12 * sum|x| of the reference's order.
 // Round-2 history (profiles/r02_rowsums.md): partitioning WITHOUT sorting each tile in LDS first
 // (every lane storing its entry straight to its block's cursor) took 47 ms for the scatter alone.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include <stdint.h>
 
@@ -135,7 +134,7 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
     (void)keep_row_form;   // (a handle keeps the regrouped copy -- `persistent` -- and repeats the accumulate pass only)
     memset(L, 0, sizeof(*L));
     size_t off = 0;
-    hipError_t e;
+
     const int64_t part_blocks = ((int64_t)nrow + (1 << kPartShift) - 1) >> kPartShift;
     L->shift = kPartShift;
     L->nblocks = (int32_t)(part_blocks > 0 ? part_blocks : 1);
@@ -180,10 +179,7 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
     // regroups every bucket by its blocks -- the same two kernels, run on the bucket's range of the intermediate.
     L->nbuckets = L->mode == 3 ? (int32_t)(((int64_t)nrow + ((int64_t)1 << kPartBucketShift) - 1) >> kPartBucketShift) : 0;
     const size_t table_entries = (size_t)L->nsuper * (size_t)table_blocks + 1;   // + the total
-    size_t temp = 0;
-    e = rocprim::exclusive_scan(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, 0, table_entries,
-                                rocprim::plus<int32_t>(), (hipStream_t)0);
-    if (e != hipSuccess) return e;
+    const size_t temp = exclusive_scan_temp_bytes((int64_t)table_entries);   // (scan.hip: hand-written since round 4)
     // queue form of the partition pass (whole aligned groups of 16 entries only): every (block, supertile) region is
     // padded to whole groups, so the regrouped copy has up to 15 slots more per region; kept to what 32-bit slots hold
     static const bool queue_allowed = [] {   // RSP_ROWS_QUEUE=0: the round-2 write-out (A/B measurements)
@@ -846,9 +842,7 @@ static hipError_t partition_pass(const double* src_x, const int32_t* src_i, int6
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    size_t temp_bytes = L.temp_bytes;
-    e = rocprim::exclusive_scan(temp, temp_bytes, (const int32_t*)table, table, 0, table_entries,
-                                rocprim::plus<int32_t>(), stream);
+    e = launch_exclusive_scan_i32(table, table, (int64_t)table_entries, 0, temp, L.temp_bytes, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rows_tile_offsets_kernel, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, stream, table, nblocks,
                        L.nsuper, boff, seg, close);

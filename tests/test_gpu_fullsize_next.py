@@ -133,8 +133,10 @@ def test_row_sums_full_size(torch_cuda, nrow, ncol, nnz, structure):
 
 
 # ---------------------------------------------------------------------------- crossprod
-def test_crossprod_tall_form_at_the_int32_limit(torch_cuda):
-    """2^31 - 1 entries in 48 columns of 45e6 rows: the matrix-core form on the largest matrix the 32-bit
+@pytest.mark.parametrize("nrow,ncol", [(45_000_000, 48), (17_000_000, 256)])
+def test_crossprod_tall_form_at_the_int32_limit(torch_cuda, nrow, ncol):
+    """2^31 - 1 entries in 48 columns of 45e6 rows (3 column tiles), and in 256 columns of 17e6 rows (16 tiles: the
+    ring batches of round 4, whose per-lane entry indices reach 2^31): the matrix-core form on the largest matrix the 32-bit
     slots can hold.  Column pairs at both ends of the arrays and in the middle against the oracle's merges
     (the exact form's order), the diagonal against the column sums of squares, symmetry, identical bits
     on a second run.
@@ -147,8 +149,9 @@ def test_crossprod_tall_form_at_the_int32_limit(torch_cuda):
     (b) within that plus the oracle's own measured distance from the exact sum of the oracle."""
     torch = torch_cuda
     need_hbm(torch, 75)
-    nrow, ncol, nnz, seed = 45_000_000, 48, INT32_MAX, 3
+    nnz, seed = INT32_MAX, 3
     p, pt, xt, it = device_matrix(torch, nrow, ncol, nnz, "equal", seed)
+    assert capi.crossprod_form(nrow, ncol, nnz) == "tall"
     a = capi.crossprod_device(xt, it, pt, nrow)
     b = capi.crossprod_device(xt, it, pt, nrow)
     assert torch.equal(a, b)
@@ -158,7 +161,7 @@ def test_crossprod_tall_form_at_the_int32_limit(torch_cuda):
     got = a.cpu().numpy()
     del a, b, xt, it
     worst_device, worst_oracle = 0.0, 0.0
-    for c0 in (0, 23, ncol - 2):
+    for c0 in (0, ncol // 2 - 1, ncol - 2):
         c1 = c0 + 2
         lo, mid, hi = int(p[c0]), int(p[c0 + 1]), int(p[c1])
         xs = oracle.gen_values(hi - lo, seed, lo, 0)

@@ -386,3 +386,23 @@ def test_handle_row_sums_segments_form_forced_onto_small_and_odd_shapes(torch_cu
     scale = np.bincount(i[keep], weights=np.abs(x[keep]), minlength=nrow)
     assert np.all(np.abs(hs - ref) <= RTOL * scale), float(np.max(np.abs(hs - ref) / np.maximum(scale, 1e-300)))
     assert np.all(hs[scale == 0] == 0.0) and not np.any(np.signbit(hs[scale == 0]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8191, 1_000_003, 4096 * 1024, 4096 * 1025 + 7, (1 << 24) + 5])
+def test_hand_written_exclusive_scan_of_the_count_tables(torch_cuda, n):
+    """csrc/scan.hip (round 4: the last library call of the row-wise paths is gone): exclusive prefix sums of 32-bit counts,
+    out of place and in place, from aligned and unaligned starts, against numpy -- exact (integer adds)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n)
+    host = rng.integers(0, 120, size=n + 3, dtype=np.int32)
+    if n > 100:
+        host[rng.integers(0, n, size=5)] = 1_000_000          # a few large cells
+    dev = torch.from_numpy(host).cuda()
+    for off in (0, 3):                                       # (off = 3: the tile loads are not 16-byte aligned)
+        src = dev[off:off + n]
+        want = np.concatenate([[0], np.cumsum(host[off:off + n].astype(np.int64))[:-1]]).astype(np.int64)
+        got = capi.exclusive_scan_device(src.contiguous() if off == 0 else src)      # a view at an odd offset stays a view
+        assert np.array_equal(got.cpu().numpy().astype(np.int64), want), (n, off)
+        buf = src.clone()
+        capi.exclusive_scan_device(buf, buf)                 # in place
+        assert np.array_equal(buf.cpu().numpy().astype(np.int64), want), (n, off, "in place")
