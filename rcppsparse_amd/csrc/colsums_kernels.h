@@ -230,6 +230,10 @@ struct CrossprodLayout {   // workspace of the row-major path
     bool tall;
     int32_t ngroups, panels_per_group, ntiles;
     size_t partial_off, flag_off;
+    // 16 tiles: the tall form finds its 32-row panels through a table T[panel][column] (crossprod.hip) in the workspace
+    bool panel_table;
+    int64_t npanels;
+    size_t table_off, has_off;
 };
 hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, CrossprodLayout* L);
 void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, int32_t* width);

@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <stdint.h>
+#include <type_traits>
 
 #include "colsums_kernels.h"
 
@@ -691,6 +692,335 @@ void crossprod_tall_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// tall form, 16 column tiles (193-256 columns): panels found through a PANEL TABLE (round 4)
+// ---------------------------------------------------------------------------------------------
+// What bounds crossprod_tall_kernel at 16 tiles is not the matrix cores (busy 45 %) but the panel build: 256
+// columns = 256 pieces per panel, each found by a dependent chain cursor -> address -> load -> ballot -> cursor
+// (profiles/r04_crossprod.json: schedules of that chain were tried for two rounds).  This form takes the chain
+// away instead.  A first pass over the row indices (4 bytes per entry, no atomics) writes a table
+//     Ts[P][c], Te[P][c] = where column c's entries with a row in panel P (32 rows) begin and end
+// -- at most 32 entries, rows ascend -- so that every address the matrix-core kernel will ever need is known
+// before it starts.  That kernel: 8 wavefronts; a panel's
+// row of T travels two panels ahead, its entries (half a wavefront per column, 16 rounds) one panel ahead, in
+// registers, while the current panel is multiplied; two panel buffers in LDS; no cursors, no ballots.  Its 136
+// tile pairs are dealt as whole tile ROWS (wavefront w: rows w and 15 - w, 17 pairs), so a k-step needs 16 LDS
+// reads for 17 MFMAs and the accumulators (136 registers) fit the 256 a wavefront of a 512-thread workgroup may
+// have: nothing is densified twice (crossprod_tall_kernel's SPLIT is gone) and x / i are read once.
+// Same sums in the same order as crossprod_tall_kernel defines them (panel by panel inside a workgroup, the
+// workgroups' results added in order), same tolerance, deterministic.
+// (Also built and measured: a panel-major COPY of the entries -- histogram, scan, fill with one atomic per run of
+// neighbours -- read back as one contiguous piece per panel: the copy alone cost 1.15 ms at 1.28e8 entries.)
+constexpr int kPanRows = 32;           // rows per panel of the table
+// Row stride of a panel in LDS = W + 17 doubles (34 banks beyond a multiple of 64).  The MFMA operand reads take 16
+// neighbouring doubles of 4 consecutive rows: with a stride of W + 1 (crossprod_tall_kernel's) the rows start 2 banks
+// apart and two of them collide on 30 of their 32 banks (SQ_LDS_BANK_CONFLICT: 37 % of the LDS cycles); 34 banks apart
+// they share 2.  The entries going in are the rows of ONE column: any odd stride spreads those over all the banks.
+constexpr int kPanPad = 17;
+
+__device__ __forceinline__ int pan_of_row(int r, int32_t nrow, int64_t npanels) {   // (a row outside the matrix: some panel; the kernel drops the entry)
+    return (unsigned)r < (unsigned)nrow ? r / kPanRows : (r < 0 ? 0 : (int)(npanels - 1));
+}
+
+// Ts[c][P] / Te[c][P] for every panel P and column c that meet; both are preset to 0 ("column c has nothing in
+// panel P": an empty range).  An entry whose predecessor lies in another panel writes Ts, one whose
+// successor does writes Te: at most two stores per entry, whatever the input; if the rows of a column do not
+// ascend (not a valid dgCMatrix) several runs may claim a cell -- the cell then holds one of them, still indices of
+// this column.
+__global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __restrict__ ri, const int32_t* __restrict__ p,
+                                                             int32_t nrow, int32_t ncol, int64_t nnz, int64_t npanels,
+                                                             int32_t* __restrict__ Ts, int32_t* __restrict__ Te) {
+    // A lane takes four neighbouring entries (one aligned 16-byte load) and their two neighbours; two such steps are
+    // in flight per wavefront.  (One entry per lane and step: 0.72 ms at 1.28e8 entries -- a wavefront waiting for
+    // 256 bytes at a time; this form: profiles/r04_crossprod.json.)
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
+    constexpr int UN = 2;
+    for (int c = wave; c < ncol; c += nwaves) {
+        int64_t a = p[c], b = p[c + 1];
+        a = a < 0 ? 0 : (a > nnz ? nnz : a);   // (an invalid p[] must not lead outside x / i)
+        b = b < a ? a : (b > nnz ? nnz : b);
+        int32_t* ts = Ts + (int64_t)c * npanels;
+        int32_t* te = Te + (int64_t)c * npanels;
+        const int64_t a4 = a & ~3ll;
+        for (int64_t g0 = a4 + (int64_t)blockIdx.x * (UN * 256); g0 < b; g0 += (int64_t)gridDim.x * (UN * 256)) {   // (wave-uniform)
+            int4 v[UN];
+            int32_t before[UN], after[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t e4 = g0 + u * 256 + lane * 4;
+                v[u] = int4{0, 0, 0, 0};
+                before[u] = after[u] = 0;
+                if (e4 < b) {
+                    if (e4 + 4 <= nnz) {
+                        v[u] = *(const int4*)(ri + e4);
+                    } else {   // (the last, partial quad of the array)
+                        v[u].x = ri[e4];
+                        if (e4 + 1 < nnz) v[u].y = ri[e4 + 1];
+                        if (e4 + 2 < nnz) v[u].z = ri[e4 + 2];
+                    }
+                    if (e4 > 0) before[u] = ri[e4 - 1];
+                    if (e4 + 4 < nnz) after[u] = ri[e4 + 4];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t e4 = g0 + u * 256 + lane * 4;
+                const int32_t rr[6] = {before[u], v[u].x, v[u].y, v[u].z, v[u].w, after[u]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t e = e4 + k;
+                    if (e < a || e >= b) continue;
+                    const int cur = pan_of_row(rr[k + 1], nrow, npanels);
+                    const int prev = e == a ? -1 : pan_of_row(rr[k], nrow, npanels);
+                    const int next = e == b - 1 ? -1 : pan_of_row(rr[k + 2], nrow, npanels);
+                    if (prev != cur) ts[cur] = (int32_t)e;
+                    if (next != cur) te[cur] = (int32_t)(e + 1);
+                }
+            }
+        }
+    }
+}
+
+// has[P] = some column has entries in panel P, read off Te (an end of a non-empty piece is never 0).  A block looks at
+// 256 panels x 32 columns: neighbouring threads, neighbouring panels.
+__global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __restrict__ Te, int32_t ncol, int64_t npanels,
+                                                           uint32_t* __restrict__ has_words) {
+    const int64_t P = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * 32, c1 = c0 + 32 < ncol ? c0 + 32 : ncol;
+    int any = 0;
+    if (P < npanels)
+        for (int c = c0; c < c1; ++c) any |= Te[(int64_t)c * npanels + P];
+    // four panels' bytes share a word of has[]: the lanes of a quad put theirs together, one atomic per word
+    uint32_t word = (any != 0 ? 1u : 0u) << (8 * (threadIdx.x & 3));
+    word |= __shfl_xor(word, 1, 64);
+    word |= __shfl_xor(word, 2, 64);
+    if ((threadIdx.x & 3) == 0 && word != 0 && P < npanels) atomicOr(&has_words[P >> 2], word);
+}
+
+// One workgroup of NT / 2 wavefronts per range of panels.
+// Tile pairs: tile row I meets the tiles (I + d) mod NT, d = 0 .. NT / 2 (rows below NT / 2) or d = 0 .. NT / 2 - 1 (the
+// others) -- every unordered pair once; wavefront w has rows w and w + NT / 2: NT + 1 pairs, the same code for every
+// wavefront (only LDS offsets differ).  A tile that wraps (J < I) is the transpose of pair (J, I) and is stored so.
+// Everything that is not an MFMA -- zeroing the other buffer, putting the next panel's entries into it, requesting
+// the entries of the panel after that -- is dealt out over the 8 k-steps of the current panel's multiplication, so
+// that it issues in the shadow of the matrix cores (a first version that did these between the barriers, after the
+// MFMA phase, took 1.51 ms at 1e6 x 256 where this one takes less; profiles/r04_crossprod.json).
+typedef double xp_v2f64 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) double xp_lds_f64;   // (LDS pointers as such: handed on as generic pointers they
+typedef __attribute__((address_space(3))) int32_t xp_lds_i32;  // become FLAT accesses, which queue behind the global loads)
+// (the life of wavefront WV as a function of its own: tiles, columns and with them every LDS offset are constants of
+// the instruction stream -- with the wavefront's number in a register the operand addresses alone were 17 vector
+// instructions per k-step, and vector instructions do not overlap f64 MFMAs on this chip)
+template <int NT, bool WIDE, int MODE>
+__device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_lds_i32* __restrict__ sT,
+                                            const uint8_t* __restrict__ has,
+                                            const double* __restrict__ x, const int32_t* __restrict__ ri,
+                                            const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
+                                            int32_t ncol, int64_t npanels, int64_t P0, int64_t P1,
+                                            int32_t* __restrict__ nonfinite, double* __restrict__ mine) {
+    constexpr int W = NT * 16, W1 = W + kPanPad, NW = NT / 2, NTH = NW * 64, RND = W / (2 * NW);
+    constexpr int KS = kPanRows / 4, NPW = NT + 1, NA = NT / 2 + 1;   // k-steps per panel; pairs per wavefront; of its first row
+    constexpr int kBufDoubles = kPanRows * W1;
+    static_assert(NTH == 2 * W, "one thread per cell of a row of the two tables");
+    static_assert(RND == 16 && KS == 8, "the rounds are dealt out over the MFMA groups by hand below");
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    xp_v4f64 acc[NPW];
+#pragma unroll
+    for (int s = 0; s < NPW; ++s) acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
+    // (wave-uniform) tile of pair s on the A side and on the B side
+    auto tile_a = [&](int s) { return s < NA ? wave : wave + NW; };
+    auto tile_b = [&](int s) { return (s < NA ? wave + s : wave + NW + (s - NA)) & (NT - 1); };
+    static_assert((NT & (NT - 1)) == 0, "tile numbers wrap with a mask");
+
+    auto zero_part = [&](int b, int m0, int m1) {   // 16-byte units tid + m * NTH, m0 <= m < m1
+        auto* z = (__attribute__((address_space(3))) xp_v2f64*)(panel + b * kBufDoubles);
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+            const int k = tid + m * NTH;
+            if (k < kBufDoubles / 2) z[k] = xp_v2f64{0.0, 0.0};
+        }
+    };
+    constexpr int ZN = (kBufDoubles / 2 + NTH - 1) / NTH;   // 9: eight full rounds and a tail
+    // Loads go under the execution mask into registers preset to "nothing".  (A select after the load -- "row = lane
+    // has an entry ? loaded : -1" -- makes the wavefront wait for what it has just requested wherever the compiler
+    // leaves the select next to the load: 1.85 instead of 1.62 ms.  Loads that are never conditional, the lanes without
+    // an entry recognised again from the tables a phase later, would let the compiler count outstanding loads exactly,
+    // but need a dozen registers more than there are: 23 spilled, reloaded in every round.)
+    int32_t treg = 0;
+    const int tcol = tid & (W - 1);
+    auto load_T = [&](int64_t P) {   // row P of the two tables ([column][panel]), one cell per thread; zeros past the last panel / column
+        treg = 0;
+        if (tcol < ncol && P < P1) treg = (tid >= W ? Te : Ts)[(int64_t)tcol * npanels + P];
+    };
+    auto put_T = [&]() { sT[tid] = treg; };
+    int32_t r_[RND];
+    double v_[RND];
+    const char* ri_b = (const char*)ri;
+    const char* x_b = (const char*)x;
+    auto request = [&](int j) {   // round j of the panel whose rows of the tables stand in sT: half a wavefront per column
+        const int c = (j * NW + wave) * 2 + half;
+        const int32_t s = sT[c], n = sT[W + c] - s;   // (0, 0: nothing of this column; at most 32 rows of a valid column fall into a panel)
+        const uint32_t at = (uint32_t)(s + l);
+        r_[j] = -1;
+        if (l < n) {
+            if (WIDE) {   // (byte offsets beyond 32 bits: 2^29 entries or more)
+                r_[j] = ri[at];
+                v_[j] = x[at];
+            } else {      // (a scalar base and a 32-bit offset per lane: one instruction per address)
+                r_[j] = *(const int32_t*)(ri_b + (uint64_t)(at << 2));
+                v_[j] = *(const double*)(x_b + (uint64_t)(at << 3));
+            }
+        }
+    };
+    auto scatter = [&](int j, int b, int32_t r0) {
+        const int c = (j * NW + wave) * 2 + half;
+        const uint32_t local = (uint32_t)(r_[j] - r0);   // (-1, "nothing", or a row of another panel -- an invalid column: not below 32)
+        panel[b * kBufDoubles + (local < (uint32_t)kPanRows ? local * W1 + c : W)] = v_[j];
+    };
+    // The 136 MFMAs of a panel in groups of four; a group's B operands (and the two A operands of a k-step that begins
+    // in it) are read from LDS while the group before it is multiplied.
+    constexpr int NM = KS * NPW, G = 4, NG = (NM + G - 1) / G;   // (groups of six: 12 more registers live, 54 spilled)
+    double opb[2][G], opa[2][2];
+    auto load_group = [&](const xp_lds_f64* pan, int g) {
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const int idx = g * G + t, ks = idx / NPW, s = idx % NPW;
+            if (idx < NM) {
+                const xp_lds_f64* prow = pan + (4 * ks + (lane >> 4)) * W1 + (lane & 15);
+                opb[g & 1][t] = prow[16 * tile_b(s)];
+                if (s == 0) {
+                    opa[ks & 1][0] = prow[16 * wave];
+                    opa[ks & 1][1] = prow[16 * (wave + NW)];
+                }
+            }
+        }
+    };
+    auto mfma_group = [&](int g) {
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const int idx = g * G + t, ks = idx / NPW, s = idx % NPW;
+            if (idx < NM)
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[ks & 1][s < NA ? 0 : 1], opb[g & 1][t], acc[s], 0, 0, 0);
+        }
+    };
+
+    // Only panels that hold entries enter the pipeline (has[], written with the tables).  "The next one" is asked for a
+    // phase ahead with a vector load (hq), so that the common case -- the next panel holds entries too -- never waits;
+    // a gap is walked with one exposed load per empty panel, a tenth of what multiplying it would cost.
+    auto next_panel = [&](int64_t P) {   // the first panel at or after P that holds entries (wave-uniform; P1 if none)
+        while (P < P1 && __builtin_amdgcn_readfirstlane((int)has[P]) == 0) ++P;
+        return P;
+    };
+    // ---- the first panel into buffer 0, the second one requested, the third one's cells of the tables requested
+    int64_t Pc = next_panel(P0);
+    zero_part(0, 0, ZN);
+    load_T(Pc);
+    put_T();
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RND; ++j) request(j);
+    int64_t Pn = Pc < P1 ? next_panel(Pc + 1) : P1;
+    load_T(Pn);
+#pragma unroll
+    for (int j = 0; j < RND; ++j) scatter(j, 0, (int32_t)((Pc < P1 ? Pc : 0) * kPanRows));
+    __syncthreads();          // (everybody has read sT)
+    put_T();
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RND; ++j) request(j);
+    int64_t Pnn = Pn < P1 ? next_panel(Pn + 1) : P1;
+    load_T(Pnn);
+    int32_t hq = Pnn + 1 < P1 ? (int32_t)has[Pnn + 1] : 1;
+    xp_lds_barrier();         // (everybody has read sT once more)
+    int b = 0;
+    while (Pc < P1) {
+        // buffer b holds panel Pc; the registers hold the entries of panel Pn and the cells of panel Pnn (requested a
+        // phase ago); the other buffer still holds the panel before Pc
+        const int o = b ^ 1;
+        put_T();              // (sT was last read before the barrier that ended the previous phase)
+        int64_t Pnnn = Pnn + 1 < P1 ? Pnn + 1 : P1;
+        if (Pnnn < P1 && __builtin_amdgcn_readfirstlane(hq) == 0) Pnnn = next_panel(Pnnn + 1);
+        load_T(Pnnn);
+        hq = Pnnn + 1 < P1 ? (int32_t)has[Pnnn + 1] : 1;
+        const int32_t r0n = (int32_t)((Pn < P1 ? Pn : 0) * kPanRows);
+        const xp_lds_f64* pan = panel + b * kBufDoubles;
+        // Group g: its MFMAs, and a share of everything else -- the groups of the first two k-steps zero the other
+        // buffer, 16 later ones move one round of entries each.  (sched_barrier: the compiler keeps this order.  All of
+        // it in two blocks, before the first and after the last MFMA: 1.87 instead of 1.62 ms at 1e6 x 256; f64 MFMAs and
+        // other vector instructions of a SIMD do not overlap -- tools/microbench/mfma_shadow.hip: 3-4 cycles per 32-bit
+        // instruction on top of the MFMA's 64 -- but LDS writes, branches and waiting for LDS do.)
+        constexpr bool mul = !(MODE & 1), side = !(MODE & 2);
+        constexpr int ZG = (2 * NPW + G - 1) / G;   // the groups of the first two k-steps share the zeroing
+        static_assert(NG >= ZG + 1 + RND, "shares of the groups");
+        if (mul) load_group(pan, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (mul && g + 1 < NG) load_group(pan, g + 1);
+            if (mul) mfma_group(g);
+            if (g < ZG) zero_part(o, g * ZN / ZG, (g + 1) * ZN / ZG);
+            if (g == ZG) xp_lds_barrier();   // the other buffer is all zero (and sT is panel Pnn's) before anybody scatters (requests)
+            if (g > ZG && g - (ZG + 1) < RND && side) {
+                scatter(g - (ZG + 1), o, r0n);
+                request(g - (ZG + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        xp_lds_barrier();     // everybody has multiplied panel Pc; the next one stands in the other buffer; sT has been read
+        b = o;
+        Pc = Pn;
+        Pn = Pnn;
+        Pnn = Pnnn;
+    }
+    // A structural zero that meets a non-finite value makes a NaN here where the reference has nothing, and a NaN
+    // stays: any sum that is not finite sends the call to the bit-identical kernels (the combine kernel then leaves
+    // the result alone), as crossprod_tall_kernel does by looking at every value it loads -- here it costs 68
+    // looks per lane and call instead of three instructions per entry.
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < NPW; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= ((uint32_t)__double2hiint(acc[s][r]) & 0x7ff00000u) == 0x7ff00000u;
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(nonfinite, 1);
+    // pair (I <= J) number q; lane: element (row, col) of the tile A_side x B_side: col = lane & 15, row = (lane >> 4) + 4 r
+#pragma unroll
+    for (int s = 0; s < NPW; ++s) {
+        const int ta = tile_a(s), tb = tile_b(s);
+        const bool wraps = tb < ta;              // computed C(ta, tb) = transpose of pair (tb, ta)
+        const int I = wraps ? tb : ta, J = wraps ? ta : tb;
+        const int q = I * NT - I * (I - 1) / 2 + (J - I);
+        double* t = mine + (size_t)q * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) + 4 * r, col = lane & 15;
+            t[wraps ? col * 16 + row : row * 16 + col] = acc[s][r];
+        }
+    }
+}
+
+template <int NT, bool WIDE, int MODE = 0>   // (MODE, measurements only: 1 = no MFMAs, 2 = no entries moved)
+__global__ __launch_bounds__(NT * 32) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __restrict__ ri,
+                             const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
+                             const uint8_t* __restrict__ has, int32_t ncol, int64_t npanels,
+                             int32_t panels_per_group, int32_t* __restrict__ nonfinite, double* __restrict__ partial) {
+    constexpr int W = NT * 16, W1 = W + kPanPad, NP = NT * (NT + 1) / 2;
+    constexpr int kBufDoubles = kPanRows * W1;
+    static_assert((kBufDoubles * 8) % 16 == 0, "a panel buffer is whole 16-byte units");
+    __shared__ __attribute__((aligned(16))) double panel[2 * kBufDoubles];
+    __shared__ int32_t sT[2 * W];
+    const int64_t P0 = (int64_t)blockIdx.x * panels_per_group;
+    const int64_t P1 = P0 + panels_per_group < npanels ? P0 + panels_per_group : npanels;
+    double* mine = partial + (size_t)blockIdx.x * NP * 256;
+    // (every wavefront meets the same barriers: the panels of a workgroup are the same for all of them)
+    // (One instruction stream for all wavefronts, the wavefront's number in a register.  A stream per wavefront, with
+    // every LDS offset a constant, saves 136 vector instructions per panel and was slower; so were two streams that
+    // multiply and move in opposite order on the two wavefronts of a SIMD.)
+    panels_body<NT, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, has, x, ri, Ts, Te, ncol, npanels, P0, P1, nonfinite,
+                                mine);
+}
+
 // out(c1, c2) = the workgroups' results for that element (both triangles).  One wavefront per element: lane l
 // adds the results of workgroups l, l + 64, ... in that order, then the 64 lane sums meet in a fixed butterfly --
 // the same association on every run.  (One thread per element walking all ~1000 workgroups took 0.3-0.5 ms,
@@ -752,6 +1082,11 @@ static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiat
 //   tall : 0.13 + nrow * width^2 / 3.8e10 per ms (the panels' multiply-adds) + 12 B per entry at 3.9 TB/s
 // Rounds 2-3 asked for columns of >= 4096 entries only, which sent sparse wide matrices (256 columns, 0.4 % dense) to a
 // form four times slower.
+static bool panel_table_enabled() {   // (RSP_CROSSPROD_PANEL_TABLE=0: round 3's kernel at 16 tiles too, for comparisons)
+    const char* pm = getenv("RSP_CROSSPROD_PANEL_TABLE");
+    return !(pm && pm[0] == '0');
+}
+
 static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
     const char* always = getenv("RSP_CROSSPROD_TALL_ALWAYS");   // (edge measurements: the round 2-3 rule, columns of >= 4096 entries)
     if (always && always[0] == '1') return true;
@@ -760,7 +1095,10 @@ static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
     const double products = (double)nnz * (double)nnz / rows + (double)nnz;
     const double t_exact = 0.04 + len * 1.0e-4 + products / 4.0e8;
     const double width = 16.0 * tall_tiles(ncol);
-    const double t_tall = 0.13 + rows * width * width / 3.8e10 + 12.0 * (double)nnz / 3.9e9;
+    double t_tall = 0.13 + rows * width * width / 3.8e10 + 12.0 * (double)nnz / 3.9e9;
+    // (16 tiles, the panel-table kernel: 1e6 rows x 256 at 10 / 50 / 90 % density 1.42 / 1.66 / 1.94 ms, 4e6 rows at 5 %
+    // 5.05 ms, 2.5e5 rows at 50 % 0.53 ms -- profiles/r04_crossprod.json)
+    if (tall_tiles(ncol) == 16 && panel_table_enabled()) t_tall = 0.10 + rows * width * width / 5.2e10 + 2.5e-9 * (double)nnz;
     return t_tall <= t_exact;
 }
 
@@ -784,6 +1122,20 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         L->panels_per_group = (int32_t)per;
         L->ngroups = (int32_t)((npanels + per - 1) / per);
         if (L->ngroups < 1) L->ngroups = 1;
+        // 16 column tiles: panels of 32 rows through a panel table (crossprod_panels_kernel), one workgroup per CU
+        if (L->ntiles == 16 && panel_table_enabled()) {
+            L->panel_table = true;
+            L->npanels = ((int64_t)nrow + kPanRows - 1) / kPanRows;
+            const char* gr = getenv("RSP_CROSSPROD_PANEL_GROUPS");
+            int64_t groups = gr ? atoll(gr) : 256;
+            if (groups < 1) groups = 1;
+            if (groups > kTallMaxGroups) groups = kTallMaxGroups;
+            int64_t pper = (L->npanels + groups - 1) / groups;
+            if (pper < 1) pper = 1;
+            L->panels_per_group = (int32_t)pper;
+            L->ngroups = (int32_t)((L->npanels + pper - 1) / pper);
+            if (L->ngroups < 1) L->ngroups = 1;
+        }
     }
     const size_t nv1 = (size_t)nrow * (size_t)L->nsplit + 1;   // virtual rows + 1
     if (nv1 > 0x7fffffffull) return hipErrorInvalidValue;
@@ -799,6 +1151,10 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         const size_t np = (size_t)L->ntiles * (L->ntiles + 1) / 2;
         L->partial_off = off; off = xp_align(off + (size_t)L->ngroups * np * 256 * 8);
         L->flag_off = off;    off = xp_align(off + 4);
+        if (L->panel_table) {
+            L->table_off = off; off = xp_align(off + 2 * (size_t)L->npanels * (size_t)ncol * 4);   // Ts, then Te
+            L->has_off = off;   off = xp_align(off + (size_t)L->npanels + 4);
+        }
     }
     L->total_bytes = off;
     return hipSuccess;
@@ -829,6 +1185,41 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
         double* partial = (double*)((char*)ws + L.partial_off);
         e = hipMemsetAsync(flag, 0, 4, stream);
         if (e != hipSuccess) return e;
+        if (L.panel_table) {
+            // the panel table (and which panels hold entries), then the matrix-core kernel that reads x / i through it
+            int32_t* Ts = (int32_t*)((char*)ws + L.table_off);
+            int32_t* Te = Ts + (size_t)L.npanels * (size_t)ncol;
+            uint8_t* has = (uint8_t*)((char*)ws + L.has_off);
+            e = hipMemsetAsync(Ts, 0, 2 * (size_t)L.npanels * (size_t)ncol * 4, stream);   // (0, 0: nothing of column c in panel P)
+            if (e == hipSuccess) e = hipMemsetAsync(has, 0, ((size_t)L.npanels + 3) / 4 * 4, stream);
+            if (e != hipSuccess) return e;
+            const int want_y = (ncol + 3) / 4;
+            int xparts = (int)(nnz / ((int64_t)ncol * 2048));   // (a part walks ~2048 entries or more)
+            if (xparts > 4096 / want_y) xparts = 4096 / want_y;
+            if (xparts < 1) xparts = 1;
+            if (nnz > 0)
+                hipLaunchKernelGGL(xp_panel_table_kernel, dim3((unsigned)xparts, (unsigned)want_y), dim3(256), 0, stream,
+                                   d_i, d_p, nrow, ncol, nnz, L.npanels, Ts, Te);
+            hipLaunchKernelGGL(xp_panel_has_kernel, dim3((unsigned)((L.npanels + 255) / 256), (unsigned)((ncol + 31) / 32)),
+                               dim3(256), 0, stream, (const int32_t*)Te, ncol, L.npanels, (uint32_t*)has);
+#define RSP_XP_LAUNCH(WIDE, M)                                                                                          \
+    hipLaunchKernelGGL((crossprod_panels_kernel<16, WIDE, M>), dim3((unsigned)L.ngroups), dim3(512), 0, stream, d_x,    \
+                       d_i, (const int32_t*)Ts, (const int32_t*)Te, (const uint8_t*)has, ncol, L.npanels,               \
+                       L.panels_per_group, flag, partial)
+            int mode = 0;
+#ifdef RSP_XP_MODES   // (a measurement build: RSP_XP_PANELS_MODE = 1 no MFMAs, 2 no entries moved, 3 neither)
+            if (const char* md = getenv("RSP_XP_PANELS_MODE")) mode = atoi(md);
+            if (nnz < (1ll << 29) && mode == 1) RSP_XP_LAUNCH(false, 1);
+            if (nnz < (1ll << 29) && mode == 2) RSP_XP_LAUNCH(false, 2);
+            if (nnz < (1ll << 29) && mode == 3) RSP_XP_LAUNCH(false, 3);
+            if (nnz >= (1ll << 29)) mode = 0;
+#endif
+            if (mode == 0) {
+                if (nnz >= (1ll << 29)) RSP_XP_LAUNCH(true, 0);
+                else RSP_XP_LAUNCH(false, 0);
+            }
+#undef RSP_XP_LAUNCH
+        } else
         switch (L.ntiles) {
             case 1: launch_tall<1, 4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
             case 2: launch_tall<2, 4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;

@@ -226,3 +226,89 @@ def test_crossprod_tall_form_rows_without_entries_and_ragged_last_panel(torch_cu
                                 nrow).cpu().numpy().T
     assert np.all(np.abs(got - ref) <= 1e-12 * scale)
     assert np.all(got[scale == 0] == 0)
+
+
+# ---- 193-256 columns: the tall form finds its 32-row panels through a panel table (crossprod_panels_kernel) ----
+
+@pytest.mark.parametrize("ncol", [200, 256])
+def test_crossprod_panel_table_form_gaps_ragged_end_and_round3_kernel_agree(torch_cuda, ncol):
+    """Panels without entries never enter the pipeline (has[]), whether the gap is two panels or 3 400 and wherever a
+    workgroup's range begins; the last panel is partial.  Against the oracle within the tall form's tolerance, the
+    same bits on every run, and the kernel it replaces (RSP_CROSSPROD_PANEL_TABLE=0) within the same tolerance."""
+    import os
+    torch = torch_cuda
+    nrow = 200_003
+    bands = [(0, 9_000), (9_100, 9_164), (60_000, 90_000), (199_000, nrow - 1)]
+    rng = np.random.default_rng(11 + ncol)
+    cols = []
+    for c in range(ncol):
+        parts = [np.sort(rng.choice(np.arange(lo, hi), size=n, replace=False))
+                 for (lo, hi), n in zip(bands, (2500, 20, 1500, 300))]
+        rows = np.concatenate(parts)
+        if c % 5 == 0:
+            rows = np.append(rows, nrow - 1)
+        cols.append(rows)
+    i = np.concatenate(cols).astype(np.int32)
+    p = np.concatenate(([0], np.cumsum([len(c) for c in cols]))).astype(np.int32)
+    x = rng.standard_normal(i.size)
+    assert capi.crossprod_form(nrow, ncol, x.size) == "tall"
+    ref = oracle.crossprod(x, i, p)
+    scale = oracle.crossprod(np.abs(x), i, p)
+    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    again = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    assert got.tobytes() == again.tobytes()
+    assert np.array_equal(got, got.T)
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale), float(np.max(np.abs(got - ref) / np.maximum(scale, 1e-300)))
+    os.environ["RSP_CROSSPROD_PANEL_TABLE"] = "0"
+    try:
+        old = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    finally:
+        del os.environ["RSP_CROSSPROD_PANEL_TABLE"]
+    assert np.all(np.abs(old - ref) <= 1e-12 * scale)
+
+
+def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda):
+    """256 columns: the panel-table kernel looks at its sums, not at every value: a NaN made by a structural zero
+    meeting an infinity stays a NaN, the flag goes up and the bit-identical kernels produce the reference's result.
+    Also with the non-finite value in the last entry of the last column, and with a value whose products overflow."""
+    torch = torch_cuda
+    nrow, ncol = 45_000, 256
+    m = synth.rsparsematrix(nrow, ncol, density=0.1, seed=9, kind=0)
+    x0, i, p = m["x"], m["i"], m["p"]
+    assert capi.crossprod_form(nrow, ncol, x0.size) == "tall"
+    it, pt = torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    for where, value in ((1234, np.inf), (x0.size - 1, np.nan), (x0.size // 3, -np.inf), (777, 1e200)):
+        x = x0.copy()
+        x[where] = value
+        if value == 1e200:
+            x[where + 1] = 1e200                                          # (its square is an infinity only in the sum)
+        with np.errstate(over="ignore", invalid="ignore"):
+            ref = oracle.crossprod(x, i, p)
+        got = capi.crossprod_device(torch.from_numpy(x).cuda(), it, pt, nrow).cpu().numpy().T
+        assert np.array_equal(got, ref, equal_nan=True), (where, value)
+
+
+def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cuda):
+    """Not a dgCMatrix -- rows that do not ascend, rows outside the matrix, column offsets that go backwards or
+    beyond nnz: the result means nothing, but the call returns, reads and writes nothing out of bounds (the entries
+    it cannot place are dropped) and the library goes on working."""
+    torch = torch_cuda
+    nrow, ncol = 45_000, 256
+    m = synth.rsparsematrix(nrow, ncol, density=0.1, seed=10, kind=0)
+    x, i0, p0 = m["x"], m["i"], m["p"]
+    rng = np.random.default_rng(0)
+    xt = torch.from_numpy(x).cuda()
+    cases = []
+    i = i0.copy(); rng.shuffle(i[: i.size // 2]); cases.append((i, p0))                      # rows in any order
+    i = i0.copy(); i[::7] = nrow + 5; i[3::11] = -3; cases.append((i, p0))                 # rows outside the matrix
+    i = i0.copy(); i[:] = 17; cases.append((i, p0))                                         # one row, stored again and again
+    p = p0.copy(); p[5] = p[9]; p[100] = x.size + 1000; p[200] = -4; cases.append((i0, p))  # offsets that are no offsets
+    for i, p in cases:
+        out = capi.crossprod_device(xt, torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda(), nrow)
+        torch.cuda.synchronize()
+        assert out.shape == (ncol, ncol)
+    ref = oracle.crossprod(x, i0, p0)
+    scale = oracle.crossprod(np.abs(x), i0, p0)
+    got = capi.crossprod_device(xt, torch.from_numpy(i0).cuda(), torch.from_numpy(p0).cuda(), nrow).cpu().numpy().T
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale)

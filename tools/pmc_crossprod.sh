@@ -18,7 +18,7 @@ import csv, glob, collections, json
 tot = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$O/pmcx_${NC}_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "crossprod_tall_kernel" in r["Kernel_Name"]:
+        if "crossprod_tall_kernel" in r["Kernel_Name"] or "crossprod_panels_kernel" in r["Kernel_Name"]:
             t = tot[r["Counter_Name"]]; t[0] += float(r["Counter_Value"]); t[1] += 1
 print(json.dumps({"ncol": $NC, "per_launch": {k: v / n for k, (v, n) in sorted(tot.items())}}))
 PY
