@@ -717,6 +717,9 @@ constexpr int kPanRows = 32;           // rows per panel of the table
 // apart and two of them collide on 30 of their 32 banks (SQ_LDS_BANK_CONFLICT: 37 % of the LDS cycles); 34 banks apart
 // they share 2.  The entries going in are the rows of ONE column: any odd stride spreads those over all the banks.
 constexpr int kPanPad = 17;
+#ifndef RSP_XP_TABLE_UN
+#define RSP_XP_TABLE_UN 2
+#endif
 
 __device__ __forceinline__ int pan_of_row(int r, int32_t nrow, int64_t npanels) {   // (a row outside the matrix: some panel; the kernel drops the entry)
     return (unsigned)r < (unsigned)nrow ? r / kPanRows : (r < 0 ? 0 : (int)(npanels - 1));
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
     // 256 bytes at a time; this form: profiles/r04_crossprod.json.)
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
-    constexpr int UN = 2;
+    constexpr int UN = RSP_XP_TABLE_UN;
     for (int c = wave; c < ncol; c += nwaves) {
         int64_t a = p[c], b = p[c + 1];
         a = a < 0 ? 0 : (a > nnz ? nnz : a);   // (an invalid p[] must not lead outside x / i)
@@ -814,6 +817,7 @@ typedef __attribute__((address_space(3))) int32_t xp_lds_i32;  // become FLAT ac
 // instructions per k-step, and vector instructions do not overlap f64 MFMAs on this chip)
 template <int NT, bool WIDE, int MODE>
 __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_lds_i32* __restrict__ sT,
+                                            xp_lds_i32* __restrict__ sSafe, xp_lds_f64* __restrict__ sStray,
                                             const uint8_t* __restrict__ has,
                                             const double* __restrict__ x, const int32_t* __restrict__ ri,
                                             const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
@@ -843,41 +847,62 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         }
     };
     constexpr int ZN = (kBufDoubles / 2 + NTH - 1) / NTH;   // 9: eight full rounds and a tail
-    // Loads go under the execution mask into registers preset to "nothing".  (A select after the load -- "row = lane
-    // has an entry ? loaded : -1" -- makes the wavefront wait for what it has just requested wherever the compiler
-    // leaves the select next to the load: 1.85 instead of 1.62 ms.  Loads that are never conditional, the lanes without
-    // an entry recognised again from the tables a phase later, would let the compiler count outstanding loads exactly,
-    // but need a dozen registers more than there are: 23 spilled, reloaded in every round.)
+    // In the loop no load is conditional and nothing is decided by what a load has just returned: a lane without an
+    // entry of its own reads an entry of the PREVIOUS panel of the pipeline (one is noted whenever a panel's cells go
+    // into sT), whose row the scatter then finds outside its panel like any stray row.  Only so does the compiler know
+    // how many loads are outstanding when an entry is needed: with loads under the execution mask it branches around
+    // them, no longer knows whether they were issued, and every round waits for the round before it -- s_waitcnt
+    // vmcnt(1) where (30) would do, 1.66 ms at 1e6 x 256; with a select after the load ("row = lane has an entry ?
+    // loaded : -1") the wavefront waits for what it has just requested (1.85 ms).
     int32_t treg = 0;
     const int tcol = tid & (W - 1);
-    auto load_T = [&](int64_t P) {   // row P of the two tables ([column][panel]), one cell per thread; zeros past the last panel / column
-        treg = 0;
-        if (tcol < ncol && P < P1) treg = (tid >= W ? Te : Ts)[(int64_t)tcol * npanels + P];
+    const int32_t* const tab = tid >= W ? Te : Ts;
+    auto load_T = [&](int64_t P) {   // row P of the two tables ([column][panel]), one cell per thread (cell 0 when there is none)
+        treg = tab[tcol < ncol && P < P1 ? (int64_t)tcol * npanels + P : 0];
     };
-    auto put_T = [&]() { sT[tid] = treg; };
+    auto put_T = [&](int q, int64_t P) {   // ... of panel P: zeros past the last panel and the last column; notes an entry of P in sSafe[q]
+        const int32_t t = tcol < ncol && P < P1 ? treg : 0;
+        sT[tid] = t;
+        const unsigned long long ends = __ballot(tid >= W && t > 0);   // (threads from W on hold Te: the end of a piece that is not empty)
+        if (ends != 0ull) {
+            const int32_t last = __builtin_amdgcn_readlane(t, __builtin_ctzll(ends)) - 1;
+            if (lane == 0) sSafe[q] = last;
+        }
+    };
     int32_t r_[RND];
     double v_[RND];
     const char* ri_b = (const char*)ri;
     const char* x_b = (const char*)x;
-    auto request = [&](int j) {   // round j of the panel whose rows of the tables stand in sT: half a wavefront per column
-        const int c = (j * NW + wave) * 2 + half;
-        const int32_t s = sT[c], n = sT[W + c] - s;   // (0, 0: nothing of this column; at most 32 rows of a valid column fall into a panel)
-        const uint32_t at = (uint32_t)(s + l);
-        r_[j] = -1;
-        if (l < n) {
-            if (WIDE) {   // (byte offsets beyond 32 bits: 2^29 entries or more)
-                r_[j] = ri[at];
-                v_[j] = x[at];
-            } else {      // (a scalar base and a 32-bit offset per lane: one instruction per address)
-                r_[j] = *(const int32_t*)(ri_b + (uint64_t)(at << 2));
-                v_[j] = *(const double*)(x_b + (uint64_t)(at << 3));
-            }
+    auto fetch = [&](int j, uint32_t at) {
+        if (WIDE) {   // (byte offsets beyond 32 bits: 2^29 entries or more)
+            r_[j] = ri[at];
+            v_[j] = x[at];
+        } else {      // (a scalar base and a 32-bit offset per lane: one instruction per address)
+            r_[j] = *(const int32_t*)(ri_b + (uint64_t)(at << 2));
+            v_[j] = *(const double*)(x_b + (uint64_t)(at << 3));
         }
     };
+    // round j of the panel whose cells stand in sT: half a wavefront per column (0, 0: nothing of this column; at most
+    // 32 rows of a valid column fall into a panel)
+    const xp_lds_i32* const sTw = sT + wave * 2 + half;
+    auto request = [&](int j, int32_t safe) {
+        const int32_t s = sTw[j * NW * 2], n = sTw[W + j * NW * 2] - s;
+        fetch(j, l < n ? (uint32_t)(s + l) : (uint32_t)safe);
+    };
+    auto request_first = [&](int j) {   // (the first panel of a workgroup has no predecessor)
+        const int32_t s = sTw[j * NW * 2], n = sTw[W + j * NW * 2] - s;
+        r_[j] = -1;
+        if (l < n) fetch(j, (uint32_t)(s + l));
+    };
+    // (LDS addresses as 32-bit numbers, the round's share of them a constant of the instruction: written as an index
+    // into panel[] the compiler kept sixteen 64-bit constants, one per round, in 32 registers)
+    const uint32_t cell0 = (uint32_t)(uintptr_t)panel + (uint32_t)(wave * 2 + half) * 8u;
+    const uint32_t stray0 = (uint32_t)(uintptr_t)sStray;
     auto scatter = [&](int j, int b, int32_t r0) {
-        const int c = (j * NW + wave) * 2 + half;
-        const uint32_t local = (uint32_t)(r_[j] - r0);   // (-1, "nothing", or a row of another panel -- an invalid column: not below 32)
-        panel[b * kBufDoubles + (local < (uint32_t)kPanRows ? local * W1 + c : W)] = v_[j];
+        const uint32_t local = (uint32_t)(r_[j] - r0);   // (-1, or a row of another panel: not below 32)
+        const uint32_t at = local < (uint32_t)kPanRows ? cell0 + (uint32_t)(b * kBufDoubles * 8) + __umul24(local, (uint32_t)(W1 * 8))
+                                                        : stray0;
+        ((xp_lds_f64*)(uintptr_t)at)[j * NW * 2] = v_[j];
     };
     // The 136 MFMAs of a panel in groups of four; a group's B operands (and the two A operands of a k-step that begins
     // in it) are read from LDS while the group before it is multiplied.
@@ -917,34 +942,37 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     int64_t Pc = next_panel(P0);
     zero_part(0, 0, ZN);
     load_T(Pc);
-    put_T();
+    put_T(0, Pc);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RND; ++j) request(j);
+    for (int j = 0; j < RND; ++j) request_first(j);
     int64_t Pn = Pc < P1 ? next_panel(Pc + 1) : P1;
     load_T(Pn);
 #pragma unroll
     for (int j = 0; j < RND; ++j) scatter(j, 0, (int32_t)((Pc < P1 ? Pc : 0) * kPanRows));
     __syncthreads();          // (everybody has read sT)
-    put_T();
+    put_T(1, Pn);
     __syncthreads();
+    {
+        const int32_t safe = __builtin_amdgcn_readfirstlane(sSafe[0]);   // an entry of panel Pc
 #pragma unroll
-    for (int j = 0; j < RND; ++j) request(j);
+        for (int j = 0; j < RND; ++j) request(j, Pc < P1 ? safe : 0);
+    }
     int64_t Pnn = Pn < P1 ? next_panel(Pn + 1) : P1;
     load_T(Pnn);
     int32_t hq = Pnn + 1 < P1 ? (int32_t)has[Pnn + 1] : 1;
     xp_lds_barrier();         // (everybody has read sT once more)
-    int b = 0;
+    int b = 0, q = 0;         // q: where this phase notes an entry of the panel whose cells it puts into sT (the other one: of the panel before)
     while (Pc < P1) {
         // buffer b holds panel Pc; the registers hold the entries of panel Pn and the cells of panel Pnn (requested a
         // phase ago); the other buffer still holds the panel before Pc
         const int o = b ^ 1;
-        put_T();              // (sT was last read before the barrier that ended the previous phase)
+        put_T(q, Pnn);        // (sT and sSafe[q] were last read before the barrier that ended the previous phase)
         int64_t Pnnn = Pnn + 1 < P1 ? Pnn + 1 : P1;
         if (Pnnn < P1 && __builtin_amdgcn_readfirstlane(hq) == 0) Pnnn = next_panel(Pnnn + 1);
         load_T(Pnnn);
         hq = Pnnn + 1 < P1 ? (int32_t)has[Pnnn + 1] : 1;
-        const int32_t r0n = (int32_t)((Pn < P1 ? Pn : 0) * kPanRows);
+        const int32_t r0n = Pn < P1 ? (int32_t)(Pn * kPanRows) : -2 * kPanRows;   // (no next panel: no row is within 32 of that)
         const xp_lds_f64* pan = panel + b * kBufDoubles;
         // Group g: its MFMAs, and a share of everything else -- the groups of the first two k-steps zero the other
         // buffer, 16 later ones move one round of entries each.  (sched_barrier: the compiler keeps this order.  All of
@@ -954,21 +982,26 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         constexpr bool mul = !(MODE & 1), side = !(MODE & 2);
         constexpr int ZG = (2 * NPW + G - 1) / G;   // the groups of the first two k-steps share the zeroing
         static_assert(NG >= ZG + 1 + RND, "shares of the groups");
+        int32_t safe = 0;
         if (mul) load_group(pan, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (mul && g + 1 < NG) load_group(pan, g + 1);
             if (mul) mfma_group(g);
             if (g < ZG) zero_part(o, g * ZN / ZG, (g + 1) * ZN / ZG);
-            if (g == ZG) xp_lds_barrier();   // the other buffer is all zero (and sT is panel Pnn's) before anybody scatters (requests)
+            if (g == ZG) {
+                xp_lds_barrier();   // the other buffer is all zero (and sT is panel Pnn's) before anybody scatters (requests)
+                safe = __builtin_amdgcn_readfirstlane(sSafe[q ^ 1]);   // an entry of panel Pn, for the lanes that have none of Pnn
+            }
             if (g > ZG && g - (ZG + 1) < RND && side) {
                 scatter(g - (ZG + 1), o, r0n);
-                request(g - (ZG + 1));
+                request(g - (ZG + 1), safe);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         xp_lds_barrier();     // everybody has multiplied panel Pc; the next one stands in the other buffer; sT has been read
         b = o;
+        q ^= 1;
         Pc = Pn;
         Pn = Pnn;
         Pnn = Pnnn;
@@ -1009,7 +1042,9 @@ void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __rest
     constexpr int kBufDoubles = kPanRows * W1;
     static_assert((kBufDoubles * 8) % 16 == 0, "a panel buffer is whole 16-byte units");
     __shared__ __attribute__((aligned(16))) double panel[2 * kBufDoubles];
-    __shared__ int32_t sT[2 * W];
+    __shared__ int32_t sT[2 * W];     // one panel's cells {Ts, Te}
+    __shared__ int32_t sSafe[2];      // an entry of the panel whose cells went into sT in this phase / the phase before
+    __shared__ double sStray[W];      // where the lanes without an entry put what they hold (a round's share of it: 16 doubles apart)
     const int64_t P0 = (int64_t)blockIdx.x * panels_per_group;
     const int64_t P1 = P0 + panels_per_group < npanels ? P0 + panels_per_group : npanels;
     double* mine = partial + (size_t)blockIdx.x * NP * 256;
@@ -1017,7 +1052,7 @@ void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __rest
     // (One instruction stream for all wavefronts, the wavefront's number in a register.  A stream per wavefront, with
     // every LDS offset a constant, saves 136 vector instructions per panel and was slower; so were two streams that
     // multiply and move in opposite order on the two wavefronts of a SIMD.)
-    panels_body<NT, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, has, x, ri, Ts, Te, ncol, npanels, P0, P1, nonfinite,
+    panels_body<NT, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, (xp_lds_i32*)sSafe, (xp_lds_f64*)sStray, has, x, ri, Ts, Te, ncol, npanels, P0, P1, nonfinite,
                                 mine);
 }
 
@@ -1045,6 +1080,41 @@ __global__ __launch_bounds__(256) void crossprod_tall_combine_kernel(const doubl
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d, 64);
     if (lane == 0) out[k] = sum;
+}
+
+// The same for the panel-table kernel's results (16 tiles, at most 256 workgroups): one workgroup of 1024 threads per
+// tile pair, thread = (quarter of the workgroups' results, element of the tile): neighbouring threads read neighbouring
+// doubles -- crossprod_tall_combine_kernel's lanes stride from one workgroup's result to the next, 68 us for 71 MB
+// where this one takes a third.  Quarter k adds the results of workgroups k, k + 4, ... in that order, the four
+// sums meet as (0 + 1) + (2 + 3): the same association on every run.  Only elements on or above the diagonal are used,
+// the others are their mirror images.
+__global__ __launch_bounds__(1024) void crossprod_panels_combine_kernel(const double* __restrict__ partial, int32_t ngroups,
+                                                                        int32_t nt, int32_t ncol,
+                                                                        const int32_t* __restrict__ nonfinite,
+                                                                        double* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ double quarter[4][256];
+    if (*nonfinite) return;
+    const int q = blockIdx.x, np = nt * (nt + 1) / 2;
+    const int k = threadIdx.x >> 8, e = threadIdx.x & 255;
+    const double* t = partial + (size_t)q * 256 + e;
+    double sum = 0.0;
+    for (int g = k; g < ngroups; g += 4) sum += t[(size_t)g * np * 256];
+    quarter[k][e] = sum;
+    __syncthreads();
+    if (k != 0) return;
+    const double total = (quarter[0][e] + quarter[1][e]) + (quarter[2][e] + quarter[3][e]);
+    int I = 0, rem = q;   // tile pair (I <= J) number q, row by row
+    while (rem >= nt - I) {
+        rem -= nt - I;
+        ++I;
+    }
+    const int J = I + rem;
+    const int a = 16 * I + (e >> 4), b = 16 * J + (e & 15);
+    if (a <= b && b < ncol) {
+        out[(size_t)a * ncol + b] = total;
+        out[(size_t)b * ncol + a] = total;
+    }
 }
 
 // nsplit slices of `width` result rows each: width <= kXMaxWidth, every slice non-empty.
@@ -1195,7 +1265,9 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             if (e != hipSuccess) return e;
             const int want_y = (ncol + 3) / 4;
             int xparts = (int)(nnz / ((int64_t)ncol * 2048));   // (a part walks ~2048 entries or more)
-            if (xparts > 4096 / want_y) xparts = 4096 / want_y;
+            const char* tp = getenv("RSP_XP_TABLE_PARTS");
+            const int cap = tp ? atoi(tp) : 4096;
+            if (xparts > cap / want_y) xparts = cap / want_y;
             if (xparts < 1) xparts = 1;
             if (nnz > 0)
                 hipLaunchKernelGGL(xp_panel_table_kernel, dim3((unsigned)xparts, (unsigned)want_y), dim3(256), 0, stream,
@@ -1231,8 +1303,12 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             default: launch_tall<16, 16, kTallSplit16>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
         }
         const int64_t outs = (int64_t)ncol * ncol;
-        hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, stream,
-                           partial, L.ngroups, L.ntiles, ncol, flag, d_out);
+        if (L.panel_table)
+            hipLaunchKernelGGL(crossprod_panels_combine_kernel, dim3((unsigned)(L.ntiles * (L.ntiles + 1) / 2)), dim3(1024), 0,
+                               stream, partial, L.ngroups, L.ntiles, ncol, flag, d_out);
+        else
+            hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, stream,
+                               partial, L.ngroups, L.ntiles, ncol, flag, d_out);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         run_if = flag;   // everything below only works if x holds a non-finite value

@@ -4,9 +4,13 @@ column length puts them on that form, with columns of very different lengths (so
 the whole matrix, clustered into a few 64-row panels, or shared by all columns; against the oracle's merges
 within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric.
 
-    python3 tools/soak_crossprod_tall.py [seconds] [seed]
+    python3 tools/soak_crossprod_tall.py [seconds] [seed] [mincol]
+
+mincol (default 1): the smallest number of columns drawn; 193 keeps every case on the panel-table kernel of
+16 column tiles.  The cost model is bypassed (RSP_CROSSPROD_TALL_ALWAYS=1): every case takes the tall form.
 """
 import sys, os, time
+os.environ["RSP_CROSSPROD_TALL_ALWAYS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -14,8 +18,10 @@ import oracle
 from rcppsparse_amd import capi
 
 
-def one(rng, case):
+def one(rng, case, mincol=1):
     ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, 129, 160, 192, 193, 256, int(rng.integers(1, 257))]))
+    if ncol < mincol:
+        ncol = int(rng.choice([mincol, 256, int(rng.integers(mincol, 257))]))
     mean_len = int(rng.integers(4096, 40000)) if ncol > 40 else int(rng.integers(4096, 90000))
     kind = int(rng.integers(0, 4))
     lens = rng.integers(0, 2 * mean_len, ncol)
@@ -67,16 +73,17 @@ def one(rng, case):
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    mincol = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     capi.load()
     rng = np.random.default_rng(seed)
     t0, n, bad, last = time.time(), 0, 0, time.time()
     while time.time() - t0 < secs:
-        bad += not one(rng, n)
+        bad += not one(rng, n, mincol)
         n += 1
         if time.time() - last > 30:
             print(f"... {n} cases, {bad} failures", flush=True)
             last = time.time()
-    print(f"soak_crossprod_tall: {n} cases, {bad} failures, seed {seed}", flush=True)
+    print(f"soak_crossprod_tall: {n} cases, {bad} failures, seed {seed}, mincol {mincol}", flush=True)
     sys.exit(1 if bad else 0)
 
 
