@@ -699,16 +699,17 @@ void crossprod_tall_kernel(
 // columns = 256 pieces per panel, each found by a dependent chain cursor -> address -> load -> ballot -> cursor
 // (profiles/r04_crossprod.json: schedules of that chain were tried for two rounds).  This form takes the chain
 // away instead.  A first pass over the row indices (4 bytes per entry, no atomics) writes a table
-//     Ts[P][c], Te[P][c] = where column c's entries with a row in panel P (32 rows) begin and end
+//     Ts[c][P], Te[c][P] = where column c's entries with a row in panel P (32 rows) begin and end
 // -- at most 32 entries, rows ascend -- so that every address the matrix-core kernel will ever need is known
-// before it starts.  That kernel: 8 wavefronts; a panel's
-// row of T travels two panels ahead, its entries (half a wavefront per column, 16 rounds) one panel ahead, in
-// registers, while the current panel is multiplied; two panel buffers in LDS; no cursors, no ballots.  Its 136
-// tile pairs are dealt as whole tile ROWS (wavefront w: rows w and 15 - w, 17 pairs), so a k-step needs 16 LDS
-// reads for 17 MFMAs and the accumulators (136 registers) fit the 256 a wavefront of a 512-thread workgroup may
-// have: nothing is densified twice (crossprod_tall_kernel's SPLIT is gone) and x / i are read once.
-// Same sums in the same order as crossprod_tall_kernel defines them (panel by panel inside a workgroup, the
-// workgroups' results added in order), same tolerance, deterministic.
+// before it starts.  That kernel: 8 wavefronts; a panel's cells of the tables travel two panels ahead, its entries
+// (half a wavefront per column, 16 rounds) one panel ahead, in registers, while the current panel is multiplied;
+// two panel buffers in LDS; no cursors, no ballots.  Its 136 tile pairs are dealt as whole tile ROWS (wavefront w:
+// rows w and w + 8 of a circulant arrangement, 17 pairs), so the accumulators (136 registers) fit the 256 a
+// wavefront of a 512-thread workgroup may have: nothing is densified twice (crossprod_tall_kernel's SPLIT is gone)
+// and x / i are read once.  The workgroups' results are added up in a fixed order (crossprod_panels_combine_kernel),
+// same tolerance as the tall form's, deterministic.
+// 1e6 x 256, 50 % dense, one MI355X: table 0.17 ms + kernel 1.27 ms (MFMA pipes busy 70 %) + combine 0.02 ms: the
+// call 1.53 ms against 2.10 ms (profiles/r04_crossprod.json; tools/compare_crossprod_panels.py).
 // (Also built and measured: a panel-major COPY of the entries -- histogram, scan, fill with one atomic per run of
 // neighbours -- read back as one contiguous piece per panel: the copy alone cost 1.15 ms at 1.28e8 entries.)
 constexpr int kPanRows = 32;           // rows per panel of the table
@@ -717,9 +718,6 @@ constexpr int kPanRows = 32;           // rows per panel of the table
 // apart and two of them collide on 30 of their 32 banks (SQ_LDS_BANK_CONFLICT: 37 % of the LDS cycles); 34 banks apart
 // they share 2.  The entries going in are the rows of ONE column: any odd stride spreads those over all the banks.
 constexpr int kPanPad = 17;
-#ifndef RSP_XP_TABLE_UN
-#define RSP_XP_TABLE_UN 2
-#endif
 
 __device__ __forceinline__ int pan_of_row(int r, int32_t nrow, int64_t npanels) {   // (a row outside the matrix: some panel; the kernel drops the entry)
     return (unsigned)r < (unsigned)nrow ? r / kPanRows : (r < 0 ? 0 : (int)(npanels - 1));
@@ -738,7 +736,7 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
     // 256 bytes at a time; this form: profiles/r04_crossprod.json.)
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
-    constexpr int UN = RSP_XP_TABLE_UN;
+    constexpr int UN = 2;   // (4: 0.20 instead of 0.17 ms)
     for (int c = wave; c < ncol; c += nwaves) {
         int64_t a = p[c], b = p[c + 1];
         a = a < 0 ? 0 : (a > nnz ? nnz : a);   // (an invalid p[] must not lead outside x / i)
@@ -806,9 +804,7 @@ __global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __rest
 // others) -- every unordered pair once; wavefront w has rows w and w + NT / 2: NT + 1 pairs, the same code for every
 // wavefront (only LDS offsets differ).  A tile that wraps (J < I) is the transpose of pair (J, I) and is stored so.
 // Everything that is not an MFMA -- zeroing the other buffer, putting the next panel's entries into it, requesting
-// the entries of the panel after that -- is dealt out over the 8 k-steps of the current panel's multiplication, so
-// that it issues in the shadow of the matrix cores (a first version that did these between the barriers, after the
-// MFMA phase, took 1.51 ms at 1e6 x 256 where this one takes less; profiles/r04_crossprod.json).
+// the entries of the panel after that -- is dealt out over the groups of MFMAs of the current panel (panels_body).
 typedef double xp_v2f64 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double xp_lds_f64;   // (LDS pointers as such: handed on as generic pointers they
 typedef __attribute__((address_space(3))) int32_t xp_lds_i32;  // become FLAT accesses, which queue behind the global loads)
@@ -908,16 +904,26 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // in it) are read from LDS while the group before it is multiplied.
     constexpr int NM = KS * NPW, G = 4, NG = (NM + G - 1) / G;   // (groups of six: 12 more registers live, 54 spilled)
     double opb[2][G], opa[2][2];
-    auto load_group = [&](const xp_lds_f64* pan, int g) {
+    // (a pair's LDS address without the k-step's share, which is a constant of the instruction: made once per panel --
+    // made per operand they were 150 vector instructions per panel, and vector instructions do not overlap f64 MFMAs)
+    uint32_t opat[NPW], opat_a[2];
+    const uint32_t lane_at = (uint32_t)(uintptr_t)panel + (uint32_t)((lane >> 4) * W1 + (lane & 15)) * 8u;
+    auto operand_addresses = [&](int b) {
+        const uint32_t base = lane_at + (uint32_t)(b * kBufDoubles * 8);
+#pragma unroll
+        for (int s = 0; s < NPW; ++s) opat[s] = base + (uint32_t)(128 * tile_b(s));
+        opat_a[0] = base + (uint32_t)(128 * wave);
+        opat_a[1] = base + (uint32_t)(128 * (wave + NW));
+    };
+    auto load_group = [&](int g) {
 #pragma unroll
         for (int t = 0; t < G; ++t) {
             const int idx = g * G + t, ks = idx / NPW, s = idx % NPW;
             if (idx < NM) {
-                const xp_lds_f64* prow = pan + (4 * ks + (lane >> 4)) * W1 + (lane & 15);
-                opb[g & 1][t] = prow[16 * tile_b(s)];
+                opb[g & 1][t] = ((const xp_lds_f64*)(uintptr_t)opat[s])[ks * 4 * W1];
                 if (s == 0) {
-                    opa[ks & 1][0] = prow[16 * wave];
-                    opa[ks & 1][1] = prow[16 * (wave + NW)];
+                    opa[ks & 1][0] = ((const xp_lds_f64*)(uintptr_t)opat_a[0])[ks * 4 * W1];
+                    opa[ks & 1][1] = ((const xp_lds_f64*)(uintptr_t)opat_a[1])[ks * 4 * W1];
                 }
             }
         }
@@ -973,7 +979,6 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         load_T(Pnnn);
         hq = Pnnn + 1 < P1 ? (int32_t)has[Pnnn + 1] : 1;
         const int32_t r0n = Pn < P1 ? (int32_t)(Pn * kPanRows) : -2 * kPanRows;   // (no next panel: no row is within 32 of that)
-        const xp_lds_f64* pan = panel + b * kBufDoubles;
         // Group g: its MFMAs, and a share of everything else -- the groups of the first two k-steps zero the other
         // buffer, 16 later ones move one round of entries each.  (sched_barrier: the compiler keeps this order.  All of
         // it in two blocks, before the first and after the last MFMA: 1.87 instead of 1.62 ms at 1e6 x 256; f64 MFMAs and
@@ -983,10 +988,13 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         constexpr int ZG = (2 * NPW + G - 1) / G;   // the groups of the first two k-steps share the zeroing
         static_assert(NG >= ZG + 1 + RND, "shares of the groups");
         int32_t safe = 0;
-        if (mul) load_group(pan, 0);
+        if (mul) {
+            operand_addresses(b);
+            load_group(0);
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (mul && g + 1 < NG) load_group(pan, g + 1);
+            if (mul && g + 1 < NG) load_group(g + 1);
             if (mul) mfma_group(g);
             if (g < ZG) zero_part(o, g * ZN / ZG, (g + 1) * ZN / ZG);
             if (g == ZG) {
@@ -1265,9 +1273,7 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             if (e != hipSuccess) return e;
             const int want_y = (ncol + 3) / 4;
             int xparts = (int)(nnz / ((int64_t)ncol * 2048));   // (a part walks ~2048 entries or more)
-            const char* tp = getenv("RSP_XP_TABLE_PARTS");
-            const int cap = tp ? atoi(tp) : 4096;
-            if (xparts > cap / want_y) xparts = cap / want_y;
+            if (xparts > 4096 / want_y) xparts = 4096 / want_y;   // (1024 ... 16384 blocks: 0.22 ... 0.16 ms, flat from 1792 on)
             if (xparts < 1) xparts = 1;
             if (nnz > 0)
                 hipLaunchKernelGGL(xp_panel_table_kernel, dim3((unsigned)xparts, (unsigned)want_y), dim3(256), 0, stream,
