@@ -893,7 +893,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // (LDS addresses as 32-bit numbers, the round's share of them a constant of the instruction: written as an index
     // into panel[] the compiler kept sixteen 64-bit constants, one per round, in 32 registers)
     const uint32_t cell0 = (uint32_t)(uintptr_t)panel + (uint32_t)(wave * 2 + half) * 8u;
-    const uint32_t stray0 = (uint32_t)(uintptr_t)sStray;
+    const uint32_t stray0 = (uint32_t)(uintptr_t)sStray + (uint32_t)lane * 8u;   // (a cell per lane: 16 lanes writing ONE address are a 16-way bank conflict, SQ_LDS_BANK_CONFLICT 36 % of the LDS cycles)
     auto scatter = [&](int j, int b, int32_t r0) {
         const uint32_t local = (uint32_t)(r_[j] - r0);   // (-1, or a row of another panel: not below 32)
         const uint32_t at = local < (uint32_t)kPanRows ? cell0 + (uint32_t)(b * kBufDoubles * 8) + __umul24(local, (uint32_t)(W1 * 8))
@@ -1052,7 +1052,7 @@ void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __rest
     __shared__ __attribute__((aligned(16))) double panel[2 * kBufDoubles];
     __shared__ int32_t sT[2 * W];     // one panel's cells {Ts, Te}
     __shared__ int32_t sSafe[2];      // an entry of the panel whose cells went into sT in this phase / the phase before
-    __shared__ double sStray[W];      // where the lanes without an entry put what they hold (a round's share of it: 16 doubles apart)
+    __shared__ double sStray[64 + 16 * (W / 16)];   // where the lanes without an entry put what they hold (lane, and a round's share: 16 doubles apart)
     const int64_t P0 = (int64_t)blockIdx.x * panels_per_group;
     const int64_t P1 = P0 + panels_per_group < npanels ? P0 + panels_per_group : npanels;
     double* mine = partial + (size_t)blockIdx.x * NP * 256;
