@@ -945,6 +945,11 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         return P;
     };
     // ---- the first panel into buffer 0, the second one requested, the third one's cells of the tables requested
+    // (sSafe: entry 0 until a panel has been seen.  A range with ONE panel that holds entries never notes a second one,
+    // and the dummy loads of its last phase would go wherever the LDS's previous owner left them pointing: a memory
+    // fault on some runs of the edge sweep, 250 000 rows = 7813 panels = 252 ranges of 31 and one of 1.)
+    if (tid < 2) sSafe[tid] = 0;
+    __syncthreads();          // (before put_T notes a real one)
     int64_t Pc = next_panel(P0);
     zero_part(0, 0, ZN);
     load_T(Pc);
@@ -1174,9 +1179,10 @@ static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
     const double t_exact = 0.04 + len * 1.0e-4 + products / 4.0e8;
     const double width = 16.0 * tall_tiles(ncol);
     double t_tall = 0.13 + rows * width * width / 3.8e10 + 12.0 * (double)nnz / 3.9e9;
-    // (16 tiles, the panel-table kernel: 1e6 rows x 256 at 10 / 50 / 90 % density 1.42 / 1.66 / 1.94 ms, 4e6 rows at 5 %
-    // 5.05 ms, 2.5e5 rows at 50 % 0.53 ms -- profiles/r04_crossprod.json)
-    if (tall_tiles(ncol) == 16 && panel_table_enabled()) t_tall = 0.10 + rows * width * width / 5.2e10 + 2.5e-9 * (double)nnz;
+    // (16 tiles, the panel-table kernel: 1e6 rows x 256 at 0.4 / 10 / 50 / 90 % density 1.20 / 1.32 / 1.53 / 1.81 ms, 4e6
+    // rows at 1 % 4.61 ms, 2.5e5 rows at 1.6 % 0.37 ms, 1e5 rows at 4 % 0.22 ms -- profiles/r04_crossprod_panels.json,
+    // r04_form_edges_crossprod.json)
+    if (tall_tiles(ncol) == 16 && panel_table_enabled()) t_tall = 0.10 + rows * width * width / 6.0e10 + 2.6e-9 * (double)nnz;
     return t_tall <= t_exact;
 }
 

@@ -151,7 +151,8 @@ def test_crossprod_needs_row_indices(torch_cuda):
 
 TALL_SHAPES = [(41_000, 100, 0.1), (50_000, 7, 0.1), (60_000, 129, 0.1), (50_000, 192, 0.1), (45_000, 200, 0.1),
                (42_000, 256, 0.1), (400_000, 1, 0.5), (300_000, 16, 0.2), (300_000, 17, 0.15), (250_000, 48, 0.2), (200_000, 64, 0.25),
-               (200_000, 65, 0.2), (150_000, 100, 0.3), (150_000, 128, 0.25), (3_000_000, 20, 0.02)]
+               (200_000, 65, 0.2), (150_000, 100, 0.3), (150_000, 128, 0.25), (3_000_000, 20, 0.02),
+               (250_000, 256, 0.0166)]   # (7813 panels of 32 rows: the last workgroup's range is ONE panel)
 
 
 @pytest.mark.parametrize("nrow,ncol,density", TALL_SHAPES)
