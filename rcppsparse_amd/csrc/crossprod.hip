@@ -799,19 +799,19 @@ __global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __rest
     if ((threadIdx.x & 3) == 0 && word != 0 && P < npanels) atomicOr(&has_words[P >> 2], word);
 }
 
-// One workgroup of NT / 2 wavefronts per range of panels.
+// One workgroup of NW wavefronts per range of panels.
 // Tile pairs: tile row I meets the tiles (I + d) mod NT, d = 0 .. NT / 2 (rows below NT / 2) or d = 0 .. NT / 2 - 1 (the
-// others) -- every unordered pair once; wavefront w has rows w and w + NT / 2: NT + 1 pairs, the same code for every
-// wavefront (only LDS offsets differ).  A tile that wraps (J < I) is the transpose of pair (J, I) and is stored so.
+// others) -- every unordered pair once.  16 tiles: 8 wavefronts, wavefront w has rows w and w + 8 (17 pairs, 136
+// accumulator registers of the 256 it may have at two wavefronts per SIMD).  12 / 8 tiles: one row per wavefront (7 / 5
+// pairs, the last one only for the rows below NT / 2), 12 wavefronts = three per SIMD / 8 wavefronts and two workgroups
+// per CU.  The same code for every wavefront (only LDS offsets differ).  A tile that wraps (J < I) is the transpose of
+// pair (J, I) and is stored so.
 // Everything that is not an MFMA -- zeroing the other buffer, putting the next panel's entries into it, requesting
 // the entries of the panel after that -- is dealt out over the groups of MFMAs of the current panel (panels_body).
 typedef double xp_v2f64 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double xp_lds_f64;   // (LDS pointers as such: handed on as generic pointers they
 typedef __attribute__((address_space(3))) int32_t xp_lds_i32;  // become FLAT accesses, which queue behind the global loads)
-// (the life of wavefront WV as a function of its own: tiles, columns and with them every LDS offset are constants of
-// the instruction stream -- with the wavefront's number in a register the operand addresses alone were 17 vector
-// instructions per k-step, and vector instructions do not overlap f64 MFMAs on this chip)
-template <int NT, bool WIDE, int MODE>
+template <int NT, int NW, bool WIDE, int MODE>
 __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_lds_i32* __restrict__ sT,
                                             xp_lds_i32* __restrict__ sSafe, xp_lds_f64* __restrict__ sStray,
                                             const uint8_t* __restrict__ has,
@@ -819,20 +819,24 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
                                             const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
                                             int32_t ncol, int64_t npanels, int64_t P0, int64_t P1,
                                             int32_t* __restrict__ nonfinite, double* __restrict__ mine) {
-    constexpr int W = NT * 16, W1 = W + kPanPad, NW = NT / 2, NTH = NW * 64, RND = W / (2 * NW);
-    constexpr int KS = kPanRows / 4, NPW = NT + 1, NA = NT / 2 + 1;   // k-steps per panel; pairs per wavefront; of its first row
+    constexpr int W = NT * 16, W1 = W + kPanPad, NTH = NW * 64, RND = W / (2 * NW);
+    constexpr bool TWO = NW * 2 == NT;                 // two tile rows per wavefront (16 tiles) or one
+    static_assert(TWO || NW == NT, "a wavefront owns one or two whole tile rows");
+    constexpr int KS = kPanRows / 4, NA = NT / 2 + 1;  // k-steps per panel; pairs of a tile row below NT / 2 (one more than of the others)
+    constexpr int NPW = TWO ? NT + 1 : NA;             // pairs per wavefront (one row: the last only if the row is below NT / 2)
     constexpr int kBufDoubles = kPanRows * W1;
-    static_assert(NTH == 2 * W, "one thread per cell of a row of the two tables");
-    static_assert(RND == 16 && KS == 8, "the rounds are dealt out over the MFMA groups by hand below");
+    static_assert(NTH >= 2 * W, "a thread per cell of a row of the two tables");
+    static_assert(RND * 2 * NW == W && KS == 8, "every column in exactly one round");
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     xp_v4f64 acc[NPW];
 #pragma unroll
     for (int s = 0; s < NPW; ++s) acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
-    // (wave-uniform) tile of pair s on the A side and on the B side
-    auto tile_a = [&](int s) { return s < NA ? wave : wave + NW; };
-    auto tile_b = [&](int s) { return (s < NA ? wave + s : wave + NW + (s - NA)) & (NT - 1); };
-    static_assert((NT & (NT - 1)) == 0, "tile numbers wrap with a mask");
+    // (wave-uniform) tile of pair s on the A side and on the B side; whether this wavefront has a pair s at all
+    auto wrap = [&](int t) { return t >= NT ? t - NT : t; };
+    auto tile_a = [&](int s) { return TWO && s >= NA ? wave + NW : wave; };
+    auto tile_b = [&](int s) { return wrap(TWO && s >= NA ? wave + NW + (s - NA) : wave + s); };
+    auto has_pair = [&](int s) { return TWO || s < NA - 1 || wave < NT / 2; };
 
     auto zero_part = [&](int b, int m0, int m1) {   // 16-byte units tid + m * NTH, m0 <= m < m1
         auto* z = (__attribute__((address_space(3))) xp_v2f64*)(panel + b * kBufDoubles);
@@ -851,14 +855,15 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // vmcnt(1) where (30) would do, 1.66 ms at 1e6 x 256; with a select after the load ("row = lane has an entry ?
     // loaded : -1") the wavefront waits for what it has just requested (1.85 ms).
     int32_t treg = 0;
-    const int tcol = tid & (W - 1);
+    const bool tcell = tid < 2 * W;                       // the threads that carry a cell: Ts of column tid, Te of column tid - W
+    const int tcol = tid < W ? tid : tid - W;
     const int32_t* const tab = tid >= W ? Te : Ts;
     auto load_T = [&](int64_t P) {   // row P of the two tables ([column][panel]), one cell per thread (cell 0 when there is none)
-        treg = tab[tcol < ncol && P < P1 ? (int64_t)tcol * npanels + P : 0];
+        treg = tab[tcell && tcol < ncol && P < P1 ? (int64_t)tcol * npanels + P : 0];
     };
     auto put_T = [&](int q, int64_t P) {   // ... of panel P: zeros past the last panel and the last column; notes an entry of P in sSafe[q]
-        const int32_t t = tcol < ncol && P < P1 ? treg : 0;
-        sT[tid] = t;
+        const int32_t t = tcell && tcol < ncol && P < P1 ? treg : 0;
+        if (tcell) sT[tid] = t;
         const unsigned long long ends = __ballot(tid >= W && t > 0);   // (threads from W on hold Te: the end of a piece that is not empty)
         if (ends != 0ull) {
             const int32_t last = __builtin_amdgcn_readlane(t, __builtin_ctzll(ends)) - 1;
@@ -900,9 +905,10 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
                                                         : stray0;
         ((xp_lds_f64*)(uintptr_t)at)[j * NW * 2] = v_[j];
     };
-    // The 136 MFMAs of a panel in groups of four; a group's B operands (and the two A operands of a k-step that begins
+    // The MFMAs of a panel (136 at 16 tiles) in groups of four (two); a group's B operands (and the two A operands of a k-step that begins
     // in it) are read from LDS while the group before it is multiplied.
-    constexpr int NM = KS * NPW, G = 4, NG = (NM + G - 1) / G;   // (groups of six: 12 more registers live, 54 spilled)
+    constexpr int NM = KS * NPW, G = NT == 16 ? 4 : 2, NG = (NM + G - 1) / G;   // (12 / 8 tiles: 0.78 / 0.39 ms with groups of two, 0.81 / 0.40 with four)
+    static_assert(2 * G <= NPW + 1, "a group and the one read ahead of it touch at most two k-steps: two sets of A operands");   // (16 tiles, groups of six: 12 more registers live, 54 spilled)
     double opb[2][G], opa[2][2];
     // (a pair's LDS address without the k-step's share, which is a constant of the instruction: made once per panel --
     // made per operand they were 150 vector instructions per panel, and vector instructions do not overlap f64 MFMAs)
@@ -913,7 +919,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
 #pragma unroll
         for (int s = 0; s < NPW; ++s) opat[s] = base + (uint32_t)(128 * tile_b(s));
         opat_a[0] = base + (uint32_t)(128 * wave);
-        opat_a[1] = base + (uint32_t)(128 * (wave + NW));
+        opat_a[1] = base + (uint32_t)(128 * (TWO ? wave + NW : wave));
     };
     auto load_group = [&](int g) {
 #pragma unroll
@@ -923,7 +929,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
                 opb[g & 1][t] = ((const xp_lds_f64*)(uintptr_t)opat[s])[ks * 4 * W1];
                 if (s == 0) {
                     opa[ks & 1][0] = ((const xp_lds_f64*)(uintptr_t)opat_a[0])[ks * 4 * W1];
-                    opa[ks & 1][1] = ((const xp_lds_f64*)(uintptr_t)opat_a[1])[ks * 4 * W1];
+                    if (TWO) opa[ks & 1][1] = ((const xp_lds_f64*)(uintptr_t)opat_a[1])[ks * 4 * W1];
                 }
             }
         }
@@ -932,8 +938,8 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
 #pragma unroll
         for (int t = 0; t < G; ++t) {
             const int idx = g * G + t, ks = idx / NPW, s = idx % NPW;
-            if (idx < NM)
-                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[ks & 1][s < NA ? 0 : 1], opb[g & 1][t], acc[s], 0, 0, 0);
+            if (idx < NM && has_pair(s))
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[ks & 1][TWO && s >= NA ? 1 : 0], opb[g & 1][t], acc[s], 0, 0, 0);
         }
     };
 
@@ -991,7 +997,8 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         // instruction on top of the MFMA's 64 -- but LDS writes, branches and waiting for LDS do.)
         constexpr bool mul = !(MODE & 1), side = !(MODE & 2);
         constexpr int ZG = (2 * NPW + G - 1) / G;   // the groups of the first two k-steps share the zeroing
-        static_assert(NG >= ZG + 1 + RND, "shares of the groups");
+        constexpr int RG = (RND + (NG - ZG - 1) - 1) / (NG - ZG - 1);   // rounds of entries per group after the barrier
+        static_assert(NG > ZG + 1 && RG >= 1, "shares of the groups");
         int32_t safe = 0;
         if (mul) {
             operand_addresses(b);
@@ -1006,9 +1013,15 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
                 xp_lds_barrier();   // the other buffer is all zero (and sT is panel Pnn's) before anybody scatters (requests)
                 safe = __builtin_amdgcn_readfirstlane(sSafe[q ^ 1]);   // an entry of panel Pn, for the lanes that have none of Pnn
             }
-            if (g > ZG && g - (ZG + 1) < RND && side) {
-                scatter(g - (ZG + 1), o, r0n);
-                request(g - (ZG + 1), safe);
+            if (g > ZG && side) {
+#pragma unroll
+                for (int k = 0; k < RG; ++k) {
+                    const int j = (g - (ZG + 1)) * RG + k;
+                    if (j < RND) {
+                        scatter(j, o, r0n);
+                        request(j, safe);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1032,6 +1045,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // pair (I <= J) number q; lane: element (row, col) of the tile A_side x B_side: col = lane & 15, row = (lane >> 4) + 4 r
 #pragma unroll
     for (int s = 0; s < NPW; ++s) {
+        if (!has_pair(s)) continue;
         const int ta = tile_a(s), tb = tile_b(s);
         const bool wraps = tb < ta;              // computed C(ta, tb) = transpose of pair (tb, ta)
         const int I = wraps ? tb : ta, J = wraps ? ta : tb;
@@ -1045,8 +1059,8 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     }
 }
 
-template <int NT, bool WIDE, int MODE = 0>   // (MODE, measurements only: 1 = no MFMAs, 2 = no entries moved)
-__global__ __launch_bounds__(NT * 32) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NT, int NW, bool WIDE, int MODE = 0>   // (MODE, measurements only: 1 = no MFMAs, 2 = no entries moved)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT == 16 ? 2 : (NT == 12 ? 3 : 4), NT == 16 ? 2 : (NT == 12 ? 3 : 4))))
 void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __restrict__ ri,
                              const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
                              const uint8_t* __restrict__ has, int32_t ncol, int64_t npanels,
@@ -1065,7 +1079,7 @@ void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __rest
     // (One instruction stream for all wavefronts, the wavefront's number in a register.  A stream per wavefront, with
     // every LDS offset a constant, saves 136 vector instructions per panel and was slower; so were two streams that
     // multiply and move in opposite order on the two wavefronts of a SIMD.)
-    panels_body<NT, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, (xp_lds_i32*)sSafe, (xp_lds_f64*)sStray, has, x, ri, Ts, Te, ncol, npanels, P0, P1, nonfinite,
+    panels_body<NT, NW, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, (xp_lds_i32*)sSafe, (xp_lds_f64*)sStray, has, x, ri, Ts, Te, ncol, npanels, P0, P1, nonfinite,
                                 mine);
 }
 
@@ -1095,28 +1109,32 @@ __global__ __launch_bounds__(256) void crossprod_tall_combine_kernel(const doubl
     if (lane == 0) out[k] = sum;
 }
 
-// The same for the panel-table kernel's results (16 tiles, at most 256 workgroups): one workgroup of 1024 threads per
-// tile pair, thread = (quarter of the workgroups' results, element of the tile): neighbouring threads read neighbouring
+// The same for the panel-table kernel's results (at most 512 workgroups): a workgroup of 1024 threads per ELEMS
+// elements of a tile pair, thread = (slice of the workgroups' results, element): neighbouring threads read neighbouring
 // doubles -- crossprod_tall_combine_kernel's lanes stride from one workgroup's result to the next, 68 us for 71 MB
-// where this one takes a third.  Quarter k adds the results of workgroups k, k + 4, ... in that order, the four
-// sums meet as (0 + 1) + (2 + 3): the same association on every run.  Only elements on or above the diagonal are used,
+// where this one takes a third.  Slice k adds the results of workgroups k, k + K, ... in that order, then the K sums
+// are added in the order of k: the same association on every run.  Only elements on or above the diagonal are used,
 // the others are their mirror images.
+template <int ELEMS>   // 256, 128 or 64: fewer elements per workgroup where there are few tile pairs
 __global__ __launch_bounds__(1024) void crossprod_panels_combine_kernel(const double* __restrict__ partial, int32_t ngroups,
                                                                         int32_t nt, int32_t ncol,
                                                                         const int32_t* __restrict__ nonfinite,
                                                                         double* __restrict__ out) {
 #pragma clang fp contract(off)
-    __shared__ double quarter[4][256];
+    constexpr int K = 1024 / ELEMS, PER = 256 / ELEMS;   // slices; workgroups per tile pair
+    __shared__ double part[K][ELEMS];
     if (*nonfinite) return;
-    const int q = blockIdx.x, np = nt * (nt + 1) / 2;
-    const int k = threadIdx.x >> 8, e = threadIdx.x & 255;
+    const int q = blockIdx.x / PER, np = nt * (nt + 1) / 2;
+    const int k = threadIdx.x / ELEMS, e = (blockIdx.x % PER) * ELEMS + threadIdx.x % ELEMS;
     const double* t = partial + (size_t)q * 256 + e;
     double sum = 0.0;
-    for (int g = k; g < ngroups; g += 4) sum += t[(size_t)g * np * 256];
-    quarter[k][e] = sum;
+    for (int g = k; g < ngroups; g += K) sum += t[(size_t)g * np * 256];
+    part[k][threadIdx.x % ELEMS] = sum;
     __syncthreads();
     if (k != 0) return;
-    const double total = (quarter[0][e] + quarter[1][e]) + (quarter[2][e] + quarter[3][e]);
+    double total = part[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < K; ++j) total += part[j][threadIdx.x];
     int I = 0, rem = q;   // tile pair (I <= J) number q, row by row
     while (rem >= nt - I) {
         rem -= nt - I;
@@ -1165,9 +1183,12 @@ static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiat
 //   tall : 0.13 + nrow * width^2 / 3.8e10 per ms (the panels' multiply-adds) + 12 B per entry at 3.9 TB/s
 // Rounds 2-3 asked for columns of >= 4096 entries only, which sent sparse wide matrices (256 columns, 0.4 % dense) to a
 // form four times slower.
-static bool panel_table_enabled() {   // (RSP_CROSSPROD_PANEL_TABLE=0: round 3's kernel at 16 tiles too, for comparisons)
+// Which tile counts take the panel-table kernel: 8, 12 and 16 (97-256 columns).  (RSP_CROSSPROD_PANEL_TABLE=0: none --
+// round 3's kernel everywhere, for comparisons; =1: 16 tiles only)
+static bool panel_table_tiles(int ntiles) {
     const char* pm = getenv("RSP_CROSSPROD_PANEL_TABLE");
-    return !(pm && pm[0] == '0');
+    const int level = pm ? atoi(pm) : 2;
+    return level >= 2 ? (ntiles == 8 || ntiles == 12 || ntiles == 16) : (level == 1 && ntiles == 16);
 }
 
 static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
@@ -1179,10 +1200,12 @@ static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
     const double t_exact = 0.04 + len * 1.0e-4 + products / 4.0e8;
     const double width = 16.0 * tall_tiles(ncol);
     double t_tall = 0.13 + rows * width * width / 3.8e10 + 12.0 * (double)nnz / 3.9e9;
-    // (16 tiles, the panel-table kernel: 1e6 rows x 256 at 0.4 / 10 / 50 / 90 % density 1.20 / 1.32 / 1.53 / 1.81 ms, 4e6
-    // rows at 1 % 4.61 ms, 2.5e5 rows at 1.6 % 0.37 ms, 1e5 rows at 4 % 0.22 ms -- profiles/r04_crossprod_panels.json,
-    // r04_form_edges_crossprod.json)
-    if (tall_tiles(ncol) == 16 && panel_table_enabled()) t_tall = 0.10 + rows * width * width / 6.0e10 + 2.6e-9 * (double)nnz;
+    // (8 / 12 / 16 tiles, the panel-table kernel.  1e6 rows x 256 at 0.4 / 10 / 50 / 90 % density 1.20 / 1.32 / 1.53 / 1.81
+    // ms, x 192 at 10 / 50 / 90 % 0.85 / 1.01 / 1.29, x 128 0.48 / 0.57 / 0.77; 4e6 rows at 5 % 4.68 / 2.98 / 1.55 ms --
+    // profiles/r04_crossprod_panels.json, r04_form_edges_crossprod.json)
+    const int nt = tall_tiles(ncol);
+    if (panel_table_tiles(nt))
+        t_tall = 0.09 + rows * width * width / (nt == 16 ? 6.0e10 : (nt == 12 ? 5.2e10 : 4.5e10)) + 2.7e-9 * (double)nnz;
     return t_tall <= t_exact;
 }
 
@@ -1207,11 +1230,11 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         L->ngroups = (int32_t)((npanels + per - 1) / per);
         if (L->ngroups < 1) L->ngroups = 1;
         // 16 column tiles: panels of 32 rows through a panel table (crossprod_panels_kernel), one workgroup per CU
-        if (L->ntiles == 16 && panel_table_enabled()) {
+        if (panel_table_tiles(L->ntiles)) {
             L->panel_table = true;
             L->npanels = ((int64_t)nrow + kPanRows - 1) / kPanRows;
             const char* gr = getenv("RSP_CROSSPROD_PANEL_GROUPS");
-            int64_t groups = gr ? atoll(gr) : 256;
+            int64_t groups = gr ? atoll(gr) : (L->ntiles == 8 ? 512 : 256);   // (8 tiles: two workgroups per CU)
             if (groups < 1) groups = 1;
             if (groups > kTallMaxGroups) groups = kTallMaxGroups;
             int64_t pper = (L->npanels + groups - 1) / groups;
@@ -1286,21 +1309,30 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
                                    d_i, d_p, nrow, ncol, nnz, L.npanels, Ts, Te);
             hipLaunchKernelGGL(xp_panel_has_kernel, dim3((unsigned)((L.npanels + 255) / 256), (unsigned)((ncol + 31) / 32)),
                                dim3(256), 0, stream, (const int32_t*)Te, ncol, L.npanels, (uint32_t*)has);
-#define RSP_XP_LAUNCH(WIDE, M)                                                                                          \
-    hipLaunchKernelGGL((crossprod_panels_kernel<16, WIDE, M>), dim3((unsigned)L.ngroups), dim3(512), 0, stream, d_x,    \
-                       d_i, (const int32_t*)Ts, (const int32_t*)Te, (const uint8_t*)has, ncol, L.npanels,               \
+#define RSP_XP_LAUNCH(NT, NW, WIDE, M)                                                                                  \
+    hipLaunchKernelGGL((crossprod_panels_kernel<NT, NW, WIDE, M>), dim3((unsigned)L.ngroups), dim3(NW * 64), 0, stream, \
+                       d_x, d_i, (const int32_t*)Ts, (const int32_t*)Te, (const uint8_t*)has, ncol, L.npanels,          \
                        L.panels_per_group, flag, partial)
+            const bool wide = nnz >= (1ll << 29);   // (byte offsets of x beyond 32 bits)
             int mode = 0;
-#ifdef RSP_XP_MODES   // (a measurement build: RSP_XP_PANELS_MODE = 1 no MFMAs, 2 no entries moved, 3 neither)
+#ifdef RSP_XP_MODES   // (a measurement build: RSP_XP_PANELS_MODE = 1 no MFMAs, 2 no entries moved, 3 neither; 16 tiles only)
             if (const char* md = getenv("RSP_XP_PANELS_MODE")) mode = atoi(md);
-            if (nnz < (1ll << 29) && mode == 1) RSP_XP_LAUNCH(false, 1);
-            if (nnz < (1ll << 29) && mode == 2) RSP_XP_LAUNCH(false, 2);
-            if (nnz < (1ll << 29) && mode == 3) RSP_XP_LAUNCH(false, 3);
-            if (nnz >= (1ll << 29)) mode = 0;
+            if (wide || L.ntiles != 16) mode = 0;
+            if (mode == 1) RSP_XP_LAUNCH(16, 8, false, 1);
+            if (mode == 2) RSP_XP_LAUNCH(16, 8, false, 2);
+            if (mode == 3) RSP_XP_LAUNCH(16, 8, false, 3);
 #endif
             if (mode == 0) {
-                if (nnz >= (1ll << 29)) RSP_XP_LAUNCH(true, 0);
-                else RSP_XP_LAUNCH(false, 0);
+                if (L.ntiles == 16) {
+                    if (wide) RSP_XP_LAUNCH(16, 8, true, 0);
+                    else RSP_XP_LAUNCH(16, 8, false, 0);
+                } else if (L.ntiles == 12) {
+                    if (wide) RSP_XP_LAUNCH(12, 12, true, 0);
+                    else RSP_XP_LAUNCH(12, 12, false, 0);
+                } else {
+                    if (wide) RSP_XP_LAUNCH(8, 8, true, 0);
+                    else RSP_XP_LAUNCH(8, 8, false, 0);
+                }
             }
 #undef RSP_XP_LAUNCH
         } else
@@ -1315,10 +1347,18 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             default: launch_tall<16, 16, kTallSplit16>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
         }
         const int64_t outs = (int64_t)ncol * ncol;
-        if (L.panel_table)
-            hipLaunchKernelGGL(crossprod_panels_combine_kernel, dim3((unsigned)(L.ntiles * (L.ntiles + 1) / 2)), dim3(1024), 0,
-                               stream, partial, L.ngroups, L.ntiles, ncol, flag, d_out);
-        else
+        if (L.panel_table) {
+            const unsigned pairs = (unsigned)(L.ntiles * (L.ntiles + 1) / 2);
+            if (L.ntiles == 16)
+                hipLaunchKernelGGL(crossprod_panels_combine_kernel<128>, dim3(pairs * 2), dim3(1024), 0, stream, partial,
+                                   L.ngroups, L.ntiles, ncol, flag, d_out);
+            else if (L.ntiles == 12)
+                hipLaunchKernelGGL(crossprod_panels_combine_kernel<128>, dim3(pairs * 2), dim3(1024), 0, stream, partial,
+                                   L.ngroups, L.ntiles, ncol, flag, d_out);
+            else
+                hipLaunchKernelGGL(crossprod_panels_combine_kernel<64>, dim3(pairs * 4), dim3(1024), 0, stream, partial,
+                                   L.ngroups, L.ntiles, ncol, flag, d_out);
+        } else
             hipLaunchKernelGGL(crossprod_tall_combine_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, stream,
                                partial, L.ngroups, L.ntiles, ncol, flag, d_out);
         e = hipGetLastError();

@@ -229,9 +229,9 @@ def test_crossprod_tall_form_rows_without_entries_and_ragged_last_panel(torch_cu
     assert np.all(got[scale == 0] == 0)
 
 
-# ---- 193-256 columns: the tall form finds its 32-row panels through a panel table (crossprod_panels_kernel) ----
+# ---- 97-256 columns: the tall form finds its 32-row panels through a panel table (crossprod_panels_kernel) ----
 
-@pytest.mark.parametrize("ncol", [200, 256])
+@pytest.mark.parametrize("ncol", [200, 256, 176, 120])
 def test_crossprod_panel_table_form_gaps_ragged_end_and_round3_kernel_agree(torch_cuda, ncol):
     """Panels without entries never enter the pipeline (has[]), whether the gap is two panels or 3 400 and wherever a
     workgroup's range begins; the last panel is partial.  Against the oracle within the tall form's tolerance, the
@@ -269,12 +269,13 @@ def test_crossprod_panel_table_form_gaps_ragged_end_and_round3_kernel_agree(torc
     assert np.all(np.abs(old - ref) <= 1e-12 * scale)
 
 
-def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda):
-    """256 columns: the panel-table kernel looks at its sums, not at every value: a NaN made by a structural zero
+@pytest.mark.parametrize("ncol", [256, 180, 112])
+def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda, ncol):
+    """16 / 12 / 8 column tiles: the panel-table kernel looks at its sums, not at every value: a NaN made by a structural zero
     meeting an infinity stays a NaN, the flag goes up and the bit-identical kernels produce the reference's result.
     Also with the non-finite value in the last entry of the last column, and with a value whose products overflow."""
     torch = torch_cuda
-    nrow, ncol = 45_000, 256
+    nrow = 45_000
     m = synth.rsparsematrix(nrow, ncol, density=0.1, seed=9, kind=0)
     x0, i, p = m["x"], m["i"], m["p"]
     assert capi.crossprod_form(nrow, ncol, x0.size) == "tall"
@@ -290,12 +291,13 @@ def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda)
         assert np.array_equal(got, ref, equal_nan=True), (where, value)
 
 
-def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cuda):
+@pytest.mark.parametrize("ncol", [256, 180, 112])
+def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cuda, ncol):
     """Not a dgCMatrix -- rows that do not ascend, rows outside the matrix, column offsets that go backwards or
     beyond nnz: the result means nothing, but the call returns, reads and writes nothing out of bounds (the entries
     it cannot place are dropped) and the library goes on working."""
     torch = torch_cuda
-    nrow, ncol = 45_000, 256
+    nrow = 45_000
     m = synth.rsparsematrix(nrow, ncol, density=0.1, seed=10, kind=0)
     x, i0, p0 = m["x"], m["i"], m["p"]
     rng = np.random.default_rng(0)
@@ -304,7 +306,7 @@ def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cud
     i = i0.copy(); rng.shuffle(i[: i.size // 2]); cases.append((i, p0))                      # rows in any order
     i = i0.copy(); i[::7] = nrow + 5; i[3::11] = -3; cases.append((i, p0))                 # rows outside the matrix
     i = i0.copy(); i[:] = 17; cases.append((i, p0))                                         # one row, stored again and again
-    p = p0.copy(); p[5] = p[9]; p[100] = x.size + 1000; p[200] = -4; cases.append((i0, p))  # offsets that are no offsets
+    p = p0.copy(); p[5] = p[9]; p[100] = x.size + 1000; p[ncol - 3] = -4; cases.append((i0, p))  # offsets that are no offsets
     for i, p in cases:
         out = capi.crossprod_device(xt, torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda(), nrow)
         torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""crossprod at 193-256 columns: the panel-table matrix-core form against the round-3 kernel it replaces
+"""crossprod at 97-256 columns: the panel-table matrix-core form (RSP_CROSSPROD_PANEL_TABLE=2: 8, 12 and 16 column tiles) against the round-3 kernel it replaces
 (RSP_CROSSPROD_PANEL_TABLE=0), same inputs: times (HIP events, median) and the largest difference relative to
 sum |x1 x2|.   gpurun -- python3 tools/compare_crossprod_panels.py [out.json]"""
 import json, os, sys
@@ -10,8 +10,11 @@ from rcppsparse_amd import capi
 
 L = capi.load()
 rows = []
-for nrow, ncol, dens in ((1_000_000, 256, 0.5), (1_000_000, 224, 0.5), (1_000_000, 200, 0.5), (1_000_000, 256, 0.1),
-                         (1_000_000, 256, 0.9), (4_000_000, 256, 0.05), (250_000, 256, 0.5)):
+SHAPES = ((1_000_000, 256, 0.5), (1_000_000, 224, 0.5), (1_000_000, 200, 0.5), (1_000_000, 256, 0.1),
+          (1_000_000, 256, 0.9), (4_000_000, 256, 0.05), (250_000, 256, 0.5),
+          (1_000_000, 192, 0.5), (1_000_000, 160, 0.5), (1_000_000, 192, 0.1), (1_000_000, 192, 0.9), (4_000_000, 192, 0.05),
+          (1_000_000, 128, 0.5), (1_000_000, 100, 0.5), (1_000_000, 128, 0.1), (1_000_000, 128, 0.9), (4_000_000, 128, 0.05))
+for nrow, ncol, dens in SHAPES:
     per = int(nrow * dens)
     nnz = per * ncol
     p = (np.arange(ncol + 1, dtype=np.int64) * per).astype(np.int32)
@@ -22,7 +25,7 @@ for nrow, ncol, dens in ((1_000_000, 256, 0.5), (1_000_000, 224, 0.5), (1_000_00
     capi.gen_row_indices_device(it, pt, nrow, 3)
     rec = {"nrow": nrow, "ncol": ncol, "density": dens}
     outs = {}
-    for name, env in (("panel_table", "1"), ("round3_kernel", "0")):
+    for name, env in (("panel_table", "2"), ("round3_kernel", "0")):
         os.environ["RSP_CROSSPROD_PANEL_TABLE"] = env
         out = torch.empty((ncol, ncol), dtype=torch.float64, device="cuda")
         ws = torch.empty(int(L.rsp_crossprod_workspace_bytes(nrow, ncol, nnz)), dtype=torch.uint8, device="cuda")
