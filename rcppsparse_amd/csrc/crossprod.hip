@@ -1183,7 +1183,8 @@ static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiat
 //   tall : 0.13 + nrow * width^2 / 3.8e10 per ms (the panels' multiply-adds) + 12 B per entry at 3.9 TB/s
 // Rounds 2-3 asked for columns of >= 4096 entries only, which sent sparse wide matrices (256 columns, 0.4 % dense) to a
 // form four times slower.
-// Which tile counts take the panel-table kernel: 8, 12 and 16 (97-256 columns).  (RSP_CROSSPROD_PANEL_TABLE=0: none --
+// Which tile counts take the panel-table kernel: 8, 12 and 16 (97-256 columns; at 4 and 6 tiles it was measured and does
+// not pay: 1e6 x 64 / 96 0.276 / 0.497 ms against 0.272 / 0.417 of the kernel that walks the CSC arrays).  (RSP_CROSSPROD_PANEL_TABLE=0: none --
 // round 3's kernel everywhere, for comparisons; =1: 16 tiles only)
 static bool panel_table_tiles(int ntiles) {
     const char* pm = getenv("RSP_CROSSPROD_PANEL_TABLE");
