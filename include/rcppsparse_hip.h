@@ -378,11 +378,11 @@ int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
  *
  * One exception to "same bits": for ncol <= 256 and columns of >= 4096 stored entries on
  * average (the tall matrices crossprod is meant for), the workspace form sums in a different
- * order -- rows are densified 64 (from 193 columns on: 32) at a time and t(P) P runs on the matrix cores, every workgroup
+ * order -- rows are densified 64 (from 97 columns on: 32) at a time and t(P) P runs on the matrix cores, every workgroup
  * over its own range of rows, results added in workgroup order: deterministic, within
  * 1e-12 * sum|x1 x2| per entry of the reference's order, and two to three orders of magnitude
  * faster than walking 48 columns of 4.5e7 rows one product after the other (7 ms against 24.8 s).  If x holds
- * a NaN or an infinity -- from 193 columns on: if any sum is not finite -- the bit-identical kernel does the work
+ * a NaN or an infinity -- from 97 columns on: if any sum is not finite -- the bit-identical kernel does the work
  * instead (a structural zero must not meet a non-finite value).  rsp_set_crossprod_exact(1), or RSP_CROSSPROD_EXACT=1 in the
  * environment, keeps the bit-identical forms everywhere; set it before asking for the workspace size.
  * The matrix-core form is taken where a cost model says it pays (its time is that of a DENSE rank update, nrow x
