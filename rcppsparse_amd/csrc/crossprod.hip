@@ -761,22 +761,43 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
                         if (e4 + 2 < nnz) v[u].z = ri[e4 + 2];
                     }
                     if (e4 > 0) before[u] = ri[e4 - 1];
-                    if (e4 + 4 < nnz) after[u] = ri[e4 + 4];
+                    if (e4 + 4 < nnz) after[u] = ri[e4 + 4];   // (the neighbours' rows from the neighbouring lanes instead: 143 against 146 us, not kept)
                 }
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int64_t e4 = g0 + u * 256 + lane * 4;
                 const int32_t rr[6] = {before[u], v[u].x, v[u].y, v[u].z, v[u].w, after[u]};
+                // (a store instruction costs the memory pipeline the same whether 4 or 64 of its lanes take part, and a piece
+                // of a 50 % dense column is ~16 entries long: instead of one store per table and entry of the quad -- eight
+                // instructions with a lane in sixteen active -- every lane queues its starts / ends and the wavefront stores
+                // until no lane has one left: mostly once per table)
+                int pan[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) pan[k] = pan_of_row(rr[k], nrow, npanels);
+                uint32_t starts = 0, ends = 0;   // bit k: entry e4 + k begins / ends its column's piece of a panel
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int64_t e = e4 + k;
                     if (e < a || e >= b) continue;
-                    const int cur = pan_of_row(rr[k + 1], nrow, npanels);
-                    const int prev = e == a ? -1 : pan_of_row(rr[k], nrow, npanels);
-                    const int next = e == b - 1 ? -1 : pan_of_row(rr[k + 2], nrow, npanels);
-                    if (prev != cur) ts[cur] = (int32_t)e;
-                    if (next != cur) te[cur] = (int32_t)(e + 1);
+                    if (e == a || pan[k] != pan[k + 1]) starts |= 1u << k;
+                    if (e == b - 1 || pan[k + 2] != pan[k + 1]) ends |= 1u << k;
+                }
+                while (__ballot(starts != 0u) != 0ull) {   // (wave-uniform)
+                    if (starts != 0u) {
+                        const int k = __builtin_ctz(starts);
+                        const int cur = k == 0 ? pan[1] : (k == 1 ? pan[2] : (k == 2 ? pan[3] : pan[4]));
+                        ts[cur] = (int32_t)(e4 + k);
+                        starts &= starts - 1;
+                    }
+                }
+                while (__ballot(ends != 0u) != 0ull) {
+                    if (ends != 0u) {
+                        const int k = __builtin_ctz(ends);
+                        const int cur = k == 0 ? pan[1] : (k == 1 ? pan[2] : (k == 2 ? pan[3] : pan[4]));
+                        te[cur] = (int32_t)(e4 + k + 1);
+                        ends &= ends - 1;
+                    }
                 }
             }
         }
