@@ -5,9 +5,10 @@
 // x1 * x2 over the common rows in ascending row order (OpenMP over c1; the package's only
 // parallel routine).  O(ncol^2) output: meant for matrices with few columns.
 //
-// Two kernels in the reference's accumulation order (bit-identical results), and a third for the tall
+// Two kernels in the reference's accumulation order (bit-identical results), and two for the tall
 // matrices the routine is meant for, where that order is a serial walk of every column (see "tall form"
-// below: dense rank-k updates on the matrix cores, results within the floating-point tolerance):
+// below: dense rank-k updates on the matrix cores, results within the floating-point tolerance --
+// crossprod_tall_kernel up to 96 columns, crossprod_panels_kernel from 97 to 256):
 //
 //  * crossprod_rows_kernel (used when the caller provides a workspace).  The row-major form of
 //    A is built first (integer row histogram, exclusive scan, cursor fill; the order of the
