@@ -868,7 +868,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
             if (k < kBufDoubles / 2) z[k] = xp_v2f64{0.0, 0.0};
         }
     };
-    constexpr int ZN = (kBufDoubles / 2 + NTH - 1) / NTH;   // 9: eight full rounds and a tail
+    constexpr int ZN = (kBufDoubles / 2 + NTH - 1) / NTH;   // (16 tiles: 9 -- eight full rounds and a tail)
     // In the loop no load is conditional and nothing is decided by what a load has just returned: a lane without an
     // entry of its own reads an entry of the PREVIOUS panel of the pipeline (one is noted whenever a panel's cells go
     // into sT), whose row the scatter then finds outside its panel like any stray row.  Only so does the compiler know
@@ -920,7 +920,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // (LDS addresses as 32-bit numbers, the round's share of them a constant of the instruction: written as an index
     // into panel[] the compiler kept sixteen 64-bit constants, one per round, in 32 registers)
     const uint32_t cell0 = (uint32_t)(uintptr_t)panel + (uint32_t)(wave * 2 + half) * 8u;
-    const uint32_t stray0 = (uint32_t)(uintptr_t)sStray + (uint32_t)lane * 8u;   // (a cell per lane: 16 lanes writing ONE address are a 16-way bank conflict, SQ_LDS_BANK_CONFLICT 36 % of the LDS cycles)
+    const uint32_t stray0 = (uint32_t)(uintptr_t)sStray + (uint32_t)lane * 8u;   // (a cell per lane rather than one for all; the LDS bank conflicts the counters show, 36 % of its cycles, are the same either way)
     auto scatter = [&](int j, int b, int32_t r0) {
         const uint32_t local = (uint32_t)(r_[j] - r0);   // (-1, or a row of another panel: not below 32)
         const uint32_t at = local < (uint32_t)kPanRows ? cell0 + (uint32_t)(b * kBufDoubles * 8) + __umul24(local, (uint32_t)(W1 * 8))
