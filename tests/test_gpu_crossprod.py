@@ -315,3 +315,33 @@ def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cud
     scale = oracle.crossprod(np.abs(x), i0, p0)
     got = capi.crossprod_device(xt, torch.from_numpy(i0).cuda(), torch.from_numpy(p0).cuda(), nrow).cpu().numpy().T
     assert np.all(np.abs(got - ref) <= 1e-12 * scale)
+
+
+@pytest.mark.parametrize("ncol", [200, 120, 40])
+def test_crossprod_device_entry_is_graph_capture_safe(torch_cuda, ncol):
+    """rsp_crossprod_device with a workspace allocates nothing and never synchronises (the exact kernels stand by on
+    a device-side flag): capturable into a HIP graph in the panel-table form (16 / 8 tiles) and in the form that walks
+    the CSC arrays (3 tiles); a replay reproduces the bits, also with new values in the same buffers (x doubled: every
+    sum exactly four times as large)."""
+    torch = torch_cuda
+    nrow = 45_000
+    m = synth.rsparsematrix(nrow, ncol, density=0.1, seed=12, kind=0)
+    x, i, p = m["x"], m["i"], m["p"]
+    assert capi.crossprod_form(nrow, ncol, x.size) == "tall"
+    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    nbytes = int(capi.load().rsp_crossprod_workspace_bytes(nrow, ncol, x.size))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    out = torch.zeros((ncol, ncol), dtype=torch.float64, device="cuda")
+    eager = capi.crossprod_device(xt, it, pt, nrow, out.clone(), workspace=ws).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        capi.crossprod_device(xt, it, pt, nrow, out, workspace=ws)      # enqueued on the capturing stream
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    xt.mul_(2.0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager * 4.0)
