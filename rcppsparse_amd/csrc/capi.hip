@@ -1341,10 +1341,22 @@ int rsp_csc_crossprod(rsp_csc_t h, double* out) {
     void* d_ws = nullptr;
     hipError_t e = hipMalloc((void**)&d_c, bytes);
     if (e == hipSuccess) e = hipMalloc(&d_ws, L.total_bytes);
+    // (this call synchronises anyway: the tall form runs alone, and only if it reports a sum that is not finite do the
+    // exact kernels run -- instead of standing by in every call, eight launches that do nothing)
+    int32_t not_finite = 0;
     if (e == hipSuccess)
-        e = rsp::launch_crossprod_rows(h->d_x, h->d_i, h->d_p, h->nrow, h->ncol, h->nnz, d_c, L, d_ws, h->stream);
+        e = rsp::launch_crossprod_rows(h->d_x, h->d_i, h->d_p, h->nrow, h->ncol, h->nnz, d_c, L, d_ws, h->stream,
+                                       L.tall ? rsp::kXpTallOnly : rsp::kXpAll);
+    if (e == hipSuccess && L.tall)
+        e = hipMemcpyAsync(&not_finite, (char*)d_ws + L.flag_off, 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_c, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && L.tall && not_finite) {
+        e = rsp::launch_crossprod_rows(h->d_x, h->d_i, h->d_p, h->nrow, h->ncol, h->nnz, d_c, L, d_ws, h->stream,
+                                       rsp::kXpExactOnly);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d_c, bytes, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
     if (d_ws) (void)hipFree(d_ws);
     if (d_c) (void)hipFree(d_c);
     if (e != hipSuccess) {

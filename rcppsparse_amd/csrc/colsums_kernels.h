@@ -237,9 +237,10 @@ struct CrossprodLayout {   // workspace of the row-major path
 };
 hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, CrossprodLayout* L);
 void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, int32_t* width);
+constexpr int kXpAll = 0, kXpTallOnly = 1, kXpExactOnly = 2;   // which part of the work launch_crossprod_rows enqueues
 hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
                                  int32_t ncol, int64_t nnz, double* d_out, const CrossprodLayout& L, void* ws,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int part = kXpAll);
 hipError_t launch_crossprod(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t ncol,
                             double* d_out, hipStream_t stream);
 

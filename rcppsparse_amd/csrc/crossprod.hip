@@ -1298,9 +1298,13 @@ static void launch_tall(const CrossprodLayout& L, const double* d_x, const int32
                        d_x, d_i, d_p, nrow, ncol, nnz, L.panels_per_group, flag, partial);
 }
 
+// part: kXpAll -- everything, nothing synchronises (the exact kernels stand by on the tall form's flag); kXpTallOnly --
+// the tall form alone (a caller that synchronises anyway looks at the flag itself: the eight launches of the exact
+// kernels that stand by are 50 us, a quarter of a 1e6 x 32 call); kXpExactOnly -- the exact kernels alone,
+// unconditionally.
 hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow,
                                  int32_t ncol, int64_t nnz, double* d_out, const CrossprodLayout& L, void* ws,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int part) {
     if (ncol <= 0) return hipSuccess;
     int32_t* rp = (int32_t*)((char*)ws + L.rp_off);
     int32_t* cursor = (int32_t*)((char*)ws + L.cursor_off);
@@ -1310,7 +1314,7 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     const size_t nv1 = (size_t)nrow * (size_t)nsplit + 1;
     hipError_t e = hipSuccess;
     const int32_t* run_if = nullptr;
-    if (L.tall) {
+    if (L.tall && part != kXpExactOnly) {
         int32_t* flag = (int32_t*)((char*)ws + L.flag_off);
         double* partial = (double*)((char*)ws + L.partial_off);
         e = hipMemsetAsync(flag, 0, 4, stream);
@@ -1387,6 +1391,7 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         run_if = flag;   // everything below only works if x holds a non-finite value
+        if (part == kXpTallOnly) return hipSuccess;
     }
     e = hipMemsetAsync(cursor, 0, nv1 * 4, stream);
     if (e != hipSuccess) return e;
