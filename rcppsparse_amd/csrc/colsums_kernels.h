@@ -191,7 +191,7 @@ constexpr int64_t kColumnsTwoWavesMaxNnz = 250000000;   // ... this many entries
 constexpr int kColumnsMaxLen = 1 << 22;    // longest (its bytes stay far below a buffer descriptor's 2^31)
 constexpr int kColumnsMaxOverMean = 4;     // no column longer than this many times the mean (one workgroup walks it)
 constexpr int kColumnsMinColumns = 128;
-constexpr int kColumnsFewMaxLen = 49152;   // fewer columns than that take the form too while the longest column has at most this many entries + nnz / 192: one workgroup streams a column alone (3.3 us + 0.14 us per 1000 entries) against the general kernels' 8.5 us + 1.1 us per 1e6 entries of the whole call (8..127 columns of 3e3..3e5 entries, profiles/r04_form_edges.json)
+constexpr int kColumnsFewMaxLen = 45056;   // fewer columns than that take the form too while the longest column has at most this many entries + nnz / 192: one workgroup streams a column alone (3.3 us + 0.14 us per 1000 entries) against the general kernels' 8.5 us + 1.1 us per 1e6 entries of the whole call (8..127 columns of 3e3..3e5 entries, profiles/r04_form_edges.json)
 hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t waves,
                                       double* d_out, double divisor, bool means, hipStream_t stream);
 

@@ -1326,7 +1326,7 @@ def test_columns_plan_edges(torch_cuda, pattern):
     and ends: the shortest column 2048 entries (4 wavefronts per column) / 2047 and 512 (2 per column, in matrices of
     up to 2.5e8 entries) / 511 (not taken), the longest four times the mean (taken) / beyond (not), 128 columns
     (taken) / 127 short ones (taken since round 4: a workgroup streams such a column in microseconds) / 60 columns of
-    2e5 entries (not: the longest column may have 49152 entries + nnz / 192 below 128 columns), an empty column (not).  Parity against the oracle on every column, also
+    2e5 entries (not: the longest column may have 45056 entries + nnz / 192 below 128 columns), an empty column (not).  Parity against the oracle on every column, also
     through the handle, whose upload makes the same plan, and with the division of the means fused."""
     torch = torch_cuda
     rng = np.random.default_rng(17)
