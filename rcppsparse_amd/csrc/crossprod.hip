@@ -720,8 +720,11 @@ constexpr int kPanRows = 32;           // rows per panel of the table
 // they share 2.  The entries going in are the rows of ONE column: any odd stride spreads those over all the banks.
 constexpr int kPanPad = 17;
 
-__device__ __forceinline__ int pan_of_row(int r, int32_t nrow, int64_t npanels) {   // (a row outside the matrix: some panel; the kernel drops the entry)
-    return (unsigned)r < (unsigned)nrow ? r / kPanRows : (r < 0 ? 0 : (int)(npanels - 1));
+// (a row outside the matrix -- negative: a large unsigned number -- lands in the last panel; the kernel drops the entry.
+// Two instructions: the table pass is bound by its vector instructions, ~37 per entry at first, not by the 4 bytes it reads)
+__device__ __forceinline__ int pan_of_row(int r, uint32_t last_panel) {
+    const uint32_t q = (uint32_t)r / (uint32_t)kPanRows;
+    return (int)(q < last_panel ? q : last_panel);
 }
 
 // Ts[c][P] / Te[c][P] for every panel P and column c that meet; both are preset to 0 ("column c has nothing in
@@ -737,6 +740,7 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
     // 256 bytes at a time; this form: profiles/r04_crossprod.json.)
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
+    const uint32_t last_panel = (uint32_t)(npanels - 1);
     constexpr int UN = 2;   // (4: 0.20 instead of 0.17 ms)
     for (int c = wave; c < ncol; c += nwaves) {
         int64_t a = p[c], b = p[c + 1];
@@ -745,6 +749,7 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
         int32_t* ts = Ts + (int64_t)c * npanels;
         int32_t* te = Te + (int64_t)c * npanels;
         const int64_t a4 = a & ~3ll;
+        const int32_t a_rel = (int32_t)(a - a4), b_rel = (int32_t)(b - a4);
         for (int64_t g0 = a4 + (int64_t)blockIdx.x * (UN * 256); g0 < b; g0 += (int64_t)gridDim.x * (UN * 256)) {   // (wave-uniform)
             int4 v[UN];
             int32_t before[UN], after[UN];
@@ -775,14 +780,15 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
                 // until no lane has one left: mostly once per table)
                 int pan[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) pan[k] = pan_of_row(rr[k], nrow, npanels);
+                for (int k = 0; k < 6; ++k) pan[k] = pan_of_row(rr[k], last_panel);
                 uint32_t starts = 0, ends = 0;   // bit k: entry e4 + k begins / ends its column's piece of a panel
+                const int32_t rel = (int32_t)(e4 - a4);   // (32-bit from here: a column is shorter than 2^31)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int64_t e = e4 + k;
-                    if (e < a || e >= b) continue;
-                    if (e == a || pan[k] != pan[k + 1]) starts |= 1u << k;
-                    if (e == b - 1 || pan[k + 2] != pan[k + 1]) ends |= 1u << k;
+                    const int32_t r = rel + k;
+                    if (r < a_rel || r >= b_rel) continue;
+                    if (r == a_rel || pan[k] != pan[k + 1]) starts |= 1u << k;
+                    if (r == b_rel - 1 || pan[k + 2] != pan[k + 1]) ends |= 1u << k;
                 }
                 while (__ballot(starts != 0u) != 0ull) {   // (wave-uniform)
                     if (starts != 0u) {
