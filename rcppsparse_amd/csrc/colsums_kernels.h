@@ -232,6 +232,7 @@ struct CrossprodLayout {   // workspace of the row-major path
     size_t partial_off, flag_off;
     // 16 tiles: the tall form finds its 32-row panels through a table T[panel][column] (crossprod.hip) in the workspace
     bool panel_table;
+    int32_t panel_rows;   // 32; 16 at 32 tiles
     int64_t npanels;
     size_t table_off, has_off;
 };

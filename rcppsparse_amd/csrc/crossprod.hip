@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void crossprod_tiles_kernel(
 constexpr int kXMaxWidth = 8192;  // accumulators (doubles) per wave in LDS
 
 // tall form (few columns, long columns)
-constexpr int kTallMaxCols = 256;        // 16 column tiles of 16: 136 tile pairs, 9 per wavefront of a 16-wave workgroup
+constexpr int kTallMaxCols = 512;        // 32 column tiles of 16 (above 16 tiles: the panel-table kernel only)
 constexpr int kTallRows = 64;            // rows of A densified in LDS at a time (a "panel")
 constexpr int kTallMaxGroups = 1280;     // workgroups = partial results to add up
 constexpr int64_t kTallMinColumnLength = 4096;   // (average) below this the exact form's serial walk takes < 0.7 ms:
@@ -722,8 +722,8 @@ constexpr int kPanPad = 17;
 
 // (a row outside the matrix -- negative: a large unsigned number -- lands in the last panel; the kernel drops the entry.
 // Two instructions: the table pass is bound by its vector instructions, ~37 per entry at first, not by the 4 bytes it reads)
-__device__ __forceinline__ int pan_of_row(int r, uint32_t last_panel) {
-    const uint32_t q = (uint32_t)r / (uint32_t)kPanRows;
+__device__ __forceinline__ int pan_of_row(int r, int shift, uint32_t last_panel) {
+    const uint32_t q = (uint32_t)r >> shift;
     return (int)(q < last_panel ? q : last_panel);
 }
 
@@ -733,8 +733,8 @@ __device__ __forceinline__ int pan_of_row(int r, uint32_t last_panel) {
 // ascend (not a valid dgCMatrix) several runs may claim a cell -- the cell then holds one of them, still indices of
 // this column.
 __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __restrict__ ri, const int32_t* __restrict__ p,
-                                                             int32_t nrow, int32_t ncol, int64_t nnz, int64_t npanels,
-                                                             int32_t* __restrict__ Ts, int32_t* __restrict__ Te) {
+                                                             int32_t panel_shift, int32_t ncol, int64_t nnz, int64_t npanels,
+                                                             int32_t* __restrict__ Ts, int32_t* __restrict__ Te) {   // (panels of 1 << panel_shift rows)
     // A lane takes four neighbouring entries (one aligned 16-byte load) and their two neighbours; two such steps are
     // in flight per wavefront.  (One entry per lane and step: 0.72 ms at 1.28e8 entries -- a wavefront waiting for
     // 256 bytes at a time; this form: profiles/r04_crossprod.json.)
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
                 // until no lane has one left: mostly once per table)
                 int pan[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) pan[k] = pan_of_row(rr[k], last_panel);
+                for (int k = 0; k < 6; ++k) pan[k] = pan_of_row(rr[k], panel_shift, last_panel);
                 uint32_t starts = 0, ends = 0;   // bit k: entry e4 + k begins / ends its column's piece of a panel
                 const int32_t rel = (int32_t)(e4 - a4);   // (32-bit from here: a column is shorter than 2^31)
 #pragma unroll
@@ -839,32 +839,35 @@ __global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __rest
 typedef double xp_v2f64 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double xp_lds_f64;   // (LDS pointers as such: handed on as generic pointers they
 typedef __attribute__((address_space(3))) int32_t xp_lds_i32;  // become FLAT accesses, which queue behind the global loads)
-template <int NT, int NW, bool WIDE, int MODE>
+template <int NT, int NW, int PR, int SPLIT, bool WIDE, int MODE>
 __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_lds_i32* __restrict__ sT,
                                             xp_lds_i32* __restrict__ sSafe, xp_lds_f64* __restrict__ sStray,
                                             const uint8_t* __restrict__ has,
                                             const double* __restrict__ x, const int32_t* __restrict__ ri,
                                             const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
-                                            int32_t ncol, int64_t npanels, int64_t P0, int64_t P1,
+                                            int32_t ncol, int64_t npanels, int64_t P0, int64_t P1, int part,
                                             int32_t* __restrict__ nonfinite, double* __restrict__ mine) {
-    constexpr int W = NT * 16, W1 = W + kPanPad, NTH = NW * 64, RND = W / (2 * NW);
-    constexpr bool TWO = NW * 2 == NT;                 // two tile rows per wavefront (16 tiles) or one
-    static_assert(TWO || NW == NT, "a wavefront owns one or two whole tile rows");
-    constexpr int KS = kPanRows / 4, NA = NT / 2 + 1;  // k-steps per panel; pairs of a tile row below NT / 2 (one more than of the others)
+    // PR rows per panel (32; 16 at 32 tiles, where two buffers of 32 x 512 would not fit the LDS): a column's piece of a
+    // panel is at most PR entries, PR lanes fetch it, CPI = 64 / PR columns go in one instruction.
+    constexpr int W = NT * 16, W1 = W + kPanPad, NTH = NW * 64, CPI = 64 / PR, RND = W / (CPI * NW);
+    constexpr bool TWO = NW * 2 == NT && SPLIT == 1;   // two tile rows per wavefront (16 tiles) or one
+    static_assert(TWO || NW * SPLIT == NT, "a wavefront owns one or two whole tile rows; SPLIT workgroups share a range of panels");
+    constexpr int KS = PR / 4, NA = NT / 2 + 1;        // k-steps per panel; pairs of a tile row below NT / 2 (one more than of the others)
     constexpr int NPW = TWO ? NT + 1 : NA;             // pairs per wavefront (one row: the last only if the row is below NT / 2)
-    constexpr int kBufDoubles = kPanRows * W1;
-    static_assert(NTH >= 2 * W, "a thread per cell of a row of the two tables");
-    static_assert(RND * 2 * NW == W && KS == 8, "every column in exactly one round");
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l = lane & 31;
+    constexpr int kBufDoubles = PR * W1;
+    constexpr int TC = (2 * W + NTH - 1) / NTH;        // cells of the tables per thread and panel (1; 2 at 32 tiles)
+    static_assert(RND * CPI * NW == W && (PR == 32 || PR == 16), "every column in exactly one round");
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane / PR, l = lane % PR;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int trow = TWO ? wave : part * NW + wave;    // this wavefront's (first) tile row
     xp_v4f64 acc[NPW];
 #pragma unroll
     for (int s = 0; s < NPW; ++s) acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
     // (wave-uniform) tile of pair s on the A side and on the B side; whether this wavefront has a pair s at all
     auto wrap = [&](int t) { return t >= NT ? t - NT : t; };
-    auto tile_a = [&](int s) { return TWO && s >= NA ? wave + NW : wave; };
-    auto tile_b = [&](int s) { return wrap(TWO && s >= NA ? wave + NW + (s - NA) : wave + s); };
-    auto has_pair = [&](int s) { return TWO || s < NA - 1 || wave < NT / 2; };
+    auto tile_a = [&](int s) { return TWO && s >= NA ? trow + NW : trow; };
+    auto tile_b = [&](int s) { return wrap(TWO && s >= NA ? trow + NW + (s - NA) : trow + s); };
+    auto has_pair = [&](int s) { return TWO || s < NA - 1 || trow < NT / 2; };
 
     auto zero_part = [&](int b, int m0, int m1) {   // 16-byte units tid + m * NTH, m0 <= m < m1
         auto* z = (__attribute__((address_space(3))) xp_v2f64*)(panel + b * kBufDoubles);
@@ -882,20 +885,33 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // them, no longer knows whether they were issued, and every round waits for the round before it -- s_waitcnt
     // vmcnt(1) where (30) would do, 1.66 ms at 1e6 x 256; with a select after the load ("row = lane has an entry ?
     // loaded : -1") the wavefront waits for what it has just requested (1.85 ms).
-    int32_t treg = 0;
-    const bool tcell = tid < 2 * W;                       // the threads that carry a cell: Ts of column tid, Te of column tid - W
-    const int tcol = tid < W ? tid : tid - W;
-    const int32_t* const tab = tid >= W ? Te : Ts;
-    auto load_T = [&](int64_t P) {   // row P of the two tables ([column][panel]), one cell per thread (cell 0 when there is none)
-        treg = tab[tcell && tcol < ncol && P < P1 ? (int64_t)tcol * npanels + P : 0];
+    int32_t treg[TC];
+    auto cell_of = [&](int k, bool& have, int& col, const int32_t*& tab) {   // cell tid + k NTH of {Ts[0..W), Te[0..W)}
+        const int idx = tid + k * NTH;
+        have = idx < 2 * W;
+        col = idx < W ? idx : idx - W;
+        tab = idx >= W ? Te : Ts;
+    };
+    auto load_T = [&](int64_t P) {   // row P of the two tables ([column][panel]), TC cells per thread (cell 0 when there is none)
+#pragma unroll
+        for (int k = 0; k < TC; ++k) {
+            bool have; int col; const int32_t* tab;
+            cell_of(k, have, col, tab);
+            treg[k] = tab[have && col < ncol && P < P1 ? (int64_t)col * npanels + P : 0];
+        }
     };
     auto put_T = [&](int q, int64_t P) {   // ... of panel P: zeros past the last panel and the last column; notes an entry of P in sSafe[q]
-        const int32_t t = tcell && tcol < ncol && P < P1 ? treg : 0;
-        if (tcell) sT[tid] = t;
-        const unsigned long long ends = __ballot(tid >= W && t > 0);   // (threads from W on hold Te: the end of a piece that is not empty)
-        if (ends != 0ull) {
-            const int32_t last = __builtin_amdgcn_readlane(t, __builtin_ctzll(ends)) - 1;
-            if (lane == 0) sSafe[q] = last;
+#pragma unroll
+        for (int k = 0; k < TC; ++k) {
+            bool have; int col; const int32_t* tab;
+            cell_of(k, have, col, tab);
+            const int32_t t = have && col < ncol && P < P1 ? treg[k] : 0;
+            if (have) sT[tid + k * NTH] = t;
+            const unsigned long long ends = __ballot(tid + k * NTH >= W && t > 0);   // (cells from W on hold Te: the end of a piece that is not empty)
+            if (ends != 0ull) {
+                const int32_t last = __builtin_amdgcn_readlane(t, __builtin_ctzll(ends)) - 1;
+                if (lane == 0) sSafe[q] = last;
+            }
         }
     };
     int32_t r_[RND];
@@ -911,31 +927,31 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
             v_[j] = *(const double*)(x_b + (uint64_t)(at << 3));
         }
     };
-    // round j of the panel whose cells stand in sT: half a wavefront per column (0, 0: nothing of this column; at most
-    // 32 rows of a valid column fall into a panel)
-    const xp_lds_i32* const sTw = sT + wave * 2 + half;
+    // round j of the panel whose cells stand in sT: PR lanes per column (0, 0: nothing of this column; at most PR rows
+    // of a valid column fall into a panel)
+    const xp_lds_i32* const sTw = sT + wave * CPI + sub;
     auto request = [&](int j, int32_t safe) {
-        const int32_t s = sTw[j * NW * 2], n = sTw[W + j * NW * 2] - s;
+        const int32_t s = sTw[j * NW * CPI], n = sTw[W + j * NW * CPI] - s;
         fetch(j, l < n ? (uint32_t)(s + l) : (uint32_t)safe);
     };
     auto request_first = [&](int j) {   // (the first panel of a workgroup has no predecessor)
-        const int32_t s = sTw[j * NW * 2], n = sTw[W + j * NW * 2] - s;
+        const int32_t s = sTw[j * NW * CPI], n = sTw[W + j * NW * CPI] - s;
         r_[j] = -1;
         if (l < n) fetch(j, (uint32_t)(s + l));
     };
     // (LDS addresses as 32-bit numbers, the round's share of them a constant of the instruction: written as an index
     // into panel[] the compiler kept sixteen 64-bit constants, one per round, in 32 registers)
-    const uint32_t cell0 = (uint32_t)(uintptr_t)panel + (uint32_t)(wave * 2 + half) * 8u;
+    const uint32_t cell0 = (uint32_t)(uintptr_t)panel + (uint32_t)(wave * CPI + sub) * 8u;
     const uint32_t stray0 = (uint32_t)(uintptr_t)sStray + (uint32_t)lane * 8u;   // (a cell per lane rather than one for all; the LDS bank conflicts the counters show, 36 % of its cycles, are the same either way)
     auto scatter = [&](int j, int b, int32_t r0) {
-        const uint32_t local = (uint32_t)(r_[j] - r0);   // (-1, or a row of another panel: not below 32)
-        const uint32_t at = local < (uint32_t)kPanRows ? cell0 + (uint32_t)(b * kBufDoubles * 8) + __umul24(local, (uint32_t)(W1 * 8))
+        const uint32_t local = (uint32_t)(r_[j] - r0);   // (-1, or a row of another panel: not below PR)
+        const uint32_t at = local < (uint32_t)PR ? cell0 + (uint32_t)(b * kBufDoubles * 8) + __umul24(local, (uint32_t)(W1 * 8))
                                                         : stray0;
-        ((xp_lds_f64*)(uintptr_t)at)[j * NW * 2] = v_[j];
+        ((xp_lds_f64*)(uintptr_t)at)[j * NW * CPI] = v_[j];
     };
     // The MFMAs of a panel (136 at 16 tiles) in groups of four (two); a group's B operands (and the two A operands of a k-step that begins
     // in it) are read from LDS while the group before it is multiplied.
-    constexpr int NM = KS * NPW, G = NT == 16 ? 4 : 2, NG = (NM + G - 1) / G;   // (12 / 8 tiles: 0.78 / 0.39 ms with groups of two, 0.81 / 0.40 with four)
+    constexpr int NM = KS * NPW, G = NT >= 16 ? 4 : 2, NG = (NM + G - 1) / G;   // (12 / 8 tiles: 0.78 / 0.39 ms with groups of two, 0.81 / 0.40 with four)
     static_assert(2 * G <= NPW + 1, "a group and the one read ahead of it touch at most two k-steps: two sets of A operands");   // (16 tiles, groups of six: 12 more registers live, 54 spilled)
     double opb[2][G], opa[2][2];
     // (a pair's LDS address without the k-step's share, which is a constant of the instruction: made once per panel --
@@ -946,8 +962,8 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         const uint32_t base = lane_at + (uint32_t)(b * kBufDoubles * 8);
 #pragma unroll
         for (int s = 0; s < NPW; ++s) opat[s] = base + (uint32_t)(128 * tile_b(s));
-        opat_a[0] = base + (uint32_t)(128 * wave);
-        opat_a[1] = base + (uint32_t)(128 * (TWO ? wave + NW : wave));
+        opat_a[0] = base + (uint32_t)(128 * trow);
+        opat_a[1] = base + (uint32_t)(128 * (TWO ? trow + NW : trow));
     };
     auto load_group = [&](int g) {
 #pragma unroll
@@ -994,7 +1010,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     int64_t Pn = Pc < P1 ? next_panel(Pc + 1) : P1;
     load_T(Pn);
 #pragma unroll
-    for (int j = 0; j < RND; ++j) scatter(j, 0, (int32_t)((Pc < P1 ? Pc : 0) * kPanRows));
+    for (int j = 0; j < RND; ++j) scatter(j, 0, (int32_t)((Pc < P1 ? Pc : 0) * PR));
     __syncthreads();          // (everybody has read sT)
     put_T(1, Pn);
     __syncthreads();
@@ -1017,7 +1033,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         if (Pnnn < P1 && __builtin_amdgcn_readfirstlane(hq) == 0) Pnnn = next_panel(Pnnn + 1);
         load_T(Pnnn);
         hq = Pnnn + 1 < P1 ? (int32_t)has[Pnnn + 1] : 1;
-        const int32_t r0n = Pn < P1 ? (int32_t)(Pn * kPanRows) : -2 * kPanRows;   // (no next panel: no row is within 32 of that)
+        const int32_t r0n = Pn < P1 ? (int32_t)(Pn * PR) : -2 * PR;   // (no next panel: no row is within PR of that)
         // Group g: its MFMAs, and a share of everything else -- the groups of the first two k-steps zero the other
         // buffer, 16 later ones move one round of entries each.  (sched_barrier: the compiler keeps this order.  All of
         // it in two blocks, before the first and after the last MFMA: 1.87 instead of 1.62 ms at 1e6 x 256; f64 MFMAs and
@@ -1087,28 +1103,40 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     }
 }
 
-template <int NT, int NW, bool WIDE, int MODE = 0>   // (MODE, measurements only: 1 = no MFMAs, 2 = no entries moved)
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT == 16 ? 2 : (NT == 12 ? 3 : 4), NT == 16 ? 2 : (NT == 12 ? 3 : 4))))
+template <int NT, int NW, int PR, int SPLIT, bool WIDE, int MODE = 0>   // (MODE, measurements only: 1 = no MFMAs, 2 = no entries moved)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT >= 16 ? 2 : (NT == 12 ? 3 : 4), NT >= 16 ? 2 : (NT == 12 ? 3 : 4))))
 void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __restrict__ ri,
                              const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
                              const uint8_t* __restrict__ has, int32_t ncol, int64_t npanels,
                              int32_t panels_per_group, int32_t* __restrict__ nonfinite, double* __restrict__ partial) {
     constexpr int W = NT * 16, W1 = W + kPanPad, NP = NT * (NT + 1) / 2;
-    constexpr int kBufDoubles = kPanRows * W1;
+    constexpr int kBufDoubles = PR * W1;
     static_assert((kBufDoubles * 8) % 16 == 0, "a panel buffer is whole 16-byte units");
     __shared__ __attribute__((aligned(16))) double panel[2 * kBufDoubles];
     __shared__ int32_t sT[2 * W];     // one panel's cells {Ts, Te}
     __shared__ int32_t sSafe[2];      // an entry of the panel whose cells went into sT in this phase / the phase before
     __shared__ double sStray[64 + 16 * (W / 16)];   // where the lanes without an entry put what they hold (lane, and a round's share: 16 doubles apart)
-    const int64_t P0 = (int64_t)blockIdx.x * panels_per_group;
+    // SPLIT workgroups (32 tiles: 4) share a range of panels, each with a quarter of the tile rows; every one of them
+    // densifies the panels for itself.  Workgroups are dealt to the 8 XCDs round-robin, so blocks b and b + 8 meet in the
+    // same L2: in every run of 8 * SPLIT blocks, block 8 h + k is part h of the run's k-th range -- what one of them has
+    // fetched the others find in their XCD's L2 (as crossprod_tall_kernel's SPLIT does).
+    int group = blockIdx.x / SPLIT, part = blockIdx.x - group * SPLIT;
+    if (SPLIT > 1) {
+        const int run = blockIdx.x / (8 * SPLIT), in_run = blockIdx.x - run * (8 * SPLIT);
+        if ((run + 1) * (8 * SPLIT) <= (int)gridDim.x) {
+            group = run * 8 + (in_run & 7);
+            part = in_run >> 3;
+        }
+    }
+    const int64_t P0 = (int64_t)group * panels_per_group;
     const int64_t P1 = P0 + panels_per_group < npanels ? P0 + panels_per_group : npanels;
-    double* mine = partial + (size_t)blockIdx.x * NP * 256;
+    double* mine = partial + (size_t)group * NP * 256;
     // (every wavefront meets the same barriers: the panels of a workgroup are the same for all of them)
     // (One instruction stream for all wavefronts, the wavefront's number in a register.  A stream per wavefront, with
     // every LDS offset a constant, saves 136 vector instructions per panel and was slower; so were two streams that
     // multiply and move in opposite order on the two wavefronts of a SIMD.)
-    panels_body<NT, NW, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, (xp_lds_i32*)sSafe, (xp_lds_f64*)sStray, has, x, ri, Ts, Te, ncol, npanels, P0, P1, nonfinite,
-                                mine);
+    panels_body<NT, NW, PR, SPLIT, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, (xp_lds_i32*)sSafe, (xp_lds_f64*)sStray, has, x,
+                                               ri, Ts, Te, ncol, npanels, P0, P1, part, nonfinite, mine);
 }
 
 // out(c1, c2) = the workgroups' results for that element (both triangles).  One wavefront per element: lane l
@@ -1198,9 +1226,9 @@ void crossprod_split(int32_t nrow, int32_t ncol, int64_t nnz, int32_t* nsplit, i
 
 static inline size_t xp_align(size_t v) { return (v + 255) / 256 * 256; }
 
-static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiated for: 1, 2, 3, 4, 6, 8, 12 or 16
+static int tall_tiles(int32_t ncol) {   // column tiles the kernels are instantiated for: 1, 2, 3, 4, 6, 8, 12, 16, 24 or 32
     const int nt = (ncol + 15) / 16;
-    return nt <= 4 ? (nt < 1 ? 1 : nt) : (nt <= 6 ? 6 : (nt <= 8 ? 8 : (nt <= 12 ? 12 : 16)));
+    return nt <= 4 ? (nt < 1 ? 1 : nt) : (nt <= 6 ? 6 : (nt <= 8 ? 8 : (nt <= 12 ? 12 : (nt <= 16 ? 16 : (nt <= 24 ? 24 : 32)))));
 }
 
 // Does the matrix-core form pay?  Its time does not depend on how sparse the matrix is -- every 64-row panel is a dense
@@ -1217,7 +1245,7 @@ static int tall_tiles(int32_t ncol) {   // column tiles the kernel is instantiat
 static bool panel_table_tiles(int ntiles) {
     const char* pm = getenv("RSP_CROSSPROD_PANEL_TABLE");
     const int level = pm ? atoi(pm) : 2;
-    return level >= 2 ? (ntiles == 8 || ntiles == 12 || ntiles == 16) : (level == 1 && ntiles == 16);
+    return level >= 2 ? (ntiles == 8 || ntiles == 12 || ntiles == 16 || ntiles == 24 || ntiles == 32) : (level == 1 && ntiles == 16);
 }
 
 static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
@@ -1230,18 +1258,20 @@ static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
     const double width = 16.0 * tall_tiles(ncol);
     double t_tall = 0.13 + rows * width * width / 3.8e10 + 12.0 * (double)nnz / 3.9e9;
     // (8 / 12 / 16 tiles, the panel-table kernel.  1e6 rows x 256 at 0.4 / 10 / 50 / 90 % density 1.20 / 1.32 / 1.53 / 1.81
-    // ms, x 192 at 10 / 50 / 90 % 0.85 / 1.01 / 1.29, x 128 0.48 / 0.57 / 0.77; 4e6 rows at 5 % 4.68 / 2.98 / 1.55 ms --
+    // ms, x 192 at 10 / 50 / 90 % 0.85 / 1.01 / 1.29, x 128 0.48 / 0.57 / 0.77; 4e6 rows at 5 % 4.68 / 2.98 / 1.55 ms; 24 / 32
+    // tiles (257-512 columns): 1e6 rows x 384 at 10 / 50 % 3.47 / 3.87 ms, x 512 6.2 ms at either --
     // profiles/r04_crossprod_panels.json, r04_form_edges_crossprod.json)
     const int nt = tall_tiles(ncol);
     if (panel_table_tiles(nt))
-        t_tall = 0.09 + rows * width * width / (nt == 16 ? 6.0e10 : (nt == 12 ? 5.2e10 : 4.5e10)) + 2.7e-9 * (double)nnz;
+        t_tall = 0.09 + rows * width * width / (nt == 32 ? 4.3e10 : (nt == 24 ? 4.4e10 : (nt == 16 ? 6.0e10 : (nt == 12 ? 5.2e10 : 4.5e10)))) + (nt == 32 ? 0.0 : 2.7e-9 * (double)nnz);
     return t_tall <= t_exact;
 }
 
 hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, CrossprodLayout* L) {
     memset(L, 0, sizeof(*L));
     crossprod_split(nrow, ncol > 0 ? ncol : 1, nnz, &L->nsplit, &L->width);
-    L->tall = !exact && ncol >= 1 && ncol <= kTallMaxCols && nnz / ncol >= kTallMinColumnLength && tall_pays(nrow, ncol, nnz);
+    L->tall = !exact && ncol >= 1 && ncol <= kTallMaxCols && nnz / ncol >= kTallMinColumnLength &&
+              (tall_tiles(ncol) <= 16 || panel_table_tiles(tall_tiles(ncol))) && tall_pays(nrow, ncol, nnz);
     if (L->tall) {   // one row-major form, unsliced, shared with the exact kernel that stands by
         L->nsplit = 1;
         L->width = ncol;
@@ -1250,7 +1280,8 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         // one round of workgroups: what fits on the chip at this tile count (registers / LDS per workgroup)
         static const int per_cu[17] = {0, 5, 5, 5, 2, 0, 2, 0, 2, 0, 0, 0, 1, 0, 0, 0, 1};
         // (16 tiles: two workgroups share every row range, so half as many ranges make one round)
-        int64_t max_groups = 256 * per_cu[L->ntiles] < kTallMaxGroups ? 256 * per_cu[L->ntiles] : kTallMaxGroups;
+        const int cu_share = L->ntiles <= 16 ? per_cu[L->ntiles] : 1;
+        int64_t max_groups = 256 * cu_share < kTallMaxGroups ? 256 * cu_share : kTallMaxGroups;
         if (L->ntiles == 16) max_groups /= kTallSplit16;
         if (L->ntiles == 12) max_groups /= kTallSplit12;
         int64_t per = (npanels + max_groups - 1) / max_groups;
@@ -1261,9 +1292,11 @@ hipError_t plan_crossprod(int32_t nrow, int32_t ncol, int64_t nnz, bool exact, C
         // 16 column tiles: panels of 32 rows through a panel table (crossprod_panels_kernel), one workgroup per CU
         if (panel_table_tiles(L->ntiles)) {
             L->panel_table = true;
-            L->npanels = ((int64_t)nrow + kPanRows - 1) / kPanRows;
+            L->panel_rows = L->ntiles > 16 ? 16 : kPanRows;   // (24 / 32 tiles: two buffers of 32 x 384 / 512 do not fit the LDS)
+            L->npanels = ((int64_t)nrow + L->panel_rows - 1) / L->panel_rows;
             const char* gr = getenv("RSP_CROSSPROD_PANEL_GROUPS");
-            int64_t groups = gr ? atoll(gr) : (L->ntiles == 8 ? 512 : 256);   // (8 tiles: two workgroups per CU)
+            // (8 tiles: two workgroups per CU; 24 / 32 tiles: three / four workgroups share a range of panels)
+            int64_t groups = gr ? atoll(gr) : (L->ntiles == 8 ? 512 : (L->ntiles == 32 ? 64 : (L->ntiles == 24 ? 85 : 256)));
             if (groups < 1) groups = 1;
             if (groups > kTallMaxGroups) groups = kTallMaxGroups;
             int64_t pper = (L->npanels + groups - 1) / groups;
@@ -1339,32 +1372,38 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             if (xparts < 1) xparts = 1;
             if (nnz > 0)
                 hipLaunchKernelGGL(xp_panel_table_kernel, dim3((unsigned)xparts, (unsigned)want_y), dim3(256), 0, stream,
-                                   d_i, d_p, nrow, ncol, nnz, L.npanels, Ts, Te);
+                                   d_i, d_p, L.panel_rows == 16 ? 4 : 5, ncol, nnz, L.npanels, Ts, Te);
             hipLaunchKernelGGL(xp_panel_has_kernel, dim3((unsigned)((L.npanels + 255) / 256), (unsigned)((ncol + 31) / 32)),
                                dim3(256), 0, stream, (const int32_t*)Te, ncol, L.npanels, (uint32_t*)has);
-#define RSP_XP_LAUNCH(NT, NW, WIDE, M)                                                                                  \
-    hipLaunchKernelGGL((crossprod_panels_kernel<NT, NW, WIDE, M>), dim3((unsigned)L.ngroups), dim3(NW * 64), 0, stream, \
-                       d_x, d_i, (const int32_t*)Ts, (const int32_t*)Te, (const uint8_t*)has, ncol, L.npanels,          \
-                       L.panels_per_group, flag, partial)
+#define RSP_XP_LAUNCH(NT, NW, PR, SPLIT, WIDE, M)                                                                       \
+    hipLaunchKernelGGL((crossprod_panels_kernel<NT, NW, PR, SPLIT, WIDE, M>), dim3((unsigned)L.ngroups * SPLIT),        \
+                       dim3(NW * 64), 0, stream, d_x, d_i, (const int32_t*)Ts, (const int32_t*)Te, (const uint8_t*)has, \
+                       ncol, L.npanels, L.panels_per_group, flag, partial)
             const bool wide = nnz >= (1ll << 29);   // (byte offsets of x beyond 32 bits)
             int mode = 0;
 #ifdef RSP_XP_MODES   // (a measurement build: RSP_XP_PANELS_MODE = 1 no MFMAs, 2 no entries moved, 3 neither; 16 tiles only)
             if (const char* md = getenv("RSP_XP_PANELS_MODE")) mode = atoi(md);
             if (wide || L.ntiles != 16) mode = 0;
-            if (mode == 1) RSP_XP_LAUNCH(16, 8, false, 1);
-            if (mode == 2) RSP_XP_LAUNCH(16, 8, false, 2);
-            if (mode == 3) RSP_XP_LAUNCH(16, 8, false, 3);
+            if (mode == 1) RSP_XP_LAUNCH(16, 8, 32, 1, false, 1);
+            if (mode == 2) RSP_XP_LAUNCH(16, 8, 32, 1, false, 2);
+            if (mode == 3) RSP_XP_LAUNCH(16, 8, 32, 1, false, 3);
 #endif
             if (mode == 0) {
-                if (L.ntiles == 16) {
-                    if (wide) RSP_XP_LAUNCH(16, 8, true, 0);
-                    else RSP_XP_LAUNCH(16, 8, false, 0);
+                if (L.ntiles == 32) {
+                    if (wide) RSP_XP_LAUNCH(32, 8, 16, 4, true, 0);
+                    else RSP_XP_LAUNCH(32, 8, 16, 4, false, 0);
+                } else if (L.ntiles == 24) {
+                    if (wide) RSP_XP_LAUNCH(24, 8, 16, 3, true, 0);
+                    else RSP_XP_LAUNCH(24, 8, 16, 3, false, 0);
+                } else if (L.ntiles == 16) {
+                    if (wide) RSP_XP_LAUNCH(16, 8, 32, 1, true, 0);
+                    else RSP_XP_LAUNCH(16, 8, 32, 1, false, 0);
                 } else if (L.ntiles == 12) {
-                    if (wide) RSP_XP_LAUNCH(12, 12, true, 0);
-                    else RSP_XP_LAUNCH(12, 12, false, 0);
+                    if (wide) RSP_XP_LAUNCH(12, 12, 32, 1, true, 0);
+                    else RSP_XP_LAUNCH(12, 12, 32, 1, false, 0);
                 } else {
-                    if (wide) RSP_XP_LAUNCH(8, 8, true, 0);
-                    else RSP_XP_LAUNCH(8, 8, false, 0);
+                    if (wide) RSP_XP_LAUNCH(8, 8, 32, 1, true, 0);
+                    else RSP_XP_LAUNCH(8, 8, 32, 1, false, 0);
                 }
             }
 #undef RSP_XP_LAUNCH
@@ -1382,7 +1421,7 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
         const int64_t outs = (int64_t)ncol * ncol;
         if (L.panel_table) {
             const unsigned pairs = (unsigned)(L.ntiles * (L.ntiles + 1) / 2);
-            if (L.ntiles == 16)
+            if (L.ntiles >= 16)
                 hipLaunchKernelGGL(crossprod_panels_combine_kernel<128>, dim3(pairs * 2), dim3(1024), 0, stream, partial,
                                    L.ngroups, L.ntiles, ncol, flag, d_out);
             else if (L.ntiles == 12)

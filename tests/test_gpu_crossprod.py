@@ -147,12 +147,13 @@ def test_crossprod_needs_row_indices(torch_cuda):
     h.close()
 
 
-# ---- the tall form (ncol <= 256, columns of >= 4096 entries): matrix cores, tolerance instead of bits ----
+# ---- the tall form (ncol <= 512, columns of >= 4096 entries): matrix cores, tolerance instead of bits ----
 
 TALL_SHAPES = [(41_000, 100, 0.1), (50_000, 7, 0.1), (60_000, 129, 0.1), (50_000, 192, 0.1), (45_000, 200, 0.1),
                (42_000, 256, 0.1), (400_000, 1, 0.5), (300_000, 16, 0.2), (300_000, 17, 0.15), (250_000, 48, 0.2), (200_000, 64, 0.25),
                (200_000, 65, 0.2), (150_000, 100, 0.3), (150_000, 128, 0.25), (3_000_000, 20, 0.02),
-               (250_000, 256, 0.0166)]   # (7813 panels of 32 rows: the last workgroup's range is ONE panel)
+               (250_000, 256, 0.0166),   # (7813 panels of 32 rows: the last workgroup's range is ONE panel)
+               (45_000, 300, 0.1), (41_000, 512, 0.1), (43_000, 385, 0.1)]   # (24 / 32 tiles: panels of 16 rows, three / four workgroups per range)
 
 
 @pytest.mark.parametrize("nrow,ncol,density", TALL_SHAPES)
@@ -233,9 +234,9 @@ def test_crossprod_tall_form_rows_without_entries_and_ragged_last_panel(torch_cu
     assert np.all(got[scale == 0] == 0)
 
 
-# ---- 97-256 columns: the tall form finds its 32-row panels through a panel table (crossprod_panels_kernel) ----
+# ---- 97-512 columns: the tall form finds its 32-row (from 257 columns on: 16-row) panels through a panel table ----
 
-@pytest.mark.parametrize("ncol", [200, 256, 176, 120])
+@pytest.mark.parametrize("ncol", [200, 256, 176, 120, 400])
 def test_crossprod_panel_table_form_gaps_ragged_end_and_round3_kernel_agree(torch_cuda, ncol):
     """Panels without entries never enter the pipeline (has[]), whether the gap is two panels or 3 400 and wherever a
     workgroup's range begins; the last panel is partial.  Against the oracle within the tall form's tolerance, the
@@ -256,24 +257,29 @@ def test_crossprod_panel_table_form_gaps_ragged_end_and_round3_kernel_agree(torc
     i = np.concatenate(cols).astype(np.int32)
     p = np.concatenate(([0], np.cumsum([len(c) for c in cols]))).astype(np.int32)
     x = rng.standard_normal(i.size)
-    assert capi.crossprod_form(nrow, ncol, x.size) == "tall"
-    ref = oracle.crossprod(x, i, p)
-    scale = oracle.crossprod(np.abs(x), i, p)
-    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
-    got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
-    again = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
-    assert got.tobytes() == again.tobytes()
-    assert np.array_equal(got, got.T)
-    assert np.all(np.abs(got - ref) <= 1e-12 * scale), float(np.max(np.abs(got - ref) / np.maximum(scale, 1e-300)))
-    os.environ["RSP_CROSSPROD_PANEL_TABLE"] = "0"
+    if ncol > 256:
+        os.environ["RSP_CROSSPROD_TALL_ALWAYS"] = "1"     # (400 columns of 4320 entries: the cost model would take the exact form)
     try:
-        old = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+        assert capi.crossprod_form(nrow, ncol, x.size) == "tall"
+        ref = oracle.crossprod(x, i, p)
+        scale = oracle.crossprod(np.abs(x), i, p)
+        xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+        got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+        again = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+        assert got.tobytes() == again.tobytes()
+        assert np.array_equal(got, got.T)
+        assert np.all(np.abs(got - ref) <= 1e-12 * scale), float(np.max(np.abs(got - ref) / np.maximum(scale, 1e-300)))
+        os.environ["RSP_CROSSPROD_PANEL_TABLE"] = "0"                # (above 256 columns: the exact form)
+        try:
+            old = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+        finally:
+            del os.environ["RSP_CROSSPROD_PANEL_TABLE"]
+        assert np.all(np.abs(old - ref) <= 1e-12 * scale)
     finally:
-        del os.environ["RSP_CROSSPROD_PANEL_TABLE"]
-    assert np.all(np.abs(old - ref) <= 1e-12 * scale)
+        os.environ.pop("RSP_CROSSPROD_TALL_ALWAYS", None)
 
 
-@pytest.mark.parametrize("ncol", [256, 180, 112])
+@pytest.mark.parametrize("ncol", [256, 180, 112, 330])
 def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda, ncol):
     """16 / 12 / 8 column tiles: the panel-table kernel looks at its sums, not at every value: a NaN made by a structural zero
     meeting an infinity stays a NaN, the flag goes up and the bit-identical kernels produce the reference's result.
@@ -302,7 +308,7 @@ def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda,
         assert np.array_equal(via_handle, ref, equal_nan=True)
 
 
-@pytest.mark.parametrize("ncol", [256, 180, 112])
+@pytest.mark.parametrize("ncol", [256, 180, 112, 500])
 def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cuda, ncol):
     """Not a dgCMatrix -- rows that do not ascend, rows outside the matrix, column offsets that go backwards or
     beyond nnz: the result means nothing, but the call returns, reads and writes nothing out of bounds (the entries
@@ -328,7 +334,7 @@ def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cud
     assert np.all(np.abs(got - ref) <= 1e-12 * scale)
 
 
-@pytest.mark.parametrize("ncol", [200, 120, 40])
+@pytest.mark.parametrize("ncol", [200, 120, 40, 300])
 def test_crossprod_device_entry_is_graph_capture_safe(torch_cuda, ncol):
     """rsp_crossprod_device with a workspace allocates nothing and never synchronises (the exact kernels stand by on
     a device-side flag): capturable into a HIP graph in the panel-table form (16 / 8 tiles) and in the form that walks

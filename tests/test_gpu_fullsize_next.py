@@ -133,11 +133,12 @@ def test_row_sums_full_size(torch_cuda, nrow, ncol, nnz, structure):
 
 
 # ---------------------------------------------------------------------------- crossprod
-@pytest.mark.parametrize("nrow,ncol", [(45_000_000, 48), (17_000_000, 256), (24_000_000, 176), (40_000_000, 112)])
+@pytest.mark.parametrize("nrow,ncol", [(45_000_000, 48), (17_000_000, 256), (24_000_000, 176), (40_000_000, 112),
+                                       (8_400_000, 512), (12_000_000, 360)])
 def test_crossprod_tall_form_at_the_int32_limit(torch_cuda, nrow, ncol):
     """2^31 - 1 entries in 48 columns of 45e6 rows (3 column tiles: the kernel that walks the CSC arrays), and in 256 / 176
-    / 112 columns (16 / 12 / 8 tiles: the panel-table kernel of round 4 with 64-bit byte offsets, entry indices up to
-    2^31 - 2 in its tables): the matrix-core form on the largest matrix the 32-bit slots can hold.  Column pairs at both ends of the arrays and in the middle against the oracle's merges
+    / 112 / 512 / 360 columns (16 / 12 / 8 / 32 / 24 tiles: the panel-table kernel of round 4 with 64-bit byte offsets, entry
+    indices up to 2^31 - 2 in its tables): the matrix-core form on the largest matrix the 32-bit slots can hold.  Column pairs at both ends of the arrays and in the middle against the oracle's merges
     (the exact form's order), the diagonal against the column sums of squares, symmetry, identical bits
     on a second run.
 

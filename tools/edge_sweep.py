@@ -326,6 +326,8 @@ def sweep_crossprod(quick):
              (250_000, 256, 4_096), (250_000, 224, 6_000), (4_000_000, 256, 40_000),
              (1_000_000, 192, 4_096), (1_000_000, 192, 8_000), (1_000_000, 192, 12_000), (1_000_000, 160, 9_000), (250_000, 192, 4_096),
              (1_000_000, 128, 6_000), (1_000_000, 100, 5_000), (250_000, 128, 4_096), (4_000_000, 128, 20_000),
+             (1_000_000, 512, 4_096), (1_000_000, 512, 12_000), (1_000_000, 512, 20_000), (1_000_000, 384, 8_000), (1_000_000, 384, 14_000),
+             (250_000, 400, 4_096), (4_000_000, 320, 30_000), (100_000, 512, 4_096),
              (1_000_000, 128, 4_096), (1_000_000, 128, 10_000), (1_000_000, 64, 4_096), (100_000, 256, 4_096),
              (4_000_000, 200, 8_000), (4_000_000, 200, 60_000)] if not quick else [(300_000, 64, 4_096)]
     for nrow, ncol, per_col in cases:

@@ -7,7 +7,7 @@ within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric.
     python3 tools/soak_crossprod_tall.py [seconds] [seed] [mincol]
 
 mincol (default 1): the smallest number of columns drawn; 193 keeps every case on the panel-table kernel of
-16 column tiles.  The cost model is bypassed (RSP_CROSSPROD_TALL_ALWAYS=1): every case takes the tall form.
+16 column tiles, 257 on its 24- and 32-tile forms (257..512 columns, 16-row panels).  The cost model is bypassed (RSP_CROSSPROD_TALL_ALWAYS=1): every case takes the tall form.
 """
 import sys, os, time
 os.environ["RSP_CROSSPROD_TALL_ALWAYS"] = "1"
@@ -21,8 +21,11 @@ from rcppsparse_amd import capi
 def one(rng, case, mincol=1):
     ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, 129, 160, 192, 193, 256, int(rng.integers(1, 257))]))
     if ncol < mincol:
-        ncol = int(rng.choice([mincol, 256, int(rng.integers(mincol, 257))]))
+        top = 512 if mincol > 256 else 256
+        ncol = int(rng.choice([mincol, top, int(rng.integers(mincol, top + 1))]))
     mean_len = int(rng.integers(4096, 40000)) if ncol > 40 else int(rng.integers(4096, 90000))
+    if ncol > 256:
+        mean_len = int(rng.integers(4096, 6000))                      # (the oracle's merges: ncol^2 x length)
     kind = int(rng.integers(0, 4))
     lens = rng.integers(0, 2 * mean_len, ncol)
     if ncol > 2 and kind != 3:
