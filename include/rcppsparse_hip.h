@@ -376,9 +376,9 @@ int rsp_row_means_device(const double *d_x, const int32_t *d_i, int32_t nrow,
  * sparse data).  Both give the same bits.  rsp_crossprod_workspace_bytes needs a usable
  * device; 0 = error.
  *
- * One exception to "same bits": for ncol <= 256 and columns of >= 4096 stored entries on
+ * One exception to "same bits": for ncol <= 512 and columns of >= 4096 stored entries on
  * average (the tall matrices crossprod is meant for), the workspace form sums in a different
- * order -- rows are densified 64 (from 97 columns on: 32) at a time and t(P) P runs on the matrix cores, every workgroup
+ * order -- rows are densified 64 (from 97 columns on: 32, from 257 on: 16) at a time and t(P) P runs on the matrix cores, every workgroup
  * over its own range of rows, results added in workgroup order: deterministic, within
  * 1e-12 * sum|x1 x2| per entry of the reference's order, and two to three orders of magnitude
  * faster than walking 48 columns of 4.5e7 rows one product after the other (7 ms against 24.8 s).  If x holds
