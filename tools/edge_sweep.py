@@ -20,7 +20,7 @@ Edges covered (knob that forces the neighbour):
   segments | regrouped      a handle's row sums: >= 128 entries per column and    rsp_set_row_segments(0 / 2)
                             row block (a trade between first and repeated calls:
                             limit 1.25 here)
-  tall | exact              crossprod: <= 256 columns of >= 4096 entries          rsp_set_crossprod_exact
+  tall | exact              crossprod: <= 512 columns of >= 4096 entries          rsp_set_crossprod_exact
 Not covered (no forcing knob; their thresholds are compile-time constants, measured in profiles/r02_* / r03_*): the
 L1 / LDS bitmap sizes of the row-restricted sums, direct / partition / coarse / two-level row sums (block counts), the
 short-call pipeline, lean rows per chunk (RSP_LEAN_ROWS is read once per process).
