@@ -20,20 +20,12 @@ THE SAME PROTOCOL AT EVERY N (so per-N values can be divided by each other):
 in order on ONE stream per rank: column-sum kernels, then (N > 1) the gatherv of that call
 -- the synchronous-call semantics of the reference function; call k+1 starts when call k,
 its gather included, is done.  Max over ranks, barrier + synchronize on both sides.
-Also reported, as separate keys that never feed `value`:
-  `latency_ms_per_call`  one call at a time: host launch -> kernels -> gatherv -> the result
-                         is complete on rank 0 and the host has seen it (SURVEY.md 8d);
-  `pipelined`            calls overlapped across steps (launches alternate over two compute
-                         streams, the gather of call k runs beside the kernel of call k+1).
-`roofline.achieved` = algorithmic bytes of one launch (8 B/nnz + 12 B/column,
-SURVEY.md 8d; i[] is never read) / mean launch duration from HIP events recorded
-on the launch stream around the kernels of the timed region (the gather is outside them).
-`parity` = EVERY column of the gathered result against the oracle, after the timed region.
-`--rendezvous gloo` is a REHEARSAL of the N > 1 control flow with real HIP compute on a box with
-fewer GPUs than ranks (ranks share devices; slices travel as host copies over gloo because RCCL
-refuses two ranks on one device).  Its line says so in `config`; it is never a multi-GPU number.
-`cpu_baseline` = the oracle (1-thread C restatement of the reference loop) timed
-on this box's host on a bounded prefix of the same matrix (rank 0, N = 1 only).
+
+The line is COMPACT (under 8000 bytes at every N, tests/test_bench_line.py): numbers and short
+codes only.  `python bench.py --explain` prints what every key means (the prose that earlier
+rounds carried inside the line); `--verbose` puts that glossary into the line as `notes`.
+Everything a reader of the driver's record needs sits as FLAT SCALARS inside `roofline`
+(the record keeps the scalars of `roofline`, `config` and `cpu_baseline`, other keys by name only).
 """
 from __future__ import annotations
 
@@ -53,11 +45,12 @@ sys.path.insert(0, ROOT)
 # starts, i.e. before torch is imported.  An explicit setting wins.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # Nothing this file measures may come from the Rcpp layer's host loop (columnsums_impl.hpp answers on the CPU when
-# a machine has no GPU): a GPU is required in this process and in every child it starts.
+# a machine has no GPU or the matrix is tiny): a GPU is required in this process and in every child it starts.
 os.environ["RCPPSPARSE_REQUIRE_GPU"] = "1"
 
 HBM_PEAK_GBPS = 8000.0     # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 SEED = 42
+LINE_BYTES_MAX = 8000      # the driver keeps the last 8 KiB of stdout
 
 WORKLOADS = {
     # name: (nrow, ncol, nnz, shape)
@@ -81,8 +74,65 @@ WORKLOADS = {
     # ~10 per column at sizes between C2 and 1e9 (the lean planned form: profiles/r03_lean_sizes.jsonl)
     "m10_3e7": (3_000_000, 3_000_000, 30_000_000, "uniform"),
     "m10_1e8": (10_000_000, 10_000_000, 100_000_000, "uniform"),
-    # small shapes for the -m gpu test that runs this file as a child process
+    # small shapes for the -m gpu tests that run this file as a child process
     "tiny": (200_000, 40_000, 4_000_000, "zipf"),
+    "tinyu": (200_000, 40_000, 4_000_000, "uniform"),
+}
+
+# What the keys of the line mean (`--explain`; `--verbose` adds it to the line as `notes`).
+GLOSSARY = {
+    "value": "nnz of the whole matrix x K / wall time of K calls issued back to back; each call in order on ONE stream per "
+             "rank: column-sum kernels, then (N > 1) that call's gatherv; max over ranks; barrier + synchronize on both sides. "
+             "Small single-GPU workloads (< 2e8 nnz, no gather): THREE such regions, `value` is the median one, "
+             "`config.regions_ms` lists ms per call of all three",
+    "config.parallelism": "single | ranges+rccl (N nnz-balanced contiguous column ranges + RCCL gatherv to rank 0) | "
+                          "rehearsal (--rendezvous gloo: ranks share the box's devices, slices travel as host copies over gloo "
+                          "because RCCL refuses two ranks on one device; a rehearsal of the N > 1 control flow with real HIP "
+                          "compute, never a multi-GPU number)",
+    "config.shards": "what every rank owned and measured, rank order: columns [c0, c1), entries, mean kernel / gather ms",
+    "config.host_stall_suspected": "ms_per_step > 1.5 x roofline.kernel_ms on a call without a gather: the host, not the device, "
+                                   "set the pace of the region",
+    "latency_ms_per_call": "one call at a time: barrier, then host launch -> kernels -> gatherv -> stream synchronize on "
+                           "rank 0 (the gathered result is complete and the host has seen it); median",
+    "pipelined": "calls overlapped across steps (launches alternate over the compute streams, the gather of call k runs on "
+                 "its own stream beside the kernel of call k+1); NOT the protocol of `value`",
+    "planned_shards": "N > 1: the protocol of `value` with every rank's launches going through an inspector-executor plan "
+                      "of its own shard (inspected once, outside the timed region); NOT `value`",
+    "direct_gather": "N > 1: every rank's kernels store into rank 0's result buffer (mapped with hipIpcOpenMemHandle) at the "
+                     "rank's displacement; per call: launch, wait for the own stream, cross a shared-memory barrier; "
+                     "NOT the protocol of `value`",
+    "roofline.achieved": "algorithmic bytes of one launch (8 B/nnz + 12 B/column, SURVEY.md 8d; i[] is never read) of rank 0's "
+                         "shard / roofline.kernel_ms",
+    "roofline.kernel_ms": "mean device time of the kernels of one call, HIP events on the launch stream.  kernel_timing = "
+                          "per_call: an event pair around the kernels of each timed call; region: ONE pair around each timed "
+                          "region / K (small calls: a pair per call would idle the queue); per_call_after: N > 1, the timed "
+                          "region carries no events, the K calls are issued once more right after it with events around "
+                          "kernels and gather",
+    "roofline.traffic": "HBM bytes of one call: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, FETCH_SIZE "
+                        "doubled (MI355X_MICROARCH.md), main kernel + fix-up.  traffic_measured_in_run true: two child passes "
+                        "of this workload on this device after the timed regions of THIS run; false: the figure of the "
+                        "committed passes under profiles/ (roofline.traffic_file)",
+    "roofline.read_ceiling_GBps": "a read-only kernel with the access shape of the column-sum kernel (same chunk grid, same "
+                                  "1 KiB nt loads, same register pipeline; no p[], no stores) over the SAME x on the SAME "
+                                  "device in the SAME run; frac_of_ceiling = achieved / read_ceiling_GBps",
+    "roofline.also_*": "more single-GPU workloads measured after the headline one, outside its timed region, by the same "
+                       "protocol, each with whole-matrix parity; never part of `value`.  <w>_frac = achieved / 8000 GB/s, "
+                       "<w>_kernel_ms, <w>_ms_per_call (median of three regions), <w>_parity_err = max |gpu - ref| / sum|x| "
+                       "over all columns, <w>_traffic_x = HBM bytes / algorithmic bytes measured in this run, "
+                       "<w>_traffic_recorded_x = the same from the committed passes under profiles/",
+    "also": "the same records whole: form = general | snapped | lean | columns; launches per call; plan_ms (plan_by = host: "
+            "rsp_column_sums_plan_create on a host copy of p[]; device: rsp_column_sums_plan_create_device, device time of "
+            "the inspection kernels); early_general_calls = calls answered by the general kernels before a device-made plan "
+            "was known",
+    "also_sharded": "N > 1 (default c3 line): the protocol of `value` run again, outside its timed region, on c5 (Zipf "
+                    "nnz/column) with the nnz-balanced partition and with the naive equal-column-count partition "
+                    "(SURVEY.md 8e's comparator); per-rank kernel ms, imbalance = max / mean entries per shard, "
+                    "whole-matrix parity",
+    "parity": "EVERY column of the gathered result against the oracle (1-thread C restatement of the reference loop), after "
+              "the timed region: |gpu - ref| <= 1e-12 x sum|x| per column; empty columns exactly +0.0",
+    "cpu_baseline": "the oracle (kind port: restatement of reference src/example.cpp:26-32), 1 thread, on this box's host on "
+                    "a bounded prefix of the same matrix, rank 0, at every N; all_cores_value: the same loop under an OpenMP "
+                    "parallel-for over the columns (NOT the reference's behaviour)",
 }
 
 
@@ -114,44 +164,43 @@ def parse_args(argv=None):
     ap.add_argument("--planned", action="store_true",
                     help="inspector-executor form: the offsets are inspected once (rsp_column_sums_plan_create, "
                          "reported as plan_ms, outside every timed region) and every call is "
-                         "rsp_column_sums_planned_device -- one launch without column search, carries or fix-up "
-                         "where no long column crosses a chunk edge.  The headline C3 `value` stays plan-free.")
+                         "rsp_column_sums_planned_device.  The headline C3 `value` stays plan-free.")
     ap.add_argument("--no-lean", action="store_true", help="--planned: keep the plan out of the lean form (A/B)")
     ap.add_argument("--try-comm", action="store_true",
                     help="--rendezvous gloo only: also take the C-ABI communicator through its multi-rank "
                          "bootstrap (unique id from rank 0, rsp_comm_init on every rank).  With ranks sharing a "
-                         "device RCCL must refuse it; the refusal is recorded in config.comm_init_rehearsal")
+                         "device RCCL must refuse it; config.comm_refused_on_ranks counts the refusals")
     ap.add_argument("--op", default="colsums", choices=["colsums", "rowsums"],
                     help="colsums (default): the headline path.  rowsums: Matrix::rowSums (reference RcppSparse.h:138-144) over "
                          "the same column-range shards -- every rank sums the rows of ITS columns (rsp_row_sums_device) and "
-                         "the partial vectors of nrow doubles are reduced in rank order to rank 0 (rsp_comm_reduce_rows over "
-                         "RCCL; over gloo in the rehearsal).  Its line carries metric 'rowSums nnz/s ...': a next-row figure, "
-                         "never the headline")
+                         "the partial vectors of nrow doubles are reduced in rank order to rank 0.  Its line carries metric "
+                         "'rowSums nnz/s ...': a next-row figure, never the headline")
     ap.add_argument("--no-planned-shards", action="store_true", help="N > 1: skip the separate planned_shards figure")
     ap.add_argument("--direct-gather", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: the separate direct_gather figure (the ranks' kernels store into rank 0's result buffer, mapped "
                          "with hipIpc).  auto = in the --rendezvous gloo rehearsal only: between DIFFERENT devices a kernel that "
-                         "writes through a mapping the driver does not honour faults, and a fault ends the whole job -- on a "
-                         "real multi-GPU node the figure is asked for explicitly (--direct-gather on), the line with `value` is not "
-                         "put at its mercy")
+                         "writes through a mapping the driver does not honour faults, and a fault ends the whole job")
     ap.add_argument("--also", default="auto",
-                    help="N = 1: more single-GPU workloads measured after the headline one, OUTSIDE its timed region, "
-                         "as compact sub-records under the key `also` (never part of `value`).  auto = every other "
-                         "single-GPU BASELINE configuration and its planned form when the headline workload is c3 "
-                         "(c2, c2:planned, c5, c4shard, c4shard:planned, vignette:planned), nothing otherwise; or a "
-                         "comma-separated list of workload[:planned]")
+                    help="N = 1: more single-GPU workloads measured after the headline one, OUTSIDE its timed region "
+                         "(never part of `value`).  auto = every other single-GPU BASELINE configuration and its planned form "
+                         "when the headline workload is c3, nothing otherwise; or a comma-separated list of workload[:planned]")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` records (profiling runs)")
+    ap.add_argument("--also-sharded", default="auto",
+                    help="N > 1: more sharded workloads by the protocol of `value`, after the headline one.  auto = c5:nnz,c5:cols "
+                         "when the headline is the default c3 line; or a comma-separated list of workload:partition; none = skip")
     ap.add_argument("--traffic-pass", default="auto", choices=["auto", "on", "off"],
                     help="roofline.traffic measured IN THIS RUN: two child runs of this file under rocprofv3 (--pmc FETCH_SIZE, "
                          "--pmc WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes) on the same device after the "
-                         "timed regions.  auto = for the default c3 line at N = 1; off = the figure of the committed passes "
-                         "(profiles/*traffic*.json), labelled as such")
+                         "timed regions.  auto = for the default c3 line at N = 1 (headline, and the plan-free c2 / c5 `also` "
+                         "records); off = the figure of the committed passes (profiles/*traffic*.json), labelled as such")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--ceiling-reps", type=int, default=5,
-                    help="launches of the read-only kernel timed for roofline.read_ceiling (0 = skip)")
+                    help="launches of the read-only kernel timed for roofline.read_ceiling_GBps (0 = skip)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: still create the RCCL communicator and run the gatherv in every "
                          "call (rehearsal of the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--verbose", action="store_true", help="add the glossary of the line's keys to the line (`notes`)")
+    ap.add_argument("--explain", action="store_true", help="print the glossary of the line's keys and exit")
     return ap.parse_args(argv)
 
 
@@ -163,7 +212,7 @@ def relaunch_under_torchrun(args) -> int:
     return subprocess.call(cmd)
 
 
-def build_offsets(name, nnz_override):
+def build_offsets(name, nnz_override=0):
     from rcppsparse_amd import synth
     nrow, ncol, nnz, shape = WORKLOADS[name]
     if nnz_override:
@@ -187,6 +236,17 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def sig(v, digits=6):
+    """Nested numbers of the line carry six significant digits (the contract's own keys stay exact)."""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, dict):
+        return {k: sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [sig(x, digits) for x in v]
+    return v
 
 
 def cpu_baseline(p, kind, target_nnz=1_000_000_000, reps=10):
@@ -215,8 +275,8 @@ def cpu_baseline(p, kind, target_nnz=1_000_000_000, reps=10):
     med = times[len(times) // 2]
     out = {
         "value": nnz_s / med, "unit": "nnz/s", "cores": 1, "kind": "port",
-        "sample": f"first {ncol_s} columns ({nnz_s} nnz) of the same matrix, "
-                  f"{reps} reps, median; best {nnz_s / times[0]:.3e} nnz/s; host has {os.cpu_count()} cpus",
+        "sample": f"first {ncol_s} columns ({nnz_s} nnz) of the same matrix, {reps} reps, median",
+        "best": nnz_s / times[0], "host_cpus": os.cpu_count(),
     }
     # optional second figure: the same per-column loop under an OpenMP parallel-for over
     # the columns on all host cores this process may use.  Not the reference's behaviour (its path
@@ -233,12 +293,11 @@ def cpu_baseline(p, kind, target_nnz=1_000_000_000, reps=10):
                 oracle.column_sums_threads(xt, ps, nthreads)
                 tt.append(time.perf_counter() - t0)
             tt.sort()
-            out["all_cores"] = {"value": nnz_s / tt[len(tt) // 2], "unit": "nnz/s", "cores": nthreads,
-                                "kind": "port + OpenMP parallel-for over columns (not in the reference); "
-                                        "cores = affinity capped by the cgroup CPU quota"}
+            out["all_cores_value"] = nnz_s / tt[len(tt) // 2]
+            out["all_cores"] = nthreads
     except Exception as e:   # never let the optional figure break the bench line
-        out["all_cores"] = {"error": str(e)[:200]}
-    return out
+        out["all_cores_error"] = str(e)[:120]
+    return sig(out)
 
 
 def parity_whole_matrix(got, p, kind, seed=SEED, first_idx=0, slab_nnz=60_000_000):
@@ -285,10 +344,12 @@ def parity_whole_matrix(got, p, kind, seed=SEED, first_idx=0, slab_nnz=60_000_00
             "empty_columns_exactly_plus_zero": empties_exact}
 
 
+def parity_ok(par):
+    return par["columns_out_of_tolerance"] == 0 and par["empty_columns_exactly_plus_zero"]
+
+
 def traffic_from_profiles(workload):
-    """(HBM bytes per launch, file) from the latest committed PMC passes (profiles/*traffic*.json).
-    Counters cannot be collected inside this run (they need rocprofv3 --pmc passes of their own,
-    MI355X_MICROARCH.md), so the figure is a recorded one and `roofline.traffic_source` says so."""
+    """(HBM bytes per launch, file) from the latest committed PMC passes (profiles/*traffic*.json)."""
     import glob
     best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
@@ -319,8 +380,8 @@ def traffic_child(args):
     torch.cuda.synchronize()
 
 
-def traffic_measured_now(args):
-    """(HBM bytes per call, how) from two counter passes run NOW as child processes on this device, or (None, why not).
+def traffic_measured_now(workload, kind):
+    """(HBM bytes per call, detail) from two counter passes run NOW as child processes on this device, or (None, why not).
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (never with a trace option); KiB -> bytes; FETCH_SIZE
     doubled (gfx950 tallies the 128-byte requests of a 16 B/lane stream at 64 B: MI355X_MICROARCH.md); main kernel + fix-up."""
     import csv
@@ -336,7 +397,7 @@ def traffic_measured_now(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--traffic-child", "--workload", args.workload, "--steps", "3", "--kind", str(args.kind)]
+                   "--traffic-child", "--workload", workload, "--steps", "3", "--kind", str(kind)]
             env = dict(os.environ, TMPDIR="/tmp")
             try:
                 pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
@@ -367,23 +428,40 @@ def traffic_measured_now(args):
 
 
 ALSO_AUTO = ("c2", "c2:planned", "c2:planned-device", "c5", "c4shard", "c4shard:planned", "vignette:planned")
-PLAN_FORMS = {3: "columns", 2: "lean", 1: "snapped", 0: "general kernels"}
+ALSO_TRAFFIC_NOW = ("c2", "c5")          # plan-free records whose HBM traffic the default line re-measures in the run
+ALSO_SHARDED_AUTO = ("c5:nnz", "c5:cols")
+PLAN_FORMS = {3: "columns", 2: "lean", 1: "snapped", 0: "general"}
+N_REGIONS_SMALL = 3
 
 
-def read_ceiling(capi, x_t, reps):
-    """roofline.read_ceiling: a hand-written read-only kernel with the access shape of the column-sum kernel
-    (same chunk grid, same 1 KiB nt loads, same register pipeline; no p[], no stores) over the SAME x on the
-    SAME device in the SAME run -- the practical ceiling SURVEY.md 8(d) asks for beside the spec peak."""
-    ms = capi.read_ceiling_device(x_t, reps=reps)
-    nbytes = 8 * x_t.numel()
-    return {"GBps": nbytes / (ms * 1e-3) / 1e9, "ms_per_launch": ms, "reps": reps, "bytes_per_launch": nbytes,
-            "of_spec_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "kernel": "read_ceiling_kernel (rsp_debug_read_ceiling_device): the chunk grid, buffer descriptors, "
-                      "nt loads and register pipeline of colsums_chunks_kernel without any column work",
-            "timing": f"one untimed launch, then {reps} launches between two HIP events on the launch stream"}
+def key_of(spec):
+    return spec.replace(":", "_").replace("-", "_")
 
 
-def also_record(torch, capi, spec, args, dev, dev_index, stream):
+def small_call_regions(torch, stream, launch_k, steps, fence, nregions=N_REGIONS_SMALL):
+    """Small calls: `nregions` timed regions of `steps` calls back to back, ONE HIP event pair around each (an event pair per
+    call would idle the queue).  Returns [(wall seconds, device ms per call)] in the order measured."""
+    out = []
+    for _ in range(nregions):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for k in range(steps):
+            launch_k(k)
+        e1.record(stream)
+        fence()
+        out.append((time.perf_counter() - t0, e0.elapsed_time(e1) / steps))
+    return out
+
+
+def median_region(regions):
+    """The region with the median wall time (an odd number of regions)."""
+    order = sorted(range(len(regions)), key=lambda k: regions[k][0])
+    return regions[order[len(order) // 2]]
+
+
+def also_record(torch, capi, spec, args, dev, dev_index, stream, traffic_now=False):
     """One more single-GPU workload, measured like the headline one (inputs resident in HBM, rotated copies of x
     where the workload would fit the Infinity Cache, K calls back to back on one stream, HIP events on that
     stream, every column against the oracle) and reported as a compact record."""
@@ -407,16 +485,12 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
         # the calls issued meanwhile are answered by the general kernels (counted here) until the host has seen the result
         capi.ColumnSumsPlan(pt, nnz=nnz, stream=stream).wait().close()   # (first use loads the inspector's kernels: not what plan_ms is about)
         torch.cuda.synchronize()
-        t_enq = time.perf_counter()
         plan = capi.ColumnSumsPlan(pt, nnz=nnz, stream=stream)
-        enqueue_ms = (time.perf_counter() - t_enq) * 1e3
         launches = [plan.prepared(xk, pt, out, ws, stream=stream) for xk in xs]
         early = 0
         while not plan.ready() and early < 10_000:
             launches[early % ncopies]()
             early += 1
-        early = {"calls_answered_by_the_general_kernels_before_the_plan_was_known": early,
-                 "plan_enqueue_ms_host": enqueue_ms}
     else:
         plan = capi.ColumnSumsPlan(p, nnz=nnz, device=dev_index) if planned else None
         launches = [(plan.prepared(xk, pt, out, ws, stream=stream) if plan is not None else
@@ -425,16 +499,11 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
         launches[k % ncopies]()
     mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
     torch.cuda.synchronize()
-    if small:      # one event pair around the region (an event pair per call would idle the queue)
-        e0, e1 = mk(), mk()
-        t0 = time.perf_counter()
-        e0.record(stream)
-        for k in range(steps):
-            launches[k % ncopies]()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        kernel_ms = e0.elapsed_time(e1) / steps
+    regions_ms = None
+    if small:
+        regions = small_call_regions(torch, stream, lambda k: launches[k % ncopies](), steps, torch.cuda.synchronize)
+        wall, kernel_ms = median_region(regions)
+        regions_ms = [w / steps * 1e3 for w, _ in regions]
     else:          # an event pair around the kernels of every call
         evs = [(mk(), mk()) for _ in range(steps)]
         t0 = time.perf_counter()
@@ -448,34 +517,35 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream):
     launches[0]()          # copy 0 (seed SEED) for the parity check
     torch.cuda.synchronize()
     par = parity_whole_matrix(out.cpu().numpy(), p, args.kind)
-    if par["columns_out_of_tolerance"] or not par["empty_columns_exactly_plus_zero"]:
+    if not parity_ok(par):
         raise SystemExit(f"parity check failed on also:{spec}: {json.dumps(par)}")
     algo = 8 * nnz + 4 * (ncol + 1) + 8 * ncol
     achieved = algo / (kernel_ms * 1e-3) / 1e9
     one_launch = plan is not None and plan.snapped
-    traffic = traffic_from_profiles(name + ("planned" if one_launch else ""))
-    rec = {"workload": spec, "shape": f"{nrow}x{ncol}, nnz={nnz}, {shape}",
-           "form": "general kernels" if plan is None else PLAN_FORMS[plan.form],
-           "launches_per_call": 1 if one_launch else 2,
+    ms_per_call = wall / steps * 1e3
+    rec = {"workload": spec,
+           "form": "general" if plan is None else PLAN_FORMS[plan.form],
+           "launches": 1 if one_launch else 2,
            "plan_ms": None if plan is None else plan.inspect_ms,
-           "plan_made": None if plan is None else ("on the device, on the launch stream (rsp_column_sums_plan_create_device); "
-                                                   "plan_ms = device time of the inspection kernels" if plan.device_made else
-                                                   "on the host from a host copy of p[] (rsp_column_sums_plan_create)"),
-           "plan_device": early,
-           "steps": steps, "x_copies_rotated": ncopies,
-           "ms_per_call": wall / steps * 1e3, "kernel_ms": kernel_ms,
-           "nnz_per_s": nnz * steps / wall,
-           "algorithmic_bytes_per_launch": algo, "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBPS,
-           "traffic": traffic[0], "traffic_source": traffic[1],
-           "parity": {"max_abs_err_over_l1": par["max_abs_err_over_l1"],
-                      "columns_out_of_tolerance": par["columns_out_of_tolerance"],
-                      "columns_checked": "all", "ncol": ncol,
-                      "empty_columns_exactly_plus_zero": par["empty_columns_exactly_plus_zero"]}}
+           "plan_by": None if plan is None else ("device" if plan.device_made else "host"),
+           "early_general_calls": early,
+           "steps": steps, "x_copies": ncopies,
+           "ms_per_call": ms_per_call, "regions_ms": regions_ms, "kernel_ms": kernel_ms,
+           "host_stall_suspected": bool(ms_per_call > 1.5 * kernel_ms),
+           "algo_bytes": algo, "frac": achieved / HBM_PEAK_GBPS,
+           "parity_err": par["max_abs_err_over_l1"], "bad_columns": par["columns_out_of_tolerance"]}
     if plan is not None:
         plan.close()
     del xs, launches, out, ws, pt
     torch.cuda.empty_cache()
-    return rec
+    measured = None
+    if traffic_now and plan is None:
+        measured, _how = traffic_measured_now(name, args.kind)
+    if measured is not None:
+        rec["traffic"], rec["traffic_in_run"] = measured, True
+    else:
+        rec["traffic"], rec["traffic_in_run"] = traffic_from_profiles(name + ("planned" if one_launch else ""))[0], False
+    return sig(rec)
 
 
 def timed_steps(torch, dist, world, stat_dev, fence, steps, step_fn):
@@ -508,7 +578,7 @@ def planned_shards_figure(ctx):
     if float(ok[0]) == 0.0:
         if plan is not None:
             plan.close()
-        return {"value": None, "note": f"not measured: a rank could not make its plan ({err})"} if rank == 0 else None
+        return {"value": None, "note": f"not measured: a rank could not make its plan ({err})"[:160]} if rank == 0 else None
     xs, pt, out, ws, s_main = ctx["xs"], ctx["pt"], ctx["out_main"], ctx["ws_main"], ctx["s_main"]
     launches = [plan.prepared(xk, pt, out, ws, stream=s_main) for xk in xs]
     n = [0]
@@ -535,12 +605,9 @@ def planned_shards_figure(ctx):
     if rank == 0:
         full = (recv if ctx["use_comm"] else out).cpu().numpy()
         par = parity_whole_matrix(full, ctx["p"], args.kind)
-        fig = {"value": ctx["nnz"] * args.steps / elapsed, "unit": "nnz/s", "ms_per_step": elapsed / args.steps * 1e3,
-               "forms_by_rank": forms, "plan_ms_rank0": plan.inspect_ms,
-               "parity": {"max_abs_err_over_l1": par["max_abs_err_over_l1"],
-                          "columns_out_of_tolerance": par["columns_out_of_tolerance"], "columns_checked": "all"},
-               "protocol": "the protocol of `value` with every rank's launches going through a plan of its own shard "
-                           "(inspected once, outside the timed region); NOT `value`"}
+        fig = sig({"value": ctx["nnz"] * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                   "forms_by_rank": forms, "plan_ms_rank0": plan.inspect_ms,
+                   "parity_err": par["max_abs_err_over_l1"], "bad_columns": par["columns_out_of_tolerance"]})
     plan.close()
     return fig
 
@@ -551,7 +618,7 @@ def direct_gather_figure(ctx):
     `mapped + displacement` as their output pointer: the exchange is the kernels' own result stores over xGMI plus one
     fence per call (every rank waits for its stream, then the ranks cross a shared-memory barrier).  Never `value`."""
     torch, dist, capi = ctx["torch"], ctx["dist"], ctx["capi"]
-    args, shard, world, rank = ctx["args"], ctx["shard"], ctx["world"], ctx["rank"]
+    args, world, rank = ctx["args"], ctx["world"], ctx["rank"]
     ncol, displs, s_main = ctx["ncol"], ctx["displs"], ctx["s_main"]
     note = None
     try:
@@ -565,7 +632,7 @@ def direct_gather_figure(ctx):
             shared = capi.SharedResult(ncol, handle=box[0])
         barrier = capi.HostBarrier(box[1], world, rank)
     except Exception as e:                      # e.g. IPC not offered by this host: say so, measure nothing
-        note = f"not measured: {e}"
+        note = f"not measured: {e}"[:160]
         ok = torch.tensor([0.0], device=ctx["stat_dev"])
     else:
         ok = torch.tensor([1.0], device=ctx["stat_dev"])
@@ -575,7 +642,7 @@ def direct_gather_figure(ctx):
         notes = [None] * world
         if world > 1:
             dist.all_gather_object(notes, note)
-        return {"value": None, "note": [n for n in notes if n] or [note]} if rank == 0 else None
+        return {"value": None, "note": ([n for n in notes if n] or [note])[0]} if rank == 0 else None
 
     class Out:                                   # what the prepared launcher needs of an output tensor
         def __init__(self, ptr):
@@ -600,12 +667,8 @@ def direct_gather_figure(ctx):
     fig = None
     if rank == 0:
         par = parity_whole_matrix(shared.read(stream=s_main), ctx["p"], args.kind)
-        fig = {"value": ctx["nnz"] * args.steps / elapsed, "unit": "nnz/s", "ms_per_step": elapsed / args.steps * 1e3,
-               "parity": {"max_abs_err_over_l1": par["max_abs_err_over_l1"],
-                          "columns_out_of_tolerance": par["columns_out_of_tolerance"], "columns_checked": "all"},
-               "protocol": "every rank's kernels store into rank 0's result buffer (mapped with hipIpcOpenMemHandle) at the "
-                           "rank's displacement; per call: launch, wait for the own stream, cross a shared-memory barrier; "
-                           "NOT the protocol of `value` (its calls are never waited for by the host)"}
+        fig = sig({"value": ctx["nnz"] * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                   "parity_err": par["max_abs_err_over_l1"], "bad_columns": par["columns_out_of_tolerance"]})
     barrier.wait()
     barrier.close()
     if rank != 0:
@@ -746,26 +809,18 @@ def main_rowsums(args):
             "config": {"workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, rows "
                                    f"ascending and distinct per column (stratified), values kind {args.kind}, seed {SEED}",
                        "op": "rowsums",
-                       "parallelism": ("single GPU" if world == 1 else
-                                       f"REHEARSAL on {torch.cuda.device_count()} device(s): {world} ranks share them; the "
-                                       "partial vectors travel as host copies over gloo and are added in rank order on rank 0"
-                                       if rehearsal else
-                                       f"{world} nnz-balanced column ranges; partial row sums reduced in rank order "
-                                       "(rsp_comm_reduce_rows: all-to-all of row slices, add, gatherv) to rank 0"),
+                       "parallelism": "single" if world == 1 else ("rehearsal" if rehearsal else "ranges+rccl"),
+                       "devices": torch.cuda.device_count(),
                        "reduce": None if reduce is None else reduce.name,
                        "rendezvous": args.rendezvous if world > 1 else None,
-                       "shards": [{"rank": r, "c0": int(t[0]), "c1": int(t[1]), "nnz": int(t[2]), "kernel_ms": float(t[3]),
-                                   "reduce_ms": float(t[4]) if world > 1 else None} for r, t in enumerate(per_rank)],
-                       "protocol": "K calls back to back; each call in order on one stream per rank: the row-sum kernels "
-                                   "of the shard, then (N > 1) that call's reduce"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "rsp_row_sums_device (histogram + partition + accumulate + combine) of rank 0's shard",
-                         "kernel_ms": kernel_ms, "reduce_ms": reduce_ms if world > 1 else None,
-                         "reduce_bytes_per_rank": None if world == 1 else 8 * nrow,
-                         "algorithmic_bytes_per_launch": algo,
-                         "kernel_timing": f"HIP events on the launch stream around the kernels (and the reduce) of each of "
-                                          f"{len(evs)} calls issued again right after the timed region"},
+                       "shards": sig([{"rank": r, "c0": int(t[0]), "c1": int(t[1]), "nnz": int(t[2]), "kernel_ms": float(t[3]),
+                                       "reduce_ms": float(t[4]) if world > 1 else None} for r, t in enumerate(per_rank)])},
+            "roofline": sig({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                             "kernel": "rsp_row_sums_device (histogram + partition + accumulate + combine) of rank 0's shard",
+                             "kernel_ms": kernel_ms, "reduce_ms": reduce_ms if world > 1 else None,
+                             "reduce_bytes_per_rank": None if world == 1 else 8 * nrow,
+                             "algorithmic_bytes_per_launch": algo, "kernel_timing": "per_call_after"}),
             "parity": {"max_abs_err_over_l1": worst, "tolerance": 1e-12, "rows_checked": "all", "nrow": nrow,
                        "rows_out_of_tolerance": nbad},
         }
@@ -779,11 +834,12 @@ def main_rowsums(args):
         print(json.dumps(out), flush=True)
 
 
-def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev, shard, counts, displs,
-                      recv):
+def make_communicator(env, counts, displs, recv, shard_ncol):
     """The C-ABI communicator (rsp_comm_*), checked with a trial gatherv of a known pattern.  If it
     cannot be created or delivers wrong data on any rank, EVERY rank switches to the same gatherv
     through torch.distributed (plumbing only, never a compute fallback); config.gather says which."""
+    torch, dist, capi = env["torch"], env["dist"], env["capi"]
+    rank, world, dev = env["rank"], env["world"], env["dev"]
     uid = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
     if rank == 0:
         uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
@@ -799,7 +855,7 @@ def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank,
 
     comm = None
     try:
-        comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+        comm = capi.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, env["local_rank"])
         ok = True
     except Exception as e:
         print(f"[rank {rank}] rsp_comm_init failed: {e}", file=sys.stderr, flush=True)
@@ -807,7 +863,7 @@ def make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank,
     if all_ok(ok):
         ok = True
         try:   # rank r sends r + 1 everywhere in its slice
-            probe = torch.full((shard.ncol,), float(rank + 1), dtype=torch.float64, device=dev)
+            probe = torch.full((shard_ncol,), float(rank + 1), dtype=torch.float64, device=dev)
             if recv is not None:
                 recv.zero_()
             comm.gatherv(probe, recv, counts, displs, 0, stream=torch.cuda.current_stream())
@@ -848,8 +904,345 @@ def rehearse_comm_init(torch, dist, capi, rank, world, dev_index):
     return everyone
 
 
+def run_sharded_workload(env, name, partition, full, nnz_override=0):
+    """One workload through the protocol of `value` on this job's ranks: generate this rank's column range in HBM, K calls back
+    to back (kernels, then the call's gatherv, in order on one stream), the kernel / gather split, every column of the gathered
+    result against the oracle.  full = the headline workload: also latency, the pipelined figure, planned_shards, direct_gather.
+    Returns the measurements on rank 0 (plain numbers), None elsewhere."""
+    torch, dist, capi, sharded, args = env["torch"], env["dist"], env["capi"], env["sharded"], env["args"]
+    rank, world, dev, dev_index, stat_dev = env["rank"], env["world"], env["dev"], env["dev_index"], env["stat_dev"]
+    rehearsal, use_comm = env["rehearsal"], env["use_comm"]
+
+    nrow, ncol, nnz, shape, p = build_offsets(name, nnz_override)
+    shard = sharded.make_shard(p, rank, world, balance=partition)
+    counts, displs = sharded.gather_layout(shard.bounds)
+
+    # inputs resident in HBM before anything is timed.  A workload that would fit in the 256 MiB
+    # Infinity Cache (C2: 80 MB) is timed over a rotation of distinct copies of x (> 400 MB in
+    # total, different seeds) so that every step reads from HBM.
+    ncopies = max(1, -(-400_000_000 // max(1, 8 * shard.nnz)))
+    xs = []
+    for k in range(ncopies):
+        xk = torch.empty(shard.nnz, dtype=torch.float64, device=dev)
+        capi.gen_values_device(xk, SEED + k, shard.x0, args.kind)
+        xs.append(xk)
+    pt = torch.from_numpy(shard.p_local).to(dev)
+    recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (use_comm and rank == 0) else None
+    if use_comm and not rehearsal and "comm" not in env:       # once per job, with the first workload's layout for its trial
+        env["comm"], env["fell_back"] = make_communicator(env, counts, displs, recv, shard.ncol)
+    comm, fell_back = env.get("comm"), env.get("fell_back", False)
+
+    def new_out():
+        return torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=dev)[:shard.ncol]
+
+    def new_gather(stream):
+        if not use_comm:
+            return None
+        if comm is not None:
+            return sharded.RcclGather(comm, counts, displs, 0, stream=stream)
+        if rehearsal:
+            return sharded.HostStagedGather(dist, rank, world, counts, displs, 0, stream=stream)
+        return sharded.TorchGather(dist, rank, world, counts, displs, 0, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    s_main = env["s_main"]
+    # ------------------------------------------------------------------ the timed protocol
+    # one call = kernels, then this call's gather, in order on s_main (rcppsparse_amd/sharded.py)
+    # rank 0 sums straight into its slice of the gathered result, so its own part of the gatherv is
+    # no copy at all (rsp_comm_gatherv skips a slice that is already in place)
+    out_main = (recv[int(displs[0]):int(displs[0]) + shard.ncol] if (recv is not None and comm is not None)
+                else new_out())
+    ws_main = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
+    plan = None
+    if args.planned and full:
+        capi.set_lean(not args.no_lean)
+        plan = capi.ColumnSumsPlan(shard.p_local, nnz=shard.nnz, device=dev_index)
+
+    def prepare(xk, out, ws, stream):
+        if plan is not None:
+            return plan.prepared(xk, pt, out, ws, stream=stream)
+        return capi.prepared_column_sums(xk, pt, out, ws, stream=stream)
+
+    launch_main = [prepare(xk, out_main, ws_main, s_main) for xk in xs]
+    calls = [0]
+
+    def compute(_shard):
+        launch_main[calls[0] % ncopies]()
+        calls[0] += 1
+        return out_main
+
+    driver = sharded.ShardedColumnSums(shard, compute, new_gather(s_main))
+    for _ in range(args.warmup):
+        driver.step(recv)
+    # Timing events are queue packets of their own: a pair around a call leaves the queue idle for a few
+    # microseconds (rocprofv3 kernel trace of C2 with events on every 4th call: 16 us of gaps per 4 calls,
+    # profiles/r03_c2.md).  Harmless around a 1.2 ms call, a fifth of a 20 us one.  So:
+    #   * large single-GPU workloads (C3): an event pair around the kernels of EVERY timed call;
+    #   * small calls without a gather (C2, a C4 shard alone): THREE timed regions, ONE event pair around each,
+    #     kernel time per launch = the region's device time / K; the median region is the one reported;
+    #   * calls with a gather (N > 1): the timed region carries no events at all (`value` is the clean
+    #     back-to-back rate); the kernel / gather split comes from the same K calls issued once more right
+    #     after it, with events around every call.
+    whole_region = (not use_comm) and shard.nnz < 200_000_000
+    per_call_events = not use_comm and not whole_region
+    mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+
+    def run_calls(with_events):
+        evs = [(mk(), mk(), mk()) for _ in range(args.steps)] if with_events else None
+        fence()
+        t_begin = time.perf_counter()
+        for k in range(args.steps):
+            if evs is None:
+                driver.step(recv)
+            else:
+                e = evs[k]
+                e[0].record(s_main)
+                driver.step(recv, on_computed=lambda e=e: e[1].record(s_main))
+                e[2].record(s_main)
+        fence()
+        return time.perf_counter() - t_begin, evs
+
+    regions_ms = None
+    if whole_region:
+        regions = small_call_regions(torch, s_main, lambda k: driver.step(recv), args.steps, fence)
+        elapsed, region_kernel_ms = median_region(regions)
+        regions_ms = [w / args.steps * 1e3 for w, _ in regions]
+        ktimes = [region_kernel_ms]
+        evs = None
+    else:
+        elapsed, evs = run_calls(per_call_events)
+        if use_comm:
+            _, evs = run_calls(True)          # the split, outside the timed region
+        ktimes = sorted(e[0].elapsed_time(e[1]) for e in evs)
+    kernel_ms = sum(ktimes) / len(ktimes)
+    gtimes = sorted(e[1].elapsed_time(e[2]) for e in evs) if use_comm else [0.0]
+    gather_ms = sum(gtimes) / len(gtimes)
+
+    lat_med = lat_min = 0.0
+    pipe = None
+    if full:
+        # -------------------------------------------------------------- latency of one call
+        lat = []
+        for _ in range(max(1, args.latency_calls)):
+            fence()
+            t1 = time.perf_counter()
+            driver.step(recv)
+            s_main.synchronize()          # rank 0: every slice has arrived; other ranks: their send is done
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        lat_med, lat_min = lat[len(lat) // 2], lat[0]
+
+        # -------------------------------------------------------------- pipelined figure (separate key)
+        if not args.no_pipelined:
+            ncs = max(1, args.compute_streams)
+            nbuf = max(ncs, args.gather_buffers - args.gather_buffers % ncs)
+            s_computes = [torch.cuda.Stream() for _ in range(ncs)]
+            s_comm = torch.cuda.Stream() if use_comm else None
+            wss = [capi.alloc_workspace(shard.ncol, shard.nnz, dev) for _ in range(ncs)]
+            outs = [new_out() for _ in range(nbuf)]
+            prepared = [[[prepare(xk, o, wss[q], s_computes[q]) for xk in xs]
+                         for o in outs] for q in range(ncs)]
+            launches = [[(lambda n, f=prepared[q][k]: f[n % ncopies]()) for k in range(nbuf)] for q in range(ncs)]
+            g = new_gather(s_comm)
+            gathers = [(None if g is None else (lambda o=o: g(o, recv))) for o in outs]
+            pl = sharded.PipelinedColumnSums(torch, launches, gathers, s_computes, s_comm, nbuf)
+            for _ in range(args.warmup):
+                pl.step()
+            pipe_elapsed = timed_steps(torch, dist, world, stat_dev, fence, args.steps, pl.step)
+            pipe = sig({"value": nnz * args.steps / pipe_elapsed, "ms_per_step": pipe_elapsed / args.steps * 1e3,
+                        "compute_streams": ncs, "output_buffers": nbuf})
+            del prepared, launches, outs, wss
+
+    # ------------------------------------------------------------------ N > 1: two more separate figures
+    planned_shards = direct_gather = None
+    if full and world > 1:
+        ctx = {"torch": torch, "dist": dist, "capi": capi, "sharded": sharded, "args": args, "rank": rank, "world": world,
+               "dev": dev, "dev_index": dev_index, "stat_dev": stat_dev, "shard": shard, "counts": counts, "displs": displs,
+               "xs": xs, "pt": pt, "s_main": s_main, "fence": fence, "nnz": nnz, "ncol": ncol, "p": p, "recv": recv,
+               "use_comm": use_comm, "out_main": out_main, "ws_main": ws_main, "new_gather": new_gather}
+        if plan is None and not args.no_planned_shards:
+            planned_shards = planned_shards_figure(ctx)
+        if args.direct_gather == "on" or (args.direct_gather == "auto" and rehearsal):
+            direct_gather = direct_gather_figure(ctx)
+
+    stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=stat_dev)
+    # what every rank owned and measured (rank order), so the line shows the whole partition
+    mine = torch.tensor([shard.c0, shard.c1, shard.x0, shard.x1, kernel_ms, gather_ms, dev_index],
+                        dtype=torch.float64, device=stat_dev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    elapsed, kernel_ms_max, gather_ms_max, lat_med_max = (float(v) for v in stats)
+    per_rank = [[float(v) for v in t] for t in per_rank]
+
+    # ------------------------------------------------------------------ parity: every column
+    # one more call on copy 0 of x (seed SEED), outside every timed region
+    calls[0] = 0
+    driver.step(recv)
+    fence()
+    H = None
+    if rank == 0:
+        full_result = (recv if use_comm else out_main).cpu().numpy()
+        parity = parity_whole_matrix(full_result, p, args.kind)
+        if not parity_ok(parity):
+            raise SystemExit(f"parity check failed ({name}, partition {partition}): {json.dumps(parity)}")
+        gname = None if not use_comm else (sharded.HostStagedGather.name if rehearsal else
+                                           sharded.TorchGather.name if fell_back else sharded.RcclGather.name)
+        H = {"workload": name, "nrow": nrow, "ncol": ncol, "nnz": nnz, "shape": shape, "partition": partition, "world": world,
+             "p": p, "elapsed": elapsed, "regions_ms": regions_ms,
+             "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
+             "kernel_ms_max_over_ranks": kernel_ms_max,
+             "kernel_timing": "region" if whole_region else ("per_call_after" if use_comm else "per_call"),
+             "gather_ms": gather_ms if use_comm else None, "gather_ms_min": gtimes[0] if use_comm else None,
+             "gather_ms_max": gtimes[-1] if use_comm else None, "gather_ms_max_over_ranks": gather_ms_max if use_comm else None,
+             # the launch rank 0 timed processed its own shard
+             "algo_bytes": 8 * shard.nnz + 4 * (shard.ncol + 1) + 8 * shard.ncol,
+             "imbalance": sharded.imbalance(p, shard.bounds), "ncopies": ncopies,
+             "shards": [{"rank": r, "device": int(t[6]), "c0": int(t[0]), "c1": int(t[1]), "x0": int(t[2]), "x1": int(t[3]),
+                         "kernel_ms": t[4], "gather_ms": t[5] if use_comm else None} for r, t in enumerate(per_rank)],
+             "parity": parity, "lat_med": lat_med, "lat_min": lat_min, "lat_med_max": lat_med_max,
+             "pipelined": pipe, "planned_shards": planned_shards, "direct_gather": direct_gather,
+             "plan": (None if plan is None else
+                      {"form": PLAN_FORMS[plan.form], "snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
+                       "entries_per_chunk": plan.chunk_elems, "max_skip": plan.max_skip,
+                       "kernel": ("colsums_columns_kernel" if plan.columns else "colsums_lean_kernel" if plan.lean else
+                                  "colsums_chunks_kernel<PLANNED>" if plan.snapped else "colsums_chunks_kernel+fixup")}),
+             "gather_name": gname, "fell_back": bool(fell_back), "x0_for_ceiling": xs[0] if full else None}
+    if plan is not None:
+        plan.close()
+    if not full:
+        del xs, launch_main, out_main, ws_main, pt, recv
+        torch.cuda.empty_cache()
+    return H
+
+
+def sharded_summary(H, steps):
+    """The flat scalars of one `also_sharded` workload (N > 1): the protocol of `value` on another matrix / partition."""
+    v = H["nnz"] * steps / H["elapsed"]
+    return sig({"value": v, "ms_per_step": H["elapsed"] / steps * 1e3, "imbalance": H["imbalance"],
+                "kernel_ms_max": H["kernel_ms_max_over_ranks"], "gather_ms_max": H["gather_ms_max_over_ranks"],
+                "kernel_ms_by_rank": [s["kernel_ms"] for s in H["shards"]],
+                "nnz_by_rank": [s["x1"] - s["x0"] for s in H["shards"]],
+                "parity_err": H["parity"]["max_abs_err_over_l1"], "bad_columns": H["parity"]["columns_out_of_tolerance"]})
+
+
+def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=None):
+    """The JSON line from the measurements (pure: tests/test_bench_line.py builds one for 8 ranks without a GPU).
+    H: what run_sharded_workload returned on rank 0 for the headline workload; extras: traffic, read ceiling, `also`
+    records, `also_sharded` summaries and the CPU baseline, each optional."""
+    world, steps = H["world"], args.steps
+    use_comm = H["gather_name"] is not None
+    achieved = H["algo_bytes"] / (H["kernel_ms"] * 1e-3) / 1e9
+    ms_per_step = H["elapsed"] / steps * 1e3
+    plan = H["plan"]
+    roof = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None, "traffic_over_algorithmic": None, "traffic_measured_in_run": False, "traffic_file": None,
+        "kernel": "colsums_chunks_kernel+fixup" if plan is None else plan["kernel"],
+        "kernel_ms": H["kernel_ms"], "kernel_ms_median": H["kernel_ms_median"], "kernel_ms_min": H["kernel_ms_min"],
+        "kernel_timing": H["kernel_timing"], "kernel_ms_max_over_ranks": H["kernel_ms_max_over_ranks"],
+        "gather_ms": H["gather_ms"], "gather_ms_min": H["gather_ms_min"], "gather_ms_max": H["gather_ms_max"],
+        "gather_ms_max_over_ranks": H["gather_ms_max_over_ranks"],
+        "algorithmic_bytes_per_launch": H["algo_bytes"],
+    }
+    tr = extras.get("traffic")
+    if tr is not None:
+        roof["traffic"] = tr["bytes"]
+        roof["traffic_over_algorithmic"] = None if tr["bytes"] is None else tr["bytes"] / H["algo_bytes"]
+        roof["traffic_measured_in_run"] = bool(tr.get("in_run"))
+        roof["traffic_file"] = tr.get("file")
+        for k in ("read_bytes", "write_bytes", "seconds", "not_measured"):
+            if tr.get(k) is not None:
+                roof["traffic_" + k] = tr[k]
+    rc = extras.get("read_ceiling")
+    if rc is not None:
+        roof["read_ceiling_GBps"] = rc["GBps"]
+        roof["read_ceiling_ms"] = rc["ms_per_launch"]
+        roof["read_ceiling_reps"] = rc["reps"]
+        roof["frac_of_ceiling"] = achieved / rc["GBps"]
+    also = extras.get("also")
+    if also:
+        for r in also:
+            k = "also_" + key_of(r["workload"])
+            roof[k + "_frac"] = r["frac"]
+            roof[k + "_kernel_ms"] = r["kernel_ms"]
+            roof[k + "_ms_per_call"] = r["ms_per_call"]
+            roof[k + "_parity_err"] = r["parity_err"]
+            if r.get("traffic") is not None:
+                roof[k + ("_traffic_x" if r.get("traffic_in_run") else "_traffic_recorded_x")] = r["traffic"] / r["algo_bytes"]
+    also_sharded = extras.get("also_sharded")
+    if also_sharded:
+        for name, s in also_sharded.items():
+            k = "also_" + key_of(name)
+            if "value" in s:
+                for f in ("value", "ms_per_step", "imbalance", "kernel_ms_max", "gather_ms_max", "parity_err"):
+                    roof[f"{k}_{f}"] = s[f]
+    cfg = {
+        "workload": f"{H['workload']}: {H['nrow']}x{H['ncol']} CSC dgCMatrix, nnz={H['nnz']}, {H['shape']} nnz/column, "
+                    f"values kind {args.kind}, seed {SEED}",
+        "parallelism": "single" if world == 1 else ("rehearsal" if rehearsal else "ranges+rccl"),
+        "devices": devices,
+        "rendezvous": args.rendezvous if world > 1 else None,
+        "partition": H["partition"],
+        "shard_imbalance_max_over_mean": H["imbalance"],
+        "chunk_rows": args.chunk_rows,
+        "x_copies_rotated": H["ncopies"],
+        "gather": H["gather_name"],
+        "gather_fell_back_to_torch_distributed": H["fell_back"],
+        "regions_ms": H["regions_ms"],
+        "host_stall_suspected": bool(not use_comm and ms_per_step > 1.5 * H["kernel_ms"]),
+        "planned": None if plan is None else {k: v for k, v in plan.items() if k != "kernel"},
+        "shards": [{"rank": s["rank"], "device": s["device"], "c0": s["c0"], "c1": s["c1"], "x0": s["x0"], "x1": s["x1"],
+                    "nnz": s["x1"] - s["x0"], "kernel_ms": s["kernel_ms"], "gather_ms": s["gather_ms"]} for s in H["shards"]],
+    }
+    if comm_rehearsal is not None:
+        refused = [("ncclCommInitRank" in s and "error 5" in s) for s in comm_rehearsal]
+        cfg["comm_refused_on_ranks"] = int(sum(refused))
+        odd = [s for s, r in zip(comm_rehearsal, refused) if not r]
+        if odd:
+            cfg["comm_rehearsal_unexpected"] = odd[0][:160]
+    line = {
+        "metric": "columnSums nnz/s + achieved HBM GB/s vs roofline, 1e9-nnz CSC at 1/2/4/8 GPUs",
+        "value": H["nnz"] * steps / H["elapsed"], "unit": "nnz/s", "n_gpus": world, "steps": steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": sig(cfg),
+        "latency_ms_per_call": H["lat_med"],
+        "latency": sig({"ms_median": H["lat_med"], "ms_min": H["lat_min"], "ms_median_max_over_ranks": H["lat_med_max"],
+                        "calls": max(1, args.latency_calls)}),
+        "pipelined": H["pipelined"],
+        "planned_shards": H["planned_shards"],
+        "direct_gather": H["direct_gather"],
+        "roofline": sig(roof),
+        "parity": sig(H["parity"]),
+    }
+    if also:
+        line["also"] = also
+        line["also_seconds"] = sig(extras.get("also_seconds"))
+    if also_sharded:
+        line["also_sharded"] = also_sharded
+    if "cpu_baseline" in extras:
+        line["cpu_baseline"] = extras["cpu_baseline"]
+    if args.verbose:
+        line["notes"] = GLOSSARY
+    return line
+
+
 def main(argv=None):
     args = parse_args(argv)
+    if args.explain:
+        for k, v in GLOSSARY.items():
+            print(f"{k}\n    {v}")
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
@@ -861,7 +1254,6 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     from rcppsparse_amd import capi, sharded
@@ -886,335 +1278,81 @@ def main(argv=None):
     capi.load()
     capi.set_tuning(args.chunk_rows)
 
-    nrow, ncol, nnz, shape, p = build_offsets(args.workload, args.nnz)
-    shard = sharded.make_shard(p, rank, world, balance=args.partition)
-    counts, displs = sharded.gather_layout(shard.bounds)
-
-    # inputs resident in HBM before anything is timed.  A workload that would fit in the 256 MiB
-    # Infinity Cache (C2: 80 MB) is timed over a rotation of distinct copies of x (> 400 MB in
-    # total, different seeds) so that every step reads from HBM.
-    ncopies = max(1, -(-400_000_000 // max(1, 8 * shard.nnz)))
-    xs = []
-    for k in range(ncopies):
-        xk = torch.empty(shard.nnz, dtype=torch.float64, device=dev)
-        capi.gen_values_device(xk, SEED + k, shard.x0, args.kind)
-        xs.append(xk)
-    pt = torch.from_numpy(shard.p_local).to(dev)
-    use_comm = world > 1 or args.force_comm
-    recv = torch.empty(ncol, dtype=torch.float64, device=dev) if (use_comm and rank == 0) else None
-    comm, fell_back = (None, False)
     comm_rehearsal = None
     if rehearsal and args.try_comm and world > 1:
         comm_rehearsal = rehearse_comm_init(torch, dist, capi, rank, world, dev_index)
-    if use_comm and not rehearsal:
-        comm, fell_back = make_communicator(args, torch, dist, capi, sharded, rank, world, local_rank, dev,
-                                            shard, counts, displs, recv)
-
-    def new_out():
-        return torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=dev)[:shard.ncol]
-
-    def new_gather(stream):
-        if not use_comm:
-            return None
-        if comm is not None:
-            return sharded.RcclGather(comm, counts, displs, 0, stream=stream)
-        if rehearsal:
-            return sharded.HostStagedGather(dist, rank, world, counts, displs, 0, stream=stream)
-        return sharded.TorchGather(dist, rank, world, counts, displs, 0, stream=stream)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # Streams come from torch's pool (non-blocking): nothing here runs on the legacy null stream,
     # which would implicitly synchronise with any blocking stream a library creates.
     torch.cuda.synchronize()
     s_main = torch.cuda.Stream()
     torch.cuda.set_stream(s_main)
+    env = {"torch": torch, "dist": dist, "capi": capi, "sharded": sharded, "args": args, "rank": rank, "world": world,
+           "local_rank": local_rank, "dev": dev, "dev_index": dev_index, "stat_dev": stat_dev, "rehearsal": rehearsal,
+           "use_comm": world > 1 or args.force_comm, "s_main": s_main}
 
-    # ------------------------------------------------------------------ the timed protocol
-    # one call = kernels, then this call's gather, in order on s_main (rcppsparse_amd/sharded.py)
-    # rank 0 sums straight into its slice of the gathered result, so its own part of the gatherv is
-    # no copy at all (rsp_comm_gatherv skips a slice that is already in place)
-    out_main = (recv[int(displs[0]):int(displs[0]) + shard.ncol] if (recv is not None and comm is not None)
-                else new_out())
-    ws_main = capi.alloc_workspace(shard.ncol, shard.nnz, dev)
-    plan = None
-    if args.planned:
-        capi.set_lean(not args.no_lean)
-        plan = capi.ColumnSumsPlan(shard.p_local, nnz=shard.nnz, device=dev_index)
-
-    def prepare(xk, out, ws, stream):
-        if plan is not None:
-            return plan.prepared(xk, pt, out, ws, stream=stream)
-        return capi.prepared_column_sums(xk, pt, out, ws, stream=stream)
-
-    launch_main = [prepare(xk, out_main, ws_main, s_main) for xk in xs]
-    calls = [0]
-
-    def compute(_shard):
-        launch_main[calls[0] % ncopies]()
-        calls[0] += 1
-        return out_main
-
-    driver = sharded.ShardedColumnSums(shard, compute, new_gather(s_main))
-    for _ in range(args.warmup):
-        driver.step(recv)
-    # Timing events are queue packets of their own: a pair around a call leaves the queue idle for a few
-    # microseconds (rocprofv3 kernel trace of C2 with events on every 4th call: 16 us of gaps per 4 calls,
-    # profiles/r03_c2.md).  Harmless around a 1.2 ms call, a fifth of a 20 us one.  So:
-    #   * large single-GPU workloads (C3): an event pair around the kernels of EVERY timed call;
-    #   * small calls without a gather (C2, a C4 shard alone): ONE event pair around the whole timed region,
-    #     kernel time per launch = the region's device time / K (launches back to back, gaps included);
-    #   * calls with a gather (N > 1): the timed region carries no events at all (`value` is the clean
-    #     back-to-back rate); the kernel / gather split comes from the same K calls issued once more right
-    #     after it, with events around every call.
-    whole_region = (not use_comm) and shard.nnz < 200_000_000
-    per_call_events = not use_comm and not whole_region
-    mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
-
-    def run_calls(with_events):
-        evs = [(mk(), mk(), mk()) for _ in range(args.steps)] if with_events else None
-        region = (mk(), mk())
-        fence()
-        t_begin = time.perf_counter()
-        region[0].record(s_main)
-        for k in range(args.steps):
-            if evs is None:
-                driver.step(recv)
-            else:
-                e = evs[k]
-                e[0].record(s_main)
-                driver.step(recv, on_computed=lambda e=e: e[1].record(s_main))
-                e[2].record(s_main)
-        region[1].record(s_main)
-        fence()
-        return time.perf_counter() - t_begin, evs, region
-
-    elapsed, evs, region = run_calls(per_call_events)
-    if use_comm:
-        _, evs, _ = run_calls(True)          # the split, outside the timed region
-    if evs is None:
-        ktimes = [region[0].elapsed_time(region[1]) / args.steps]
-    else:
-        ktimes = sorted(e[0].elapsed_time(e[1]) for e in evs)
-    kernel_ms = sum(ktimes) / len(ktimes)
-    gtimes = sorted(e[1].elapsed_time(e[2]) for e in evs) if use_comm else [0.0]
-    gather_ms = sum(gtimes) / len(gtimes)
-    n_event_calls = 0 if evs is None else len(evs)
-
-    # ------------------------------------------------------------------ latency of one call
-    lat = []
-    for _ in range(max(1, args.latency_calls)):
-        fence()
-        t1 = time.perf_counter()
-        driver.step(recv)
-        s_main.synchronize()          # rank 0: every slice has arrived; other ranks: their send is done
-        lat.append((time.perf_counter() - t1) * 1e3)
-    lat.sort()
-    lat_med, lat_min = lat[len(lat) // 2], lat[0]
-
-    # ------------------------------------------------------------------ pipelined figure (separate key)
-    pipe = None
-    if not args.no_pipelined:
-        ncs = max(1, args.compute_streams)
-        nbuf = max(ncs, args.gather_buffers - args.gather_buffers % ncs)
-        s_computes = [torch.cuda.Stream() for _ in range(ncs)]
-        s_comm = torch.cuda.Stream() if use_comm else None
-        wss = [capi.alloc_workspace(shard.ncol, shard.nnz, dev) for _ in range(ncs)]
-        outs = [new_out() for _ in range(nbuf)]
-        prepared = [[[prepare(xk, o, wss[q], s_computes[q]) for xk in xs]
-                     for o in outs] for q in range(ncs)]
-        launches = [[(lambda n, f=prepared[q][k]: f[n % ncopies]()) for k in range(nbuf)] for q in range(ncs)]
-        g = new_gather(s_comm)
-        gathers = [(None if g is None else (lambda o=o: g(o, recv))) for o in outs]
-        pl = sharded.PipelinedColumnSums(torch, launches, gathers, s_computes, s_comm, nbuf)
-        for _ in range(args.warmup):
-            pl.step()
-        fence()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            pl.step()
-        fence()
-        pipe_elapsed = time.perf_counter() - t2
-        pstats = torch.tensor([pipe_elapsed], dtype=torch.float64, device=stat_dev)
-        if world > 1:
-            dist.all_reduce(pstats, op=dist.ReduceOp.MAX)
-        pipe_elapsed = float(pstats[0])
-        pipe = {"value": nnz * args.steps / pipe_elapsed, "unit": "nnz/s",
-                "ms_per_step": pipe_elapsed / args.steps * 1e3, "compute_streams": ncs, "output_buffers": nbuf,
-                "protocol": "calls overlapped across steps: launches alternate over the compute streams, the "
-                            "gather of call k runs on its own stream beside the kernel of call k+1; "
-                            "NOT the protocol of `value`"}
-        del prepared, launches, outs, wss
-
-    # ------------------------------------------------------------------ N > 1: two more separate figures
-    ctx = {"torch": torch, "dist": dist, "capi": capi, "sharded": sharded, "args": args, "rank": rank, "world": world,
-           "dev": dev, "dev_index": dev_index, "stat_dev": stat_dev, "shard": shard, "counts": counts, "displs": displs,
-           "xs": xs, "pt": pt, "s_main": s_main, "fence": fence, "nnz": nnz, "ncol": ncol, "p": p, "recv": recv,
-           "use_comm": use_comm, "out_main": out_main, "ws_main": ws_main, "new_gather": new_gather}
-    planned_shards = direct_gather = None
-    if world > 1 and plan is None and not args.no_planned_shards:
-        planned_shards = planned_shards_figure(ctx)
-    if world > 1 and (args.direct_gather == "on" or (args.direct_gather == "auto" and rehearsal)):
-        direct_gather = direct_gather_figure(ctx)
-    elif world > 1:
-        direct_gather = {"value": None, "note": "not run: --direct-gather auto measures it in the --rendezvous gloo rehearsal only; "
-                                                "ask for it with --direct-gather on"} if rank == 0 else None
-
-    stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=stat_dev)
-    # what every rank owned and measured (rank order), so the line shows the whole partition
-    mine = torch.tensor([shard.c0, shard.c1, shard.x0, shard.x1, kernel_ms, gather_ms, dev_index],
-                        dtype=torch.float64, device=stat_dev)
-    per_rank = [torch.zeros_like(mine) for _ in range(world)]
-    if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        dist.all_gather(per_rank, mine)
-    else:
-        per_rank = [mine]
-    elapsed, kernel_ms_max, gather_ms_max, lat_med_max = (float(v) for v in stats)
-    per_rank = [[float(v) for v in t] for t in per_rank]
-
-    # ------------------------------------------------------------------ parity: every column
-    # one more call on copy 0 of x (seed SEED), outside every timed region
-    calls[0] = 0
-    driver.step(recv)
-    fence()
-    result = None
-    if rank == 0:
-        full = (recv if use_comm else out_main).cpu().numpy()
-        parity = parity_whole_matrix(full, p, args.kind)
-        if parity["columns_out_of_tolerance"] or not parity["empty_columns_exactly_plus_zero"]:
-            raise SystemExit(f"parity check failed: {json.dumps(parity)}")
-        # the launch rank 0 timed processed its own shard
-        algo_bytes = 8 * shard.nnz + 4 * (shard.ncol + 1) + 8 * shard.ncol
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        value = nnz * args.steps / elapsed
-        # (a one-launch planned call has counter passes of its own: profiles/*_<workload>planned_traffic.json)
-        traffic_key = args.workload + ("planned" if plan is not None and plan.snapped else "")
-        traffic = traffic_from_profiles(traffic_key) if world == 1 else (None, None)
-        traffic_source = (None if traffic[1] is None else
-                          f"{traffic[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in a "
-                          "SEPARATE earlier run (FETCH_SIZE doubled per MI355X_MICROARCH.md), not measured in this run")
-        gname = None if not use_comm else (sharded.HostStagedGather.name if rehearsal else
-                                           sharded.TorchGather.name if fell_back else sharded.RcclGather.name)
-        result = {
-            "metric": "columnSums nnz/s + achieved HBM GB/s vs roofline, 1e9-nnz CSC at 1/2/4/8 GPUs",
-            "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, "
-                            f"values kind {args.kind}, seed {SEED}",
-                "parallelism": ("single GPU" if world == 1 else
-                                f"REHEARSAL on {torch.cuda.device_count()} device(s): {world} ranks share them; "
-                                f"column ranges as at N = {world}, slices gathered as host copies over gloo"
-                                if rehearsal else
-                                f"{world} nnz-balanced contiguous column ranges + RCCL gatherv to rank 0"),
-                "rendezvous": args.rendezvous if world > 1 else None,
-                "comm_init_rehearsal": comm_rehearsal,
-                "shards": [{"rank": r, "device": int(t[6]), "c0": int(t[0]), "c1": int(t[1]), "x0": int(t[2]),
-                            "x1": int(t[3]), "nnz": int(t[3] - t[2]), "kernel_ms": t[4],
-                            "gather_ms": t[5] if use_comm else None} for r, t in enumerate(per_rank)],
-                "protocol": "K calls back to back; each call in order on one stream per rank: kernels, then "
-                            "that call's gatherv (N > 1); identical at every N",
-                "partition": args.partition,
-                "shard_imbalance_max_over_mean": sharded.imbalance(p, shard.bounds),
-                "chunk_rows": args.chunk_rows,
-                "planned": (None if plan is None else
-                            {"form": PLAN_FORMS[plan.form],
-                             "snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
-                             "entries_per_chunk": plan.chunk_elems, "max_skip": plan.max_skip,
-                             "note": "inspection of p[] on the host, once, outside every timed region; a snapped "
-                                     "plan makes a call ONE launch (no column search, carries or fix-up)"}),
-                "x_copies_rotated": ncopies,
-                "gather": gname,
-                "gather_fell_back_to_torch_distributed": bool(fell_back),
-            },
-            "latency_ms_per_call": lat_med,
-            "latency": {"ms_median": lat_med, "ms_min": lat_min, "ms_median_max_over_ranks": lat_med_max,
-                        "calls": len(lat),
-                        "protocol": "one call at a time: barrier, then host launch -> kernels -> gatherv -> stream "
-                                    "synchronize on rank 0 (the gathered result is complete and the host has seen it)"},
-            "pipelined": pipe,
-            "planned_shards": planned_shards,
-            "direct_gather": direct_gather,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic[0], "traffic_source": traffic_source,
-                "kernel": ("colsums_columns_kernel (one launch)" if plan is not None and plan.columns else
-                           "colsums_lean_kernel (one launch)" if plan is not None and plan.lean else
-                           "colsums_chunks_kernel<PLANNED> (one launch)" if plan is not None and plan.snapped
-                           else "colsums_chunks_kernel (+ colsums_fixup_kernel)"),
-                "kernel_ms": kernel_ms, "kernel_ms_median": ktimes[len(ktimes) // 2], "kernel_ms_min": ktimes[0],
-                "kernel_timing": (f"ONE HIP event pair on the launch stream around the {args.steps} timed calls, "
-                                  "divided by their number (small calls: an event pair per call would idle the queue)"
-                                  if whole_region else
-                                  f"HIP events on the launch stream around the kernels (and the gather) of each of "
-                                  f"{n_event_calls} calls issued again right after the timed region, which itself "
-                                  "carries no events" if use_comm else
-                                  f"HIP events on the launch stream around the kernels of each of the "
-                                  f"{n_event_calls} timed calls"),
-                "kernel_ms_max_over_ranks": kernel_ms_max,
-                "gather_ms": gather_ms if use_comm else None,
-                "gather_ms_min_max": [gtimes[0], gtimes[-1]] if use_comm else None,
-                "gather_ms_max_over_ranks": gather_ms_max if use_comm else None,
-                "algorithmic_bytes_per_launch": algo_bytes,
-            },
-            "parity": parity,
-        }
-        want_pass = args.traffic_pass == "on" or (args.traffic_pass == "auto" and args.workload == "c3" and plan is None)
-        if world == 1 and want_pass:
+    H = run_sharded_workload(env, args.workload, args.partition, full=True, nnz_override=args.nnz)
+    extras = {}
+    default_c3 = args.workload == "c3" and not args.planned and not args.nnz
+    if rank == 0 and world == 1:
+        traffic_key = args.workload + ("planned" if H["plan"] is not None and H["plan"]["snapped"] else "")
+        recorded, src = traffic_from_profiles(traffic_key)
+        extras["traffic"] = {"bytes": recorded, "in_run": False, "file": src}
+        want_pass = args.traffic_pass == "on" or (args.traffic_pass == "auto" and default_c3)
+        if want_pass:
             # counters cannot be read inside a timed run: two short child runs of the same workload under rocprofv3, now,
             # on this device (their launches are the plan-free call's: the kernels `roofline` is about)
             t_pass = time.perf_counter()
-            measured, how = traffic_measured_now(args)
+            measured, how = traffic_measured_now(args.workload, args.kind)
             if measured is not None:
-                result["roofline"]["traffic"] = measured
-                result["roofline"]["traffic_source"] = (
-                    "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two child passes of this "
-                    "workload on this device after the timed regions (separate passes, FETCH_SIZE doubled per "
-                    "MI355X_MICROARCH.md; main kernel + fix-up of one call)")
-                result["roofline"]["traffic_detail"] = dict(how, over_algorithmic=measured / algo_bytes,
-                                                            seconds=time.perf_counter() - t_pass)
+                extras["traffic"] = dict(how, bytes=measured, in_run=True, file=None, seconds=time.perf_counter() - t_pass)
             else:
-                result["roofline"]["traffic_detail"] = {"not_measured_in_this_run": how,
-                                                        "seconds": time.perf_counter() - t_pass}
-        if world == 1 and args.ceiling_reps > 0:
+                extras["traffic"]["not_measured"] = str(how)[:160]
+        if args.ceiling_reps > 0:
             # the same x (copy 0), the same device, the same run; after every timed region
-            rc = read_ceiling(capi, xs[0], args.ceiling_reps)
-            rc["frac_of_ceiling"] = achieved / rc["GBps"]
-            rc["note"] = ("frac_of_ceiling = roofline.achieved (algorithmic bytes: x, p and the sums) / the GB/s of "
-                          "the read-only kernel (x alone)")
-            result["roofline"]["read_ceiling"] = rc
-        if world == 1 and not args.no_also:
-            specs = (ALSO_AUTO if args.workload == "c3" and not args.planned else ()) if args.also == "auto" else \
+            x0 = H["x0_for_ceiling"]
+            ms = capi.read_ceiling_device(x0, reps=args.ceiling_reps)
+            extras["read_ceiling"] = {"GBps": 8 * x0.numel() / (ms * 1e-3) / 1e9, "ms_per_launch": ms,
+                                      "reps": args.ceiling_reps}
+        if not args.no_also:
+            specs = (ALSO_AUTO if default_c3 else ()) if args.also == "auto" else \
                 tuple(t for t in args.also.split(",") if t)
             if specs:
+                H["x0_for_ceiling"] = None
                 t_also = time.perf_counter()
-                recs = [also_record(torch, capi, spec, args, dev, dev_index, s_main) for spec in specs]
-                result["also"] = {"records": recs, "seconds": time.perf_counter() - t_also,
-                                  "note": "more single-GPU workloads measured after the headline one, outside its "
-                                          "timed region, by the same protocol; never part of `value`"}
-                # (the driver's record keeps `roofline` whole and only the NAMES of other extra keys: the same
-                # records travel there as well)
-                result["roofline"]["also"] = recs
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(p, args.kind)
-        elif world == 1:
-            result["cpu_baseline"] = None
+                extras["also"] = [also_record(torch, capi, spec, args, dev, dev_index, s_main,
+                                              traffic_now=want_pass and spec in ALSO_TRAFFIC_NOW) for spec in specs]
+                extras["also_seconds"] = time.perf_counter() - t_also
+    if world > 1:
+        specs = (ALSO_SHARDED_AUTO if default_c3 and args.partition == "nnz" else ()) if args.also_sharded == "auto" else \
+            tuple(t for t in args.also_sharded.split(",") if t and t != "none")
+        if specs:
+            if H is not None:
+                H["x0_for_ceiling"] = None
+            torch.cuda.empty_cache()
+            summaries = {}
+            for spec in specs:
+                name, _, part = spec.partition(":")
+                Hs = run_sharded_workload(env, name, part or "nnz", full=False)
+                if Hs is not None:
+                    summaries[key_of(spec)] = sharded_summary(Hs, args.steps)
+            if rank == 0:
+                extras["also_sharded"] = summaries
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0 at EVERY N (the other ranks wait at the barrier below): the reference loop on this box's host cores, same run
+        extras["cpu_baseline"] = cpu_baseline(H["p"], args.kind)
+    elif rank == 0:
+        extras["cpu_baseline"] = None
+    comm = env.get("comm")
     if comm is not None:
         torch.cuda.synchronize()
         comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if result is not None:
-        print(json.dumps(result), flush=True)
+    if rank == 0:
+        line = assemble_line(args, H, extras, devices=torch.cuda.device_count(), rehearsal=rehearsal,
+                             comm_rehearsal=comm_rehearsal)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -48,7 +48,9 @@ def _run_bench(*flags, timeout=900):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # the contract: ONE JSON line
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    d["_line_bytes"] = len(lines[0])                  # (the driver keeps the last 8 KiB of stdout)
+    return d
 
 
 def test_bench_child_process_runs_the_comm_path_at_shard_size(torch_cuda):
@@ -66,15 +68,15 @@ def test_bench_child_process_runs_the_comm_path_at_shard_size(torch_cuda):
     assert par["empty_columns_exactly_plus_zero"] is True
     # both protocols are reported, and the like-for-like one is the metric
     assert d["latency_ms_per_call"] > 0 and d["latency"]["calls"] >= 1
-    assert d["pipelined"]["value"] > 0 and "NOT the protocol" in d["pipelined"]["protocol"]
+    assert d["pipelined"]["value"] > 0 and d["pipelined"]["compute_streams"] == 2
     assert d["value"] == pytest.approx(125_000_000 * 8 / (d["ms_per_step"] * 8e-3), rel=1e-9)
     # a call cannot be faster than its kernels; a single call pays the host round trip on top
     roof = d["roofline"]
     assert roof["kernel_ms"] <= d["ms_per_step"] * 1.02
     assert d["latency_ms_per_call"] >= roof["kernel_ms_min"]
     # the mean gather time lies between the individual gather timings
-    lo, hi = roof["gather_ms_min_max"]
-    assert lo <= roof["gather_ms"] <= hi
+    assert roof["gather_ms_min"] <= roof["gather_ms"] <= roof["gather_ms_max"]
+    assert roof["kernel_timing"] == "per_call_after"                   # a call with a gather: the timed region carries no events
     assert 0.3 < roof["frac"] < 1.0
 
 
@@ -94,37 +96,51 @@ def test_bench_child_process_default_protocol_small(torch_cuda):
 
 
 def test_bench_line_measures_its_own_ceiling_traffic_and_more_workloads(torch_cuda):
-    """Round 4: the N = 1 line carries, measured in the same run on the same device,
-    `roofline.read_ceiling` (a read-only kernel with the column sums' access shape over the same x), `roofline.traffic`
-    from two rocprofv3 counter passes run as child processes (not a constant from an earlier round), and `also`: more
-    workloads by the same protocol, each with whole-matrix parity -- here a C4 shard as the headline and C2 three ways."""
+    """The N = 1 line carries, measured in the same run on the same device and as FLAT SCALARS of `roofline` (what the driver's
+    record keeps): the read ceiling (a read-only kernel with the column sums' access shape over the same x), the HBM traffic
+    from two rocprofv3 counter passes run as child processes (also for the plan-free `also` record c2), and per `also`
+    workload frac / kernel ms / ms per call (median of three regions) / parity -- here a C4 shard as the headline (a small
+    call: three regions of its own) and C2 three ways.  The whole line fits the driver's 8 KiB tail."""
     torch_cuda.cuda.empty_cache()
     d = _run_bench("--workload", "c4shard", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--traffic-pass", "on",
                    "--also", "c2,c2:planned,c2:planned-device")
+    assert d["_line_bytes"] < 8000
     roof = d["roofline"]
-    rc = roof["read_ceiling"]
-    assert 3000 < rc["GBps"] < 8000 and rc["bytes_per_launch"] == 8 * 125_000_000 and rc["reps"] == 5
-    assert 0.5 < rc["frac_of_ceiling"] < 1.05 and rc["frac_of_ceiling"] == pytest.approx(roof["achieved"] / rc["GBps"], rel=1e-9)
-    assert roof["traffic_source"].startswith("measured in this run"), roof.get("traffic_detail")
-    assert 0.98 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.10       # 1 GB of x: past every cache
-    assert roof["traffic_detail"]["read_bytes"] > 100 * roof["traffic_detail"]["write_bytes"]
-    recs = {r["workload"]: r for r in d["also"]["records"]}
-    assert set(recs) == {"c2", "c2:planned", "c2:planned-device"} and roof["also"] == d["also"]["records"]
-    for r in recs.values():
-        assert r["parity"]["columns_out_of_tolerance"] == 0 and r["parity"]["columns_checked"] == "all"
-        assert r["x_copies_rotated"] >= 5 and 0.2 < r["frac"] < 1.0
-    assert recs["c2"]["form"] == "general kernels" and recs["c2"]["launches_per_call"] == 2
+    assert all(not isinstance(v, (dict, list)) for v in roof.values())
+    assert 3000 < roof["read_ceiling_GBps"] < 8000 and roof["read_ceiling_reps"] == 5
+    assert 0.5 < roof["frac_of_ceiling"] < 1.05
+    assert roof["frac_of_ceiling"] == pytest.approx(roof["achieved"] / roof["read_ceiling_GBps"], rel=1e-4)
+    assert roof["traffic_measured_in_run"] is True, roof.get("traffic_not_measured")
+    assert 0.98 < roof["traffic_over_algorithmic"] < 1.10                                # 1 GB of x: past every cache
+    assert roof["traffic"] == pytest.approx(roof["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"], rel=1e-4)
+    assert roof["traffic_read_bytes"] > 100 * roof["traffic_write_bytes"]
+    assert roof["kernel_timing"] == "region" and len(d["config"]["regions_ms"]) == 3     # a small call without a gather
+    assert d["ms_per_step"] == pytest.approx(sorted(d["config"]["regions_ms"])[1], rel=1e-4)   # `value` is the median region
+    assert d["config"]["host_stall_suspected"] is False
+    recs = {r["workload"]: r for r in d["also"]}
+    assert set(recs) == {"c2", "c2:planned", "c2:planned-device"} and "also" not in roof
+    for spec, r in recs.items():
+        assert r["bad_columns"] == 0 and r["x_copies"] >= 5 and 0.2 < r["frac"] < 1.0
+        assert len(r["regions_ms"]) == 3 and r["ms_per_call"] == pytest.approx(sorted(r["regions_ms"])[1], rel=1e-4)
+        assert r["host_stall_suspected"] is False and r["ms_per_call"] < 1.5 * r["kernel_ms"]
+        k = "also_" + spec.replace(":", "_").replace("-", "_")
+        assert roof[k + "_frac"] == r["frac"] and roof[k + "_kernel_ms"] == r["kernel_ms"]
+        assert roof[k + "_ms_per_call"] == r["ms_per_call"] and roof[k + "_parity_err"] == r["parity_err"]
+    assert recs["c2"]["form"] == "general" and recs["c2"]["launches"] == 2
+    assert recs["c2"]["traffic_in_run"] is True and 0.98 < roof["also_c2_traffic_x"] < 1.15   # re-measured now, not a constant
     for k in ("c2:planned", "c2:planned-device"):
-        assert recs[k]["form"] == "lean" and recs[k]["launches_per_call"] == 1
-        assert recs[k]["parity"]["max_abs_err_over_l1"] == 0.0                          # the reference's bits
+        assert recs[k]["form"] == "lean" and recs[k]["launches"] == 1
+        assert recs[k]["parity_err"] == 0.0                                               # the reference's bits
         assert recs[k]["kernel_ms"] < recs["c2"]["kernel_ms"]
+        assert recs[k]["traffic_in_run"] is False
     dev = recs["c2:planned-device"]
-    assert "on the device" in dev["plan_made"] and dev["plan_ms"] < 1.0                 # device time of the inspection kernels
-    assert dev["plan_device"]["calls_answered_by_the_general_kernels_before_the_plan_was_known"] >= 0
+    assert dev["plan_by"] == "device" and dev["plan_ms"] < 1.0                            # device time of the inspection kernels
+    assert dev["early_general_calls"] >= 0 and recs["c2:planned"]["plan_by"] == "host"
 
 
 @pytest.mark.parametrize("workload,world,nnz,ncol", [("c4shard", 2, 125_000_000, 125_000),
-                                                     ("tiny", 3, 4_000_000, 40_000)])
+                                                     ("tiny", 3, 4_000_000, 40_000),
+                                                     ("c3", 6, 1_000_000_000, 1_000_000)])
 def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload, world, nnz, ncol):
     """`bench.py --gpus N --rendezvous gloo`: bench.py starts N ranks under torch.distributed.run
     (fresh child processes; nothing here re-executes a process that has touched the GPU), every
@@ -132,13 +148,19 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     rsp_column_sums_device, the slices are gathered to rank 0 (as host copies over gloo: RCCL
     refuses two ranks on one device) and rank 0 checks EVERY column of the gathered result against
     the oracle.  What this pins: the rank != 0 control flow of bench.py, the partition, the
-    displacements, the max-over-ranks statistics and the N > 1 shape of the JSON line."""
+    displacements, the max-over-ranks statistics and the N > 1 shape of the JSON line.
+    The c3 case is the DEFAULT line of the driver's multi-GPU run (BASELINE config 4) at SIX ranks -- this pool allows at
+    most six processes on one card, so six is as close to the driver's eight as a one-GPU box gets (the 8-rank layout,
+    partition and line are covered without a GPU in tests/test_bench_line.py and tests/test_sharded_gloo.py) -- with
+    everything such a line carries: planned_shards, direct_gather with six mappers, the Zipf matrix (BASELINE config 5)
+    by the same protocol under both partitions (`also_sharded`), and the CPU loop timed on rank 0."""
     torch_cuda.cuda.empty_cache()
     d = _run_bench("--gpus", str(world), "--rendezvous", "gloo", "--try-comm", "--workload", workload,
-                   "--steps", "8", "--warmup", "2", "--latency-calls", "5")
+                   "--steps", "8", "--warmup", "2", "--latency-calls", "5", timeout=1500)
+    assert d["_line_bytes"] < 8000
     assert d["n_gpus"] == world and d["steps"] == 8 and d["scaling"] == "strong"
     cfg = d["config"]
-    assert cfg["rendezvous"] == "gloo" and "REHEARSAL" in cfg["parallelism"]
+    assert cfg["rendezvous"] == "gloo" and cfg["parallelism"] == "rehearsal"
     assert cfg["gather"] == sharded.HostStagedGather.name and cfg["gather_fell_back_to_torch_distributed"] is False
     shards = cfg["shards"]
     assert [s["rank"] for s in shards] == list(range(world))
@@ -148,7 +170,7 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
         assert b["x0"] == a["x1"] > 0 and b["c0"] == a["c1"] > 0      # rank r > 0 starts inside x
     assert all(s["kernel_ms"] > 0 for s in shards)                     # every rank timed its own launches
     per = [s["nnz"] for s in shards]
-    assert cfg["shard_imbalance_max_over_mean"] == pytest.approx(max(per) / (sum(per) / world), rel=1e-12)
+    assert cfg["shard_imbalance_max_over_mean"] == pytest.approx(max(per) / (sum(per) / world), rel=1e-5)
     assert cfg["shard_imbalance_max_over_mean"] < 1.05
     par = d["parity"]
     assert par["columns_checked"] == "all" and par["ncol"] == ncol
@@ -159,23 +181,36 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     assert d["pipelined"]["value"] > 0
     assert d["value"] == pytest.approx(nnz * 8 / (d["ms_per_step"] * 8e-3), rel=1e-9)
     roof = d["roofline"]
-    assert roof["kernel_ms_max_over_ranks"] >= max(s["kernel_ms"] for s in shards) * (1 - 1e-9)
+    assert roof["kernel_ms_max_over_ranks"] >= max(s["kernel_ms"] for s in shards) * (1 - 1e-4)
     assert roof["algorithmic_bytes_per_launch"] == 8 * shards[0]["nnz"] + 4 * (shards[0]["c1"] + 1) + 8 * shards[0]["c1"]
-    assert "cpu_baseline" not in d                                       # rank 0 at N = 1 only
+    cb = d["cpu_baseline"]                                               # rank 0, at every N, in the same run
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1e8
     # round 4: the two further figures of an N > 1 line, each with its own whole-matrix parity, neither feeding `value`
     ps = d["planned_shards"]
-    assert ps["value"] > 0 and len(ps["forms_by_rank"]) == world and "NOT `value`" in ps["protocol"]
-    assert ps["parity"]["columns_out_of_tolerance"] == 0 and ps["parity"]["max_abs_err_over_l1"] <= RTOL
-    if workload == "c4shard":
+    assert ps["value"] > 0 and len(ps["forms_by_rank"]) == world
+    assert ps["bad_columns"] == 0 and ps["parity_err"] <= RTOL
+    if workload in ("c4shard", "c3"):
         assert ps["forms_by_rank"] == ["columns"] * world            # columns of ~1000 entries in shards of <= 2.5e8
     dg = d["direct_gather"]
     assert dg["value"] is not None, dg                                # the ranks mapped rank 0's buffer (hipIpc) ...
-    assert dg["parity"]["columns_out_of_tolerance"] == 0 and dg["parity"]["max_abs_err_over_l1"] <= RTOL   # ... and wrote into it
-    assert "NOT the protocol of `value`" in dg["protocol"]
+    assert dg["bad_columns"] == 0 and dg["parity_err"] <= RTOL        # ... and wrote into it
     # --try-comm: the C-ABI communicator's multi-rank bootstrap ran between the rank processes (unique id
     # from rank 0, rsp_comm_init everywhere) and RCCL refused the shared device on EVERY rank, cleanly
-    seen = cfg["comm_init_rehearsal"]
-    assert len(seen) == world and all("ncclCommInitRank" in s and "error 5" in s for s in seen), seen
+    assert cfg["comm_refused_on_ranks"] == world and "comm_rehearsal_unexpected" not in cfg, cfg
+    if workload == "c3":
+        # BASELINE config 5 inside the default N > 1 line: the Zipf matrix by the protocol of `value`, nnz-balanced and
+        # with the naive equal-column-count partition (SURVEY 8e's comparator), every column against the oracle
+        a = d["also_sharded"]
+        assert set(a) == {"c5_nnz", "c5_cols"}
+        for k, rec in a.items():
+            assert rec["value"] > 0 and rec["bad_columns"] == 0 and rec["parity_err"] <= RTOL
+            assert len(rec["kernel_ms_by_rank"]) == world and sum(rec["nnz_by_rank"]) == nnz
+            assert rec["imbalance"] == pytest.approx(max(rec["nnz_by_rank"]) / (nnz / world), rel=1e-5)
+            for f in ("value", "ms_per_step", "imbalance", "kernel_ms_max", "gather_ms_max", "parity_err"):
+                assert roof[f"also_{k}_{f}"] == rec[f]                # the flat scalars the driver's record keeps
+        assert a["c5_nnz"]["imbalance"] < 1.05 <= a["c5_cols"]["imbalance"]      # what the nnz-balanced cut is for
+    else:
+        assert "also_sharded" not in d
 
 
 @pytest.mark.parametrize("shape", ["uniform", "zipf"])
@@ -321,7 +356,7 @@ def test_bench_rowsums_over_column_range_shards(torch_cuda, world, workload, nro
     roof = d["roofline"]
     assert roof["algorithmic_bytes_per_launch"] == 12 * shards[0]["nnz"] + 8 * nrow and 0 < roof["frac"] < 1
     if world > 1:
-        assert d["config"]["reduce"] == sharded.GlooReduceRows.name and "REHEARSAL" in d["config"]["parallelism"]
+        assert d["config"]["reduce"] == sharded.GlooReduceRows.name and d["config"]["parallelism"] == "rehearsal"
         assert roof["reduce_ms"] > 0 and roof["reduce_bytes_per_rank"] == 8 * nrow
     else:
         assert d["config"]["reduce"] is None and roof["reduce_ms"] is None
@@ -446,7 +481,7 @@ def test_bench_child_process_planned_c2(torch_cuda):
     pl = d["config"]["planned"]
     assert pl["form"] == "lean" and pl["snapped"] is True and pl["plan_ms"] > 0 and pl["chunks"] > 10_000
     assert d["roofline"]["kernel"].startswith("colsums_lean_kernel")
-    assert "ONE HIP event pair" in d["roofline"]["kernel_timing"]
+    assert d["roofline"]["kernel_timing"] == "region" and len(d["config"]["regions_ms"]) == 3
     par = d["parity"]
     assert par["columns_checked"] == "all" and par["ncol"] == 1_000_000 and par["columns_out_of_tolerance"] == 0
     assert par["max_abs_err_over_l1"] == 0.0

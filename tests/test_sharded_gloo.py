@@ -74,6 +74,57 @@ def test_sharded_columnsums_over_gloo(world, shape):
         assert imb < 1.05
 
 
+def _eight_worker(rank, world, port, partition, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p, x = _matrix("zipf")
+        shard = sharded.make_shard(p, rank, world, balance=partition)
+        counts, displs = sharded.gather_layout(shard.bounds)
+
+        def compute(sh):   # stand-in for rsp_column_sums_device on this rank's HBM shard
+            return torch.from_numpy(oracle.column_sums(x[sh.x0:sh.x1], sh.p_local))
+
+        recv = torch.empty(len(p) - 1, dtype=torch.float64) if rank == 0 else None
+        # the exchange of bench.py --rendezvous gloo (host copies over gloo), the driver of `value`
+        driver = sharded.ShardedColumnSums(shard, compute, sharded.HostStagedGather(dist, rank, world, counts, displs, 0))
+        for _ in range(3):                       # back-to-back calls reuse the staging buffers
+            driver.step(recv)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (shard.c0, shard.c1, shard.x0, shard.x1))
+        if rank == 0:
+            ref = oracle.column_sums(x, p)
+            q.put((bool(recv.numpy().tobytes() == ref.tobytes()), everyone, [int(c) for c in counts], [int(d) for d in displs],
+                   sharded.imbalance(p, shard.bounds)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("partition", ["nnz", "cols"])
+def test_eight_ranks_over_gloo_both_partitions(partition):
+    """World size 8 -- the driver's node -- on CPU: eight processes, the 8-entry counts / displacements, the nnz-balanced
+    cut of SURVEY.md 8e (bounds[k] = lower_bound(p, k * nnz / 8)) and the naive equal-column-count comparator, on a Zipf
+    matrix; the gathered result has the oracle's bits and every rank reports the range the formula gives it."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_eight_worker, args=(world, _free_port(), partition, q), nprocs=world, join=True)
+    same, everyone, counts, displs, imb = q.get()
+    assert same
+    p, _ = _matrix("zipf")
+    ncol, nnz = len(p) - 1, int(p[-1])
+    if partition == "nnz":
+        want = [0] + [int(np.searchsorted(p, (k * nnz) // world, side="left")) for k in range(1, world)] + [ncol]
+        assert imb <= 1.0 + int(np.diff(p).max()) / (nnz / world)      # no column is split: at most one column over the mean
+    else:
+        want = [(k * ncol) // world for k in range(world + 1)]
+    assert [e[0] for e in everyone] + [ncol] == want
+    assert all(a[1] == b[0] and a[3] == b[2] for a, b in zip(everyone, everyone[1:]))        # the ranges tile columns and x
+    assert [e[2] for e in everyone] == [int(p[c]) for c in want[:-1]]
+    assert counts == [b - a for a, b in zip(want, want[1:])] and displs == want[:-1] and sum(counts) == ncol
+
+
 def test_shards_tile_the_matrix_exactly():
     p, _ = _matrix("zipf")
     for world in (1, 2, 3, 8):
