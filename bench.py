@@ -206,9 +206,33 @@ def parse_args(argv=None):
 
 def relaunch_under_torchrun(args) -> int:
     """`python bench.py --gpus N` typed by hand: start the N ranks as a child."""
+    port = str(29500 + os.getpid() % 2000)
+    if args.rendezvous == "gloo":
+        # the rehearsal on a box with fewer GPUs than ranks: the ranks are started directly, with the environment
+        # torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  torchrun's agent process
+        # itself holds the GPU open on this image, and this pool allows six processes per card: without the agent a
+        # one-GPU box takes six ranks instead of five (five under pytest, whose own process holds a context too).
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = 0
+        while procs:
+            for pr in list(procs):
+                code = pr.poll()
+                if code is None:
+                    continue
+                procs.remove(pr)
+                if code != 0 and rc == 0:       # one rank failed: the others would wait for it in a collective forever
+                    rc = code
+                    for other in procs:
+                        other.terminate()       # (exactly the processes started above)
+            time.sleep(0.05)
+        return rc
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
 
 

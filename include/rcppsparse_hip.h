@@ -70,6 +70,17 @@ int rsp_device_count(int *count);
  */
 int rsp_column_sums_host(const double *x, const int32_t *p, int32_t ncol,
                          int64_t nnz, double *sums, int device);
+/*
+ * What the library keeps between calls, and how to give it back.  rsp_column_sums_host keeps ONE stream and
+ * one grow-only set of device buffers (x, p, sums, workspace) per device, so that an R session calling
+ * columnSums(A) again and again does not pay a stream creation, four allocations and four frees per call (they
+ * cost more than the transfers and kernels of any matrix below ~1e7 entries).  A call that would need more than
+ * 1 GiB in total (RSP_ONE_SHOT_KEEP_MB in the environment) allocates for itself and frees before it returns.
+ * Host pointers are never kept.  Concurrent one-shot calls on one device take turns (a mutex per device);
+ * calls on different devices run side by side.  rsp_release_cached() frees everything kept, on every device
+ * (the R package calls it when it is unloaded); the next call simply allocates again.
+ */
+int rsp_release_cached(void);
 
 /*
  * The same one-shot call spread over several GPUs of the node: the columns are cut

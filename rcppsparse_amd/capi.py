@@ -29,7 +29,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/rcppsparse_hip.h declares (checked by tests/test_capi_nogpu.py)
 EXPORTED_SYMBOLS = (
     "rsp_version", "rsp_last_error", "rsp_device_count",
-    "rsp_column_sums_host", "rsp_column_sums_host_multi",
+    "rsp_column_sums_host", "rsp_column_sums_host_multi", "rsp_release_cached",
     "rsp_mcsc_upload", "rsp_mcsc_column_sums", "rsp_mcsc_free",
     "rsp_mcsc_upload_csc", "rsp_mcsc_column_means", "rsp_mcsc_row_sums", "rsp_mcsc_row_means",
     "rsp_csc_upload", "rsp_csc_column_sums", "rsp_csc_column_means", "rsp_csc_free",
@@ -250,6 +250,11 @@ def column_sums_host(x, p, ncol=None, device: int = 0) -> np.ndarray:
     out = np.empty(ncol, dtype=np.float64)
     _check(load().rsp_column_sums_host(_dp(x), _ip(p), ncol, x.size, _dp(out), device))
     return out
+
+
+def release_cached() -> None:
+    """Frees what the library keeps between calls (the one-shot entry's per-device stream and buffers)."""
+    _check(load().rsp_release_cached())
 
 
 def column_sums_host_multi(x, p, ncol=None, devices=None) -> np.ndarray:

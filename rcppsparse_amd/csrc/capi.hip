@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <atomic>
+#include <mutex>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -1366,13 +1367,116 @@ int rsp_csc_crossprod(rsp_csc_t h, double* out) {
     return RSP_OK;
 }
 
+// ---- one-shot host entry: a grow-only arena per device instead of stream + 4 x hipMalloc / hipFree per call ----
+// The exported columnSums(A) of the R package lands here once per call (reference src/example.cpp:26-32 is one
+// synchronous call).  Creating a stream, four allocations and four frees around every call cost more than the
+// transfers and the kernels of any matrix below ~1e7 entries (round 4: C2 one-shot 3.7 ms against 1.9 ms of
+// upload + 0.23 ms of resident call), so the library keeps ONE stream and ONE set of buffers per device between
+// calls and only ever grows them.  Calls that need more than kOneShotKeepBytes in total (RSP_ONE_SHOT_KEEP_MB,
+// default 1 GiB) allocate what they need for the call and give it back: next to a transfer of that size the
+// allocations are noise, and an R session should not sit on 8 GB of HBM because it once summed a big matrix.
+// rsp_release_cached() frees everything the library keeps; the R package calls it from R_unload_RcppSparse.
+// Thread safety: the arena of a device is held under its mutex for the duration of a call -- concurrent one-shot
+// calls on ONE device take turns, calls on different devices run side by side.
+namespace {
+struct OneShotArena {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    void* buf[4] = {nullptr, nullptr, nullptr, nullptr};   // x, p, sums, workspace
+    size_t cap[4] = {0, 0, 0, 0};
+};
+constexpr int kMaxArenaDevices = 64;
+OneShotArena g_arena[kMaxArenaDevices];
+
+size_t one_shot_keep_bytes() {
+    static const size_t v = [] {
+        const char* s = getenv("RSP_ONE_SHOT_KEEP_MB");
+        const long long mb = s ? atoll(s) : 1024;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return v;
+}
+
+void arena_release(OneShotArena& a) {   // caller holds a.mu and has made the device current
+    if (a.stream) (void)hipStreamSynchronize(a.stream);
+    for (int k = 0; k < 4; ++k) {
+        if (a.buf[k]) (void)hipFree(a.buf[k]);
+        a.buf[k] = nullptr;
+        a.cap[k] = 0;
+    }
+    if (a.stream) (void)hipStreamDestroy(a.stream);
+    a.stream = nullptr;
+}
+}  // namespace
+
+int rsp_release_cached(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return RSP_OK;   // no runtime, nothing kept
+    }
+    for (int d = 0; d < n && d < kMaxArenaDevices; ++d) {
+        std::lock_guard<std::mutex> lock(g_arena[d].mu);
+        if (!g_arena[d].stream && !g_arena[d].buf[0] && !g_arena[d].buf[1] && !g_arena[d].buf[2] && !g_arena[d].buf[3]) continue;
+        DeviceGuard on(d);
+        if (on.error() != hipSuccess) continue;
+        arena_release(g_arena[d]);
+    }
+    return RSP_OK;
+}
+
 int rsp_column_sums_host(const double* x, const int32_t* p, int32_t ncol, int64_t nnz, double* sums,
                          int device) {
     if (!sums && ncol > 0) return fail(RSP_ERR_BAD_ARG, "sums is null");
-    rsp_csc_t h = nullptr;
-    if (int rc = csc_upload(x, nullptr, p, 0, ncol, nnz, device, false, &h)) return rc;
-    const int rc = rsp_csc_column_sums(h, sums);
-    rsp_csc_free(h);
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (!p || (nnz > 0 && !x)) return fail(RSP_ERR_BAD_ARG, "x or p is null");
+    if (int rc = check_offsets_host(p, ncol, nnz)) return rc;
+    if (int rc = require_device(device)) return rc;
+    if (ncol == 0) return RSP_OK;
+    if (device >= kMaxArenaDevices) return fail(RSP_ERR_BAD_ARG, "device %d is beyond the %d devices the one-shot entry keeps buffers for", device, kMaxArenaDevices);
+    DeviceGuard on(device);
+    HIP_TRY(on.error());
+    // x is padded to a whole 16-byte pair so the device copy never ends mid-load
+    const size_t need[4] = {(((size_t)nnz * 8 + 15) & ~(size_t)15) + 16, ((size_t)ncol + 1) * 4, (size_t)ncol * 8,
+                            rsp_column_sums_workspace_bytes(ncol, nnz)};
+    OneShotArena& a = g_arena[device];
+    std::lock_guard<std::mutex> lock(a.mu);
+    hipError_t e = hipSuccess;
+    if (!a.stream) e = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking);
+    const bool keep = need[0] + need[1] + need[2] + need[3] <= one_shot_keep_bytes();
+    void* own[4] = {nullptr, nullptr, nullptr, nullptr};   // buffers of a call too large to keep
+    void* buf[4];
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) {
+        if (keep) {
+            if (a.cap[k] < need[k]) {   // grow: a quarter more than asked, so a sequence of slightly larger matrices settles
+                if (a.buf[k]) (void)hipFree(a.buf[k]);
+                a.buf[k] = nullptr;
+                a.cap[k] = 0;
+                const size_t want = need[k] + need[k] / 4 + 256;
+                e = hipMalloc(&a.buf[k], want);
+                if (e == hipSuccess) a.cap[k] = want;
+            }
+            buf[k] = a.buf[k];
+        } else {
+            e = hipMalloc(&own[k], need[k]);
+            buf[k] = own[k];
+        }
+    }
+    int rc = RSP_OK;
+    if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(buf[0], x, (size_t)nnz * 8, hipMemcpyHostToDevice, a.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(buf[1], p, need[1], hipMemcpyHostToDevice, a.stream);
+    if (e == hipSuccess)
+        rc = enqueue((const double*)buf[0], (const int32_t*)buf[1], ncol, nnz, (double*)buf[2], buf[3], need[3], 1.0, false,
+                     a.stream);
+    if (e == hipSuccess && rc == RSP_OK) e = hipMemcpyAsync(sums, buf[2], need[2], hipMemcpyDeviceToHost, a.stream);
+    const hipError_t es = hipStreamSynchronize(a.stream);   // host buffers are only borrowed: nothing of this call is left in flight
+    if (e == hipSuccess) e = es;
+    for (int k = 0; k < 4; ++k)
+        if (own[k]) (void)hipFree(own[k]);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_HIP, "one-shot column sums failed: %s", hipGetErrorString(e));
+    }
     return rc;
 }
 

@@ -8,16 +8,23 @@
 // handed over as raw pointers (REAL(x), INTEGER(p)); i[] is not passed: the
 // reference never reads it on this path (RcppSparse.h:227 row() is not called).
 //
-// A machine WITHOUT any HIP device (SURVEY.md 8b "CPU fallback selected when no device", section 5): the
-// reference's columnSums always answers, so this layer -- above the C ABI, never inside it -- answers too, with
-// the reference's own loop (example.cpp:28-30) over THIS package's Matrix::InnerIterator into the vector that
-// is already allocated.  It is selected only when rsp_device_count() reports zero devices; with a device
-// present every failure stays an error (a non-zero status becomes a C++ exception, which Rcpp's END_RCPP turns
-// into an R error, reference src/RcppExports.cpp:23).  RCPPSPARSE_REQUIRE_GPU=1 in the environment (or the R
-// option RcppSparse.require_gpu = TRUE, which the Rcpp build passes in) switches the CPU answer off: no device
-// is then the R error it was before.  This repository's tests, bench.py and smoke() all run with it set, so
-// nothing measured or checked on a GPU box can come from the CPU loop; last_backend() tells which path ran.
-// The C ABI itself has no fallback (librcppsparse_hip.so returns RSP_ERR_NO_DEVICE).
+// WHICH PATH ANSWERS (SURVEY.md 8b "CPU fallback selected when no device", section 5 "min-nnz threshold for GPU
+// offload").  The reference's columnSums always answers and costs a few nanoseconds per entry; a call through the
+// device costs two transfers, two launches and a synchronisation whatever the size (~0.1 ms), so on a SMALL matrix
+// the reference's own loop on the host is the faster answer and the drop-in must never be slower than what it
+// replaces.  This layer -- above the C ABI, never inside it -- therefore answers with the reference's loop
+// (example.cpp:28-30) over THIS package's Matrix::InnerIterator
+//   * when rsp_device_count() reports zero devices, and
+//   * when the matrix holds fewer than min_nnz stored entries: options(RcppSparse.min_nnz = n) in R, else
+//     RCPPSPARSE_MIN_NNZ in the environment, else kDefaultMinNnz -- the crossover measured on an MI355X box
+//     (tools/measure_host_path.py, profiles/r05_one_shot.json); 0 sends every matrix to the GPU.
+// With a device present and the matrix large enough every failure stays an error (a non-zero status becomes a C++
+// exception, which Rcpp's END_RCPP turns into an R error, reference src/RcppExports.cpp:23).
+// RCPPSPARSE_REQUIRE_GPU=1 in the environment (or the R option RcppSparse.require_gpu = TRUE, which the Rcpp build
+// passes in) switches BOTH host answers off: every call goes to the device, and no device is the R error it was
+// before.  This repository's tests, bench.py and smoke() all run with it set, so nothing measured or checked on a
+// GPU box can come from the CPU loop; last_backend() tells which path ran.
+// The C ABI itself has no fallback (librcppsparse_hip.so returns RSP_ERR_NO_DEVICE) and no threshold.
 #ifndef RCPPSPARSE_COLUMNSUMS_IMPL_HPP
 #define RCPPSPARSE_COLUMNSUMS_IMPL_HPP
 
@@ -51,21 +58,40 @@ inline bool gpu_required(int option) {
     return s && s[0] && !(s[0] == '0' && !s[1]);
 }
 
-// the path a columnSums() call would take now: the GPU whenever one is visible; otherwise the CPU loop,
-// unless a GPU is required ("none": the call is an error)
-inline int choose_backend(int require_gpu_option = -1) {
+// Stored entries below which the host loop answers although a device is present.  Measured on an MI355X box
+// (profiles/r05_one_shot.json): the one-shot device call and the 1-thread loop cross between 1e5 and 1e6 entries.
+constexpr long long kDefaultMinNnz = 250000;
+
+// option: the R-level twin (options(RcppSparse.min_nnz = n)), or -1 when R has no such option -> environment, default
+inline long long min_nnz_setting(long long option = -1) {
+    if (option >= 0) return option;
+    const char* s = std::getenv("RCPPSPARSE_MIN_NNZ");
+    if (s && s[0]) {
+        const long long v = std::atoll(s);
+        return v < 0 ? 0 : v;
+    }
+    return kDefaultMinNnz;
+}
+
+// the path a columnSums() call on a matrix of `nnz` stored entries would take now (nnz < 0: a matrix large enough
+// for the device): the GPU when one is visible and the matrix is not below the threshold; otherwise the CPU loop;
+// a GPU required: always the GPU ("none" without one: the call is an error)
+inline int choose_backend(int require_gpu_option = -1, long long nnz = -1, long long min_nnz_option = -1) {
     int ndev = 0;
-    if (rsp_device_count(&ndev) == RSP_OK && ndev > 0) return kBackendHip;
-    return gpu_required(require_gpu_option) ? kBackendNone : kBackendCpu;
+    const bool have = rsp_device_count(&ndev) == RSP_OK && ndev > 0;
+    if (gpu_required(require_gpu_option)) return have ? kBackendHip : kBackendNone;
+    if (!have) return kBackendCpu;
+    return (nnz >= 0 && nnz < min_nnz_setting(min_nnz_option)) ? kBackendCpu : kBackendHip;
 }
 
 template <class MatrixT, class Traits>
-typename Traits::NumVec column_sums_via_hip(MatrixT& A, int require_gpu_option = -1) {
+typename Traits::NumVec column_sums_via_hip(MatrixT& A, int require_gpu_option = -1, long long min_nnz_option = -1) {
     const unsigned int ncol = A.cols();                       // RcppSparse.h:45
     typename Traits::NumVec sums = Traits::zeros(ncol);       // example.cpp:27
-    const int backend = choose_backend(require_gpu_option);
+    const int backend = choose_backend(require_gpu_option, (long long)A.n_nonzero(), min_nnz_option);
     if (backend == kBackendCpu) {
-        // no device on this machine: the reference loop, one InnerIterator per column (example.cpp:28-30)
+        // no device on this machine, or a matrix below the offload threshold: the reference loop, one InnerIterator
+        // per column (example.cpp:28-30)
         for (unsigned int col = 0; col < ncol; ++col)
             for (typename MatrixT::InnerIterator it(A, (int)col); it; ++it) sums[col] += it.value();
         last_backend() = kBackendCpu;

@@ -163,10 +163,26 @@ int seam_columnSums_opt(const double* x, const int* i, const int* p, const int* 
     });
 }
 
+// ... and with the offload threshold's option twin: min_nnz >= 0 as options(RcppSparse.min_nnz = n), -1 = the
+// environment (RCPPSPARSE_MIN_NNZ), else the measured default
+int seam_columnSums_opt2(const double* x, const int* i, const int* p, const int* dim, int nnz, int require_gpu,
+                         long long min_nnz, double* out) {
+    return guarded([&] {
+        Matrix A = view(x, i, p, dim, nnz);
+        NumericVector s = rcppsparse_core::column_sums_via_hip<Matrix, Traits>(A, require_gpu, min_nnz);
+        for (std::size_t k = 0; k < s.size(); ++k) out[k] = s[k];
+    });
+}
+
 // 0 none, 1 hip, 2 cpu: the path the most recent columnSums took (last != 0) / a call would take now
 int seam_backend(int last, int require_gpu) {
     return last ? rcppsparse_core::last_backend() : rcppsparse_core::choose_backend(require_gpu);
 }
+// ... for a matrix of `nnz` stored entries under the offload threshold (min_nnz as above)
+int seam_backend_for(long long nnz, int require_gpu, long long min_nnz) {
+    return rcppsparse_core::choose_backend(require_gpu, nnz, min_nnz);
+}
+long long seam_min_nnz(long long option) { return rcppsparse_core::min_nnz_setting(option); }
 
 // the reference loop over the mirror's InnerIterator (CPU; tests iterator semantics)
 int seam_columnSums_by_iterator(const double* x, const int* i, const int* p, const int* dim, int nnz,

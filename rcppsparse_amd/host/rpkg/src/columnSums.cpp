@@ -8,6 +8,14 @@ int require_gpu_option() {
     if (o == R_NilValue) return -1;
     return Rf_asLogical(o) == TRUE ? 1 : 0;
 }
+// options(RcppSparse.min_nnz = n): matrices with fewer stored entries are summed by the host loop; not set: -1
+// (RCPPSPARSE_MIN_NNZ in the environment, else the measured default)
+long long min_nnz_option() {
+    SEXP o = Rf_GetOption1(Rf_install("RcppSparse.min_nnz"));
+    if (o == R_NilValue) return -1;
+    const double v = Rf_asReal(o);
+    return v >= 0 ? (long long)v : -1;
+}
 }  // namespace
 
 //' Sum every column of a sparse matrix on the GPU
@@ -18,8 +26,13 @@ int require_gpu_option() {
 //' HIP segmented-sum kernel (AMD Instinct MI355X) through the C interface in
 //' \code{rcppsparse_hip.h}.  On a machine without any GPU the function still answers, like the CPU
 //' original: the same column loop runs on the host (\code{columnSumsBackend(last = TRUE)} then says
-//' \code{"cpu"}).  \code{options(RcppSparse.require_gpu = TRUE)} or \code{RCPPSPARSE_REQUIRE_GPU=1} in the
-//' environment turn that off: no GPU is then an R error.  With a GPU present a failure is always an error.
+//' \code{"cpu"}).  The host loop also answers for small matrices -- fewer than
+//' \code{getOption("RcppSparse.min_nnz")} stored entries (else \code{RCPPSPARSE_MIN_NNZ} in the environment,
+//' else 250000, the measured crossover): a trip through the GPU costs about 0.1 ms whatever the size, the loop
+//' a few nanoseconds per entry, and the function is never slower than the CPU original.
+//' \code{options(RcppSparse.require_gpu = TRUE)} or \code{RCPPSPARSE_REQUIRE_GPU=1} in the
+//' environment turn both off: every call goes to the GPU and no GPU is then an R error.  With a GPU present
+//' a failure is always an error.
 //'
 //' @param A a \code{dgCMatrix} (package Matrix)
 //' @return numeric vector of length \code{ncol(A)}
@@ -31,8 +44,11 @@ int require_gpu_option() {
 //[[Rcpp::export]]
 Rcpp::NumericVector columnSums(RcppSparse::Matrix& A) {
     // the result vector is allocated here, on the R main thread; the shim only fills it
-    return rcppsparse_core::column_sums_via_hip<RcppSparse::Matrix, RcppSparse::RcppTraits>(A, require_gpu_option());
+    return rcppsparse_core::column_sums_via_hip<RcppSparse::Matrix, RcppSparse::RcppTraits>(A, require_gpu_option(), min_nnz_option());
 }
+
+// (no R-level export: called by R_unload_RcppSparse in rcpp_glue.cpp)
+void releaseCached() { (void)rsp_release_cached(); }
 
 //' Which path answers columnSums()
 //'

@@ -34,6 +34,7 @@ SEXP gpuMatrixMulti(RcppSparse::Matrix& A, Rcpp::IntegerVector devices);
 Rcpp::NumericVector gpuMultiReduce(SEXP handle, int what);
 void gpuFreeMulti(SEXP handle);
 SEXP columnSumsBackend(int last);
+void releaseCached();   // columnSums.cpp: rsp_release_cached() of the C ABI
 
 namespace {
 
@@ -166,5 +167,9 @@ void R_init_RcppSparse(DllInfo* dll) {
     R_registerRoutines(dll, /*.C*/ NULL, /*.Call*/ routines, /*.Fortran*/ NULL, /*.External*/ NULL);
     R_useDynamicSymbols(dll, FALSE);   // only registered names resolve
 }
+
+// R runs this when the package's shared object is unloaded (library.dynam.unload / detach(unload = TRUE)): the C library
+// keeps a stream and a few device buffers per GPU between columnSums() calls (rsp_column_sums_host) -- give them back.
+void R_unload_RcppSparse(DllInfo*) { releaseCached(); }
 
 }  // extern "C"

@@ -70,7 +70,31 @@ def columnSums_opt(m, require_gpu: int = -1) -> np.ndarray:
     return out
 
 
+def columnSums_opt2(m, require_gpu: int = -1, min_nnz: int = -1) -> np.ndarray:
+    """... and with the offload threshold's option twin: min_nnz >= 0 as options(RcppSparse.min_nnz = n) (matrices with
+    fewer stored entries are answered by the host loop although a GPU is present), -1 = RCPPSPARSE_MIN_NNZ / default."""
+    x, i, p, d = _slots(m)
+    out = np.empty(int(d[1]), dtype=np.float64)
+    _check(load().seam_columnSums_opt2(*_args(x, i, p, d), ctypes.c_int(int(require_gpu)), ctypes.c_longlong(int(min_nnz)),
+                                       out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
 BACKENDS = ("none", "hip", "cpu")
+
+
+def backend_for(nnz: int, require_gpu: int = -1, min_nnz: int = -1) -> str:
+    """The path columnSums would take now on a matrix of `nnz` stored entries."""
+    L = load()
+    L.seam_backend_for.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong]
+    return BACKENDS[int(L.seam_backend_for(int(nnz), int(require_gpu), int(min_nnz)))]
+
+
+def min_nnz(option: int = -1) -> int:
+    L = load()
+    L.seam_min_nnz.argtypes = [ctypes.c_longlong]
+    L.seam_min_nnz.restype = ctypes.c_longlong
+    return int(L.seam_min_nnz(int(option)))
 
 
 def backend(last: bool = False, require_gpu: int = -1) -> str:

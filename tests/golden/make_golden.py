@@ -78,6 +78,20 @@ def main():
     # non-finite values propagate like the plain += of the reference
     x = np.array([1.0, np.inf, 2.0, -np.inf, np.inf, np.nan, 1.0, 4.0], dtype=np.float64)
     save("nonfinite", x, [0, 1, 0, 1, 2, 0, 1, 0], [0, 2, 5, 7, 8], [3, 4])
+    # R's NA_real_ is the signalling NaN 0x7FF00000000007A2 (low word 1954); the reference's plain += (src/example.cpp:30)
+    # hands it back quieted with the payload kept, which R still prints as NA.  Columns 0-5 hold NA beside finite or
+    # infinite values only: every form has to return the oracle's x86 bits for them (0x7FF80000000007A2).  Columns 6-8 mix
+    # NA with a NaN of another payload: which of the two comes back depends on the order of the adds (R's own
+    # documentation calls it platform-dependent); the x86 bits of the sequential loop are stored beside them.
+    na = np.frombuffer(np.array([0x7FF00000000007A2], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    nan = np.frombuffer(np.array([0x7FF8000000000000], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    cols = [[na], [1.5, na, 2.5], [na, 1.5, 2.5], [1.5, 2.5, na], [na, np.inf], [-np.inf, na, 3.0],
+            [nan, na], [na, nan], [np.inf, -np.inf, na]]
+    x = np.concatenate([np.array(c, dtype=np.float64) for c in cols])
+    assert x.view(np.uint64)[0] == 0x7FF00000000007A2          # the signalling pattern survived numpy
+    p = np.concatenate([[0], np.cumsum([len(c) for c in cols])])
+    i = np.concatenate([np.arange(len(c)) for c in cols])
+    save("na_payload", x, i, p, [3, len(cols)])
     # ragged: lengths 0..40 interleaved with empties, odd nnz
     rng = np.random.default_rng(7)
     counts = rng.integers(0, 41, size=301)

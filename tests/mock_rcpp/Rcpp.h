@@ -265,6 +265,11 @@ inline SEXP Rf_GetOption1(SEXP sym) {
     return it == Rcpp::mock_options().end() ? R_NilValue : it->second;
 }
 inline int Rf_asLogical(SEXP s) { return (s && s->integer && !s->integer->empty() && (*s->integer)[0] != 0) ? TRUE : FALSE; }
+inline double Rf_asReal(SEXP s) {
+    if (s && s->num && !s->num->empty()) return (*s->num)[0];
+    if (s && s->integer && !s->integer->empty()) return (double)(*s->integer)[0];
+    return -1.0;
+}
 inline SEXP R_ExternalPtrTag(SEXP s) { return (s && s->tag) ? s->tag : R_NilValue; }
 #ifndef NULL
 #define NULL 0

@@ -8,6 +8,8 @@
 //   driver handle_nogpu        -> gpuMatrix(A) on a machine without a GPU must be an R error
 //   driver kat_cpu             -> the same matrix on a machine WITHOUT a GPU: the host loop answers (reference bits),
 //                                 columnSumsBackend() says "cpu"; with options(RcppSparse.require_gpu = TRUE) an R error
+//   driver min_nnz             -> the offload threshold on a machine WITH a GPU: options(RcppSparse.min_nnz = n) /
+//                                 RCPPSPARSE_MIN_NNZ decide between the host loop and the device; a required GPU overrides
 //   driver backend             -> prints columnSumsBackend() / columnSumsBackend(last = TRUE) before any call
 //   driver handle_swap         -> a "gpuMatrixMulti" handed to a single-GPU routine (and the reverse), an edited Dim (GPU)
 //   driver handle_methods      -> colMeans / rowSums / rowMeans / crossprod on the handle, and the same matrix
@@ -19,6 +21,7 @@
 
 extern "C" SEXP _RcppSparse_columnSums(SEXP);
 extern "C" void R_init_RcppSparse(DllInfo*);
+extern "C" void R_unload_RcppSparse(DllInfo*);
 
 static SEXP dgc(bool with_p) {
     Rcpp::S4 A(std::string("dgCMatrix"));
@@ -177,6 +180,30 @@ int main(int argc, char** argv) {
         if (!fn(dgc(true))->error.empty()) return 76;
         return 0;
     }
+    if (mode == "min_nnz") {
+        call1 backend = 0;
+        for (int k = 0; dll.registered[k].name; ++k)
+            if (std::string(dll.registered[k].name) == "_RcppSparse_columnSumsBackend") backend = (call1)dll.registered[k].fun;
+        if (!backend) return 90;
+        SEXP last = Rcpp::wrap(Rcpp::IntegerVector::create(1, 0));
+        const double want[5] = {0.0, 0.41, 0.35, 0.84 + 0.37, 0.26};
+        // the vignette's matrix holds 5 stored entries: one line per setting -- "<setting> <backend that answered>"
+        struct { const char* name; int min_nnz; int require; } cases[] = {
+            {"default", -2, -1}, {"min_nnz=0", 0, -1}, {"min_nnz=6", 6, -1}, {"min_nnz=5", 5, -1}, {"min_nnz=6+require_gpu", 6, 1}};
+        for (unsigned k = 0; k < sizeof cases / sizeof cases[0]; ++k) {
+            Rcpp::mock_options().erase("RcppSparse.min_nnz");
+            Rcpp::mock_options().erase("RcppSparse.require_gpu");
+            if (cases[k].min_nnz >= 0)
+                Rcpp::mock_options()["RcppSparse.min_nnz"] = Rcpp::wrap(Rcpp::NumericVector(1, (double)cases[k].min_nnz));   // options(RcppSparse.min_nnz = 6): a double, as R stores it
+            if (cases[k].require >= 0)
+                Rcpp::mock_options()["RcppSparse.require_gpu"] = Rcpp::wrap(Rcpp::IntegerVector::create(cases[k].require, 0));
+            SEXP r = fn(dgc(true));
+            if (!r->error.empty()) { std::printf("R error: %s\n", r->error.c_str()); return 91; }
+            if (r->num->size() != 5 || std::memcmp(&(*r->num)[0], want, sizeof want) != 0) return 92;   // the same bits either way
+            std::printf("%s %s\n", cases[k].name, backend(last)->str.c_str());
+        }
+        return 0;
+    }
     if (mode == "handle_swap") {
         call2 gpu_matrix = 0, gpu_reduce = 0, gpu_multi = 0, multi_reduce = 0;
         call1 gpu_sums = 0, gpu_free = 0, multi_free = 0;
@@ -229,6 +256,9 @@ int main(int argc, char** argv) {
         if (!r->error.empty()) { std::printf("R error: %s\n", r->error.c_str()); return 16; }
         const double want[5] = {0.0, 0.41, 0.35, 0.84 + 0.37, 0.26};
         if (r->num->size() != 5 || std::memcmp(&(*r->num)[0], want, sizeof want) != 0) return 17;
+        R_unload_RcppSparse(&dll);                     // the unload hook gives the library's kept buffers back ...
+        r = fn(dgc(true));                             // ... and a later call simply allocates again
+        if (!r->error.empty() || std::memcmp(&(*r->num)[0], want, sizeof want) != 0) return 18;
         std::printf("columnSums via .Call ok\n");
         return 0;
     }

@@ -340,6 +340,75 @@ def test_nonfinite_values_do_not_leak_between_columns(torch_cuda, launch_mode):
     assert np.isfinite(np.delete(got, [10, 50, 90])).all()
 
 
+NA_REAL_BITS = 0x7FF00000000007A2       # R's NA_real_: a signalling NaN whose low word is 1954
+NA_QUIETED_BITS = 0x7FF80000000007A2    # what x86's addsd makes of it, and what R still prints as NA
+
+
+@pytest.mark.parametrize("form", ["host", "seam", "device", "handle", "lean", "planned_no_lean", "columns"])
+def test_na_real_comes_back_as_na_like_the_reference(torch_cuda, form):
+    """reference src/example.cpp:30 is a plain `+=`: an NA_real_ in a column survives it on x86 (quieted, payload 1954 kept),
+    so the reference returns NA, which R prints as NA and not as NaN.  Every form of the device path has to do the same, BIT
+    FOR BIT, for every column whose only NaN is NA -- alone, beside finite values at any position, beside infinities, in
+    columns of 1 to 100000 entries (in-order short-column path, wave trees, chunk carries).  A column that mixes NA with a
+    NaN of ANOTHER payload returns one of the two payloads; which one depends on the order of the adds (on the CPU too:
+    R's documentation calls it platform-dependent), so there only the class and "one of the inputs' payloads" are pinned.
+    The rule is written down in include/rcppsparse_hip.h and INTEGRATION.md section 2."""
+    torch = torch_cuda
+    g = load_golden("na_payload")
+    short_x, short_p = g["x"], g["p"]
+    assert short_x.view(np.uint64)[0] == NA_REAL_BITS and g["sums"].view(np.uint64)[0] == NA_QUIETED_BITS
+    na = short_x[0]
+    cols = [short_x[short_p[c]:short_p[c + 1]] for c in range(len(short_p) - 1)]
+    pure = [True] * 6 + [False] * 3                     # (tests/golden/make_golden.py: columns 0-5 hold no NaN but NA)
+    lengths = [40, 40, 40, 64, 64] if form == "lean" else [40, 40, 40, 1000, 1000, 100_000, 100_000]
+    spots = [0, 20, 39, 0, 63] if form == "lean" else [0, 20, 39, 500, 999, 0, 77_777]
+    for k, (n, at) in enumerate(zip(lengths, spots)):
+        v = synth.gen_values(n, seed=60 + k, kind=0)
+        v[at] = na
+        cols.append(v)
+        pure.append(True)
+    cols.insert(3, synth.gen_values(17, seed=59, kind=0))     # a finite neighbour in between: nothing leaks
+    pure.insert(3, None)
+    x = np.concatenate(cols)
+    p = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32)
+    assert int(np.count_nonzero(x.view(np.uint64) == NA_REAL_BITS)) == sum(1 for q in pure if q is not None)
+    ref = oracle.column_sums(x, p)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    nrow = max(len(c) for c in cols)
+    try:
+        if form == "host":
+            got = capi.column_sums_host(x, p)
+        elif form == "seam":                            # RcppSparse::Matrix -> exported columnSums -> the shim
+            from rcppsparse_amd import hostseam
+            i = np.concatenate([np.arange(len(c), dtype=np.int32) for c in cols])
+            got = hostseam.columnSums({"x": x, "i": i, "p": p, "Dim": np.array([nrow, len(cols)], dtype=np.int32)})
+            assert hostseam.backend(last=True) == "hip"
+        elif form == "device":
+            got = capi.column_sums_device(xt, pt).cpu().numpy()
+        elif form == "handle":
+            h = capi.DeviceCSC(x, p, (nrow, len(cols)))
+            got = h.column_sums()
+            h.close()
+        else:
+            capi.set_lean({"lean": 2, "planned_no_lean": 0}.get(form, 1))
+            capi.set_columns_form(2 if form == "columns" else 1)
+            plan = capi.ColumnSumsPlan(p, nnz=int(x.size))
+            assert {"lean": 2, "columns": 3}.get(form, plan.form) == plan.form
+            got = plan.column_sums(xt, pt).cpu().numpy()
+            plan.close()
+    finally:
+        capi.set_lean(1)
+        capi.set_columns_form(1)
+    gb, rb = got.view(np.uint64), ref.view(np.uint64)
+    for c, q in enumerate(pure):
+        if q is None:
+            assert np.isfinite(got[c]) and abs(got[c] - ref[c]) <= RTOL * np.abs(cols[c]).sum()
+        elif q:
+            assert gb[c] == rb[c] == NA_QUIETED_BITS, (form, c, hex(int(gb[c])), hex(int(rb[c])))
+        else:       # NA and another NaN in one column: a NaN carrying one of the two payloads (0 or 1954), quiet
+            assert np.isnan(got[c]) and (int(gb[c]) & 0x7FFFFFFFFFFFFFFF) in (NA_QUIETED_BITS, 0x7FF8000000000000), (form, c, hex(int(gb[c])))
+
+
 def test_bit_stable_run_to_run(torch_cuda):
     torch = torch_cuda
     counts = synth.zipf_counts(5000, 2_000_000, seed=1, nrow=300_000)

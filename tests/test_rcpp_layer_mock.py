@@ -113,6 +113,53 @@ def test_without_a_gpu_columnSums_answers_on_the_host_like_the_reference(driver)
     assert r.returncode == 72 and "no HIP device" in r.stdout               # ... and the first call is the R error
 
 
+def test_offload_threshold_settings_without_a_gpu():
+    """SURVEY.md section 5 "min-nnz threshold for GPU offload": the setting's three sources in their order --
+    options(RcppSparse.min_nnz = n), RCPPSPARSE_MIN_NNZ, the measured default -- and the decision itself.  Without a GPU
+    the host loop answers whatever the threshold says, and a required GPU is "none" (an R error) whatever it says."""
+    from rcppsparse_amd import capi, hostseam
+    keep = os.environ.pop("RCPPSPARSE_MIN_NNZ", None)
+    try:
+        assert hostseam.min_nnz() == 250_000 and hostseam.min_nnz(17) == 17 and hostseam.min_nnz(0) == 0
+        os.environ["RCPPSPARSE_MIN_NNZ"] = "4000"
+        assert hostseam.min_nnz() == 4000 and hostseam.min_nnz(17) == 17          # the R option wins over the environment
+        os.environ["RCPPSPARSE_MIN_NNZ"] = "-3"
+        assert hostseam.min_nnz() == 0
+    finally:
+        os.environ.pop("RCPPSPARSE_MIN_NNZ", None)
+        if keep is not None:
+            os.environ["RCPPSPARSE_MIN_NNZ"] = keep
+    if capi.device_count() == 0:
+        for nnz in (0, 10, 10**9):
+            assert hostseam.backend_for(nnz, require_gpu=0, min_nnz=1000) == "cpu"
+            assert hostseam.backend_for(nnz, require_gpu=1, min_nnz=1000) == "none"
+    else:
+        assert hostseam.backend_for(999, require_gpu=0, min_nnz=1000) == "cpu"       # below the threshold: the host loop
+        assert hostseam.backend_for(1000, require_gpu=0, min_nnz=1000) == "hip"
+        assert hostseam.backend_for(10, require_gpu=0, min_nnz=0) == "hip"           # 0: every matrix goes to the device
+        assert hostseam.backend_for(10, require_gpu=1, min_nnz=1000) == "hip"        # a required GPU overrides the threshold
+
+
+@pytest.mark.gpu
+def test_offload_threshold_through_dot_call_on_a_gpu_box(driver):
+    """The exported columnSums(A) on a machine WITH a GPU, through .Call: the vignette's matrix (5 stored entries) is answered
+    by the host loop under the default threshold -- the drop-in is never slower than the reference on the reference's own
+    examples (README.md:33-38) --, by the device with options(RcppSparse.min_nnz = 0) or a threshold of 5, by the host loop
+    with 6; options(RcppSparse.require_gpu = TRUE) sends it to the device whatever the threshold; RCPPSPARSE_MIN_NNZ=0 in the
+    environment does what the option does; and RCPPSPARSE_REQUIRE_GPU=1 (this suite's setting) keeps every call on the
+    device.  The sums are the reference's bits on both paths."""
+    r = run(driver, "min_nnz", require_gpu=None)
+    assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
+    assert [ln.split() for ln in r.stdout.splitlines()] == [["default", "cpu"], ["min_nnz=0", "hip"], ["min_nnz=6", "cpu"],
+                                                            ["min_nnz=5", "hip"], ["min_nnz=6+require_gpu", "hip"]]
+    env = dict(os.environ, RCPPSPARSE_MIN_NNZ="0")
+    env.pop("RCPPSPARSE_REQUIRE_GPU", None)
+    r = subprocess.run([driver, "min_nnz"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and r.stdout.splitlines()[0].split() == ["default", "hip"]
+    r = run(driver, "min_nnz", require_gpu="1")
+    assert r.returncode == 0 and all(ln.split()[1] == "hip" for ln in r.stdout.splitlines())
+
+
 def test_host_only_build_of_the_package_without_the_hip_library(tmp_path):
     """./configure's second branch (no librcppsparse_hip.so on the machine): the package's sources plus
     src/nohip_stubs.c, NOT linked against the library.  It behaves like the GPU build on a box without a GPU:
