@@ -72,7 +72,7 @@ def test_bench_child_process_runs_the_comm_path_at_shard_size(torch_cuda):
     assert d["value"] == pytest.approx(125_000_000 * 8 / (d["ms_per_step"] * 8e-3), rel=1e-9)
     # a call cannot be faster than its kernels; a single call pays the host round trip on top
     roof = d["roofline"]
-    assert roof["kernel_ms"] <= d["ms_per_step"] * 1.02
+    assert roof["kernel_ms"] <= d["ms_per_step"] * 1.06        # (the split comes from a second pass with events around every call)
     assert d["latency_ms_per_call"] >= roof["kernel_ms_min"]
     # the mean gather time lies between the individual gather timings
     assert roof["gather_ms_min"] <= roof["gather_ms"] <= roof["gather_ms_max"]
@@ -209,7 +209,9 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
             assert rec["imbalance"] == pytest.approx(max(rec["nnz_by_rank"]) / (nnz / world), rel=1e-5)
             for f in ("value", "ms_per_step", "imbalance", "kernel_ms_max", "gather_ms_max", "parity_err"):
                 assert roof[f"also_{k}_{f}"] == rec[f]                # the flat scalars the driver's record keeps
-        assert a["c5_nnz"]["imbalance"] < 1.05 <= a["c5_cols"]["imbalance"]      # what the nnz-balanced cut is for
+        # no column is split: the nnz-balanced cut is at most one column (<= nrow = 1 % of the entries) over the mean, and
+        # never worse than the equal-column-count cut of the same (randomly permuted) Zipf matrix
+        assert a["c5_nnz"]["imbalance"] <= 1.0 + world * 0.0101 and a["c5_nnz"]["imbalance"] <= a["c5_cols"]["imbalance"]
     else:
         assert "also_sharded" not in d
 
