@@ -120,7 +120,11 @@ GLOSSARY = {
                        "<w>_kernel_ms, <w>_ms_per_call (median of three regions), <w>_parity_err = max |gpu - ref| / sum|x| "
                        "over all columns, <w>_traffic_x = HBM bytes / algorithmic bytes measured in this run, "
                        "<w>_traffic_recorded_x = the same from the committed passes under profiles/",
-    "also": "the same records whole: form = general | snapped | lean | columns; launches per call; plan_ms (plan_by = host: "
+    "config.shards[].form": "the form rank r's calls took: rsp_column_sums_device plans for itself (include/rcppsparse_hip.h) -- "
+                            "general kernels on the first calls, then lean / columns where the device-side inspection of p[] "
+                            "selects them; the timed regions start after every rank has settled (--planned: the caller's plan)",
+    "also": "the same records whole: form = general | snapped | lean | columns; planned_by = entry (the plan-free entry's own "
+            "plan) | caller (rsp_column_sums_plan_*); launches per call; plan_ms (plan_by = host: "
             "rsp_column_sums_plan_create on a host copy of p[]; device: rsp_column_sums_plan_create_device, device time of "
             "the inspection kernels); early_general_calls = calls answered by the general kernels before a device-made plan "
             "was known",
@@ -399,6 +403,8 @@ def traffic_child(args):
     out = torch.empty(ncol, dtype=torch.float64, device="cuda")
     ws = capi.alloc_workspace(ncol, nnz, "cuda")
     run = capi.prepared_column_sums(x, pt, out, ws)
+    run()
+    capi.column_sums_device_form(pt, nnz, wait=True)     # the entry plans for itself: count the form it settles on
     for _ in range(max(1, args.steps)):
         run()
     torch.cuda.synchronize()
@@ -436,21 +442,30 @@ def traffic_measured_now(workload, kind):
                     return None, f"the {counter} pass exited with {pr.returncode}: {err.decode(errors='replace')[-200:]}"
             except OSError as e:
                 return None, f"the {counter} pass could not be started: {e}"
-            per = {}
+            rows = []      # (dispatch id, kernel family, KiB) of every column-sum launch of the child, in dispatch order
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     if r["Counter_Name"] != counter:
                         continue
-                    for k in ("colsums_chunks_kernel", "colsums_fixup_kernel"):
+                    for k in COLSUM_KERNELS:
                         if k in r["Kernel_Name"]:
-                            per.setdefault(k, []).append(float(r["Counter_Value"]))
-            if "colsums_chunks_kernel" not in per:
-                return None, f"the {counter} pass reported no colsums_chunks_kernel launch"
-            means[counter] = sum(sum(v) / len(v) for v in per.values())      # KiB per call: main kernel + fix-up
+                            rows.append((int(r.get("Dispatch_Id", len(rows))), k, float(r["Counter_Value"])))
+            if not rows:
+                return None, f"the {counter} pass reported no column-sum launch"
+            rows.sort()
+            # the child's last calls all take the form the entry has settled on: the last launch names it
+            last = rows[-1][1]
+            fams = ("colsums_chunks_kernel", "colsums_fixup_kernel") if last in ("colsums_chunks_kernel", "colsums_fixup_kernel") else (last,)
+            means[counter] = 0.0
+            for fam in fams:      # KiB per call: mean over the last three launches of each kernel of the call
+                vals = [v for _, k, v in rows if k == fam][-3:]
+                means[counter] += sum(vals) / len(vals)
+            family = "+".join(f.replace("colsums_", "").replace("_kernel", "") for f in fams)
     rd, wr = 2 * 1024 * means["FETCH_SIZE"], 1024 * means["WRITE_SIZE"]
-    return rd + wr, {"read_bytes": rd, "write_bytes": wr}
+    return rd + wr, {"read_bytes": rd, "write_bytes": wr, "kernels": family}
 
 
+COLSUM_KERNELS = ("colsums_chunks_kernel", "colsums_fixup_kernel", "colsums_lean_kernel", "colsums_columns_kernel")
 ALSO_AUTO = ("c2", "c2:planned", "c2:planned-device", "c5", "c4shard", "c4shard:planned", "vignette:planned")
 ALSO_TRAFFIC_NOW = ("c2", "c5")          # plan-free records whose HBM traffic the default line re-measures in the run
 ALSO_SHARDED_AUTO = ("c5:nnz", "c5:cols")
@@ -521,6 +536,12 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream, traffic_now=Fal
                      capi.prepared_column_sums(xk, pt, out, ws, stream=stream)) for xk in xs]
     for k in range(max(args.warmup, ncopies)):
         launches[k % ncopies]()
+    auto_form = None
+    if plan is None:
+        # the plan-free entry plans for itself (include/rcppsparse_hip.h): wait until it has settled on a form, then warm that
+        auto_form = capi.column_sums_device_form(pt, nnz, wait=True)
+        for k in range(max(args.warmup, ncopies)):
+            launches[k % ncopies]()
     mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
     torch.cuda.synchronize()
     regions_ms = None
@@ -545,10 +566,11 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream, traffic_now=Fal
         raise SystemExit(f"parity check failed on also:{spec}: {json.dumps(par)}")
     algo = 8 * nnz + 4 * (ncol + 1) + 8 * ncol
     achieved = algo / (kernel_ms * 1e-3) / 1e9
-    one_launch = plan is not None and plan.snapped
+    one_launch = (plan is not None and plan.snapped) or auto_form in ("lean", "columns")
     ms_per_call = wall / steps * 1e3
     rec = {"workload": spec,
-           "form": "general" if plan is None else PLAN_FORMS[plan.form],
+           "form": (auto_form if auto_form != "unknown" else "general") if plan is None else PLAN_FORMS[plan.form],
+           "planned_by": "entry" if plan is None else "caller",
            "launches": 1 if one_launch else 2,
            "plan_ms": None if plan is None else plan.inspect_ms,
            "plan_by": None if plan is None else ("device" if plan.device_made else "host"),
@@ -566,7 +588,7 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream, traffic_now=Fal
     if traffic_now and plan is None:
         measured, _how = traffic_measured_now(name, args.kind)
     if measured is not None:
-        rec["traffic"], rec["traffic_in_run"] = measured, True
+        rec["traffic"], rec["traffic_in_run"], rec["traffic_kernels"] = measured, True, _how["kernels"]
     else:
         rec["traffic"], rec["traffic_in_run"] = traffic_from_profiles(name + ("planned" if one_launch else ""))[0], False
     return sig(rec)
@@ -1003,6 +1025,16 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
     driver = sharded.ShardedColumnSums(shard, compute, new_gather(s_main))
     for _ in range(args.warmup):
         driver.step(recv)
+    form_code = {"general": 0, "lean": 2, "columns": 3}
+    if plan is None and shard.nnz > 0:
+        # rsp_column_sums_device plans for itself: every rank waits until ITS entry has settled on a form (outside every timed
+        # region: the inspection is ~23 us of device time behind the first call), then warms that form
+        my_form = capi.column_sums_device_form(pt, shard.nnz, wait=True)
+        my_form = form_code.get(my_form, 0)
+        for _ in range(args.warmup):
+            driver.step(recv)
+    else:
+        my_form = 0 if plan is None else plan.form
     # Timing events are queue packets of their own: a pair around a call leaves the queue idle for a few
     # microseconds (rocprofv3 kernel trace of C2 with events on every 4th call: 16 us of gaps per 4 calls,
     # profiles/r03_c2.md).  Harmless around a 1.2 ms call, a fifth of a 20 us one.  So:
@@ -1096,7 +1128,7 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
 
     stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=stat_dev)
     # what every rank owned and measured (rank order), so the line shows the whole partition
-    mine = torch.tensor([shard.c0, shard.c1, shard.x0, shard.x1, kernel_ms, gather_ms, dev_index],
+    mine = torch.tensor([shard.c0, shard.c1, shard.x0, shard.x1, kernel_ms, gather_ms, dev_index, my_form],
                         dtype=torch.float64, device=stat_dev)
     per_rank = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
@@ -1131,7 +1163,9 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
              "algo_bytes": 8 * shard.nnz + 4 * (shard.ncol + 1) + 8 * shard.ncol,
              "imbalance": sharded.imbalance(p, shard.bounds), "ncopies": ncopies,
              "shards": [{"rank": r, "device": int(t[6]), "c0": int(t[0]), "c1": int(t[1]), "x0": int(t[2]), "x1": int(t[3]),
-                         "kernel_ms": t[4], "gather_ms": t[5] if use_comm else None} for r, t in enumerate(per_rank)],
+                         "kernel_ms": t[4], "gather_ms": t[5] if use_comm else None, "form": PLAN_FORMS[int(t[7])]}
+                        for r, t in enumerate(per_rank)],
+             "form": PLAN_FORMS[int(my_form)],
              "parity": parity, "lat_med": lat_med, "lat_min": lat_min, "lat_med_max": lat_med_max,
              "pipelined": pipe, "planned_shards": planned_shards, "direct_gather": direct_gather,
              "plan": (None if plan is None else
@@ -1170,7 +1204,8 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
     roof = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "traffic": None, "traffic_over_algorithmic": None, "traffic_measured_in_run": False, "traffic_file": None,
-        "kernel": "colsums_chunks_kernel+fixup" if plan is None else plan["kernel"],
+        "kernel": ({"lean": "colsums_lean_kernel (the entry's own plan)", "columns": "colsums_columns_kernel (the entry's own plan)"}
+                   .get(H.get("form"), "colsums_chunks_kernel+fixup") if plan is None else plan["kernel"]),
         "kernel_ms": H["kernel_ms"], "kernel_ms_median": H["kernel_ms_median"], "kernel_ms_min": H["kernel_ms_min"],
         "kernel_timing": H["kernel_timing"], "kernel_ms_max_over_ranks": H["kernel_ms_max_over_ranks"],
         "gather_ms": H["gather_ms"], "gather_ms_min": H["gather_ms_min"], "gather_ms_max": H["gather_ms_max"],
@@ -1183,7 +1218,7 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         roof["traffic_over_algorithmic"] = None if tr["bytes"] is None else tr["bytes"] / H["algo_bytes"]
         roof["traffic_measured_in_run"] = bool(tr.get("in_run"))
         roof["traffic_file"] = tr.get("file")
-        for k in ("read_bytes", "write_bytes", "seconds", "not_measured"):
+        for k in ("read_bytes", "write_bytes", "seconds", "not_measured", "kernels"):
             if tr.get(k) is not None:
                 roof["traffic_" + k] = tr[k]
     rc = extras.get("read_ceiling")
@@ -1225,7 +1260,8 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         "host_stall_suspected": bool(not use_comm and ms_per_step > 1.5 * H["kernel_ms"]),
         "planned": None if plan is None else {k: v for k, v in plan.items() if k != "kernel"},
         "shards": [{"rank": s["rank"], "device": s["device"], "c0": s["c0"], "c1": s["c1"], "x0": s["x0"], "x1": s["x1"],
-                    "nnz": s["x1"] - s["x0"], "kernel_ms": s["kernel_ms"], "gather_ms": s["gather_ms"]} for s in H["shards"]],
+                    "nnz": s["x1"] - s["x0"], "kernel_ms": s["kernel_ms"], "gather_ms": s["gather_ms"],
+                    "form": s.get("form", "general")} for s in H["shards"]],
     }
     if comm_rehearsal is not None:
         refused = [("ncclCommInitRank" in s and "error 5" in s) for s in comm_rehearsal]

@@ -145,7 +145,7 @@ int rsp_csc_column_means(rsp_csc_t handle, double *means);
 int rsp_csc_dims(rsp_csc_t handle, int32_t *nrow, int32_t *ncol, int64_t *nnz);
 /* The upload inspects p[] once (beside the copies) and freezes the result in the handle: which form the
  * handle's column sums take -- 0 general kernels, 1 snapped, 2 lean, 3 columns (rsp_column_sums_plan_info).
- * The settings in force AT UPLOAD decide (rsp_set_lean / RSP_LEAN, RSP_COLUMNS_FORM, the chunking knobs);
+ * The settings in force AT UPLOAD decide (RSP_LEAN, RSP_COLUMNS_FORM, the chunking knobs: rsp_debug_set);
  * changing them later does not touch existing handles.  rsp_csc_set_planned(h, 0) sends the handle's
  * column sums through the general kernels whatever the plan says (A/B measurements), 1 switches back. */
 int rsp_csc_column_form(rsp_csc_t handle);
@@ -160,10 +160,28 @@ int rsp_csc_free(rsp_csc_t handle);
  * aligned.  d_workspace is scratch of at least
  * rsp_column_sums_workspace_bytes(ncol, nnz) bytes, 16-byte aligned; it carries
  * no state between calls, but calls that may run concurrently (different streams)
- * need a workspace each.  Graph-capture safe (no allocation, no synchronisation
- * inside).  Many calls on small or medium matrices: alternating them over two
+ * need a workspace each.  Graph-capture safe (a call on a capturing stream
+ * allocates nothing and waits for nothing).  Many calls on small or medium
+ * matrices: alternating them over two
  * streams (two workspaces) lets one call fill the chip while the previous one
  * drains (bench.py does this for the 1/8 shards of the multi-GPU runs: -15 %).
+ *
+ * These two entries PLAN FOR THEMSELVES (matrices of at least 2^20 entries).  The first call on
+ * (device, d_p, ncol, nnz) runs the general kernels and enqueues a device-side inspection of d_p behind them on
+ * `stream` (rsp_column_sums_plan_create_device: ~23 us for 1e6 columns; nothing waits).  Once the host has seen its
+ * result -- an event query per call -- later calls with the same key take the form it selects: lean (every column
+ * short: ONE launch, every column bit-identical to the reference loop; BASELINE config 2: 0.51 -> ~0.7 of the
+ * HBM roofline) or columns (every column long: one launch); other matrices stay on the general kernels.  The
+ * caller promises NOTHING about d_p between calls: the kernels of this path check every column's offsets against
+ * the p[] of the call they run in, sum a column whose offsets have changed straight from x (clamped to [0, nnz]),
+ * and make the library inspect again -- never a wrong sum, only a slower call.  Up to 16 keys are remembered per
+ * process (least recently used first out); rsp_release_cached() forgets them all.  Consequences: the first calls
+ * and the later ones agree within the documented tolerance, not bit for bit, and which call is the first planned
+ * one depends on timing; a capture records whatever form is known when it is made.  RSP_AUTO_PLAN=0 in the
+ * environment (or rsp_debug_set("auto_plan", 0)) keeps every call on the general kernels, bit-stable from the first
+ * call; explicit plans (below) and handles choose their form once, at creation / upload.
+ * rsp_column_sums_device_form: the form calls with that key take now -- 0 general kernels, 2 lean, 3 columns,
+ * -1 not known (yet); wait != 0 blocks until the inspection's result has been seen (measurements).
  */
 size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz);
 int rsp_column_sums_device(const double *d_x, const int32_t *d_p, int32_t ncol,
@@ -175,6 +193,7 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
                             int32_t ncol, int64_t nnz, double *d_means,
                             void *d_workspace, size_t workspace_bytes,
                             void *stream);
+int rsp_column_sums_device_form(const int32_t *d_p, int32_t ncol, int64_t nnz, int wait);
 /*
  * Inspector-executor form for callers that can show p[] to the host once (a resident matrix summed many
  * times; rsp_csc_upload does this by itself, the one-shot rsp_column_sums_host does not: it sums once).  The inspector walks the chunk
@@ -193,7 +212,7 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
  * stride, so that a wavefront requests its rows of x, its header and its offsets in the same instant (2 B per
  * column, p[] itself is not read again), puts both into LDS and adds every column in storage order from +0.0:
  * every column then comes out BIT-IDENTICAL to the reference loop.  It is selected up to a mean column length of 60
- * (longer columns leave a chunk's 64 lanes too few columns: tools/edge_sweep.py); rsp_set_lean(0) / RSP_LEAN=0 keeps
+ * (longer columns leave a chunk's 64 lanes too few columns: tools/edge_sweep.py); RSP_LEAN=0 (rsp_debug_set("lean", 0)) keeps
  * plans out of that form, 2 takes it wherever every column is <= 64 entries (A/B measurements, tests).
  * When every column is LONG and of similar length (at least 2048 entries -- 512 in matrices of up to 2.5e8
  * entries --, none above four times the mean, at least 128 columns; the reference vignette's 100000 x 1000 benchmark matrix) the plan takes the COLUMNS form:
@@ -243,11 +262,6 @@ int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double *d_x,
                                    int32_t nrow_for_means, double *d_sums,
                                    void *d_workspace, size_t workspace_bytes, void *stream);
 int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan);
-int rsp_set_lean(int on);
-/* Plans made from now on: 0 never take the columns form, 1 where it is the faster one (default; RSP_COLUMNS_FORM),
- * 2 on every matrix whose longest column the kernel can take, whatever the lengths (measurements on both sides of
- * the thresholds, tools/edge_sweep.py; results stay within the documented tolerance). */
-int rsp_set_columns_form(int mode);
 /*
  * Generic column reduction ("next" row f3): the same column-iteration loop with a
  * different per-element body, out[c] = sum_j f(x[j]) over column c's stored entries --
@@ -282,12 +296,11 @@ int rsp_column_reduce_device(const double *d_x, const int32_t *d_p, int32_t ncol
  * assumption) and needs the workspace of rsp_column_sums_in_rows_workspace_bytes.
  * A device-side check hands matrices with giant columns back to the general kernel
  * (probes served by L2), which is also what a workspace of only
- * rsp_column_sums_workspace_bytes, rsp_set_row_slices(0) or RSP_ROW_SLICES=0 select
+ * rsp_column_sums_workspace_bytes or RSP_ROW_SLICES=0 (rsp_debug_set("row_slices", 0)) select
  * (2: the slice form wherever nrow > 2^20, whatever the shape -- tests).
  * Both forms are deterministic and within 1e-12 * sum|x_col| of the reference's order.
  */
 size_t rsp_column_sums_in_rows_workspace_bytes(int32_t nrow, int32_t ncol, int64_t nnz);
-int rsp_set_row_slices(int on);
 /* which form a call of these sizes with that much workspace takes (the slice form's device-side check aside) */
 #define RSP_IN_ROWS_FORM_L1     0   /* bitmap <= 16 KB: probed through L1                    */
 #define RSP_IN_ROWS_FORM_LDS    1   /* <= 128 KB: whole bitmap in LDS                        */
@@ -350,7 +363,7 @@ int rsp_debug_read_ceiling_device(const double *d_x, int64_t nnz, double *d_sink
  * device), nothing is regrouped: a table of every column's contiguous piece per row block
  * is built on first use (4 B per column and block) and every call reads the uploaded x / i
  * once, 12 B/nnz, also where the other forms would read them once per row block (2-4
- * blocks) or keep a 12 B/nnz copy.  rsp_set_row_segments(0) / RSP_ROW_SEGMENTS=0 keeps
+ * blocks) or keep a 12 B/nnz copy.  RSP_ROW_SEGMENTS=0 (rsp_debug_set("row_segments", 0)) keeps
  * handles on the other forms; 2 takes the segments form wherever it is possible (tests).
  * rsp_csc_row_form tells which form a handle's row sums have taken.
  */
@@ -362,7 +375,6 @@ int rsp_debug_read_ceiling_device(const double *d_x, int64_t nnz, double *d_sink
 int rsp_csc_row_sums(rsp_csc_t handle, double *sums);     /* nrow doubles, host */
 int rsp_csc_row_means(rsp_csc_t handle, double *means);
 int rsp_csc_row_form(rsp_csc_t handle);
-int rsp_set_row_segments(int mode);
 size_t rsp_row_sums_workspace_bytes(int32_t nrow, int64_t nnz);
 int rsp_row_sums_device(const double *d_x, const int32_t *d_i, int32_t nrow,
                         int64_t nnz, double *d_sums, void *d_workspace,
@@ -504,25 +516,42 @@ int rsp_gen_values_device(double *d_x, int64_t n, uint64_t seed,
 int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
                                int32_t ncol, uint64_t seed, void *stream);
 
-/* ---- tuning knobs (experiments; defaults are chosen per problem size) --- */
-/* chunk_rows: 128-element rows of x owned by one wavefront (0 = automatic; any value is
- * clamped so that one chunk never exceeds 1 GiB of x). */
-int rsp_set_tuning(int chunk_rows);
-/* Taper of the automatic chunking: the last tail_permille / 1000 of x is cut into chunks of
- * tail_chunk_rows rows, which are dispatched last and fill the chip while the long chunks of
- * the final round finish at different times.  (0, 0) = no taper, (-1, -1) = built-in default.
- * Results stay within the documented tolerance for every setting. */
-int rsp_set_taper(int tail_permille, int tail_chunk_rows);
+/* ---- measurement and test knobs ------------------------------------------ */
+/*
+ * ONE entry for every process-wide knob (round 5; earlier rounds exported a setter each).  None of them is needed to
+ * use the library: defaults are chosen per problem size, and results stay within the documented tolerance for every
+ * value.  tools/ and the tests use them for A/B runs and to put a form on both sides of its threshold.  The same
+ * names in upper case with the prefix RSP_ are read from the environment once, at first use (RSP_LEAN, RSP_TAPER =
+ * "permille,rows", ...); a value set here wins.  Plans and handles sample the knobs when they are MADE; the
+ * device-pointer entries read them at every call.  Keys:
+ *   "chunk_rows"      128-element rows of x owned by one wavefront (0 = automatic; clamped to 1 GiB of x per chunk)
+ *   "taper_permille"  the last value / 1000 of x is cut into shorter chunks, dispatched last (-1 default, 0 none) ...
+ *   "taper_rows"      ... of this many rows (<= 0: default)
+ *   "experiment"      alternative builds of the main kernel: 0 production, 1 = 16 rows in flight, 2 / 3 = 1 / 2
+ *                     wavefronts per workgroup, 4 = default cache policy instead of nt loads, 5 = 4 rows in flight
+ *   "lean"            plans: 0 never the lean form, 1 where it is the faster one (default), 2 wherever it applies
+ *   "columns_form"    plans: 0 never, 1 where faster (default), 2 on every matrix whose longest column the kernel takes
+ *   "row_segments"    handles' row sums: 0 never the segments form, 1 where faster (default), 2 wherever possible
+ *   "row_slices"      row-restricted sums: 0 never the slice-major form, 1 where faster (default), 2 wherever possible
+ *   "auto_plan"       rsp_column_sums_device / rsp_column_means_device plan for themselves (1, default) or never (0)
+ * An unknown key is RSP_ERR_BAD_ARG.  rsp_debug_get reads the value in force (environment and defaults resolved).
+ * Threads: the knobs are atomics -- setting one while another thread is inside a call is safe and takes effect for
+ * calls (plans, handles) that start afterwards; two libraries' worth of callers in one process share them, which is
+ * why nothing a production caller needs goes through here.  The per-use switches are rsp_set_crossprod_exact (below
+ * Matrix::crossprod) and rsp_csc_set_planned (per handle).
+ * THREAD SAFETY OF THE LIBRARY: every entry may be called from any thread.  Calls on DIFFERENT handles, plans,
+ * communicators or streams may run concurrently; calls on ONE handle / plan / communicator must not overlap (a
+ * handle is owned by one thread at a time).  The one-shot host entries serialise per device (rsp_column_sums_host
+ * holds its device's buffers for the call); the plan-free device entries take a process-wide mutex for the few
+ * hundred nanoseconds of their bookkeeping.  rsp_last_error is per thread.
+ */
+int rsp_debug_set(const char *key, int value);
+int rsp_debug_get(const char *key, int *value);
 /* How a call over nnz entries is cut into chunks (one wavefront each) under the settings in force:
  * plan4 = { elements per body chunk, number of body chunks, elements per tail chunk, total chunks }.
  * Chunk w starts at w * body for w < nbody and at nbody * body + (w - nbody) * tail after that; all
  * sizes are multiples of 128 elements.  Pure host arithmetic, no device needed (tools, tests). */
 int rsp_plan_describe(int64_t nnz, int32_t *plan4);
-/* Selects an alternative build of the main kernel for A/B measurements
- * (0 = production; 1 = 16 rows in flight; 2 / 3 = 1 / 2 wavefronts per workgroup;
- * 4 = default cache policy instead of nt loads).  Not for production use; results
- * stay within the documented tolerance for every value. */
-int rsp_set_experiment(int variant);
 
 #ifdef __cplusplus
 }

@@ -36,21 +36,21 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_workspace_bytes", "rsp_column_sums_device", "rsp_column_means_device",
     "rsp_column_sums_device_timed", "rsp_column_reduce_device", "rsp_column_sums_in_rows_device",
     "rsp_column_sums_plan_create", "rsp_column_sums_plan_create_device", "rsp_column_sums_plan_info",
-    "rsp_column_sums_planned_device", "rsp_column_sums_plan_destroy", "rsp_set_lean",
-    "rsp_column_sums_in_rows_workspace_bytes", "rsp_set_row_slices", "rsp_column_sums_in_rows_form",
-    "rsp_csc_row_form", "rsp_set_row_segments",
+    "rsp_column_sums_planned_device", "rsp_column_sums_plan_destroy", "rsp_column_sums_device_form",
+    "rsp_column_sums_in_rows_workspace_bytes", "rsp_column_sums_in_rows_form",
+    "rsp_csc_row_form", "rsp_debug_set", "rsp_debug_get",
     "rsp_csc_crossprod", "rsp_crossprod_workspace_bytes", "rsp_crossprod_device",
     "rsp_csc_row_sums", "rsp_csc_row_means", "rsp_row_sums_workspace_bytes", "rsp_row_sums_device",
     "rsp_row_means_device",
     "rsp_partition_columns", "rsp_rebase_offsets",
     "rsp_comm_unique_id", "rsp_comm_init", "rsp_comm_gatherv", "rsp_comm_destroy",
     "rsp_comm_reduce_rows_workspace_bytes", "rsp_comm_reduce_rows", "rsp_add_partials_device",
-    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_set_tuning", "rsp_set_taper", "rsp_plan_describe", "rsp_set_crossprod_exact",
-    "rsp_set_experiment", "rsp_debug_read_ceiling_device",
+    "rsp_gen_values_device", "rsp_gen_row_indices_device", "rsp_plan_describe", "rsp_set_crossprod_exact",
+    "rsp_debug_read_ceiling_device",
     "rsp_column_sums_plan_ready", "rsp_column_sums_plan_wait", "rsp_debug_plan_image",
     "rsp_shared_result_alloc", "rsp_shared_result_open", "rsp_shared_result_close", "rsp_shared_result_read",
     "rsp_host_barrier_create", "rsp_host_barrier_wait", "rsp_host_barrier_destroy",
-    "rsp_set_columns_form", "rsp_crossprod_form", "rsp_debug_exclusive_scan_device",
+    "rsp_crossprod_form", "rsp_debug_exclusive_scan_device",
     "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
 )
 
@@ -129,10 +129,9 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_column_sums_plan_ready.argtypes = [vp]
     L.rsp_column_sums_plan_wait.argtypes = [vp]
     L.rsp_debug_plan_image.argtypes = [vp, c.c_int, vp, c.c_size_t, c.POINTER(c.c_size_t)]
-    L.rsp_set_lean.argtypes = [c.c_int]
-    L.rsp_set_columns_form.argtypes = [c.c_int]
-    L.rsp_set_row_slices.argtypes = [c.c_int]
-    L.rsp_set_row_segments.argtypes = [c.c_int]
+    L.rsp_debug_set.argtypes = [c.c_char_p, c.c_int]
+    L.rsp_debug_get.argtypes = [c.c_char_p, c.POINTER(c.c_int)]
+    L.rsp_column_sums_device_form.argtypes = [vp, i32, i64, c.c_int]
     L.rsp_csc_row_form.argtypes = [c.c_void_p]
     L.rsp_column_sums_in_rows_form.argtypes = [i32, i32, i64, c.c_size_t]
     L.rsp_column_sums_in_rows_workspace_bytes.argtypes = [i32, i32, i64]
@@ -167,9 +166,6 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_host_barrier_destroy.argtypes = [vp]
     L.rsp_gen_values_device.argtypes = [vp, i64, u64, u64, c.c_int, vp]
     L.rsp_gen_row_indices_device.argtypes = [vp, vp, i32, i32, u64, vp]
-    L.rsp_set_tuning.argtypes = [c.c_int]
-    L.rsp_set_experiment.argtypes = [c.c_int]
-    L.rsp_set_taper.argtypes = [c.c_int, c.c_int]
     L.rsp_set_crossprod_exact.argtypes = [c.c_int]
     L.rsp_plan_describe.argtypes = [i64, ip]
     L.rsp_debug_exclusive_scan_device.argtypes = [vp, vp, i64, vp]
@@ -203,8 +199,31 @@ def device_count() -> int:
     return n.value
 
 
+def debug_set(key: str, value: int) -> None:
+    """One process-wide measurement / test knob (rsp_debug_set; the keys are listed in include/rcppsparse_hip.h)."""
+    _check(load().rsp_debug_set(key.encode(), int(value)))
+
+
+def debug_get(key: str) -> int:
+    v = ctypes.c_int(0)
+    _check(load().rsp_debug_get(key.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
 def set_tuning(chunk_rows: int = 0) -> None:
-    _check(load().rsp_set_tuning(int(chunk_rows)))
+    debug_set("chunk_rows", chunk_rows)
+
+
+def set_auto_plan(on: bool = True) -> None:
+    """rsp_column_sums_device / rsp_column_means_device plan for themselves (default) or stay on the general kernels."""
+    debug_set("auto_plan", int(bool(on)))
+
+
+def column_sums_device_form(p_t, nnz: int, wait: bool = False) -> str:
+    """The form plan-free calls on these offsets take now (rsp_column_sums_device_form): 'general', 'lean', 'columns', or
+    'unknown' (no call with this key yet, or the inspection's result has not been seen; wait=True blocks for it)."""
+    r = int(load().rsp_column_sums_device_form(p_t.data_ptr(), p_t.numel() - 1, int(nnz), int(bool(wait))))
+    return {0: "general", 2: "lean", 3: "columns"}.get(r, "unknown")
 
 
 def set_crossprod_exact(exact: bool) -> None:
@@ -215,7 +234,8 @@ def set_crossprod_exact(exact: bool) -> None:
 
 def set_taper(tail_permille: int = -1, tail_chunk_rows: int = -1) -> None:
     """(0, 0) = no taper, (-1, -1) = the library's default."""
-    _check(load().rsp_set_taper(int(tail_permille), int(tail_chunk_rows)))
+    debug_set("taper_permille", tail_permille)
+    debug_set("taper_rows", tail_chunk_rows)
 
 
 def plan_describe(nnz: int) -> dict:
@@ -227,18 +247,18 @@ def plan_describe(nnz: int) -> dict:
 
 def set_lean(on=True) -> None:
     """Plans made from now on: 0 / False never take the lean form, 1 / True where it is the faster one (default: every
-    column <= 64 entries and a mean of at most 60), 2 wherever it applies at all (rsp_set_lean; A/B measurements, tests)."""
-    _check(load().rsp_set_lean(int(on)))
+    column <= 64 entries and a mean of at most 60), 2 wherever it applies at all (rsp_debug_set "lean"; A/B measurements, tests)."""
+    debug_set("lean", int(on))
 
 
 def set_columns_form(mode: int = 1) -> None:
     """Plans made from now on: 0 never the columns form, 1 where it is the faster one (default), 2 wherever the
-    kernel can run at all (rsp_set_columns_form; edge measurements)."""
-    _check(load().rsp_set_columns_form(int(mode)))
+    kernel can run at all (rsp_debug_set "columns_form"; edge measurements)."""
+    debug_set("columns_form", int(mode))
 
 
 def set_experiment(variant: int = 0) -> None:
-    _check(load().rsp_set_experiment(int(variant)))
+    debug_set("experiment", int(variant))
 
 
 # ---------------------------------------------------------------- host paths
@@ -505,14 +525,14 @@ def in_rows_form(nrow: int, ncol: int, nnz: int, workspace_bytes: int | None = N
 
 def set_row_segments(mode) -> None:
     """Handles' row sums: 0 never the segments form, 1 where it is the faster one (default), 2 wherever it is
-    possible (tests) (rsp_set_row_segments).  Looked at when a handle's row sums are asked for the first time."""
-    _check(load().rsp_set_row_segments(int(mode)))
+    possible (tests) (rsp_debug_set "row_segments").  Looked at when a handle's row sums are asked for the first time."""
+    debug_set("row_segments", int(mode))
 
 
 def set_row_slices(on) -> None:
     """0 / False: row-restricted sums over more than 2^20 rows always probe the bitmap in L2; 1 / True: the slice-major
-    form where it is the faster one (default); 2: wherever it is possible at all (tests) (rsp_set_row_slices)."""
-    _check(load().rsp_set_row_slices(int(on)))
+    form where it is the faster one (default); 2: wherever it is possible at all (tests) (rsp_debug_set "row_slices")."""
+    debug_set("row_slices", int(on))
 
 
 def row_set_bitmap(rows, nrow: int) -> np.ndarray:

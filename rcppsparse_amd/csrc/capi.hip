@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <string>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -398,12 +399,6 @@ int rsp_device_count(int* count) {
     return RSP_OK;
 }
 
-int rsp_set_tuning(int chunk_rows) {
-    if (chunk_rows < 0) return fail(RSP_ERR_BAD_ARG, "chunk_rows is negative");
-    g_chunk_rows_override.store(chunk_rows, std::memory_order_relaxed);   // (make_plan clamps it to kMaxChunkRows)
-    return RSP_OK;
-}
-
 int rsp_plan_describe(int64_t nnz, int32_t* plan4) {
     if (!plan4) return fail(RSP_ERR_BAD_ARG, "plan4 is null");
     if (int rc = check_sizes(0, nnz)) return rc;
@@ -415,10 +410,60 @@ int rsp_plan_describe(int64_t nnz, int32_t* plan4) {
     return RSP_OK;
 }
 
-int rsp_set_taper(int tail_permille, int tail_chunk_rows) {
-    if (tail_permille > 1000) return fail(RSP_ERR_BAD_ARG, "tail_permille is above 1000");
-    g_taper_permille.store(tail_permille < 0 ? -1 : tail_permille, std::memory_order_relaxed);
-    g_taper_rows.store(tail_chunk_rows <= 0 ? -1 : tail_chunk_rows, std::memory_order_relaxed);
+// ---- measurement / test knobs: ONE entry instead of a setter per knob ----------------
+// Process-wide atomics; plans and handles sample them when they are MADE.  Not part of what a production caller
+// needs: tools/ and the tests use them for A/B runs and to force a form on both sides of its threshold.
+namespace {
+int clamp012(int v) { return v <= 0 ? 0 : (v >= 2 ? 2 : 1); }
+int auto_plan_setting();
+std::atomic<int> g_auto_plan{-1};   // "auto_plan": 0 / 1; -1 = RSP_AUTO_PLAN from the environment, else 1
+}  // namespace
+
+int rsp_debug_set(const char* key, int value) {
+    if (!key) return fail(RSP_ERR_BAD_ARG, "key is null");
+    const std::string k(key);
+    if (k == "chunk_rows") {            // 128-element rows of x per wavefront (0 = automatic; clamped to 1 GiB of x per chunk)
+        if (value < 0) return fail(RSP_ERR_BAD_ARG, "chunk_rows is negative");
+        g_chunk_rows_override.store(value, std::memory_order_relaxed);
+    } else if (k == "taper_permille") { // the last value / 1000 of x in shorter chunks (-1 = built-in default, 0 = no taper)
+        if (value > 1000) return fail(RSP_ERR_BAD_ARG, "taper_permille is above 1000");
+        g_taper_permille.store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    } else if (k == "taper_rows") {     // ... of this many rows (<= 0: built-in default)
+        g_taper_rows.store(value <= 0 ? -1 : value, std::memory_order_relaxed);
+    } else if (k == "experiment") {     // alternative builds of the main kernel (0 = production)
+        if (value < 0) return fail(RSP_ERR_BAD_ARG, "experiment is negative");
+        g_variant.store(value, std::memory_order_relaxed);
+    } else if (k == "lean") {           // plans: 0 never lean, 1 where it is the faster form, 2 wherever it applies
+        g_lean.store(clamp012(value), std::memory_order_relaxed);
+    } else if (k == "columns_form") {   // plans: 0 never, 1 where faster, 2 on every matrix the kernel can take
+        g_columns_form.store(clamp012(value), std::memory_order_relaxed);
+    } else if (k == "row_segments") {   // handles' row sums: 0 never the segments form, 1 where faster, 2 wherever possible
+        g_row_segments.store(clamp012(value), std::memory_order_relaxed);
+    } else if (k == "row_slices") {     // row-restricted sums: 0 never the slice-major form, 1 where faster, 2 wherever possible
+        g_row_slices.store(clamp012(value), std::memory_order_relaxed);
+    } else if (k == "auto_plan") {      // the plan-free device entries plan for themselves (1, default) or never (0)
+        g_auto_plan.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+    } else {
+        return fail(RSP_ERR_BAD_ARG, "unknown knob '%s'", key);
+    }
+    return RSP_OK;
+}
+
+int rsp_debug_get(const char* key, int* value) {
+    if (!key || !value) return fail(RSP_ERR_BAD_ARG, "key or value is null");
+    const std::string k(key);
+    int pm, rows;
+    bool chosen;
+    if (k == "chunk_rows") *value = chunk_rows_setting();
+    else if (k == "taper_permille") { taper_setting(&pm, &rows, &chosen); *value = pm; }
+    else if (k == "taper_rows") { taper_setting(&pm, &rows, &chosen); *value = rows; }
+    else if (k == "experiment") { const int v = g_variant.load(std::memory_order_relaxed); *value = v < 0 ? env_int("RSP_VARIANT") : v; }
+    else if (k == "lean") *value = lean_setting();
+    else if (k == "columns_form") *value = columns_form_setting();
+    else if (k == "row_segments") *value = row_segments_setting();
+    else if (k == "row_slices") *value = row_slices_setting();
+    else if (k == "auto_plan") *value = auto_plan_setting();
+    else return fail(RSP_ERR_BAD_ARG, "unknown knob '%s'", key);
     return RSP_OK;
 }
 
@@ -430,12 +475,6 @@ int rsp_debug_read_stamps(unsigned long long* host, int n) {   // diagnostic bui
 }
 #endif
 
-int rsp_set_experiment(int variant) {
-    if (variant < 0) return fail(RSP_ERR_BAD_ARG, "variant is negative");
-    g_variant.store(variant, std::memory_order_relaxed);
-    return RSP_OK;
-}
-
 size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz) {
     (void)ncol;
     if (nnz <= 0 || nnz > INT32_MAX) return 256;
@@ -444,17 +483,19 @@ size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz) {
     return rsp::workspace_bytes_for(make_plan(nnz).nchunks);
 }
 
+static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
+                        size_t ws_bytes, double divisor, bool means, hipStream_t stream);
+
 int rsp_column_sums_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,
                            double* d_sums, void* d_workspace, size_t workspace_bytes, void* stream) {
-    return enqueue(d_x, d_p, ncol, nnz, d_sums, d_workspace, workspace_bytes, 1.0, false,
-                   (hipStream_t)stream);
+    return auto_enqueue(d_x, d_p, ncol, nnz, d_sums, d_workspace, workspace_bytes, 1.0, false, (hipStream_t)stream);
 }
 
 int rsp_column_means_device(const double* d_x, const int32_t* d_p, int32_t nrow, int32_t ncol,
                             int64_t nnz, double* d_means, void* d_workspace, size_t workspace_bytes,
                             void* stream) {
-    return enqueue(d_x, d_p, ncol, nnz, d_means, d_workspace, workspace_bytes, (double)nrow, true,
-                   (hipStream_t)stream);
+    return auto_enqueue(d_x, d_p, ncol, nnz, d_means, d_workspace, workspace_bytes, (double)nrow, true,
+                        (hipStream_t)stream);
 }
 
 // A plan's image goes to the device over a non-blocking stream of its own: a copy on the legacy null stream would
@@ -759,16 +800,6 @@ int rsp_debug_plan_image(rsp_colsums_plan_t plan, int what, void* host, size_t c
     return RSP_OK;
 }
 
-int rsp_set_lean(int on) {
-    g_lean.store(on <= 0 ? 0 : (on >= 2 ? 2 : 1), std::memory_order_relaxed);
-    return RSP_OK;
-}
-
-int rsp_set_columns_form(int mode) {
-    g_columns_form.store(mode <= 0 ? 0 : (mode >= 2 ? 2 : 1), std::memory_order_relaxed);
-    return RSP_OK;
-}
-
 int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t* info4, double* inspect_ms) {
     if (!plan || !info4) return fail(RSP_ERR_BAD_ARG, "null plan or output");
     if (int rc = plan_poll(plan, nullptr, true)) return rc;   // (a device-made plan: wait for its inspection)
@@ -797,6 +828,81 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
     delete plan;
     return RSP_OK;
 }
+
+// ---- the plan-free device entries plan for themselves --------------------------------------------------------
+// rsp_column_sums_device / rsp_column_means_device are what a caller with device pointers uses when it knows
+// nothing about plans (BASELINE config 2 through them: 0.46-0.51 of the HBM roofline on the general kernels, 0.70
+// through a plan).  The library therefore remembers the offsets it has been shown: the FIRST call on (device, d_p,
+// ncol, nnz) runs the general kernels and enqueues the device-side inspection of d_p BEHIND them on the caller's
+// stream (23 us for 1e6 columns, nothing waits); once the host has seen the statistics (an event query per call,
+// never a wait) calls with that key take the form they select -- lean (every column short: one launch, the
+// reference's bits) or columns (every column long: one launch); matrices with neither keep the general kernels and
+// cost nothing further.
+// Nobody has promised that d_p still holds the offsets that were inspected.  The kernels of this path do not rest
+// on it: the lean kernel compares every column's image offsets with the p[] of THIS call and sums a column that
+// differs straight from x; the columns kernel reads p[] itself.  Both clamp to [0, nnz] and raise a page-locked
+// `stale` word, and a call that finds it raised inspects again (a fresh image; the old one is kept until
+// rsp_release_cached, a launch of an earlier call on another stream may still be reading it) -- after kAutoMaxStrikes
+// such rounds the key stays on the general kernels.  So: never a wrong sum, whatever the caller does with d_p.
+// A call on a CAPTURING stream never inspects, polls or allocates: it records the form known at that moment, and a
+// replayed lean / columns launch validates against the p[] of the replay like any other.
+// What this costs a caller: results of the first calls (general kernels) and of later ones (planned form) agree
+// within the documented tolerance, not bit for bit, and the call at which the form changes depends on when the
+// statistics arrive.  rsp_debug_set("auto_plan", 0) / RSP_AUTO_PLAN=0 keeps every call on the general kernels
+// (bit-stable from the first call); explicit plans and handles are as deterministic as before; the one-shot host
+// entry never plans (it sees new offsets at the same address in every call).
+namespace {
+constexpr int kAutoMaxEntries = 16;
+constexpr int kAutoMaxStrikes = 4;
+constexpr int64_t kAutoMinNnz = 1 << 20;   // smaller calls are launch-bound either way: two launches against one, nothing to plan for
+struct AutoEntry {
+    int device = -1;
+    const int32_t* d_p = nullptr;
+    int32_t ncol = 0;
+    int64_t nnz = 0;
+    rsp_colsums_plan* plan = nullptr;   // device-made; nullptr: dead (stays on the general kernels)
+    int32_t* h_stale = nullptr;         // page-locked: raised by a kernel that found p[] changed under the plan
+    uint64_t last_use = 0;
+    int strikes = 0;
+    int last_form = 0;                  // form of the most recent call with this key (rsp_column_sums_device_form)
+    std::vector<rsp_colsums_plan*> retired;
+};
+std::mutex g_auto_mu;
+std::vector<AutoEntry> g_auto;
+uint64_t g_auto_tick = 0;
+
+int auto_plan_setting() {
+    int v = g_auto_plan.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static const int env = [] {
+            const char* s = getenv("RSP_AUTO_PLAN");
+            return (s && s[0]) ? (atoi(s) != 0 ? 1 : 0) : 1;
+        }();
+        v = env;
+    }
+    return v;
+}
+
+void auto_entry_release(AutoEntry& e) {   // caller holds g_auto_mu; the device has been synchronised
+    DeviceGuard on(e.device);
+    if (e.plan) rsp_column_sums_plan_destroy(e.plan);
+    for (rsp_colsums_plan* r : e.retired) rsp_column_sums_plan_destroy(r);
+    if (e.h_stale) (void)hipHostFree(e.h_stale);
+    e.plan = nullptr;
+    e.retired.clear();
+    e.h_stale = nullptr;
+}
+
+void auto_release_all() {
+    std::lock_guard<std::mutex> lock(g_auto_mu);
+    for (AutoEntry& e : g_auto) {
+        DeviceGuard on(e.device);
+        (void)hipDeviceSynchronize();   // launches that read an image may still be in flight on any stream
+        auto_entry_release(e);
+    }
+    g_auto.clear();
+}
+}  // namespace
 
 static int planned_enqueue(rsp_colsums_plan_t plan, const double* d_x, const int32_t* d_p, double* d_out,
                            void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
@@ -847,6 +953,122 @@ int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double* d_x, c
     return planned_enqueue(plan, d_x, d_p, d_sums, d_workspace, workspace_bytes,
                            nrow_for_means > 0 ? (double)nrow_for_means : 1.0, nrow_for_means > 0,
                            (hipStream_t)stream);
+}
+
+static int auto_inspect(AutoEntry& e, hipStream_t stream) {   // caller holds g_auto_mu; enqueues behind what is on `stream`
+    rsp_colsums_plan* pl = nullptr;
+    if (rsp_column_sums_plan_create_device(e.d_p, e.ncol, e.nnz, stream, &pl) != RSP_OK) {
+        e.plan = nullptr;   // (no memory for an image: this key stays on the general kernels; not an error of the call)
+        return RSP_OK;
+    }
+    e.plan = pl;
+    return RSP_OK;
+}
+
+static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
+                        size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
+    if (auto_plan_setting() == 0 || nnz < kAutoMinNnz || ncol <= 0 || nnz > INT32_MAX || !d_p || !d_x || !d_out ||
+        ((uintptr_t)d_x & 15) != 0)
+        return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_auto_mu);
+    ++g_auto_tick;
+    AutoEntry* e = nullptr;
+    for (AutoEntry& c : g_auto)
+        if (c.device == device && c.d_p == d_p && c.ncol == ncol && c.nnz == nnz) e = &c;
+    if (!e) {
+        // the general kernels answer this call; the inspection goes behind them (a capture records no inspection)
+        if (int rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream)) return rc;
+        if (capturing) return RSP_OK;
+        if ((int)g_auto.size() >= kAutoMaxEntries) {
+            // full: the entry that has gone unused longest makes room -- if it has been idle for a while (its images may
+            // still be read by launches in flight: the device is waited for, which is why this is kept rare)
+            size_t victim = 0;
+            for (size_t k = 1; k < g_auto.size(); ++k)
+                if (g_auto[k].last_use < g_auto[victim].last_use) victim = k;
+            if (g_auto_tick - g_auto[victim].last_use < 64) return RSP_OK;   // everything in use: this key stays unplanned
+            {
+                DeviceGuard on(g_auto[victim].device);
+                (void)hipDeviceSynchronize();
+                auto_entry_release(g_auto[victim]);
+            }
+            g_auto.erase(g_auto.begin() + (long)victim);
+        }
+        AutoEntry ne;
+        ne.device = device;
+        ne.d_p = d_p;
+        ne.ncol = ncol;
+        ne.nnz = nnz;
+        ne.last_use = g_auto_tick;
+        if (hipHostMalloc((void**)&ne.h_stale, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return RSP_OK;
+        }
+        *ne.h_stale = 0;
+        auto_inspect(ne, stream);
+        if (!ne.plan) {
+            (void)hipHostFree(ne.h_stale);
+            return RSP_OK;
+        }
+        g_auto.push_back(ne);
+        return RSP_OK;
+    }
+    e->last_use = g_auto_tick;
+    rsp_colsums_plan* pl = e->plan;
+    if (pl && !capturing && *(volatile int32_t*)e->h_stale != 0) {
+        // a kernel found p[] changed under the plan: this call on the general kernels, a fresh inspection behind it
+        // (into a NEW image: a launch of an earlier call may still be reading the old one)
+        if (int rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream)) return rc;
+        e->last_form = 0;
+        (void)plan_poll(pl, stream, false);
+        e->retired.push_back(pl);
+        e->plan = nullptr;
+        *(volatile int32_t*)e->h_stale = 0;
+        if (++e->strikes < kAutoMaxStrikes) auto_inspect(*e, stream);
+        return RSP_OK;
+    }
+    if (pl && !pl->known && !capturing) {
+        if (int rc = plan_poll(pl, stream, false)) return rc;
+    }
+    if (pl && pl->known && pl->lean) {
+        HIP_TRY(rsp::launch_column_sums_lean(d_x, (int32_t)nnz, pl->d_lean_hdr, pl->d_lean_offs, pl->lean_stride_dwords,
+                                             pl->lean_chunks, pl->lean_rows, d_out, divisor, means, stream, d_p, ncol,
+                                             e->h_stale));
+        e->last_form = 2;
+        return RSP_OK;
+    }
+    if (pl && pl->known && pl->columns) {
+        // lengths the choice of the form rested on, with room: a column outside [min / 4, 4 max] says the matrix has changed
+        const int32_t lo = pl->columns_min / 4, hi = pl->columns_max > rsp::kColumnsMaxLen / 4 ? rsp::kColumnsMaxLen : 4 * pl->columns_max;
+        HIP_TRY(rsp::launch_column_sums_columns(d_x, d_p, ncol, pl->columns_waves, d_out, divisor, means, stream, (int32_t)nnz,
+                                                lo, hi, e->h_stale));
+        e->last_form = 3;
+        return RSP_OK;
+    }
+    e->last_form = 0;
+    return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
+}
+
+int rsp_column_sums_device_form(const int32_t* d_p, int32_t ncol, int64_t nnz, int wait) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    std::lock_guard<std::mutex> lock(g_auto_mu);
+    for (AutoEntry& c : g_auto)
+        if (c.device == device && c.d_p == d_p && c.ncol == ncol && c.nnz == nnz) {
+            if (!c.plan) return 0;                               // given up on: the general kernels
+            if (!c.plan->known) {
+                if (plan_poll(c.plan, nullptr, wait != 0) != RSP_OK || !c.plan->known) return -1;
+            }
+            return c.plan->lean ? 2 : (c.plan->columns ? 3 : 0);   // (a snapped plan is not taken here: general kernels)
+        }
+    return -1;
 }
 
 int rsp_column_reduce_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, int op,
@@ -908,11 +1130,6 @@ int rsp_column_sums_in_rows_form(int32_t nrow, int32_t ncol, int64_t nnz, size_t
         workspace_bytes >= rsp::workspace_bytes_for(make_plan(nnz).nchunks) + kRowSlicesFlagBytes)
         return RSP_IN_ROWS_FORM_SLICES;
     return RSP_IN_ROWS_FORM_L2;
-}
-
-int rsp_set_row_slices(int on) {
-    g_row_slices.store(on <= 0 ? 0 : (on >= 2 ? 2 : 1), std::memory_order_relaxed);
-    return RSP_OK;
 }
 
 int rsp_column_sums_device_timed(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,
@@ -1263,10 +1480,6 @@ int rsp_csc_row_form(rsp_csc_t h) {
     return h->row_layout.mode == 3 ? RSP_ROW_FORM_TWO_LEVEL : RSP_ROW_FORM_PARTITION;
 }
 
-int rsp_set_row_segments(int mode) {
-    g_row_segments.store(mode <= 0 ? 0 : (mode >= 2 ? 2 : 1), std::memory_order_relaxed);
-    return RSP_OK;
-}
 int rsp_csc_row_means(rsp_csc_t h, double* means) { return csc_rows(h, means, true); }
 
 // ---- Matrix::crossprod (RcppSparse.h:159-194) -----------------------------------------------
@@ -1410,6 +1623,7 @@ void arena_release(OneShotArena& a) {   // caller holds a.mu and has made the de
 }  // namespace
 
 int rsp_release_cached(void) {
+    auto_release_all();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
         (void)hipGetLastError();

@@ -192,8 +192,10 @@ constexpr int kColumnsMaxLen = 1 << 22;    // longest (its bytes stay far below 
 constexpr int kColumnsMaxOverMean = 4;     // no column longer than this many times the mean (one workgroup walks it)
 constexpr int kColumnsMinColumns = 128;
 constexpr int kColumnsFewMaxLen = 45056;   // fewer columns than that take the form too while the longest column has at most this many entries + nnz / 192: one workgroup streams a column alone (3.3 us + 0.14 us per 1000 entries) against the general kernels' 8.5 us + 1.1 us per 1e6 entries of the whole call (8..127 columns of 3e3..3e5 entries, profiles/r04_form_edges.json)
+// stale != nullptr: the guarded build (offsets clamped to [0, nnz]; a column length outside [len_lo, len_hi] sets *stale)
 hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t waves,
-                                      double* d_out, double divisor, bool means, hipStream_t stream);
+                                      double* d_out, double divisor, bool means, hipStream_t stream, int32_t nnz = 0,
+                                      int32_t len_lo = 0, int32_t len_hi = 0, int32_t* stale = nullptr);
 
 // Segments form of the row sums (rowsums.hip): behind a handle whose columns' rows ascend; no regrouped copy
 struct RowSegmentsLayout {
@@ -211,9 +213,12 @@ hipError_t launch_row_segments_reduce(const double* d_x, const int32_t* d_i, int
                                       const RowSegmentsLayout& L, void* persist, double* d_out, double divisor,
                                       bool means, hipStream_t stream);
 
+// d_p and stale given: the self-validating build (every column's image offsets compared with d_p; a column that differs is
+// summed again straight from x and *stale is set)
 hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d_hdr, const uint32_t* d_offs,
                                    int32_t stride_dwords, int32_t nchunks, int32_t rows, double* d_out, double divisor,
-                                   bool means, hipStream_t stream);
+                                   bool means, hipStream_t stream, const int32_t* d_p = nullptr, int32_t ncol = 0,
+                                   int32_t* stale = nullptr);
 
 // out[j] = ((part_0[j] + part_1[j]) + ...) + part_{nparts-1}[j] (+ 0.0, / divisor): the shards' partial row sums
 // added in shard order.  part_k = parts + k * stride, except part own_idx = own (own_idx < 0: none).

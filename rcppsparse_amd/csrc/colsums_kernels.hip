@@ -1192,10 +1192,20 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 // column's entries from LDS in storage order from +0.0: EVERY column comes out bit-identical to the reference
 // loop (src/example.cpp:28-30), also the one that reaches past the chunk's grid end (the chunk reads one row
 // more: the inspector guarantees no column reaches further).  One launch, no carries, no workspace.
-template <bool MEANS, int R>   // R = rows of x per chunk
+//
+// VALIDATE (the plan-free entry's own plans, capi.hip auto_enqueue): the image was made from the p[] that stood at this
+// address some calls ago, and nobody has promised that it still stands there.  Every lane therefore also loads ITS
+// column's two offsets from the p[] of THIS call and compares them with the image's: equal -> the sum it made from LDS is
+// the sum of exactly [p[c], p[c + 1]) and is stored; different -> the column is summed again straight from x[p[c] ..
+// p[c + 1]) by the whole wavefront (any length, clamped to [0, nnz]: reads stay in bounds for any p[]) and *stale is
+// set, which makes the host inspect again behind a later call.  Every column belongs to exactly one lane of one chunk
+// (the image is a complete image of SOME offsets of the same ncol), so the result is right for ANY p[] -- the image only
+// decides how fast.  Costs 4 B per column of extra reads, one round trip behind the header, off the sums' own path.
+template <bool MEANS, int R, bool VALIDATE = false>   // R = rows of x per chunk
 __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
     const double* __restrict__ x, int32_t nnz, const int2* __restrict__ hdr, const uint32_t* __restrict__ offs,
-    int32_t stride_dwords, int32_t nchunks, double* __restrict__ out, double divisor) {
+    int32_t stride_dwords, int32_t nchunks, double* __restrict__ out, double divisor,
+    const int32_t* __restrict__ p = nullptr, int32_t ncol = 0, int32_t* __restrict__ stale = nullptr) {
 #pragma clang fp contract(off)
     typedef Policy<MEANS, kOpSum> P;
     constexpr int kElems = (R + 1) * kRowElems;   // the chunk's rows and the one after
@@ -1235,6 +1245,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
     for (int t0 = 0; t0 < ncols; t0 += 64) {
         const int col = t0 + lane;
         const bool active = col < ncols;
+        int32_t plo = 0, phi = 0;
+        if (VALIDATE && active) {   // (c0 + ncols <= ncol by construction of the image: p[c0 + col + 1] exists)
+            plo = p[c0 + col];
+            phi = p[c0 + col + 1];
+        }
         const int lo = active ? (int)off16[col] : 0;
         const int hi = active ? (int)off16[col + 1] : 0;
         const int n = hi - lo;   // (0 <= lo <= hi <= kElems by construction of the plan)
@@ -1253,24 +1268,48 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
             const double t0_ = s + e0, t1 = t0_ + e1, t2 = t1 + e2;
             s = rem == 0 ? s : (rem == 1 ? t0_ : (rem == 2 ? t1 : t2));
         }
-        if (active) out[c0 + col] = P::finish(s, divisor);
+        if (!VALIDATE) {
+            if (active) out[c0 + col] = P::finish(s, divisor);
+        } else {
+            // the image's [lo, hi) against this call's offsets (unsigned: cs + lo may pass 2^31 - 1 near the end of x)
+            const bool same = (uint32_t)plo == (uint32_t)cs + (uint32_t)lo && (uint32_t)phi == (uint32_t)cs + (uint32_t)hi;
+            if (active && same) out[c0 + col] = P::finish(s, divisor);
+            uint64_t bad = __ballot(active && !same);
+            if (bad != 0ull && lane == 0) *stale = 1;
+            while (bad != 0ull) {   // rare: p[] changed under the plan -- these columns straight from x, whole wavefront each
+                const int l = __builtin_ctzll(bad);
+                bad &= bad - 1;
+                int32_t a = __builtin_amdgcn_readlane(plo, l), b = __builtin_amdgcn_readlane(phi, l);
+                a = a < 0 ? 0 : (a > nnz ? nnz : a);
+                b = b < a ? a : (b > nnz ? nnz : b);
+                double part = 0.0;
+                for (int64_t j = (int64_t)a + lane; j < (int64_t)b; j += 64) part += x[j];
+                const double total = wave_allreduce<P>(part);
+                if (lane == l) out[c0 + col] = P::finish(total, divisor);
+            }
+        }
     }
 }
 
 hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d_hdr, const uint32_t* d_offs,
                                    int32_t stride_dwords, int32_t nchunks, int32_t rows, double* d_out, double divisor,
-                                   bool means, hipStream_t stream) {
+                                   bool means, hipStream_t stream, const int32_t* d_p, int32_t ncol, int32_t* stale) {
     if (nchunks <= 0) return hipSuccess;
     const dim3 grid((nchunks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * 64);
     const size_t lds = (size_t)kWavesPerWG * (size_t)stride_dwords * 4;
+    const bool validate = d_p != nullptr && stale != nullptr;
+#define RSP_LEAN_V(R_, M_, V_)                                                                                       \
+    hipLaunchKernelGGL((colsums_lean_kernel<M_, R_, V_>), grid, block, lds, stream, d_x, nnz, d_hdr, d_offs,          \
+                       stride_dwords, nchunks, d_out, divisor, d_p, ncol, stale)
 #define RSP_LEAN(R_)                                                                                               \
     do {                                                                                                            \
-        if (means)                                                                                                  \
-            hipLaunchKernelGGL((colsums_lean_kernel<true, R_>), grid, block, lds, stream, d_x, nnz, d_hdr, d_offs,    \
-                               stride_dwords, nchunks, d_out, divisor);                                             \
-        else                                                                                                        \
-            hipLaunchKernelGGL((colsums_lean_kernel<false, R_>), grid, block, lds, stream, d_x, nnz, d_hdr, d_offs,   \
-                               stride_dwords, nchunks, d_out, divisor);                                             \
+        if (means) {                                                                                                \
+            if (validate) RSP_LEAN_V(R_, true, true);                                                               \
+            else RSP_LEAN_V(R_, true, false);                                                                       \
+        } else {                                                                                                    \
+            if (validate) RSP_LEAN_V(R_, false, true);                                                              \
+            else RSP_LEAN_V(R_, false, false);                                                                      \
+        }                                                                                                           \
     } while (0)
     switch (rows) {
         case 2: RSP_LEAN(2); break;
@@ -1284,6 +1323,7 @@ hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d
         default: return hipErrorInvalidValue;
     }
 #undef RSP_LEAN
+#undef RSP_LEAN_V
     return hipGetLastError();
 }
 
@@ -1299,21 +1339,34 @@ hipError_t launch_column_sums_lean(const double* d_x, int32_t nnz, const int2* d
 // where the column ends (what lies beyond reads as +0.0, so there is no tail code); lane sums -> fixed wave tree ->
 // the wavefronts' sums added in wavefront order by one lane.  One launch, no workspace, no plan memory.
 // Deterministic; like the general kernel on long columns, within tolerance of the reference's order, not its bits.
-template <int WPG, bool MEANS>
+// GUARDED (the plan-free entry's own plans): the offsets are this call's, so the sums are right whatever stood at p[]
+// when the plan was made; they are clamped to [0, nnz] (reads stay in bounds for any p[]) and a column outside
+// [len_lo, len_hi] -- lengths the choice of this form did not rest on -- sets *stale, so that the host inspects again.
+template <int WPG, bool MEANS, bool GUARDED = false>
 __global__ __launch_bounds__(WPG * 64) void colsums_columns_kernel(const double* __restrict__ x,
                                                                    const int32_t* __restrict__ p, int32_t ncol,
-                                                                   double* __restrict__ out, double divisor) {
+                                                                   double* __restrict__ out, double divisor,
+                                                                   int32_t nnz = 0, int32_t len_lo = 0, int32_t len_hi = 0,
+                                                                   int32_t* __restrict__ stale = nullptr) {
     typedef Policy<MEANS, kOpSum> P;
     __shared__ double s_part[WPG];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int c = blockIdx.x;
-    const int32_t lo = p[c], hi = p[c + 1];
+    int32_t lo = p[c], hi = p[c + 1];
+    if (GUARDED) {
+        lo = lo < 0 ? 0 : (lo > nnz ? nnz : lo);
+        hi = hi < lo ? lo : (hi > nnz ? nnz : hi);
+        if (threadIdx.x == 0 && (hi - lo < len_lo || hi - lo > len_hi)) *stale = 1;
+    }
     const int32_t n = hi - lo;
     const int32_t nrows = (int32_t)(((int64_t)n + kRowElems - 1) / kRowElems);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + lo), 0, n * 8, 0x00020000);
     double a0 = 0.0, a1 = 0.0;
     constexpr int kInFlight = 8;
+    if (GUARDED && n > kColumnsMaxLen) {   // (a column no plan of this form was made for: its bytes may not fit a descriptor)
+        for (int64_t j = (int64_t)lo + threadIdx.x; j < (int64_t)hi; j += WPG * 64) a0 += x[j];
+    } else
     for (int r0 = wave; r0 < nrows; r0 += WPG * kInFlight) {
         d2 v[kInFlight];
 #pragma unroll
@@ -1337,16 +1390,22 @@ __global__ __launch_bounds__(WPG * 64) void colsums_columns_kernel(const double*
 }
 
 hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int32_t ncol, int32_t waves,
-                                      double* d_out, double divisor, bool means, hipStream_t stream) {
+                                      double* d_out, double divisor, bool means, hipStream_t stream, int32_t nnz,
+                                      int32_t len_lo, int32_t len_hi, int32_t* stale) {
     if (ncol <= 0) return hipSuccess;
+    const bool guarded = stale != nullptr;
+#define RSP_COLUMNS_G(W_, M_, G_)                                                                                 \
+    hipLaunchKernelGGL((colsums_columns_kernel<W_, M_, G_>), dim3(ncol), dim3(W_ * 64), 0, stream, d_x, d_p, ncol,  \
+                       d_out, divisor, nnz, len_lo, len_hi, stale)
 #define RSP_COLUMNS(W_)                                                                                          \
     do {                                                                                                         \
-        if (means)                                                                                               \
-            hipLaunchKernelGGL((colsums_columns_kernel<W_, true>), dim3(ncol), dim3(W_ * 64), 0, stream, d_x, d_p, \
-                               ncol, d_out, divisor);                                                            \
-        else                                                                                                     \
-            hipLaunchKernelGGL((colsums_columns_kernel<W_, false>), dim3(ncol), dim3(W_ * 64), 0, stream, d_x, d_p, \
-                               ncol, d_out, divisor);                                                            \
+        if (means) {                                                                                             \
+            if (guarded) RSP_COLUMNS_G(W_, true, true);                                                          \
+            else RSP_COLUMNS_G(W_, true, false);                                                                 \
+        } else {                                                                                                 \
+            if (guarded) RSP_COLUMNS_G(W_, false, true);                                                         \
+            else RSP_COLUMNS_G(W_, false, false);                                                                \
+        }                                                                                                        \
     } while (0)
     switch (waves) {
         case 2: RSP_COLUMNS(2); break;
@@ -1356,6 +1415,7 @@ hipError_t launch_column_sums_columns(const double* d_x, const int32_t* d_p, int
         default: return hipErrorInvalidValue;
     }
 #undef RSP_COLUMNS
+#undef RSP_COLUMNS_G
     return hipGetLastError();
 }
 

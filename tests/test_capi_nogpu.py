@@ -128,7 +128,9 @@ def test_argument_errors_do_not_need_a_device():
     rc = L.rsp_column_sums_host(None, p.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), -3, 0,
                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0)
     assert rc == capi.RSP_ERR_BAD_ARG
-    assert L.rsp_set_tuning(-1) == capi.RSP_ERR_BAD_ARG and L.rsp_set_experiment(-1) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_debug_set(b"chunk_rows", -1) == capi.RSP_ERR_BAD_ARG and L.rsp_debug_set(b"experiment", -1) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_debug_set(b"no_such_knob", 1) == capi.RSP_ERR_BAD_ARG and b"no_such_knob" in L.rsp_last_error()
+    assert L.rsp_debug_set(None, 1) == capi.RSP_ERR_BAD_ARG
     assert L.rsp_partition_columns(None, 3, 2, None) == capi.RSP_ERR_BAD_ARG
     assert L.rsp_csc_free(None) == capi.RSP_OK          # freeing nothing is fine
     assert L.rsp_comm_destroy(None) == capi.RSP_OK
@@ -178,7 +180,7 @@ def test_chunk_plan_tiles_x_exactly(nnz):
 def test_automatic_chunk_plan_policy():
     """The automatic policy: short calls (one round of wavefronts) get 20-row chunks and no taper; calls of
     more than two rounds get 256-row chunks with the last tenth of x in 64-row chunks; an explicit
-    rsp_set_tuning switches the taper off."""
+    rsp_debug_set("chunk_rows", n) switches the taper off."""
     c2 = capi.plan_describe(10**7)
     assert c2["body_elems"] == 20 * 128 and c2["nchunks"] == c2["nbody"] == -(-78125 // 20)
     shard = capi.plan_describe(125_000_000)

@@ -1,0 +1,356 @@
+"""-m gpu: the plan-free device entries plan for themselves (round 5).
+
+rsp_column_sums_device / rsp_column_means_device (include/rcppsparse_hip.h) remember the offsets they are shown: the
+first call with (device, d_p, ncol, nnz) runs the general kernels and enqueues a device-side inspection of d_p behind
+them; once the host has seen its result, calls with that key take the lean form (every column short: one launch, the
+reference's bits) or the columns form (every column long).  The caller promises nothing about d_p between calls, so
+the kernels of this path check every column's offsets against the p[] of the call they run in -- what these tests are
+mostly about: offsets changed in place under an adopted plan, captured calls replayed over changed offsets, two
+matrices over two workspaces and streams, offsets that are not a dgCMatrix's at all.  Never a wrong sum, only a slower
+call.  The reference has one synchronous call and no such state (src/example.cpp:26-32): the oracle is its loop."""
+import numpy as np
+import pytest
+
+import oracle
+from rcppsparse_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def torch_auto():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked tests need a GPU: the HIP path has no CPU fallback")
+    capi.load()
+    capi.set_auto_plan(True)          # (the suite's default is off: tests/conftest.py)
+    capi.release_cached()
+    yield torch
+    capi.release_cached()
+    capi.set_auto_plan(False)
+
+
+def check(got, x, p, exact=False):
+    ref = oracle.column_sums(x, p)
+    if exact:
+        assert got.tobytes() == ref.tobytes()
+        return
+    scale = oracle.column_abs_sums(x, p)
+    err = np.abs(got - ref)
+    assert np.all(err <= RTOL * scale), float(np.max(err / np.maximum(scale, 1e-300)))
+    empty = np.diff(p) == 0
+    assert np.all(got[empty] == 0.0) and not np.any(np.signbit(got[empty]))
+
+
+def short_matrix(ncol, mean, seed):
+    """every column <= 64 entries (the lean form's shape: BASELINE config 2 is 1e6 columns of ~10)"""
+    rng = np.random.default_rng(seed)
+    counts = np.minimum(rng.poisson(mean, size=ncol), 64).astype(np.int64)
+    counts[rng.integers(0, ncol, size=ncol // 50)] = 0
+    p = synth.offsets_from_counts(counts)
+    return p, synth.gen_values(int(p[-1]), seed=seed, kind=0)
+
+
+def settled(torch, xt, pt, out, ws, stream=None):
+    """calls until the entry has settled on a form for these offsets; returns the form"""
+    capi.column_sums_device(xt, pt, out, ws, stream=stream)
+    form = capi.column_sums_device_form(pt, xt.numel(), wait=True)
+    capi.column_sums_device(xt, pt, out, ws, stream=stream)
+    torch.cuda.synchronize()
+    return form
+
+
+def test_c2_shaped_calls_settle_on_the_lean_form_with_the_references_bits(torch_auto):
+    torch = torch_auto
+    p, x = short_matrix(300_000, 10, seed=1)
+    nnz = int(p[-1])
+    assert nnz >= 2**20
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.empty(len(p) - 1, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(len(p) - 1, nnz)
+    assert capi.column_sums_device_form(pt, nnz) == "unknown"                  # never seen
+    capi.column_sums_device(xt, pt, out, ws)
+    first = out.cpu().numpy()
+    check(first, x, p)                                                         # the general kernels answered the first call
+    assert capi.column_sums_device_form(pt, nnz, wait=True) == "lean"
+    capi.column_sums_device(xt, pt, out, ws)
+    check(out.cpu().numpy(), x, p, exact=True)                                 # lean: every column in the reference's order
+    # ... bit-identical to the form a caller gets by asking for a plan
+    capi.set_lean(1)
+    plan = capi.ColumnSumsPlan(p, nnz=nnz)
+    assert plan.lean
+    assert plan.column_sums(xt, pt).cpu().numpy().tobytes() == out.cpu().numpy().tobytes()
+    plan.close()
+    # another x behind the same offsets is the same key (bench.py rotates copies of x): still lean, still exact
+    x2 = synth.gen_values(nnz, seed=77, kind=0)
+    capi.column_sums_device(torch.from_numpy(x2).cuda(), pt, out, ws)
+    check(out.cpu().numpy(), x2, p, exact=True)
+    # colMeans through the same entry and the same plan (RcppSparse.h:145-150)
+    means = capi.column_sums_device(xt, pt, nrow_for_means=12345).cpu().numpy()
+    assert means.tobytes() == (oracle.column_sums(x, p) / 12345).tobytes()
+
+
+def test_offsets_changed_in_place_under_an_adopted_plan_never_give_wrong_sums(torch_auto):
+    """The same device buffers, new contents -- what a caching allocator or an in-place update of the matrix does.  The
+    call right after the change runs the stale lean image: every changed column is caught by the kernel's own comparison and
+    summed straight from x.  The call after that inspects again; then the new matrix has its own plan."""
+    torch = torch_auto
+    ncol = 250_000
+    p, x = short_matrix(ncol, 9, seed=2)
+    nnz = int(p[-1])
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    assert settled(torch, xt, pt, out, ws) == "lean"
+    rng = np.random.default_rng(3)
+    variants = []
+    # (a) a few boundaries moved by one or two entries; (b) another matrix altogether, same ncol and nnz;
+    # (c) one giant column swallowing a third of x and a run of empty columns; (d) everything in the last column
+    a = p.copy()
+    for c in rng.integers(1, ncol - 1, size=200):
+        if a[c - 1] < a[c] < a[c + 1]:
+            a[c] += int(rng.integers(-1, 2))
+    variants.append(a)
+    counts = rng.multinomial(nnz, np.full(ncol, 1.0 / ncol)).astype(np.int64)
+    variants.append(synth.offsets_from_counts(counts))
+    g = np.zeros(ncol, dtype=np.int64)
+    g[1000] = nnz // 3
+    rest = nnz - nnz // 3
+    g[50_000:50_000 + rest // 7] = 7
+    g[ncol - 1] += nnz - int(g.sum())
+    variants.append(synth.offsets_from_counts(g))
+    last = np.zeros(ncol + 1, dtype=np.int32)
+    last[-1] = nnz
+    variants.append(last)
+    for q in variants:
+        q = np.ascontiguousarray(q, dtype=np.int32)
+        assert q[0] == 0 and q[-1] == nnz and np.all(np.diff(q) >= 0)
+        pt.copy_(torch.from_numpy(q))                                     # in place: same address, same sizes
+        torch.cuda.synchronize()
+        for _ in range(4):                                                # stale image -> re-inspection -> new plan (or none)
+            out.fill_(-1.0)
+            capi.column_sums_device(xt, pt, out, ws)
+            check(out.cpu().numpy(), x, q)
+        form = capi.column_sums_device_form(pt, nnz, wait=True)
+        assert form in ("lean", "general", "columns")
+        out.fill_(-1.0)
+        capi.column_sums_device(xt, pt, out, ws)
+        check(out.cpu().numpy(), x, q, exact=(form == "lean"))
+
+
+def test_captured_calls_validate_against_the_offsets_of_the_replay(torch_auto):
+    """A HIP graph records whatever form is known when it is captured and looks at nothing itself; the recorded lean launch
+    still compares every column with the p[] it finds at replay time."""
+    torch = torch_auto
+    ncol = 200_000
+    p, x = short_matrix(ncol, 11, seed=4)
+    nnz = int(p[-1])
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert settled(torch, xt, pt, out, ws) == "lean"
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            capi.column_sums_device(xt, pt, out, ws)
+        out.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        check(out.cpu().numpy(), x, p, exact=True)
+        # new values AND new offsets in the captured buffers: the replay sums the new matrix
+        p2, x2 = short_matrix(ncol, 11, seed=5)
+        n2 = int(p2[-1])
+        if n2 > nnz:                                                       # same sizes: cut or pad the last columns
+            p2 = np.minimum(p2, nnz).astype(np.int32)
+        else:
+            p2 = p2.copy()
+            p2[-1] = nnz
+        x2 = synth.gen_values(nnz, seed=55, kind=0)
+        xt.copy_(torch.from_numpy(x2))
+        pt.copy_(torch.from_numpy(p2))
+        out.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        check(out.cpu().numpy(), x2, p2)
+        g.replay()                                                         # (nothing learns inside a graph: still right)
+        torch.cuda.synchronize()
+        check(out.cpu().numpy(), x2, p2)
+    # a capture of a key the library has never seen records the general kernels and plans nothing
+    p3, x3 = short_matrix(150_000, 10, seed=6)
+    xt3, pt3 = torch.from_numpy(x3).cuda(), torch.from_numpy(p3).cuda()
+    out3 = torch.empty(len(p3) - 1, dtype=torch.float64, device="cuda")
+    ws3 = capi.alloc_workspace(len(p3) - 1, len(x3))
+    with torch.cuda.stream(s):
+        g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g3, stream=s):
+            capi.column_sums_device(xt3, pt3, out3, ws3)
+        g3.replay()
+        torch.cuda.synchronize()
+    check(out3.cpu().numpy(), x3, p3)
+    assert capi.column_sums_device_form(pt3, len(x3)) == "unknown"
+
+
+def test_two_matrices_two_workspaces_two_streams_interleaved(torch_auto):
+    torch = torch_auto
+    mats = []
+    for seed, mean in ((7, 8), (8, 14)):
+        p, x = short_matrix(220_000, mean, seed=seed)
+        mats.append((p, x, torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    wss = [capi.alloc_workspace(220_000, max(len(m[1]) for m in mats)) for _ in range(2)]
+    outs = [[torch.empty(220_000, dtype=torch.float64, device="cuda") for _ in range(2)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for rnd in range(12):                                                  # matrix m over workspace / stream (m + rnd) % 2
+        for m, (p, x, xt, pt) in enumerate(mats):
+            k = (m + rnd) % 2
+            capi.column_sums_device(xt, pt, outs[m][k], wss[k], stream=streams[k])
+        if rnd == 2:
+            for m, (p, x, xt, pt) in enumerate(mats):
+                assert capi.column_sums_device_form(pt, len(x), wait=True) == "lean"
+        torch.cuda.synchronize()
+        for m, (p, x, xt, pt) in enumerate(mats):
+            check(outs[m][(m + rnd) % 2].cpu().numpy(), x, p, exact=rnd > 2)
+
+
+def test_long_columns_settle_on_the_columns_form_and_notice_a_different_matrix(torch_auto):
+    torch = torch_auto
+    ncol = 1000
+    rng = np.random.default_rng(9)
+    counts = rng.integers(3000, 5200, size=ncol).astype(np.int64)          # the reference vignette's shape, smaller
+    p = synth.offsets_from_counts(counts)
+    x = synth.gen_values(int(p[-1]), seed=9, kind=0)
+    nnz = int(p[-1])
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    assert settled(torch, xt, pt, out, ws) == "columns"
+    check(out.cpu().numpy(), x, p)
+    again = out.clone()
+    capi.column_sums_device(xt, pt, out, ws)
+    assert torch.equal(out, again)                                        # settled: bit-stable from here on
+    # the same buffers now hold a matrix of 990 empty columns and 10 giant ones: right at once, re-inspected afterwards
+    g = np.zeros(ncol, dtype=np.int64)
+    g[::100] = nnz // 10
+    g[-1] += nnz - int(g.sum())
+    q = synth.offsets_from_counts(g)
+    pt.copy_(torch.from_numpy(q))
+    for _ in range(3):
+        out.fill_(-1.0)
+        capi.column_sums_device(xt, pt, out, ws)
+        check(out.cpu().numpy(), x, q)
+    assert capi.column_sums_device_form(pt, nnz, wait=True) in ("general", "columns")
+    capi.column_sums_device(xt, pt, out, ws)
+    check(out.cpu().numpy(), x, q)
+
+
+def test_offsets_that_are_no_dgcmatrix_stay_in_bounds_under_an_adopted_plan(torch_auto):
+    """The device entries trust the caller's p[] for the VALUES of the sums only: reads and writes stay in bounds for any
+    content (include/rcppsparse_hip.h) -- also when a lean or columns plan made from valid offsets is in force."""
+    torch = torch_auto
+    rng = np.random.default_rng(10)
+    # (offsets that are garbage name garbage ranges: a call may then be slow -- every column is summed over whatever its two
+    # offsets say -- so the lean case stays small here)
+    for make, want in ((lambda: short_matrix(120_000, 10, seed=11), "lean"),
+                       (lambda: (synth.offsets_from_counts(np.full(600, 4000, dtype=np.int64)),
+                                 synth.gen_values(600 * 4000, seed=12, kind=0)), "columns")):
+        p, x = make()
+        ncol, nnz = len(p) - 1, int(p[-1])
+        xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+        guard = torch.full((ncol + 64,), 7.0, dtype=torch.float64, device="cuda")
+        out = guard[32:32 + ncol]
+        ws = capi.alloc_workspace(ncol, nnz)
+        assert settled(torch, xt, pt, out, ws) == want
+        for bad in (rng.integers(-2**31, 2**31 - 1, size=ncol + 1), np.full(ncol + 1, nnz + 5), np.arange(ncol + 1)[::-1] * 3):
+            pt.copy_(torch.from_numpy(np.ascontiguousarray(bad, dtype=np.int64).astype(np.int32)))
+            capi.column_sums_device(xt, pt, out, ws)
+            torch.cuda.synchronize()                                      # no fault ...
+            assert bool(torch.all(guard[:32] == 7.0)) and bool(torch.all(guard[32 + ncol:] == 7.0))   # ... nothing outside the result
+        pt.copy_(torch.from_numpy(p))
+        for _ in range(3):
+            capi.column_sums_device(xt, pt, out, ws)
+        torch.cuda.synchronize()
+        check(out.cpu().numpy(), x, p)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_adopted_forms_against_the_oracle(torch_auto, seed):
+    """Random shapes on both sides of the forms' conditions, each summed before the plan is known, after it, and after the
+    offsets were replaced in place by another random matrix of the same sizes."""
+    torch = torch_auto
+    rng = np.random.default_rng(100 + seed)
+    kind = seed % 4
+    if kind == 0:        # short columns, some chunks crowded
+        mean = rng.uniform(3, 30)
+        ncol = max(int(rng.integers(120_000, 400_000)), int(1.4e6 / mean))
+        counts = np.minimum(rng.poisson(mean, size=ncol), 64).astype(np.int64)
+    elif kind == 1:      # short columns with long runs of empty ones
+        ncol = int(rng.integers(200_000, 500_000))
+        counts = np.where(rng.random(ncol) < 0.3, rng.integers(1, 65, size=ncol), 0).astype(np.int64)
+    elif kind == 2:      # long similar columns
+        ncol = int(rng.integers(300, 900))
+        counts = rng.integers(4000, 9000, size=ncol).astype(np.int64)
+    else:                # Zipf: neither form
+        ncol = int(rng.integers(5_000, 50_000))
+        counts = synth.zipf_counts(ncol, 2_000_000, seed=seed, nrow=400_000)
+    p = synth.offsets_from_counts(counts)
+    nnz = int(p[-1])
+    if nnz < 2**20:
+        pytest.skip("below the size the entry plans for")
+    x = synth.gen_values(nnz, seed=seed, kind=seed % 2)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    capi.column_sums_device(xt, pt, out, ws)
+    check(out.cpu().numpy(), x, p)
+    form = capi.column_sums_device_form(pt, nnz, wait=True)
+    assert form in ("lean", "columns", "general")
+    if kind == 3:
+        assert form == "general"
+    for _ in range(2):
+        capi.column_sums_device(xt, pt, out, ws)
+    check(out.cpu().numpy(), x, p, exact=(form == "lean"))
+    q = synth.offsets_from_counts(rng.multinomial(nnz, rng.dirichlet(np.full(ncol, 0.7))).astype(np.int64))
+    pt.copy_(torch.from_numpy(q))
+    for _ in range(3):
+        out.fill_(-1.0)
+        capi.column_sums_device(xt, pt, out, ws)
+        check(out.cpu().numpy(), x, q)
+
+
+def test_auto_plan_off_keeps_every_call_on_the_general_kernels(torch_auto):
+    torch = torch_auto
+    p, x = short_matrix(200_000, 10, seed=20)
+    nnz = int(p[-1])
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    capi.set_auto_plan(False)
+    try:
+        assert capi.debug_get("auto_plan") == 0
+        first = capi.column_sums_device(xt, pt).cpu().numpy().tobytes()
+        for _ in range(5):
+            assert capi.column_sums_device(xt, pt).cpu().numpy().tobytes() == first     # bit-stable from the first call
+        assert capi.column_sums_device_form(pt, nnz) == "unknown"
+    finally:
+        capi.set_auto_plan(True)
+    assert capi.debug_get("auto_plan") == 1
+
+
+def test_more_keys_than_the_library_remembers(torch_auto):
+    """16 keys are remembered; further matrices are summed by the general kernels until an old key has gone unused."""
+    torch = torch_auto
+    capi.release_cached()
+    keep = []
+    for k in range(20):
+        p, x = short_matrix(110_000, 10, seed=30 + k)
+        xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+        keep.append((p, x, xt, pt))
+        out = capi.column_sums_device(xt, pt)
+        check(out.cpu().numpy(), x, p)
+    torch.cuda.synchronize()
+    forms = [capi.column_sums_device_form(pt, len(x), wait=True) for p, x, xt, pt in keep]
+    assert forms[:16] == ["lean"] * 16 and set(forms[16:]) <= {"unknown", "lean"}
+    for p, x, xt, pt in keep:
+        check(capi.column_sums_device(xt, pt).cpu().numpy(), x, p)
+    capi.release_cached()
+    assert capi.column_sums_device_form(keep[0][3], len(keep[0][1])) == "unknown"

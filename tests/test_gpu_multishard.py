@@ -126,13 +126,20 @@ def test_bench_line_measures_its_own_ceiling_traffic_and_more_workloads(torch_cu
         k = "also_" + spec.replace(":", "_").replace("-", "_")
         assert roof[k + "_frac"] == r["frac"] and roof[k + "_kernel_ms"] == r["kernel_ms"]
         assert roof[k + "_ms_per_call"] == r["ms_per_call"] and roof[k + "_parity_err"] == r["parity_err"]
-    assert recs["c2"]["form"] == "general" and recs["c2"]["launches"] == 2
+    # the plan-free entry plans for itself (round 5): BASELINE config 2 through rsp_column_sums_device settles on the lean
+    # form by its own device-side inspection -- one launch, the reference's bits -- without the caller asking for a plan
+    assert recs["c2"]["form"] == "lean" and recs["c2"]["launches"] == 1 and recs["c2"]["planned_by"] == "entry"
+    assert recs["c2"]["parity_err"] == 0.0 and recs["c2"]["frac"] > 0.55
     assert recs["c2"]["traffic_in_run"] is True and 0.98 < roof["also_c2_traffic_x"] < 1.15   # re-measured now, not a constant
+    assert recs["c2"]["traffic_kernels"] == "lean"
     for k in ("c2:planned", "c2:planned-device"):
-        assert recs[k]["form"] == "lean" and recs[k]["launches"] == 1
+        assert recs[k]["form"] == "lean" and recs[k]["launches"] == 1 and recs[k]["planned_by"] == "caller"
         assert recs[k]["parity_err"] == 0.0                                               # the reference's bits
-        assert recs[k]["kernel_ms"] < recs["c2"]["kernel_ms"]
+        assert recs[k]["kernel_ms"] < 1.25 * recs["c2"]["kernel_ms"]                      # (the entry's own plan also checks p[]: 4 B per column more)
         assert recs[k]["traffic_in_run"] is False
+    # the headline here, one C4 shard, settles on the columns form the same way
+    assert roof["kernel"].startswith("colsums_columns_kernel") and d["config"]["shards"][0]["form"] == "columns"
+    assert roof["traffic_kernels"] == "columns"
     dev = recs["c2:planned-device"]
     assert dev["plan_by"] == "device" and dev["plan_ms"] < 1.0                            # device time of the inspection kernels
     assert dev["early_general_calls"] >= 0 and recs["c2:planned"]["plan_by"] == "host"
@@ -170,6 +177,10 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     for a, b in zip(shards, shards[1:]):
         assert b["x0"] == a["x1"] > 0 and b["c0"] == a["c1"] > 0      # rank r > 0 starts inside x
     assert all(s["kernel_ms"] > 0 for s in shards)                     # every rank timed its own launches
+    if workload in ("c4shard", "c3"):                                  # every rank's plan-free entry settled on the columns form
+        assert [s["form"] for s in shards] == ["columns"] * world
+    else:
+        assert all(s["form"] in ("general", "lean", "columns") for s in shards)
     per = [s["nnz"] for s in shards]
     assert cfg["shard_imbalance_max_over_mean"] == pytest.approx(max(per) / (sum(per) / world), rel=1e-5)
     assert cfg["shard_imbalance_max_over_mean"] < 1.05

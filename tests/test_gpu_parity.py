@@ -1176,7 +1176,7 @@ def test_rccl_single_rank_gatherv_roundtrip(torch_cuda):
 
 # ------------------------------------------------------------------ robustness
 def test_chunk_rows_knob_is_clamped(torch_cuda):
-    """rsp_set_tuning accepts any chunk_rows, but one chunk never exceeds 1 GiB of x (byte counts
+    """rsp_debug_set("chunk_rows", n) accepts any chunk_rows, but one chunk never exceeds 1 GiB of x (byte counts
     and offsets inside a chunk are 32-bit in the kernel): 2^22 and 2^30 rows per chunk give the
     same, correct sums as the automatic chunking on a matrix spanning several such chunks."""
     torch = torch_cuda
@@ -1203,7 +1203,7 @@ def test_chunk_rows_knob_is_clamped(torch_cuda):
 
 @pytest.mark.parametrize("taper", [(0, 0), (150, 64), (500, 16), (1000, 32), (999, 1)])
 def test_tapered_chunking_keeps_parity_and_bits(torch_cuda, taper):
-    """rsp_set_taper: the last part of x in shorter chunks.  Every setting stays within tolerance
+    """rsp_debug_set("taper_permille" / "taper_rows"): the last part of x in shorter chunks.  Every setting stays within tolerance
     of the oracle, bit-stable (an explicit setting applies to a call of any length), with a giant
     column crossing the body/tail edge and short columns on both sides of it; the tapered plan really
     has more chunks than the plain one."""

@@ -366,7 +366,7 @@ def test_handle_row_sums_take_the_segments_form_where_columns_are_long(torch_cud
     (32_768, 15, 1000, ""), (32_769, 16, 1000, "invalid"),
 ])
 def test_handle_row_sums_segments_form_forced_onto_small_and_odd_shapes(torch_cuda, nrow, ncol, mean, extra):
-    """The segments form on shapes it would not choose (rsp_set_row_segments(2)): one column, fewer columns than
+    """The segments form on shapes it would not choose (rsp_debug_set("row_segments", 2)): one column, fewer columns than
     staging wavefronts, empty matrices' worth of columns, a last row block of one row, 62 blocks with three entries
     per column, repeated rows, row indices outside [0, nrow) (left out, as in every form)."""
     x, i, p = _sorted_columns_matrix(nrow, ncol, mean, seed=nrow % 1000 + ncol, invalid=extra == "invalid",

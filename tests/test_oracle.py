@@ -40,6 +40,14 @@ def test_golden_fixtures_bit_exact(name):
 def test_python_transcription_agrees(name):
     g = load_golden(name)
     got = oracle.column_sums_py(g["x"], g["p"], int(g["Dim"][1]))
+    if name == "na_payload":
+        # columns 0-5 hold NA_real_ beside finite / infinite values: NA (payload 1954, quieted) from the C restatement and
+        # from this transcription alike.  Columns 6-8 mix NA with a NaN of another payload: WHICH payload an x86 add returns
+        # depends on the operand order the compiler chose -- gcc's loop and CPython's float add differ on this very box
+        # (what R's documentation means by "platform-dependent") -- so only the class is common ground there.
+        assert got[:6].tobytes() == g["sums"][:6].tobytes() and int(got[:1].view(np.uint64)[0]) == 0x7FF80000000007A2
+        assert np.all(np.isnan(got[6:])) and np.all(np.isnan(g["sums"][6:]))
+        return
     assert got.tobytes() == g["sums"].tobytes()
 
 

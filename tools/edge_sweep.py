@@ -10,14 +10,14 @@ exit code 1 (and `ok: false` in the JSON line of that edge).
     python tools/edge_sweep.py [--quick] [--only lean,columns,...] [--out profiles/r04_form_edges.json]   (on the GPU box)
 
 Edges covered (knob that forces the neighbour):
-  lean | snapped            every column <= 64 entries                          rsp_set_lean(0)
+  lean | snapped            every column <= 64 entries                          rsp_debug_set("lean", 0)
   snapped | general         no column reaches > 512 past a chunk edge            the plan-free entry
-  columns | general         min column >= 2048 (4 wavefronts) / >= 512 up to     the plan-free entry; rsp_set_columns_form(2)
+  columns | general         min column >= 2048 (4 wavefronts) / >= 512 up to     the plan-free entry; rsp_debug_set("columns_form", 2)
                             2.5e8 entries (2 wavefronts); max <= 4 x mean         forces the columns form on the far side
-  taper | no taper          calls of more than 12288 body chunks                 rsp_set_taper
-  slices | L2 probes        row-restricted sums, > 2^20 rows: >= 16384 columns,   rsp_set_row_slices(0 / 2)
+  taper | no taper          calls of more than 12288 body chunks                 rsp_debug_set("taper_*")
+  slices | L2 probes        row-restricted sums, > 2^20 rows: >= 16384 columns,   rsp_debug_set("row_slices", 0 / 2)
                             >= 32 entries per column and slice
-  segments | regrouped      a handle's row sums: >= 128 entries per column and    rsp_set_row_segments(0 / 2)
+  segments | regrouped      a handle's row sums: >= 128 entries per column and    rsp_debug_set("row_segments", 0 / 2)
                             row block (a trade between first and repeated calls:
                             limit 1.25 here)
   tall | exact              crossprod: <= 512 columns of >= 4096 entries          rsp_set_crossprod_exact

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the segments form of a handle's row sums (rowsums.hip; forced: rsp_set_row_segments(2)) against
+"""Soak of the segments form of a handle's row sums (rowsums.hip; forced: rsp_debug_set("row_segments", 2)) against
 numpy.bincount: random row counts above one block (2..20 blocks, now and then 60+), 1..3000 columns, column lengths
 from 0 to hundreds, repeated rows, row indices outside [0, nrow), and every fifth matrix with a column whose rows do
 not ascend (the handle must notice and take another form).  Prints one JSON line.

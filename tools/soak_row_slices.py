@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the slice-major row-restricted sums (colsums_rowslices.hip) against the oracle's restricted loop:
-random row counts above 2^20 (2..7 slices, partial last slice), 1..50000 columns (the form is forced: rsp_set_row_slices(2)), Poisson column lengths from 0..5 to hundreds
+random row counts above 2^20 (2..7 slices, partial last slice), 1..50000 columns (the form is forced: rsp_debug_set("row_slices", 2)), Poisson column lengths from 0..5 to hundreds
 with empty and long columns (some beyond the device-side guard, which must hand the call to the general kernel),
 row sets from empty to full, both restrictions.  Prints one JSON line.
     python3 tools/soak_row_slices.py [cases] [seed]"""

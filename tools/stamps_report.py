@@ -31,11 +31,12 @@ def main():
     L.rsp_debug_read_stamps.argtypes = [vp, ctypes.c_int]
     stream = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None   # "waves,rows"
     if taper:
-        L.rsp_set_taper(taper[0], taper[1])
+        L.rsp_debug_set(b"taper_permille", taper[0])
+        L.rsp_debug_set(b"taper_rows", taper[1])
         if len(taper) > 2:
-            L.rsp_set_tuning(taper[2])
+            L.rsp_debug_set(b"chunk_rows", taper[2])
     if stream and len(stream) > 2:
-        L.rsp_set_experiment(stream[2])     # third field of an (otherwise unused) "a,b,experiment" argument
+        L.rsp_debug_set(b"experiment", stream[2])     # third field of an (otherwise unused) "a,b,experiment" argument
     nrow, ncol, nnz, shape, p = build_offsets(wl, 0)
     pt = torch.from_numpy(p).cuda()
     xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
