@@ -158,12 +158,30 @@ def test_exported_columnSums_answers_on_the_host_when_the_machine_has_no_gpu(nam
 
 
 @pytest.mark.gpu
-def test_with_a_gpu_present_the_host_loop_is_never_selected():
+def test_with_a_gpu_present_the_host_loop_answers_small_matrices_only_when_allowed():
+    """Round 5 ("min-nnz threshold for GPU offload"): with a GPU present the exported columnSums goes to the
+    device -- except for matrices below the threshold when no GPU is REQUIRED, which the reference's own loop answers faster
+    (profiles/r05_one_shot.json).  This suite runs with RCPPSPARSE_REQUIRE_GPU=1 (tests/conftest.py), so require_gpu = -1
+    (the environment decides) and 1 mean the device whatever the size; 0 lets the threshold speak."""
     g = load_golden(golden_names()[0])
-    for req in (-1, 0, 1):
+    nnz = int(len(g["x"]))
+    for req in (-1, 1):
         assert hostseam.backend(require_gpu=req) == "hip"
         hostseam.columnSums_opt(g, require_gpu=req)
         assert hostseam.backend(last=True) == "hip"
+        assert hostseam.backend_for(nnz, require_gpu=req, min_nnz=10**9) == "hip"
+    assert hostseam.backend(require_gpu=0) == "hip"                    # (a matrix large enough)
+    a = hostseam.columnSums_opt2(g, require_gpu=0, min_nnz=nnz + 1)     # below the threshold: the host loop
+    assert hostseam.backend(last=True) == "cpu"
+    b = hostseam.columnSums_opt2(g, require_gpu=0, min_nnz=nnz)         # at it: the device
+    assert hostseam.backend(last=True) == "hip"
+    c = hostseam.columnSums_opt2(g, require_gpu=0, min_nnz=0)
+    assert hostseam.backend(last=True) == "hip"
+    assert a.tobytes() == np.asarray(g["sums"], dtype=np.float64).tobytes() and b.tobytes() == c.tobytes()
+    scale = oracle.column_abs_sums(g["x"], g["p"])
+    assert np.all(np.abs(a - b) <= 1e-12 * scale)
+    hostseam.columnSums_opt(g, require_gpu=0)                           # the default threshold (250000): a golden fixture is small
+    assert hostseam.backend(last=True) == "cpu"
 
 
 @pytest.mark.gpu
