@@ -120,6 +120,7 @@ GLOSSARY = {
                        "<w>_kernel_ms, <w>_ms_per_call (median of three regions), <w>_parity_err = max |gpu - ref| / sum|x| "
                        "over all columns, <w>_traffic_x = HBM bytes / algorithmic bytes measured in this run, "
                        "<w>_traffic_recorded_x = the same from the committed passes under profiles/",
+    "config.auto_plan": "1 (default): the plan-free entry plans for itself; 0: RSP_AUTO_PLAN=0 in the environment -- general kernels only",
     "config.shards[].form": "the form rank r's calls took: rsp_column_sums_device plans for itself (include/rcppsparse_hip.h) -- "
                             "general kernels on the first calls, then lean / columns where the device-side inspection of p[] "
                             "selects them; the timed regions start after every rank has settled (--planned: the caller's plan)",
@@ -1165,7 +1166,7 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
              "shards": [{"rank": r, "device": int(t[6]), "c0": int(t[0]), "c1": int(t[1]), "x0": int(t[2]), "x1": int(t[3]),
                          "kernel_ms": t[4], "gather_ms": t[5] if use_comm else None, "form": PLAN_FORMS[int(t[7])]}
                         for r, t in enumerate(per_rank)],
-             "form": PLAN_FORMS[int(my_form)],
+             "form": PLAN_FORMS[int(my_form)], "auto_plan": capi.debug_get("auto_plan"),
              "parity": parity, "lat_med": lat_med, "lat_min": lat_min, "lat_med_max": lat_med_max,
              "pipelined": pipe, "planned_shards": planned_shards, "direct_gather": direct_gather,
              "plan": (None if plan is None else
@@ -1253,6 +1254,7 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         "partition": H["partition"],
         "shard_imbalance_max_over_mean": H["imbalance"],
         "chunk_rows": args.chunk_rows,
+        "auto_plan": H.get("auto_plan", 1),
         "x_copies_rotated": H["ncopies"],
         "gather": H["gather_name"],
         "gather_fell_back_to_torch_distributed": H["fell_back"],

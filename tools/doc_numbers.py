@@ -21,15 +21,19 @@ P = os.path.join(ROOT, "profiles")
 
 
 def kernel_avgs(path):
+    """(main kernel us, fix-up us or None) of the profiled calls: the column-sum kernel launched most often (the plan-free
+    entry plans for itself since round 5: a command's first calls run the general kernels, the rest the form it settles on)"""
     main = fix = None
+    calls, name = 0, ""
     if not os.path.exists(path):
         return None, None
     for r in csv.DictReader(open(path)):
-        if "colsums_chunks_kernel" in r["Name"] or "colsums_lean_kernel" in r["Name"] or "colsums_columns_kernel" in r["Name"]:
-            main = float(r["AverageNs"]) / 1e3
+        if ("colsums_chunks_kernel" in r["Name"] or "colsums_lean_kernel" in r["Name"] or "colsums_columns_kernel" in r["Name"]) \
+                and int(r["Calls"]) > calls:
+            main, calls, name = float(r["AverageNs"]) / 1e3, int(r["Calls"]), r["Name"]
         if "colsums_fixup_kernel" in r["Name"]:
             fix = float(r["AverageNs"]) / 1e3
-    return main, fix
+    return main, (fix if "colsums_chunks_kernel" in name else None)
 
 
 def driver_record(rnd):
@@ -79,7 +83,11 @@ def main():
         tag = d["config"]["workload"].split(":")[0]
         form = (d["config"].get("planned") or {}).get("form")
         ptag = tag + ("planned" if form in ("lean", "snapped", "columns") else "")
-        label = tag if form is None else f"{tag} `--planned` ({form} form)"
+        auto = d["config"]["shards"][0].get("form") if form is None else None
+        label = (tag + (f" (the entry's own plan: {auto} form)" if auto in ("lean", "columns") else "")) if form is None else f"{tag} `--planned` ({form} form)"
+        if form is None and d["config"].get("auto_plan") == 0:
+            label = f"{tag} `RSP_AUTO_PLAN=0` (general kernels)"
+            ptag = tag + "general"
         if form == "snapped" and any((x["config"].get("planned") or {}).get("form") == "lean" and
                                      x["config"]["workload"].split(":")[0] == tag for x in lines):
             ptag = None               # (the committed planned profile of this workload is the lean run's)
@@ -99,34 +107,41 @@ def main():
                    f"{100 * p['roofline']['frac']:.1f} % of 8 TB/s.  The rows above are the builder's runs of THIS round's code on "
                    f"the devices `gpurun` handed out (c3 on them: 1.19-1.24 ms, 81-85 %, device to device).")
     # what the default line measures beside the headline figure (round 4): the read-only ceiling, its own traffic, more workloads
-    full = next((d for d in ([drv[1]] if drv and drv[0] == rnd else []) + lines if (d["roofline"].get("read_ceiling"))), None)
+    # (round 5: flat scalars in `roofline` -- what the driver's record keeps; the `also` list itself travels in the line only)
+    full = next((d for d in ([drv[1]] if drv and drv[0] == rnd else []) + lines if (d["roofline"].get("read_ceiling_GBps"))), None)
     if full:
         r = full["roofline"]
-        rc = r["read_ceiling"]
         src = "the driver's run" if (drv and drv[0] == rnd and full is drv[1]) else "the builder's default run (`bench.py`, no flags)"
         out.append("")
         out.append(f"In the same run as the c3 line ({src}): a read-only kernel with the column sums' access shape over the same 8 GB of x "
-                   f"reaches **{rc['GBps']:.0f} GB/s** ({100 * rc['of_spec_peak']:.1f} % of the 8 TB/s spec peak) -- the c3 call is at "
-                   f"**{100 * rc['frac_of_ceiling']:.1f} % of that measured ceiling**"
+                   f"reaches **{r['read_ceiling_GBps']:.0f} GB/s** ({100 * r['read_ceiling_GBps'] / 8000:.1f} % of the 8 TB/s spec peak) -- the c3 call is at "
+                   f"**{100 * r['frac_of_ceiling']:.1f} % of that measured ceiling**"
                    + (f"; HBM traffic of one call from two rocprofv3 counter passes run by the bench itself: {r['traffic'] / 1e9:.4f} GB = "
-                      f"{r['traffic'] / r['algorithmic_bytes_per_launch']:.4f} x the algorithmic bytes" if str(r.get("traffic_source", "")).startswith("measured in this run") else "") + ".")
-        also = r.get("also") or (full.get("also") or {}).get("records")
-        if also:
+                      f"{r['traffic_over_algorithmic']:.4f} x the algorithmic bytes" if r.get("traffic_measured_in_run") else "") + ".")
+        names = sorted({k[5:-5] for k in r if k.startswith("also_") and k.endswith("_frac")}, key=lambda n: list(r).index(f"also_{n}_frac"))
+        recs = {a["workload"].replace(":", "_").replace("-", "_"): a for a in (full.get("also") or [])}
+        if names:
             out.append("")
-            out.append("| `also` record of that line | form | launches per call | ms per call | kernels, HIP events (ms) | of 8 TB/s | plan (ms) | parity: max err / column 1-norm |")
+            out.append("| `also` workload of that line (flat scalars `roofline.also_<w>_*`) | form | planned by | ms per call (median of 3 regions) | kernels, HIP events (ms) | of 8 TB/s | HBM bytes / algorithmic | parity: max err / column 1-norm |")
             out.append("|---|---|---|---|---|---|---|---|")
-            for a in also:
-                plan = "-" if a.get("plan_ms") is None else f"{a['plan_ms']:.3f}" + (" (device time; made on the device)" if "on the device" in str(a.get("plan_made")) else " (host)")
-                out.append(f"| {a['workload']} | {a['form']} | {a['launches_per_call']} | {a['ms_per_call']:.4f} | {a['kernel_ms']:.4f} | "
-                           f"{100 * a['frac']:.1f} % | {plan} | {a['parity']['max_abs_err_over_l1']:.1e} |")
+            for n in names:
+                a = recs.get(n, {})
+                tx = r.get(f"also_{n}_traffic_x")
+                trx = r.get(f"also_{n}_traffic_recorded_x")
+                traffic = f"{tx:.3f} (this run)" if tx is not None else (f"{trx:.3f} (profiles/)" if trx is not None else "-")
+                by = {"entry": "the entry itself", "caller": "the caller's plan"}.get(a.get("planned_by"), "-")
+                if a.get("plan_by") == "device":
+                    by += " (made on the device)"
+                out.append(f"| {n} | {a.get('form', '-')} | {by} | {r[f'also_{n}_ms_per_call']:.4f} | {r[f'also_{n}_kernel_ms']:.4f} | "
+                           f"{100 * r[f'also_{n}_frac']:.1f} % | {traffic} | {r[f'also_{n}_parity_err']:.1e} |")
     cpu = [d for d in lines if d.get("cpu_baseline")]
     if cpu:
         c = cpu[0]["cpu_baseline"]
         out.append("")
         out.append(f"CPU baseline in the same run (oracle, {c['cores']} thread, {c['sample'].split(',')[0]}): "
                    f"{c['value']:.3e} nnz/s" + (f"; the same loop under an OpenMP parallel-for over the columns on "
-                                                 f"{c['all_cores']['cores']} cores (not what the reference does): "
-                                                 f"{c['all_cores']['value']:.3e} nnz/s" if "value" in c.get("all_cores", {}) else "") + ".")
+                                                 f"{c['all_cores']} cores (not what the reference does): "
+                                                 f"{c['all_cores_value']:.3e} nnz/s" if "all_cores_value" in c else "") + ".")
     table = "\n".join(out) + "\n"
     open(os.path.join(P, f"{rnd}_numbers.md"), "w").write(
         f"# Measured numbers of round {rnd[1:]} (generated by tools/doc_numbers.py; do not edit)\n\n" + table)
