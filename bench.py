@@ -1027,11 +1027,11 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
     for _ in range(args.warmup):
         driver.step(recv)
     form_code = {"general": 0, "lean": 2, "columns": 3}
-    if plan is None and shard.nnz > 0:
+    if plan is None:
         # rsp_column_sums_device plans for itself: every rank waits until ITS entry has settled on a form (outside every timed
-        # region: the inspection is ~23 us of device time behind the first call), then warms that form
-        my_form = capi.column_sums_device_form(pt, shard.nnz, wait=True)
-        my_form = form_code.get(my_form, 0)
+        # region: the inspection is ~23 us of device time behind the first call), then warms that form.  (The same number of
+        # steps on every rank, whatever its shard holds: a step with a gather is a collective.)
+        my_form = form_code.get(capi.column_sums_device_form(pt, shard.nnz, wait=True), 0) if shard.nnz > 0 else 0
         for _ in range(args.warmup):
             driver.step(recv)
     else:

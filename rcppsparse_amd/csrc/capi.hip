@@ -843,7 +843,7 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
 // differs straight from x; the columns kernel reads p[] itself.  Both clamp to [0, nnz] and raise a page-locked
 // `stale` word, and a call that finds it raised inspects again (a fresh image; the old one is kept until
 // rsp_release_cached, a launch of an earlier call on another stream may still be reading it) -- after kAutoMaxStrikes
-// such rounds the key stays on the general kernels.  So: never a wrong sum, whatever the caller does with d_p.
+// such rounds without kAutoForgive clean planned calls in between the key stays on the general kernels.  So: never a wrong sum, whatever the caller does with d_p.
 // A call on a CAPTURING stream never inspects, polls or allocates: it records the form known at that moment, and a
 // replayed lean / columns launch validates against the p[] of the replay like any other.
 // What this costs a caller: results of the first calls (general kernels) and of later ones (planned form) agree
@@ -854,6 +854,7 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
 namespace {
 constexpr int kAutoMaxEntries = 16;
 constexpr int kAutoMaxStrikes = 4;
+constexpr int kAutoForgive = 64;
 constexpr int64_t kAutoMinNnz = 1 << 20;   // smaller calls are launch-bound either way: two launches against one, nothing to plan for
 struct AutoEntry {
     int device = -1;
@@ -864,6 +865,7 @@ struct AutoEntry {
     int32_t* h_stale = nullptr;         // page-locked: raised by a kernel that found p[] changed under the plan
     uint64_t last_use = 0;
     int strikes = 0;
+    int clean = 0;                      // planned calls since the last stale round: kAutoForgive of them wipe the strikes
     int last_form = 0;                  // form of the most recent call with this key (rsp_column_sums_device_form)
     std::vector<rsp_colsums_plan*> retired;
 };
@@ -1024,6 +1026,7 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
         // (into a NEW image: a launch of an earlier call may still be reading the old one)
         if (int rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream)) return rc;
         e->last_form = 0;
+        e->clean = 0;
         (void)plan_poll(pl, stream, false);
         e->retired.push_back(pl);
         e->plan = nullptr;
@@ -1039,6 +1042,7 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
                                              pl->lean_chunks, pl->lean_rows, d_out, divisor, means, stream, d_p, ncol,
                                              e->h_stale));
         e->last_form = 2;
+        if (++e->clean >= kAutoForgive) e->strikes = 0;
         return RSP_OK;
     }
     if (pl && pl->known && pl->columns) {
@@ -1047,6 +1051,7 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
         HIP_TRY(rsp::launch_column_sums_columns(d_x, d_p, ncol, pl->columns_waves, d_out, divisor, means, stream, (int32_t)nnz,
                                                 lo, hi, e->h_stale));
         e->last_form = 3;
+        if (++e->clean >= kAutoForgive) e->strikes = 0;
         return RSP_OK;
     }
     e->last_form = 0;
@@ -1270,12 +1275,16 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
             inspector_started = false;   // (no thread to be had: inspect afterwards, on this one)
         }
     }
+    static const bool timing = env_int("RSP_UPLOAD_TIMING") != 0;   // (phases of an upload to stderr: tools/measure_upload.py)
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [&t_begin] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_x, xbytes ? xbytes : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_p, ((size_t)ncol + 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, ncol ? (size_t)ncol * 8 : 8);
     if (e == hipSuccess) e = hipMalloc(&h->d_ws, h->ws_bytes);
     if (e == hipSuccess && i && nnz > 0) e = hipMalloc((void**)&h->d_i, (size_t)nnz * 4);
+    const double t_alloc = ms_since();
     if (e == hipSuccess && nnz > 0)
         e = hipMemcpyAsync(h->d_x, x, (size_t)nnz * 8, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess)
@@ -1291,8 +1300,13 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
         if (e == hipSuccess) e = hipMemcpyAsync(&h->rows_unsorted, d_flag, 4, hipMemcpyDeviceToHost, h->stream);
         h->rows_checked = e == hipSuccess;
     }
+    const double t_enqueued = ms_since();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);   // host buffers are only borrowed
+    const double t_copied = ms_since();
     if (inspector_started) inspector.join();
+    if (timing)
+        fprintf(stderr, "[rsp upload] nnz %lld ncol %d: allocations %.3f ms, copies enqueued %.3f, copies done %.3f, inspector joined %.3f\n",
+                (long long)nnz, ncol, t_alloc, t_enqueued, t_copied, ms_since());
     if (e != hipSuccess) {
         if (planned) rsp_column_sums_plan_destroy(planned);
         rsp_csc_free(h);

@@ -253,10 +253,15 @@ def test_dot_call_columnSums_on_the_gpu(driver):
     r = run(driver, "kat")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "columnSums via .Call ok" in r.stdout
-    # with a GPU present the host loop is never selected, whatever the requirement says
+    # with a GPU present a matrix large enough goes to the device ("now"); the vignette's five entries are below the
+    # offload threshold, so without a required GPU the host loop answered them (round 5; RcppSparse.min_nnz)
     assert run(driver, "backend", require_gpu=None).stdout.split() == ["hip", "none"]
     r = run(driver, "kat_cpu", require_gpu=None)
-    assert "backend now=hip last=hip" in r.stdout
+    assert "backend now=hip last=cpu" in r.stdout
+    env = dict(os.environ, RCPPSPARSE_MIN_NNZ="0")
+    env.pop("RCPPSPARSE_REQUIRE_GPU", None)
+    r = subprocess.run([driver, "kat_cpu"], capture_output=True, text=True, timeout=120, env=env)
+    assert "backend now=hip last=hip" in r.stdout          # threshold 0: every matrix to the device
 
 
 @pytest.mark.gpu

@@ -7,7 +7,7 @@ that slot's (ncol, nnz) into the device buffer IN PLACE (short columns / arbitra
 empty columns / long similar columns), sometimes new values too, and calls the entry one to four times; EVERY call's
 result is compared with the oracle (lean form: bit for bit).  Between steps the library is in every state there is: plan
 unknown, known, stale, re-inspecting, given up (after four stale rounds a key stays on the general kernels;
-rsp_release_cached every 400 steps starts it over).
+rsp_release_cached every 60 steps starts it over).
     python tools/soak_auto_plan.py [seconds] [seed]          (on the GPU box)"""
 import json
 import os
@@ -93,7 +93,7 @@ def main():
     forms, fams, exact_calls, worst = {}, {}, 0, 0.0
     while time.time() - t0 < seconds:
         s = slots[int(rng.integers(0, len(slots)))]
-        if s["p"] is None or rng.random() < 0.7:
+        if s["p"] is None or rng.random() < 0.35:
             s["p"], fam = random_offsets(rng, s["ncol"], s["nnz"])
             fams[fam] = fams.get(fam, 0) + 1
             s["pt"].copy_(torch.from_numpy(s["p"]))               # in place: same address, same sizes, new offsets
@@ -127,7 +127,7 @@ def main():
                 exact_calls += 1
             forms[form] = forms.get(form, 0) + 1
         steps += 1
-        if steps % 400 == 0:
+        if steps % 60 == 0:
             capi.release_cached()
     print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "steps": steps, "calls_checked": calls,
                       "calls_with_the_references_bits": exact_calls, "form_after_call": forms, "offset_families": fams,
