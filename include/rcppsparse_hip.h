@@ -143,7 +143,9 @@ int rsp_csc_column_sums(rsp_csc_t handle, double *sums);
 int rsp_csc_column_means(rsp_csc_t handle, double *means);
 /* Dim[0], Dim[1], length(x) of the resident copy (any output may be NULL). */
 int rsp_csc_dims(rsp_csc_t handle, int32_t *nrow, int32_t *ncol, int64_t *nnz);
-/* The upload inspects p[] once (beside the copies) and freezes the result in the handle: which form the
+/* The upload inspects p[] once -- on a host thread beside the copies, or (65536 columns and more; round 5) on the
+ * device behind the copy of p[], where it costs microseconds instead of milliseconds -- and freezes the result in the
+ * handle: which form the
  * handle's column sums take -- 0 general kernels, 1 snapped, 2 lean, 3 columns (rsp_column_sums_plan_info).
  * The settings in force AT UPLOAD decide (RSP_LEAN, RSP_COLUMNS_FORM, the chunking knobs: rsp_debug_set);
  * changing them later does not touch existing handles.  rsp_csc_set_planned(h, 0) sends the handle's

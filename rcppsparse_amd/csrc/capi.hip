@@ -1264,7 +1264,13 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
     rsp_colsums_plan* planned = nullptr;
     std::thread inspector;
     bool inspector_started = false;
-    if (with_plan) {
+    // From 65536 columns on the inspection runs ON THE DEVICE behind the copy of p[] (round 5): the host inspector costs
+    // ~6 us per 1000 columns and was what an upload of a C2-sized matrix waited for (copies 1.7 ms, inspector 8.0 ms); the
+    // device inspector is 23 us for 1e6 columns.  Same images bit for bit; its lean image has room for 3 x the mean
+    // number of columns per chunk + 16 (at least 126), so a matrix with a denser chunk takes the snapped / general form here.
+    constexpr int32_t kUploadDeviceInspectMinCols = 65536;
+    const bool device_inspect = with_plan && ncol >= kUploadDeviceInspectMinCols && nnz > 0;
+    if (with_plan && !device_inspect) {
         try {
             inspector = std::thread([&planned, p, ncol, nnz, device] {
                 if (hipSetDevice(device) != hipSuccess) return;
@@ -1300,8 +1306,15 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
         if (e == hipSuccess) e = hipMemcpyAsync(&h->rows_unsorted, d_flag, 4, hipMemcpyDeviceToHost, h->stream);
         h->rows_checked = e == hipSuccess;
     }
+    if (e == hipSuccess && device_inspect &&
+        rsp_column_sums_plan_create_device(h->d_p, ncol, nnz, h->stream, &planned) != RSP_OK)
+        planned = nullptr;   // (no memory for the images: the handle simply runs the general kernels)
     const double t_enqueued = ms_since();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);   // host buffers are only borrowed
+    if (e == hipSuccess && device_inspect && planned && plan_poll(planned, nullptr, true) != RSP_OK) {
+        rsp_column_sums_plan_destroy(planned);
+        planned = nullptr;
+    }
     const double t_copied = ms_since();
     if (inspector_started) inspector.join();
     if (timing)
@@ -1312,7 +1325,7 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
         rsp_csc_free(h);
         return fail(RSP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
-    if (with_plan && !inspector_started && plan_make(p, ncol, nnz, device, &planned) != RSP_OK) planned = nullptr;
+    if (with_plan && !device_inspect && !inspector_started && plan_make(p, ncol, nnz, device, &planned) != RSP_OK) planned = nullptr;
     h->plan = planned;
     *handle = h;
     return RSP_OK;
