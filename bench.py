@@ -591,7 +591,8 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream, traffic_now=Fal
     if measured is not None:
         rec["traffic"], rec["traffic_in_run"], rec["traffic_kernels"] = measured, True, _how["kernels"]
     else:
-        rec["traffic"], rec["traffic_in_run"] = traffic_from_profiles(name + ("planned" if one_launch else ""))[0], False
+        # (committed passes: <workload>_traffic.json is the plan-free command's, <workload>planned_traffic.json the --planned one's)
+        rec["traffic"], rec["traffic_in_run"] = traffic_from_profiles(name + ("planned" if plan is not None and plan.snapped else ""))[0], False
     return sig(rec)
 
 

@@ -1282,8 +1282,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
                 int32_t a = __builtin_amdgcn_readlane(plo, l), b = __builtin_amdgcn_readlane(phi, l);
                 a = a < 0 ? 0 : (a > nnz ? nnz : a);
                 b = b < a ? a : (b > nnz ? nnz : b);
-                double part = 0.0;
-                for (int64_t j = (int64_t)a + lane; j < (int64_t)b; j += 64) part += x[j];
+                // (compensated: a column of any length may stand here -- 1e9 entries over 64 lanes are 1.6e7 sequential adds
+                // per lane, whose rounding alone would reach the 1e-12 bar; this path is rare, four flops per entry cost nothing)
+                double part = 0.0, comp = 0.0;
+                for (int64_t j = (int64_t)a + lane; j < (int64_t)b; j += 64) {
+                    const double y = x[j] - comp, t = part + y;
+                    comp = (t - part) - y;
+                    if (!(__builtin_fabs(t) < __builtin_huge_val())) comp = 0.0;   // (an infinity or a NaN -- NA_real_ -- goes through as the plain += would carry it)
+                    part = t;
+                }
                 const double total = wave_allreduce<P>(part);
                 if (lane == l) out[c0 + col] = P::finish(total, divisor);
             }
@@ -1365,7 +1372,13 @@ __global__ __launch_bounds__(WPG * 64) void colsums_columns_kernel(const double*
     double a0 = 0.0, a1 = 0.0;
     constexpr int kInFlight = 8;
     if (GUARDED && n > kColumnsMaxLen) {   // (a column no plan of this form was made for: its bytes may not fit a descriptor)
-        for (int64_t j = (int64_t)lo + threadIdx.x; j < (int64_t)hi; j += WPG * 64) a0 += x[j];
+        double comp = 0.0;   // (compensated, as in the lean kernel's fall-back: any length may stand here)
+        for (int64_t j = (int64_t)lo + threadIdx.x; j < (int64_t)hi; j += WPG * 64) {
+            const double y = x[j] - comp, t = a0 + y;
+            comp = (t - a0) - y;
+            if (!(__builtin_fabs(t) < __builtin_huge_val())) comp = 0.0;
+            a0 = t;
+        }
     } else
     for (int r0 = wave; r0 < nrows; r0 += WPG * kInFlight) {
         d2 v[kInFlight];

@@ -274,6 +274,51 @@ def test_offsets_that_are_no_dgcmatrix_stay_in_bounds_under_an_adopted_plan(torc
         check(out.cpu().numpy(), x, p)
 
 
+def test_infinities_and_na_go_through_the_changed_column_fall_back_like_a_plain_add(torch_auto):
+    """The fall-back that sums a changed column straight from x is compensated (a column of any length may stand there); an
+    infinity, a NaN or R's NA_real_ must still come out as the reference's plain += carries them."""
+    torch = torch_auto
+    ncol = 150_000
+    p, x = short_matrix(ncol, 10, seed=40)
+    nnz = int(p[-1])
+    x = x.copy()
+    na = np.frombuffer(np.array([0x7FF00000000007A2], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    rng = np.random.default_rng(41)
+    q = synth.offsets_from_counts(rng.multinomial(nnz, np.full(ncol, 1.0 / ncol)).astype(np.int64))
+    long_cols = np.flatnonzero(np.diff(q) >= 6)[:400:40]                  # ten columns of the NEW matrix with room for specials
+    kinds = []
+    for k, c in enumerate(long_cols):
+        a = int(q[c])
+        if k % 5 == 0:
+            x[a + 2] = na; kinds.append("na")
+        elif k % 5 == 1:
+            x[a + 1] = np.inf; kinds.append("inf")
+        elif k % 5 == 2:
+            x[a] = -np.inf; x[a + 3] = 7.0; kinds.append("-inf")
+        elif k % 5 == 3:
+            x[a + 1] = np.inf; x[a + 4] = -np.inf; kinds.append("nan")
+        else:
+            x[a + 5] = na; x[a] = np.inf; kinds.append("na")
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    assert settled(torch, xt, pt, out, ws) == "lean"
+    pt.copy_(torch.from_numpy(q))                                         # every column now differs from the image: all through the fall-back
+    capi.column_sums_device(xt, pt, out, ws)
+    got = out.cpu().numpy()
+    ref = oracle.column_sums(x, q)
+    finite = np.isfinite(ref)
+    scale = oracle.column_abs_sums(x, q)
+    assert np.all(np.abs(got[finite] - ref[finite]) <= RTOL * scale[finite])
+    for c, kind in zip(long_cols, kinds):
+        if kind == "na":
+            assert int(got[c:c + 1].view(np.uint64)[0]) == 0x7FF80000000007A2 == int(ref[c:c + 1].view(np.uint64)[0])
+        elif kind == "nan":
+            assert np.isnan(got[c]) and np.isnan(ref[c])
+        else:
+            assert got[c] == ref[c] == (np.inf if kind == "inf" else -np.inf)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_adopted_forms_against_the_oracle(torch_auto, seed):
     """Random shapes on both sides of the forms' conditions, each summed before the plan is known, after it, and after the

@@ -130,6 +130,8 @@ def main():
                 trx = r.get(f"also_{n}_traffic_recorded_x")
                 traffic = f"{tx:.3f} (this run)" if tx is not None else (f"{trx:.3f} (profiles/)" if trx is not None else "-")
                 by = {"entry": "the entry itself", "caller": "the caller's plan"}.get(a.get("planned_by"), "-")
+                if a.get("form") == "general":
+                    by = "-"
                 if a.get("plan_by") == "device":
                     by += " (made on the device)"
                 out.append(f"| {n} | {a.get('form', '-')} | {by} | {r[f'also_{n}_ms_per_call']:.4f} | {r[f'also_{n}_kernel_ms']:.4f} | "
