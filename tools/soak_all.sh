@@ -17,4 +17,5 @@ else
   step 400 soak_all_slices.log python3 $R/tools/soak_row_slices.py 300 9
   step 300 soak_all_xp.log python3 $R/tools/soak_crossprod_tall.py
   step 300 soak_all_devplan.log python3 $R/tools/soak_device_plan.py 150 11
+  step 300 soak_all_autoplan.log python3 $R/tools/soak_auto_plan.py 150 5
 fi
