@@ -536,6 +536,7 @@ int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
  *   "row_segments"    handles' row sums: 0 never the segments form, 1 where faster (default), 2 wherever possible
  *   "row_slices"      row-restricted sums: 0 never the slice-major form, 1 where faster (default), 2 wherever possible
  *   "auto_plan"       rsp_column_sums_device / rsp_column_means_device plan for themselves (1, default) or never (0)
+ *   "auto_min_nnz"    ... for matrices of at least this many entries (default 2^20; tests lower it to 1)
  * An unknown key is RSP_ERR_BAD_ARG.  rsp_debug_get reads the value in force (environment and defaults resolved).
  * Threads: the knobs are atomics -- setting one while another thread is inside a call is safe and takes effect for
  * calls (plans, handles) that start afterwards; two libraries' worth of callers in one process share them, which is

@@ -417,6 +417,7 @@ namespace {
 int clamp012(int v) { return v <= 0 ? 0 : (v >= 2 ? 2 : 1); }
 int auto_plan_setting();
 std::atomic<int> g_auto_plan{-1};   // "auto_plan": 0 / 1; -1 = RSP_AUTO_PLAN from the environment, else 1
+std::atomic<int> g_auto_min_nnz{1 << 20};   // "auto_min_nnz": calls below it never plan for themselves (tests lower it)
 }  // namespace
 
 int rsp_debug_set(const char* key, int value) {
@@ -443,6 +444,8 @@ int rsp_debug_set(const char* key, int value) {
         g_row_slices.store(clamp012(value), std::memory_order_relaxed);
     } else if (k == "auto_plan") {      // the plan-free device entries plan for themselves (1, default) or never (0)
         g_auto_plan.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+    } else if (k == "auto_min_nnz") {   // ... for matrices of at least this many entries (default 2^20; the parity suite lowers it to 1)
+        g_auto_min_nnz.store(value < 1 ? 1 : value, std::memory_order_relaxed);
     } else {
         return fail(RSP_ERR_BAD_ARG, "unknown knob '%s'", key);
     }
@@ -463,6 +466,7 @@ int rsp_debug_get(const char* key, int* value) {
     else if (k == "row_segments") *value = row_segments_setting();
     else if (k == "row_slices") *value = row_slices_setting();
     else if (k == "auto_plan") *value = auto_plan_setting();
+    else if (k == "auto_min_nnz") *value = g_auto_min_nnz.load(std::memory_order_relaxed);
     else return fail(RSP_ERR_BAD_ARG, "unknown knob '%s'", key);
     return RSP_OK;
 }
@@ -855,7 +859,7 @@ namespace {
 constexpr int kAutoMaxEntries = 16;
 constexpr int kAutoMaxStrikes = 4;
 constexpr int kAutoForgive = 64;
-constexpr int64_t kAutoMinNnz = 1 << 20;   // smaller calls are launch-bound either way: two launches against one, nothing to plan for
+// (calls below 2^20 entries -- g_auto_min_nnz, "auto_min_nnz" -- are launch-bound either way: two launches against one)
 struct AutoEntry {
     int device = -1;
     const int32_t* d_p = nullptr;
@@ -969,7 +973,7 @@ static int auto_inspect(AutoEntry& e, hipStream_t stream) {   // caller holds g_
 
 static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
                         size_t ws_bytes, double divisor, bool means, hipStream_t stream) {
-    if (auto_plan_setting() == 0 || nnz < kAutoMinNnz || ncol <= 0 || nnz > INT32_MAX || !d_p || !d_x || !d_out ||
+    if (auto_plan_setting() == 0 || nnz < (int64_t)g_auto_min_nnz.load(std::memory_order_relaxed) || ncol <= 0 || nnz > INT32_MAX || !d_p || !d_x || !d_out ||
         ((uintptr_t)d_x & 15) != 0)
         return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
     int device = 0;

@@ -62,7 +62,7 @@ _MODE = {"launch": "general"}
 PLANS_SEEN = {"snapped": 0, "general": 0}
 
 
-@pytest.fixture(params=["general", "planned", "planned_no_lean"])
+@pytest.fixture(params=["general", "planned", "planned_no_lean", "auto"])
 def launch_mode(request):
     """The same parity tests through rsp_column_sums_device (per-chunk column search, carries, fix-up launch)
     and through the inspector-executor form (rsp_column_sums_plan_create + rsp_column_sums_planned_device: one
@@ -70,8 +70,16 @@ def launch_mode(request):
     _MODE["launch"] = request.param
     capi.load()
     capi.set_lean(2 if request.param != "planned_no_lean" else 0)   # (2: the lean form wherever it applies -- it would otherwise take only means <= 60)
+    if request.param == "auto":
+        # round 5: the plan-free entry as it behaves by DEFAULT -- planning for itself -- with the size it starts at lowered
+        # from 2^20 entries to 1, so that every matrix of these tests goes through its own plan and its validating kernels
+        capi.set_auto_plan(True)
+        capi.debug_set("auto_min_nnz", 1)
     yield request.param
     capi.set_lean(1)
+    capi.set_auto_plan(False)
+    capi.debug_set("auto_min_nnz", 1 << 20)
+    capi.release_cached()
     _MODE["launch"] = "general"
 
 
@@ -94,6 +102,19 @@ def dev_colsums(torch, x, p, **kw):
         again = plan.column_sums(xt, pt)                    # bit-stable, and the plan is reusable
         assert out.cpu().numpy().tobytes() == again.cpu().numpy().tobytes()
         plan.close()
+        return out.cpu().numpy()
+    if _MODE["launch"] == "auto" and not kw:
+        # first call: the general kernels + the inspection behind them; once its result has been seen the entry's own plan
+        # (lean / columns where they apply) answers, bit-stable from then on
+        capi.release_cached()                               # (16 keys are remembered: every matrix of the suite gets its own plan)
+        first = capi.column_sums_device(xt, pt)
+        form = capi.column_sums_device_form(pt, xt.numel(), wait=True) if xt.numel() > 0 and pt.numel() > 1 else "general"
+        PLANS_SEEN["auto_" + form] = PLANS_SEEN.get("auto_" + form, 0) + 1
+        out = capi.column_sums_device(xt, pt)
+        again = capi.column_sums_device(xt, pt)
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == again.cpu().numpy().tobytes()
+        del first
         return out.cpu().numpy()
     out = capi.column_sums_device(xt, pt, **kw)
     torch.cuda.synchronize()
@@ -261,7 +282,7 @@ def test_short_columns_come_out_in_reference_order_bit_exact(torch_cuda, launch_
     exact = got.view(np.uint64) == ref.view(np.uint64)
     assert np.all(exact[inside]), int(np.count_nonzero(~exact[inside]))
     assert np.count_nonzero(inside) > 0.985 * ncol
-    if launch_mode == "planned":      # the lean form: a lane adds its whole column in storage order, chunk edge or not
+    if launch_mode in ("planned", "auto"):      # the lean form (the entry's own plan takes it too): a lane adds its whole column in storage order, chunk edge or not
         assert np.all(exact)
 
 
