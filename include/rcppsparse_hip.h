@@ -179,7 +179,10 @@ int rsp_csc_free(rsp_csc_t handle);
  * and make the library inspect again -- never a wrong sum, only a slower call.  Up to 16 keys are remembered per
  * process (least recently used first out); rsp_release_cached() forgets them all.  Consequences: the first calls
  * and the later ones agree within the documented tolerance, not bit for bit, and which call is the first planned
- * one depends on timing; a capture records whatever form is known when it is made.  RSP_AUTO_PLAN=0 in the
+ * one depends on timing.  A call on a CAPTURING stream always records the general kernels (a graph outlives the
+ * call, the library's plan images do not belong to it): to put the planned form into a graph, make the plan
+ * yourself (rsp_column_sums_plan_create_device, rsp_column_sums_plan_wait) and capture
+ * rsp_column_sums_planned_device -- the plan's lifetime is then yours.  RSP_AUTO_PLAN=0 in the
  * environment (or rsp_debug_set("auto_plan", 0)) keeps every call on the general kernels, bit-stable from the first
  * call; explicit plans (below) and handles choose their form once, at creation / upload.
  * rsp_column_sums_device_form: the form calls with that key take now -- 0 general kernels, 2 lean, 3 columns,

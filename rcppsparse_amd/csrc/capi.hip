@@ -848,8 +848,8 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
 // `stale` word, and a call that finds it raised inspects again (a fresh image; the old one is kept until
 // rsp_release_cached, a launch of an earlier call on another stream may still be reading it) -- after kAutoMaxStrikes
 // such rounds without kAutoForgive clean planned calls in between the key stays on the general kernels.  So: never a wrong sum, whatever the caller does with d_p.
-// A call on a CAPTURING stream never inspects, polls or allocates: it records the form known at that moment, and a
-// replayed lean / columns launch validates against the p[] of the replay like any other.
+// A call on a CAPTURING stream records the general kernels and touches none of this: a graph outlives the call, the
+// images belong to the library.
 // What this costs a caller: results of the first calls (general kernels) and of later ones (planned form) agree
 // within the documented tolerance, not bit for bit, and the call at which the form changes depends on when the
 // statistics arrive.  rsp_debug_set("auto_plan", 0) / RSP_AUTO_PLAN=0 keeps every call on the general kernels
@@ -981,6 +981,10 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
     const bool capturing = cs != hipStreamCaptureStatusNone;
+    // A capture records the general kernels, whatever is known about these offsets: a graph outlives this call, and the
+    // images of the entry's own plans belong to the library (an eviction or rsp_release_cached would leave the graph a
+    // dangling pointer).  A caller that wants the planned form in a graph makes the plan itself and owns its lifetime.
+    if (capturing) return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
     std::lock_guard<std::mutex> lock(g_auto_mu);
     ++g_auto_tick;
     AutoEntry* e = nullptr;
@@ -989,7 +993,6 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
     if (!e) {
         // the general kernels answer this call; the inspection goes behind them (a capture records no inspection)
         if (int rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream)) return rc;
-        if (capturing) return RSP_OK;
         if ((int)g_auto.size() >= kAutoMaxEntries) {
             // full: the entry that has gone unused longest makes room -- if it has been idle for a while (its images may
             // still be read by launches in flight: the device is waited for, which is why this is kept rare)
@@ -1025,7 +1028,7 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
     }
     e->last_use = g_auto_tick;
     rsp_colsums_plan* pl = e->plan;
-    if (pl && !capturing && *(volatile int32_t*)e->h_stale != 0) {
+    if (pl && *(volatile int32_t*)e->h_stale != 0) {
         // a kernel found p[] changed under the plan: this call on the general kernels, a fresh inspection behind it
         // (into a NEW image: a launch of an earlier call may still be reading the old one)
         if (int rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream)) return rc;
@@ -1038,7 +1041,7 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
         if (++e->strikes < kAutoMaxStrikes) auto_inspect(*e, stream);
         return RSP_OK;
     }
-    if (pl && !pl->known && !capturing) {
+    if (pl && !pl->known) {
         if (int rc = plan_poll(pl, stream, false)) return rc;
     }
     if (pl && pl->known && pl->lean) {

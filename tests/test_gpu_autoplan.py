@@ -139,9 +139,10 @@ def test_offsets_changed_in_place_under_an_adopted_plan_never_give_wrong_sums(to
         check(out.cpu().numpy(), x, q, exact=(form == "lean"))
 
 
-def test_captured_calls_validate_against_the_offsets_of_the_replay(torch_auto):
-    """A HIP graph records whatever form is known when it is captured and looks at nothing itself; the recorded lean launch
-    still compares every column with the p[] it finds at replay time."""
+def test_a_capture_records_the_general_kernels_and_owns_nothing_of_the_library(torch_auto):
+    """A HIP graph outlives the call that was captured, and the images of the entry's own plans belong to the library (an
+    eviction or rsp_release_cached frees them): a call on a capturing stream therefore records the general kernels whatever
+    is known about the offsets.  The graph keeps working after rsp_release_cached and over new values AND new offsets."""
     torch = torch_auto
     ncol = 200_000
     p, x = short_matrix(ncol, 11, seed=4)
@@ -152,21 +153,23 @@ def test_captured_calls_validate_against_the_offsets_of_the_replay(torch_auto):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         assert settled(torch, xt, pt, out, ws) == "lean"
+        planned_bits = out.cpu().numpy().tobytes()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             capi.column_sums_device(xt, pt, out, ws)
+        capi.release_cached()                                              # everything the library kept is gone ...
         out.fill_(-1.0)
-        g.replay()
+        g.replay()                                                         # ... and the graph does not care
         torch.cuda.synchronize()
-        check(out.cpu().numpy(), x, p, exact=True)
-        # new values AND new offsets in the captured buffers: the replay sums the new matrix
-        p2, x2 = short_matrix(ncol, 11, seed=5)
-        n2 = int(p2[-1])
-        if n2 > nnz:                                                       # same sizes: cut or pad the last columns
-            p2 = np.minimum(p2, nnz).astype(np.int32)
-        else:
-            p2 = p2.copy()
-            p2[-1] = nnz
+        check(out.cpu().numpy(), x, p)
+        capi.set_auto_plan(False)
+        general_bits = capi.column_sums_device(xt, pt).cpu().numpy().tobytes()
+        capi.set_auto_plan(True)
+        assert out.cpu().numpy().tobytes() == general_bits                 # what was recorded is the general kernels
+        assert planned_bits == oracle.column_sums(x, p).tobytes()          # (the eager call before it had the lean plan's bits)
+        p2, _ = short_matrix(ncol, 11, seed=5)
+        p2 = np.minimum(p2, nnz).astype(np.int32)
+        p2[-1] = nnz
         x2 = synth.gen_values(nnz, seed=55, kind=0)
         xt.copy_(torch.from_numpy(x2))
         pt.copy_(torch.from_numpy(p2))
@@ -174,22 +177,17 @@ def test_captured_calls_validate_against_the_offsets_of_the_replay(torch_auto):
         g.replay()
         torch.cuda.synchronize()
         check(out.cpu().numpy(), x2, p2)
-        g.replay()                                                         # (nothing learns inside a graph: still right)
-        torch.cuda.synchronize()
-        check(out.cpu().numpy(), x2, p2)
-    # a capture of a key the library has never seen records the general kernels and plans nothing
-    p3, x3 = short_matrix(150_000, 10, seed=6)
-    xt3, pt3 = torch.from_numpy(x3).cuda(), torch.from_numpy(p3).cuda()
-    out3 = torch.empty(len(p3) - 1, dtype=torch.float64, device="cuda")
-    ws3 = capi.alloc_workspace(len(p3) - 1, len(x3))
+    # to have the PLANNED form in a graph the caller makes the plan and owns it (rsp_column_sums_plan_*):
+    plan = capi.ColumnSumsPlan(pt, nnz=nnz, stream=s).wait()
     with torch.cuda.stream(s):
-        g3 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g3, stream=s):
-            capi.column_sums_device(xt3, pt3, out3, ws3)
-        g3.replay()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=s):
+            plan.column_sums(xt, pt, out, ws)
+        out.fill_(-1.0)
+        g2.replay()
         torch.cuda.synchronize()
-    check(out3.cpu().numpy(), x3, p3)
-    assert capi.column_sums_device_form(pt3, len(x3)) == "unknown"
+    check(out.cpu().numpy(), x2, p2, exact=plan.lean)
+    plan.close()
 
 
 def test_two_matrices_two_workspaces_two_streams_interleaved(torch_auto):
