@@ -1013,9 +1013,13 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
         ne.ncol = ncol;
         ne.nnz = nnz;
         ne.last_use = g_auto_tick;
-        if (hipHostMalloc((void**)&ne.h_stale, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+        // (coherent: a kernel's store has to reach the host's next look without a synchronisation in between)
+        if (hipHostMalloc((void**)&ne.h_stale, sizeof(int32_t), hipHostMallocCoherent) != hipSuccess) {
             (void)hipGetLastError();
-            return RSP_OK;
+            if (hipHostMalloc((void**)&ne.h_stale, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return RSP_OK;
+            }
         }
         *ne.h_stale = 0;
         auto_inspect(ne, stream);
