@@ -1221,17 +1221,30 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
     const int32_t left = nnz - cs;
     const int32_t avail = left < kElems ? left : kElems;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(x + cs), 0, avail * 8, 0x00020000);
+    // (VALIDATE: the header goes first -- loads return in order, so it is there first -- and the offsets of this call's
+    // p[] are requested as soon as it is, while the rows of x are still on their way: the check then waits for nothing
+    // the sums do not wait for anyway)
+    int2 h = make_int2(0, 0);
+    if (VALIDATE) h = hdr[w];
     d2 v[R + 1];
 #pragma unroll
     for (int r = 0; r <= R; ++r)
         v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16, r * 1024, kLoadAux));
-    const int2 h = hdr[w];
+    if (!VALIDATE) h = hdr[w];
     // the chunk's offsets: stride_dwords dwords (two 16-bit offsets each), the same count for every chunk
     const uint32_t* mine = offs + (size_t)w * (size_t)stride_dwords;
     uint32_t od[kLeanMaxOffsetDwords / 64];
 #pragma unroll
     for (int t = 0; t < kLeanMaxOffsetDwords / 64; ++t)
         od[t] = (t * 64 + lane) < stride_dwords ? mine[t * 64 + lane] : 0u;
+    int32_t plo0 = 0, phi0 = 0;   // VALIDATE: this call's offsets of the chunk's first 64 columns
+    if (VALIDATE) {
+        const int c0v = __builtin_amdgcn_readfirstlane(h.x), ncv = __builtin_amdgcn_readfirstlane(h.y);
+        if (lane < ncv) {
+            plo0 = p[c0v + lane];
+            phi0 = p[c0v + lane + 1];
+        }
+    }
     double* stage = s_stage[wave_in_wg];
     uint32_t* so = s_offs + (size_t)wave_in_wg * stride_dwords;
 #pragma unroll
@@ -1245,8 +1258,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void colsums_lean_kernel(
     for (int t0 = 0; t0 < ncols; t0 += 64) {
         const int col = t0 + lane;
         const bool active = col < ncols;
-        int32_t plo = 0, phi = 0;
-        if (VALIDATE && active) {   // (c0 + ncols <= ncol by construction of the image: p[c0 + col + 1] exists)
+        int32_t plo = plo0, phi = phi0;
+        if (VALIDATE && t0 > 0 && active) {   // (c0 + ncols <= ncol by construction of the image: p[c0 + col + 1] exists)
             plo = p[c0 + col];
             phi = p[c0 + col + 1];
         }
