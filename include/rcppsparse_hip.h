@@ -177,7 +177,9 @@ int rsp_csc_free(rsp_csc_t handle);
  * caller promises NOTHING about d_p between calls: the kernels of this path check every column's offsets against
  * the p[] of the call they run in, sum a column whose offsets have changed straight from x (clamped to [0, nnz]),
  * and make the library inspect again -- never a wrong sum, only a slower call.  Up to 16 keys are remembered per
- * process (least recently used first out); rsp_release_cached() forgets them all.  Consequences: the first calls
+ * process; a 17th is planned only once a remembered one has gone unused for 64 calls, and forgetting that one
+ * waits for the device (the ONE case in which these entries synchronise: launches in flight may still read its
+ * images); rsp_release_cached() forgets them all (it waits for the device too).  Consequences: the first calls
  * and the later ones agree within the documented tolerance, not bit for bit, and which call is the first planned
  * one depends on timing.  A call on a CAPTURING stream always records the general kernels (a graph outlives the
  * call, the library's plan images do not belong to it): to put the planned form into a graph, make the plan
