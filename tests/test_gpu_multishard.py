@@ -178,8 +178,12 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     for a, b in zip(shards, shards[1:]):
         assert b["x0"] == a["x1"] > 0 and b["c0"] == a["c1"] > 0      # rank r > 0 starts inside x
     assert all(s["kernel_ms"] > 0 for s in shards)                     # every rank timed its own launches
-    if workload in ("c4shard", "c3"):                                  # every rank's plan-free entry settled on the columns form
+    if workload == "c4shard":                                          # every rank's plan-free entry settled on the columns form
         assert [s["form"] for s in shards] == ["columns"] * world
+    elif workload == "c3":
+        # (a quarter of C3 is 2.5e8 entries +- a column: right AT the size up to which columns of ~1000 entries take the
+        # columns form, kColumnsTwoWavesMaxNnz -- either side of it is a valid choice, rank by rank)
+        assert all(s["form"] in ("columns", "general") for s in shards)
     else:
         assert all(s["form"] in ("general", "lean", "columns") for s in shards)
     per = [s["nnz"] for s in shards]
@@ -202,8 +206,10 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     ps = d["planned_shards"]
     assert ps["value"] > 0 and len(ps["forms_by_rank"]) == world
     assert ps["bad_columns"] == 0 and ps["parity_err"] <= RTOL
-    if workload in ("c4shard", "c3"):
+    if workload == "c4shard":
         assert ps["forms_by_rank"] == ["columns"] * world            # columns of ~1000 entries in shards of <= 2.5e8
+    elif workload == "c3":
+        assert all(f in ("columns", "general kernels", "general") for f in ps["forms_by_rank"])
     dg = d["direct_gather"]
     assert dg["value"] is not None, dg                                # the ranks mapped rank 0's buffer (hipIpc) ...
     assert dg["bad_columns"] == 0 and dg["parity_err"] <= RTOL        # ... and wrote into it
