@@ -490,6 +490,17 @@ size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz) {
 static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
                         size_t ws_bytes, double divisor, bool means, hipStream_t stream);
 
+}  // extern "C"
+namespace rsp {
+// the general kernels, no planning: for the library's own one-shot paths (multigpu.cpp: rsp_column_sums_host_multi sees new
+// offsets at a fresh address in every call -- nothing to remember)
+int column_sums_general(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
+                        size_t ws_bytes, hipStream_t stream) {
+    return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, 1.0, false, stream);
+}
+}  // namespace rsp
+extern "C" {
+
 int rsp_column_sums_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz,
                            double* d_sums, void* d_workspace, size_t workspace_bytes, void* stream) {
     return auto_enqueue(d_x, d_p, ncol, nnz, d_sums, d_workspace, workspace_bytes, 1.0, false, (hipStream_t)stream);

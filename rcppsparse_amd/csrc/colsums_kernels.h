@@ -101,6 +101,10 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               int32_t bitmap_words = 0, const int2* plan_rec = nullptr,
                               const int32_t* run_if = nullptr);
 
+// rsp_column_sums_device without the entry's own planning (capi.hip): the library's one-shot paths use it
+int column_sums_general(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
+                        size_t ws_bytes, hipStream_t stream);
+
 // ---- device-side inspector (inspect_device.hip): the plans of inspect.hpp for offsets that live in HBM ----
 constexpr int kInspectMaxBlocksColumns = 1024;   // blocks of the pass over p[] (grid-stride): one partial record each
 constexpr int kInspectMaxBlocksChunks = 256;     // blocks of the pass over the lean chunks

@@ -166,7 +166,7 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
                 ok = check(hipMemcpyAsync(d_x, x + n0, (size_t)nk * 8, hipMemcpyHostToDevice, st), "H2D x");
             ok = ok && check(hipMemcpyAsync(d_p, pk.data(), ((size_t)nc + 1) * 4, hipMemcpyHostToDevice, st), "H2D p");
             if (ok) {
-                const int rc = rsp_column_sums_device(d_x, d_p, nc, nk, d_out, d_ws, wsb, st);
+                const int rc = rsp::column_sums_general(d_x, d_p, nc, nk, d_out, d_ws, wsb, st);   // (a one-shot call: nothing to plan for)
                 if (rc != RSP_OK) {
                     status[k] = rc;
                     message[k] = rsp_last_error();   // this thread's message

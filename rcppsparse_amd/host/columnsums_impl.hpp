@@ -42,6 +42,27 @@ inline int default_device() {
     return s ? std::atoi(s) : 0;
 }
 
+// Several GPUs for the one-shot path (opt-in): RCPPSPARSE_DEVICES = "all" (one column range per visible device) or a
+// comma-separated list of ordinals ("0,1,2,3"; an ordinal may repeat).  The one-shot call is bound by the host link
+// (C3 145 ms at 55 GB/s against 1.2 ms of kernel); rsp_column_sums_host_multi cuts the columns into
+// nnz-balanced ranges and sends every range over ITS device's link from a host thread of its own.  Not set (default): one
+// device, RCPPSPARSE_DEVICE.  Returns the number of listed devices (0: not set, -1: "all"); ordinals into out[0..n).
+inline int devices_setting(int* out, int capacity) {
+    const char* s = std::getenv("RCPPSPARSE_DEVICES");
+    if (!s || !s[0]) return 0;
+    if (s[0] == 'a' || s[0] == 'A') return -1;
+    int n = 0;
+    while (*s && n < capacity) {
+        char* end = 0;
+        const long v = std::strtol(s, &end, 10);
+        if (end == s) break;
+        out[n++] = (int)v;
+        s = end;
+        while (*s == ',' || *s == ' ') ++s;
+    }
+    return n;
+}
+
 enum Backend { kBackendNone = 0, kBackendHip = 1, kBackendCpu = 2 };
 inline const char* backend_name(int b) { return b == kBackendHip ? "hip" : (b == kBackendCpu ? "cpu" : "none"); }
 
@@ -105,7 +126,11 @@ typename Traits::NumVec column_sums_via_hip(MatrixT& A, int require_gpu_option =
     const long long nnz = (long long)A.n_nonzero();           // RcppSparse.h:48
     const double* px = nnz ? &A.x[0] : (const double*)0;
     // (no device and a GPU required: the shim's RSP_ERR_NO_DEVICE is the error)
-    const int rc = rsp_column_sums_host(px, &A.p[0], (int)ncol, nnz, &sums[0], default_device());
+    int devs[64];
+    const int ndev = devices_setting(devs, 64);
+    const int rc = ndev == 0 ? rsp_column_sums_host(px, &A.p[0], (int)ncol, nnz, &sums[0], default_device())
+                             : rsp_column_sums_host_multi(px, &A.p[0], (int)ncol, nnz, &sums[0], ndev < 0 ? (const int*)0 : devs,
+                                                          ndev < 0 ? 0 : ndev);
     if (rc != RSP_OK)
         throw std::runtime_error(std::string("RcppSparse columnSums (HIP): ") + rsp_last_error());
     last_backend() = kBackendHip;

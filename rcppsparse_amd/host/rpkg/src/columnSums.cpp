@@ -30,6 +30,9 @@ long long min_nnz_option() {
 //' \code{getOption("RcppSparse.min_nnz")} stored entries (else \code{RCPPSPARSE_MIN_NNZ} in the environment,
 //' else 250000, the measured crossover): a trip through the GPU costs about 0.1 ms whatever the size, the loop
 //' a few nanoseconds per entry, and the function is never slower than the CPU original.
+//' On a machine with several GPUs \code{RCPPSPARSE_DEVICES=all} (or a list such as \code{0,1,2,3}) in the
+//' environment spreads the call over them: the matrix is cut into column ranges of equal numbers of stored entries
+//' and every range travels over its own GPU's host link, which is what bounds a call on host data.
 //' \code{options(RcppSparse.require_gpu = TRUE)} or \code{RCPPSPARSE_REQUIRE_GPU=1} in the
 //' environment turn both off: every call goes to the GPU and no GPU is then an R error.  With a GPU present
 //' a failure is always an error.

@@ -24,6 +24,11 @@ int rsp_column_sums_host(const double *x, const int32_t *p, int32_t ncol, int64_
     (void)x; (void)p; (void)ncol; (void)nnz; (void)sums; (void)device;
     return RSP_ERR_NO_DEVICE;
 }
+int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol, int64_t nnz, double *sums, const int *devices,
+                               int ndevices) {
+    (void)x; (void)p; (void)ncol; (void)nnz; (void)sums; (void)devices; (void)ndevices;
+    return RSP_ERR_NO_DEVICE;
+}
 int rsp_release_cached(void) { return RSP_OK; }   /* nothing is ever kept in this build */
 int rsp_csc_upload(const double *x, const int32_t *i, const int32_t *p, int32_t nrow, int32_t ncol, int64_t nnz,
                    int device, rsp_csc_t *handle) {

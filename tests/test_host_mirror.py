@@ -185,6 +185,32 @@ def test_with_a_gpu_present_the_host_loop_answers_small_matrices_only_when_allow
 
 
 @pytest.mark.gpu
+def test_exported_columnSums_over_several_devices_when_asked(monkeypatch):
+    """RCPPSPARSE_DEVICES (round 5, opt-in): the exported columnSums spreads a call on host data over several GPUs --
+    rsp_column_sums_host_multi: nnz-balanced column ranges, one host thread and one host link per range.  On this box the
+    "several" are device 0 three times (an ordinal may repeat); "all" is every visible device.  Same sums as the
+    one-device call within the tolerance, bit-identical run to run; not set: one device as before."""
+    m = synth.rsparsematrix(4000, 1500, density=0.05, seed=31)
+    monkeypatch.delenv("RCPPSPARSE_DEVICES", raising=False)
+    one = hostseam.columnSums(m)
+    scale = oracle.column_abs_sums(m["x"], m["p"])
+    ref = oracle.column_sums(m["x"], m["p"])
+    assert np.all(np.abs(one - ref) <= 1e-12 * scale)
+    for setting in ("0,0,0", "all", " 0 , 0"):
+        monkeypatch.setenv("RCPPSPARSE_DEVICES", setting)
+        got = hostseam.columnSums(m)
+        assert hostseam.backend(last=True) == "hip"
+        assert np.all(np.abs(got - ref) <= 1e-12 * scale), setting
+        assert got.tobytes() == hostseam.columnSums(m).tobytes()
+    monkeypatch.setenv("RCPPSPARSE_DEVICES", "7")                       # no such device on a one-GPU box: an R error, not a crash
+    from rcppsparse_amd import capi
+    if capi.device_count() < 8:
+        with pytest.raises(hostseam.SeamError) as e:
+            hostseam.columnSums(m)
+        assert "out of range" in str(e.value)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", golden_names())
 def test_exported_columnSums_through_the_hip_shim(name):
     g = load_golden(name)
