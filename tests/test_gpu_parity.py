@@ -530,6 +530,76 @@ def test_c3_full_size_properties(torch_cuda, shape, kind):
     assert torch.equal(out2, out * 2.0)
 
 
+def _small_integers(idx):
+    """an integer in [-3, 3] per element index: the same few integer operations on the host (numpy) and on the device (torch)"""
+    return ((idx * 2654435761) >> 13) % 7 - 3
+
+
+@pytest.mark.parametrize("shape", ["uniform", "zipf"])
+def test_c3_c5_integer_valued_entries_sum_exactly_in_every_form(torch_cuda, shape):
+    """Known answers at full size that rest on NOTHING but integer arithmetic -- not on the oracle, not on any
+    floating-point order.  Every entry is an integer in [-3, 3]; every partial sum of any grouping is then an integer far
+    below 2^53, so EVERY summation order gives the exact column sum, and the expected value is computed on the host in int64
+    from a running total sampled at the column boundaries p[c] (reference RcppSparse.h:220-221: column c is [p[c], p[c+1])).
+    One misplaced entry -- a boundary off by one, an entry added twice or dropped at a chunk, shard or plan edge -- changes
+    an integer.  Through the general kernels, a caller's plan, and (BASELINE configs 4 / 5) the eight column-range shards
+    through the plan-free entry planning for itself."""
+    torch = torch_cuda
+    nrow, ncol, nnz = 10_000_000, 1_000_000, 1_000_000_000
+    if torch.cuda.get_device_properties(0).total_memory < 24 * 2**30:
+        pytest.skip("needs >= 24 GB of HBM")
+    torch.cuda.empty_cache()
+    counts = (synth.uniform_counts(ncol, nnz, seed=42, nrow=nrow) if shape == "uniform"
+              else synth.zipf_counts(ncol, nnz, seed=42, nrow=nrow))
+    p = synth.offsets_from_counts(counts)
+    p64 = p.astype(np.int64)
+    # expected sums: running total of the integer sequence at every column boundary, chunk by chunk, in int64
+    S = np.zeros(ncol + 1, dtype=np.int64)
+    base, step = 0, 50_000_000
+    for s0 in range(0, nnz, step):
+        n = min(step, nnz - s0)
+        csum = np.cumsum(_small_integers(np.arange(s0, s0 + n, dtype=np.int64)))
+        lo, hi = np.searchsorted(p64, s0, side="left"), np.searchsorted(p64, s0 + n, side="right")
+        loc = p64[lo:hi] - s0
+        S[lo:hi] = base + np.where(loc > 0, csum[np.maximum(loc, 1) - 1], 0)
+        base += int(csum[-1])
+    want = (S[1:] - S[:-1]).astype(np.float64)
+    assert np.all(np.abs(want) <= 3 * counts) and want[counts == 0].sum() == 0
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    for s0 in range(0, nnz, 100_000_000):
+        n = min(100_000_000, nnz - s0)
+        xt[s0:s0 + n] = _small_integers(torch.arange(s0, s0 + n, dtype=torch.int64, device="cuda")).double()
+    pt = torch.from_numpy(p).cuda()
+    # (1) the general kernels (this suite keeps the plan-free entry from planning for itself: tests/conftest.py)
+    got = capi.column_sums_device(xt, pt).cpu().numpy()
+    assert got.tobytes() == (want + 0.0).tobytes(), int(np.count_nonzero(got != want))
+    # (2) a caller's plan, whatever form it takes for this matrix
+    plan = capi.ColumnSumsPlan(p, nnz=nnz)
+    assert plan.column_sums(xt, pt).cpu().numpy().tobytes() == got.tobytes()
+    plan.close()
+    # (3) BASELINE configs 4 / 5: eight nnz-balanced column ranges, each through the plan-free entry planning for itself
+    capi.set_auto_plan(True)
+    try:
+        from rcppsparse_amd import sharded
+        forms = []
+        for r in range(8):
+            sh = sharded.make_shard(p, r, 8)
+            xs, ps = xt[sh.x0:sh.x1], torch.from_numpy(sh.p_local).cuda()
+            out = torch.empty(sh.ncol, dtype=torch.float64, device="cuda")
+            ws = capi.alloc_workspace(sh.ncol, sh.nnz)
+            capi.column_sums_device(xs, ps, out, ws)
+            assert out.cpu().numpy().tobytes() == got[sh.c0:sh.c1].tobytes(), (shape, r, "first call")
+            forms.append(capi.column_sums_device_form(ps, sh.nnz, wait=True))
+            out.fill_(-1.0)
+            capi.column_sums_device(xs, ps, out, ws)
+            assert out.cpu().numpy().tobytes() == got[sh.c0:sh.c1].tobytes(), (shape, r, forms[-1])
+        if shape == "uniform":
+            assert forms == ["columns"] * 8
+    finally:
+        capi.set_auto_plan(False)
+        capi.release_cached()
+
+
 # ------------------------------------------- "next" row f1: colSums / colMeans on device
 @pytest.mark.parametrize("label,ncol,mean", REGIMES)
 def test_column_means_follow_reference_division(torch_cuda, label, ncol, mean):
