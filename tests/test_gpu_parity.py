@@ -584,7 +584,7 @@ def test_c3_c5_integer_valued_entries_sum_exactly_in_every_form(torch_cuda, shap
         forms = []
         for r in range(8):
             sh = sharded.make_shard(p, r, 8)
-            xs, ps = xt[sh.x0:sh.x1], torch.from_numpy(sh.p_local).cuda()
+            xs, ps = xt[sh.x0:sh.x1].clone(), torch.from_numpy(sh.p_local).cuda()   # (a shard's x in a buffer of its own: d_x must be 16-byte aligned)
             out = torch.empty(sh.ncol, dtype=torch.float64, device="cuda")
             ws = capi.alloc_workspace(sh.ncol, sh.nnz)
             capi.column_sums_device(xs, ps, out, ws)
