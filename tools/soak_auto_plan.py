@@ -88,7 +88,7 @@ def main():
                       "pt": torch.zeros(ncol + 1, dtype=torch.int32, device="cuda"),
                       "out": torch.empty(ncol, dtype=torch.float64, device="cuda"), "ws": capi.alloc_workspace(ncol, nnz),
                       "p": None})
-    t0 = time.time()
+    t0 = last_note = time.time()
     steps = calls = 0
     forms, fams, exact_calls, worst = {}, {}, 0, 0.0
     while time.time() - t0 < seconds:
@@ -129,6 +129,9 @@ def main():
         steps += 1
         if steps % 60 == 0:
             capi.release_cached()
+        if time.time() - last_note > 60:            # (a run that writes nothing for minutes is taken to be hung)
+            last_note = time.time()
+            print(f"[soak_auto_plan] {int(last_note - t0)} s: {steps} steps, {calls} calls checked", file=sys.stderr, flush=True)
     print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "steps": steps, "calls_checked": calls,
                       "calls_with_the_references_bits": exact_calls, "form_after_call": forms, "offset_families": fams,
                       "worst_err_over_l1": worst, "slots": [[s["ncol"], s["nnz"]] for s in slots], "mismatches": 0}))
