@@ -849,7 +849,14 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
                                             int32_t* __restrict__ nonfinite, double* __restrict__ mine) {
     // PR rows per panel (32; 16 at 32 tiles, where two buffers of 32 x 512 would not fit the LDS): a column's piece of a
     // panel is at most PR entries, PR lanes fetch it, CPI = 64 / PR columns go in one instruction.
-    constexpr int W = NT * 16, W1 = W + kPanPad, NTH = NW * 64, CPI = 64 / PR, RND = W / (CPI * NW);
+    // SPLIT > 1 (24 / 32 tiles): the workgroups of a panel range each own NT / SPLIT tile rows, and tile row I only meets the
+    // tiles I .. I + NT / 2 -- so a workgroup densifies only the WL = NT / SPLIT + NT / 2 tiles its rows meet (20 of 24, 24
+    // of 32), kept in LDS in LOCAL order: local tile t = tile (t0 + t) mod NT with t0 its first tile row.  Round 5: the other
+    // vector instructions beside the MFMAs were 3.4 per MFMA at these widths against 1.6 at 16 tiles, every workgroup
+    // zeroing / requesting / scattering ALL columns for a third / a quarter of the MFMAs (profiles/r05_crossprod_wide.json).
+    constexpr bool LOCAL = SPLIT > 1;
+    constexpr int WL = LOCAL ? NT / SPLIT + NT / 2 : NT;   // tiles a workgroup densifies
+    constexpr int W = WL * 16, W1 = W + kPanPad, NTH = NW * 64, CPI = 64 / PR, RND = W / (CPI * NW);
     constexpr bool TWO = NW * 2 == NT && SPLIT == 1;   // two tile rows per wavefront (16 tiles) or one
     static_assert(TWO || NW * SPLIT == NT, "a wavefront owns one or two whole tile rows; SPLIT workgroups share a range of panels");
     constexpr int KS = PR / 4, NA = NT / 2 + 1;        // k-steps per panel; pairs of a tile row below NT / 2 (one more than of the others)
@@ -860,6 +867,8 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     const int tid = threadIdx.x, lane = tid & 63, sub = lane / PR, l = lane % PR;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int trow = TWO ? wave : part * NW + wave;    // this wavefront's (first) tile row
+    const int t0 = LOCAL ? part * NW : 0;              // (LOCAL: the workgroup's first tile row = local tile 0)
+    static_assert(!LOCAL || !TWO, "local tile order is for one tile row per wavefront");
     xp_v4f64 acc[NPW];
 #pragma unroll
     for (int s = 0; s < NPW; ++s) acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
@@ -867,6 +876,10 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     auto wrap = [&](int t) { return t >= NT ? t - NT : t; };
     auto tile_a = [&](int s) { return TWO && s >= NA ? trow + NW : trow; };
     auto tile_b = [&](int s) { return wrap(TWO && s >= NA ? trow + NW + (s - NA) : trow + s); };
+    // where these tiles stand in the panel buffer (LOCAL: wave + s never reaches WL, nothing wraps)
+    auto lds_tile_a = [&](int s) { return LOCAL ? wave : tile_a(s); };
+    auto lds_tile_b = [&](int s) { return LOCAL ? wave + s : tile_b(s); };
+    static_assert(!LOCAL || (NW - 1) + (NT / 2) < WL, "every pair's B tile lies inside the densified tiles");
     auto has_pair = [&](int s) { return TWO || s < NA - 1 || trow < NT / 2; };
 
     auto zero_part = [&](int b, int m0, int m1) {   // 16-byte units tid + m * NTH, m0 <= m < m1
@@ -886,6 +899,11 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // vmcnt(1) where (30) would do, 1.66 ms at 1e6 x 256; with a select after the load ("row = lane has an entry ?
     // loaded : -1") the wavefront waits for what it has just requested (1.85 ms).
     int32_t treg[TC];
+    auto global_col = [&](int col) {   // column of the matrix that stands at (local) column `col` of the panel buffer
+        if (!LOCAL) return col;
+        const int g = col + 16 * t0;
+        return g >= 16 * NT ? g - 16 * NT : g;
+    };
     auto cell_of = [&](int k, bool& have, int& col, const int32_t*& tab) {   // cell tid + k NTH of {Ts[0..W), Te[0..W)}
         const int idx = tid + k * NTH;
         have = idx < 2 * W;
@@ -897,7 +915,8 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         for (int k = 0; k < TC; ++k) {
             bool have; int col; const int32_t* tab;
             cell_of(k, have, col, tab);
-            treg[k] = tab[have && col < ncol && P < P1 ? (int64_t)col * npanels + P : 0];
+            const int gcol = global_col(col);
+            treg[k] = tab[have && gcol < ncol && P < P1 ? (int64_t)gcol * npanels + P : 0];
         }
     };
     auto put_T = [&](int q, int64_t P) {   // ... of panel P: zeros past the last panel and the last column; notes an entry of P in sSafe[q]
@@ -905,7 +924,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         for (int k = 0; k < TC; ++k) {
             bool have; int col; const int32_t* tab;
             cell_of(k, have, col, tab);
-            const int32_t t = have && col < ncol && P < P1 ? treg[k] : 0;
+            const int32_t t = have && global_col(col) < ncol && P < P1 ? treg[k] : 0;
             if (have) sT[tid + k * NTH] = t;
             const unsigned long long ends = __ballot(tid + k * NTH >= W && t > 0);   // (cells from W on hold Te: the end of a piece that is not empty)
             if (ends != 0ull) {
@@ -961,9 +980,9 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     auto operand_addresses = [&](int b) {
         const uint32_t base = lane_at + (uint32_t)(b * kBufDoubles * 8);
 #pragma unroll
-        for (int s = 0; s < NPW; ++s) opat[s] = base + (uint32_t)(128 * tile_b(s));
-        opat_a[0] = base + (uint32_t)(128 * trow);
-        opat_a[1] = base + (uint32_t)(128 * (TWO ? trow + NW : trow));
+        for (int s = 0; s < NPW; ++s) opat[s] = base + (uint32_t)(128 * lds_tile_b(s));
+        opat_a[0] = base + (uint32_t)(128 * lds_tile_a(0));
+        opat_a[1] = base + (uint32_t)(128 * (TWO ? trow + NW : lds_tile_a(0)));
     };
     auto load_group = [&](int g) {
 #pragma unroll
@@ -1109,7 +1128,8 @@ void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __rest
                              const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
                              const uint8_t* __restrict__ has, int32_t ncol, int64_t npanels,
                              int32_t panels_per_group, int32_t* __restrict__ nonfinite, double* __restrict__ partial) {
-    constexpr int W = NT * 16, W1 = W + kPanPad, NP = NT * (NT + 1) / 2;
+    constexpr int WL = SPLIT > 1 ? NT / SPLIT + NT / 2 : NT;   // (tiles a workgroup densifies: panels_body)
+    constexpr int W = WL * 16, W1 = W + kPanPad, NP = NT * (NT + 1) / 2;
     constexpr int kBufDoubles = PR * W1;
     static_assert((kBufDoubles * 8) % 16 == 0, "a panel buffer is whole 16-byte units");
     __shared__ __attribute__((aligned(16))) double panel[2 * kBufDoubles];
