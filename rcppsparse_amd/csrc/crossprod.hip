@@ -1280,10 +1280,11 @@ static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
     // (8 / 12 / 16 tiles, the panel-table kernel.  1e6 rows x 256 at 0.4 / 10 / 50 / 90 % density 1.20 / 1.32 / 1.53 / 1.81
     // ms, x 192 at 10 / 50 / 90 % 0.85 / 1.01 / 1.29, x 128 0.48 / 0.57 / 0.77; 4e6 rows at 5 % 4.68 / 2.98 / 1.55 ms; 24 / 32
     // tiles (257-512 columns): 1e6 rows x 384 at 10 / 50 % 3.47 / 3.87 ms, x 512 6.2 ms at either --
-    // profiles/r04_crossprod_panels.json, r04_form_edges_crossprod.json)
+    // profiles/r04_crossprod_panels.json, r04_form_edges_crossprod.json; round 5, local tile order: x 384 3.3 / 3.5 ms,
+    // x 512 5.5 ms, profiles/r05_crossprod_wide.json)
     const int nt = tall_tiles(ncol);
     if (panel_table_tiles(nt))
-        t_tall = 0.09 + rows * width * width / (nt == 32 ? 4.3e10 : (nt == 24 ? 4.4e10 : (nt == 16 ? 6.0e10 : (nt == 12 ? 5.2e10 : 4.5e10)))) + (nt == 32 ? 0.0 : 2.7e-9 * (double)nnz);
+        t_tall = 0.09 + rows * width * width / (nt == 32 ? 4.8e10 : (nt == 24 ? 4.8e10 : (nt == 16 ? 6.0e10 : (nt == 12 ? 5.2e10 : 4.5e10)))) + (nt == 32 ? 0.0 : 2.7e-9 * (double)nnz);
     return t_tall <= t_exact;
 }
 

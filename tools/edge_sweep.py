@@ -365,6 +365,7 @@ def main():
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     capi.load()
+    capi.set_auto_plan(False)      # ("the plan-free entry" below means the general kernels: since round 5 it would otherwise plan for itself)
     torch.cuda.set_device(0)
     global LIMIT
     LIMIT = args.limit
