@@ -65,6 +65,17 @@ int main(void) {
         double l1 = 0.0; for (int j = pp[c]; j < pp[c + 1]; ++j) l1 += fabs(xx[j]);
         if (fabs(out[c] - ref[c]) > 1e-12 * l1) { fprintf(stderr, "column %d: %.17g vs %.17g\n", c, out[c], ref[c]); return 1; }
     }
+    /* round 5: the same call again -- the library has kept its stream and buffers; give them back; the next call simply
+     * allocates again.  One knob entry instead of a setter per knob; an unknown key is an error, not a crash. */
+    if (rsp_column_sums_host(xx, pp, ncol, nnz, out, 0) != RSP_OK) return fail("ragged, second call");
+    if (rsp_release_cached() != RSP_OK) return fail("release_cached");
+    if (rsp_column_sums_host(x, p, 5, 5, got, 0) != RSP_OK || memcmp(got, want, sizeof want) != 0) return fail("after release_cached");
+    int knob = -1;
+    if (rsp_debug_get("auto_plan", &knob) != RSP_OK || knob != 1) return fail("debug_get auto_plan");
+    if (rsp_debug_set("auto_plan", 0) != RSP_OK || rsp_debug_get("auto_plan", &knob) != RSP_OK || knob != 0) return fail("debug_set");
+    if (rsp_debug_set("auto_plan", 1) != RSP_OK) return fail("debug_set back");
+    if (rsp_debug_set("no_such_knob", 1) != RSP_ERR_BAD_ARG) { fprintf(stderr, "unknown knob accepted\n"); return 1; }
+    if (rsp_column_sums_device_form(NULL, 5, 5, 0) != -1) { fprintf(stderr, "a form for offsets never seen\n"); return 1; }
     printf("cabi_smoke ok (%ld nnz, %d columns)\n", nnz, ncol);
     return 0;
 }
