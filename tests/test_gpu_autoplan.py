@@ -8,6 +8,8 @@ the kernels of this path check every column's offsets against the p[] of the cal
 mostly about: offsets changed in place under an adopted plan, captured calls replayed over changed offsets, two
 matrices over two workspaces and streams, offsets that are not a dgCMatrix's at all.  Never a wrong sum, only a slower
 call.  The reference has one synchronous call and no such state (src/example.cpp:26-32): the oracle is its loop."""
+import os
+
 import numpy as np
 import pytest
 
@@ -360,6 +362,63 @@ def test_fuzz_adopted_forms_against_the_oracle(torch_auto, seed):
         out.fill_(-1.0)
         capi.column_sums_device(xt, pt, out, ws)
         check(out.cpu().numpy(), x, q)
+
+
+def test_the_entrys_own_lean_plan_at_the_int32_limit(torch_auto):
+    """nnz = 2^31 - 1, the most the reference's 32-bit p[] can address (RcppSparse.h:30), in 2.1e8 columns of ten entries: the
+    device-side inspection of 860 MB of offsets, a lean image of 4.2e6 chunks, and the validating kernel's comparisons next
+    to 2^31 (chunk start + offset passes INT32_MAX in the last chunks).  Entries are small integers, so the expected sums
+    are exact whatever the order and come from integer arithmetic alone."""
+    torch = torch_auto
+    if torch.cuda.get_device_properties(0).total_memory < 48 * 2**30:
+        pytest.skip("needs >= 48 GB of HBM")
+    try:
+        free_host = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        free_host = 0
+    if free_host < 12 * 2**30:
+        pytest.skip("needs >= 12 GB of free host memory")
+    torch.cuda.empty_cache()
+    nnz, per = 2**31 - 1, 10
+    ncol = -(-nnz // per)
+    f = lambda idx: ((idx * 2654435761) >> 13) % 7 - 3   # noqa: E731  (the same few integer operations on host and device)
+    want = np.empty(ncol, dtype=np.float64)
+    step = 50_000_000
+    for s0 in range(0, nnz, step):
+        n = min(step, nnz - s0)
+        v = f(np.arange(s0, s0 + n, dtype=np.int64))
+        full = n // per
+        want[s0 // per:s0 // per + full] = v[:full * per].reshape(full, per).sum(axis=1)
+        if full * per < n:
+            want[s0 // per + full] = v[full * per:].sum()
+    xt = torch.empty(nnz, dtype=torch.float64, device="cuda")
+    for s0 in range(0, nnz, 100_000_000):
+        n = min(100_000_000, nnz - s0)
+        xt[s0:s0 + n] = f(torch.arange(s0, s0 + n, dtype=torch.int64, device="cuda")).double()
+    pt = torch.clamp(torch.arange(0, ncol + 1, dtype=torch.int64, device="cuda") * per, max=nnz).to(torch.int32)
+    assert int(pt[-1]) == nnz and int(pt[-2]) == (ncol - 1) * per
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    capi.column_sums_device(xt, pt, out, ws)                              # the general kernels + the inspection behind them
+    assert out.cpu().numpy().tobytes() == (want + 0.0).tobytes()
+    assert capi.column_sums_device_form(pt, nnz, wait=True) == "lean"
+    out.fill_(-1.0)
+    capi.column_sums_device(xt, pt, out, ws)
+    assert out.cpu().numpy().tobytes() == (want + 0.0).tobytes()
+    # the last columns moved by one entry, in place: caught and summed straight from x, right next to 2^31
+    q = pt.clone()
+    q[-3] -= 1
+    q[-2] += 2
+    pt.copy_(q)
+    want2 = want.copy()
+    tail = f(np.arange(nnz - 40, nnz, dtype=np.int64))
+    qh = q[-5:].cpu().numpy().astype(np.int64)
+    for k in range(4):
+        want2[ncol - 4 + k] = tail[qh[k] - (nnz - 40):qh[k + 1] - (nnz - 40)].sum()
+    out.fill_(-1.0)
+    capi.column_sums_device(xt, pt, out, ws)
+    assert out.cpu().numpy().tobytes() == (want2 + 0.0).tobytes()
+    capi.release_cached()
 
 
 def test_auto_plan_off_keeps_every_call_on_the_general_kernels(torch_auto):
