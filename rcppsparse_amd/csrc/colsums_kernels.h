@@ -118,10 +118,12 @@ struct DeviceInspectLayout {   // the plan memory of a device-made plan (byte of
 hipError_t launch_inspect_device(const int32_t* d_p, int32_t ncol, int32_t nnz, const LaunchPlan& grid,
                                  const DeviceInspectLayout& L, void* d_mem, PlanStats* stats_out, hipStream_t stream);
 
-// hand-written exclusive prefix sum of 32-bit counts (scan.hip): out[k] = initial + in[0] + ... + in[k - 1]; out may be in
+// hand-written exclusive prefix sum of 32-bit counts (scan.hip): out[k] = initial + in[0] + ... + in[k - 1]; out may be in;
+// out2: an optional second copy of the result; run_if: an optional device word -- 0 when the launches run = they do nothing
 size_t exclusive_scan_temp_bytes(int64_t n);
 hipError_t launch_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t initial, void* temp,
-                                     size_t temp_bytes, hipStream_t stream);
+                                     size_t temp_bytes, hipStream_t stream, const int32_t* run_if = nullptr,
+                                     int32_t* out2 = nullptr);
 
 // the main kernel's access shape without any column work (rsp_debug_read_ceiling_device)
 hipError_t launch_read_ceiling(const double* d_x, int32_t nnz, const LaunchPlan& plan, double* d_sink,

@@ -34,6 +34,7 @@
 // loop.  Only entries that are stored take part, so a non-finite value never meets a structural
 // zero.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <stdint.h>
 #include <type_traits>
@@ -186,6 +187,13 @@ __global__ __launch_bounds__(256) void xp_count_rows_kernel(const int32_t* __res
             if ((unsigned)r < (unsigned)nrow) atomicAdd(&cnt[(int64_t)r * nsplit + slice], 1);
         }
     }
+}
+
+// the counts start at zero -- as a kernel (not a memset) where the row-major form only stands by
+__global__ __launch_bounds__(256) void xp_zero_if_kernel(int32_t* __restrict__ a, int64_t n,
+                                                         const int32_t* __restrict__ run_if) {
+    if (*run_if == 0) return;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) a[k] = 0;
 }
 
 // entry e of column c goes to the next free slot of its virtual row
@@ -1377,16 +1385,16 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     if (L.tall && part != kXpExactOnly) {
         int32_t* flag = (int32_t*)((char*)ws + L.flag_off);
         double* partial = (double*)((char*)ws + L.partial_off);
-        e = hipMemsetAsync(flag, 0, 4, stream);
+        // ONE memset: the flag, and behind it in the workspace the panel table (0, 0: nothing of column c in panel P)
+        // and which panels hold entries (round 5: three memsets before)
+        const size_t zero_end = L.panel_table ? L.has_off + ((size_t)L.npanels + 3) / 4 * 4 : L.flag_off + 4;
+        e = hipMemsetAsync(flag, 0, zero_end - L.flag_off, stream);
         if (e != hipSuccess) return e;
         if (L.panel_table) {
             // the panel table (and which panels hold entries), then the matrix-core kernel that reads x / i through it
             int32_t* Ts = (int32_t*)((char*)ws + L.table_off);
             int32_t* Te = Ts + (size_t)L.npanels * (size_t)ncol;
             uint8_t* has = (uint8_t*)((char*)ws + L.has_off);
-            e = hipMemsetAsync(Ts, 0, 2 * (size_t)L.npanels * (size_t)ncol * 4, stream);   // (0, 0: nothing of column c in panel P)
-            if (e == hipSuccess) e = hipMemsetAsync(has, 0, ((size_t)L.npanels + 3) / 4 * 4, stream);
-            if (e != hipSuccess) return e;
             const int want_y = (ncol + 3) / 4;
             int xparts = (int)(nnz / ((int64_t)ncol * 2048));   // (a part walks ~2048 entries or more)
             if (xparts > 4096 / want_y) xparts = 4096 / want_y;   // (1024 ... 16384 blocks: 0.22 ... 0.16 ms, flat from 1792 on)
@@ -1459,7 +1467,15 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
         run_if = flag;   // everything below only works if x holds a non-finite value
         if (part == kXpTallOnly) return hipSuccess;
     }
-    e = hipMemsetAsync(cursor, 0, nv1 * 4, stream);
+    // Standing by (run_if): SIX launches that read the flag and return -- no memset, no scan, no copy happens unless
+    // a sum was not finite (round 5; before: eight operations, of which the memset of the cursors, the three scan
+    // kernels and a device-to-device copy of the row offsets did their work in every call: 1e6 rows x 32 columns
+    // 0.125 -> see profiles/r05_crossprod_standby.json).
+    if (run_if)
+        hipLaunchKernelGGL(xp_zero_if_kernel, dim3((unsigned)std::min<size_t>((nv1 + 1023) / 1024, 4096)), dim3(256), 0,
+                           stream, cursor, (int64_t)nv1, run_if);
+    else
+        e = hipMemsetAsync(cursor, 0, nv1 * 4, stream);
     if (e != hipSuccess) return e;
     const int want = (ncol + 3) / 4;
     // ~4096 wavefronts: columns over y (4 per block), parts of a column over x
@@ -1471,9 +1487,10 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
     if (nnz > 0)
         hipLaunchKernelGGL(xp_count_rows_kernel, cgrid, dim3(256), 0, stream, d_i, d_p, nrow, ncol, nsplit, width,
                            cursor, run_if);
-    e = launch_exclusive_scan_i32(cursor, rp, (int64_t)nv1, 0, (char*)ws + L.temp_off, L.temp_bytes, stream);
-    if (e != hipSuccess) return e;
-    e = hipMemcpyAsync(cursor, rp, nv1 * 4, hipMemcpyDeviceToDevice, stream);
+    // (row offsets into rp AND, as the fill pass's cursors, over the counts themselves: the scan reads a tile whole
+    // before it writes any of it)
+    e = launch_exclusive_scan_i32(cursor, rp, (int64_t)nv1, 0, (char*)ws + L.temp_off, L.temp_bytes, stream, run_if,
+                                  cursor);
     if (e != hipSuccess) return e;
     if (nnz > 0)
         hipLaunchKernelGGL(xp_fill_rows_kernel, cgrid, dim3(256), 0, stream, d_x, d_i, d_p, nrow, ncol, nsplit, width,

@@ -406,3 +406,17 @@ def test_hand_written_exclusive_scan_of_the_count_tables(torch_cuda, n):
         buf = src.clone()
         capi.exclusive_scan_device(buf, buf)                 # in place
         assert np.array_equal(buf.cpu().numpy().astype(np.int64), want), (n, off, "in place")
+
+
+def test_exclusive_scan_above_the_self_prefix_limit(torch_cuda):
+    """scan.hip, round 5: up to 8192 tiles of 4096 counts every block of the last pass adds up the totals before it for
+    itself; beyond that the one-block pass over the totals is back.  One size on the far side of the limit."""
+    torch = torch_cuda
+    n = 4096 * 8193 + 11
+    host = np.random.default_rng(5).integers(0, 40, size=n, dtype=np.int32)
+    want = np.concatenate([[0], np.cumsum(host.astype(np.int64))[:-1]])
+    buf = torch.from_numpy(host).cuda()
+    got = capi.exclusive_scan_device(buf)
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+    capi.exclusive_scan_device(buf, buf)
+    assert np.array_equal(buf.cpu().numpy().astype(np.int64), want)
