@@ -819,17 +819,39 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
     }
 }
 
-// has[P] = some column has entries in panel P, read off Te (an end of a non-empty piece is never 0).  A block looks at
-// 256 panels x 32 columns: neighbouring threads, neighbouring panels.
+// has[P] = which workgroups of a panel range find entries in panel P, read off Te (an end of a non-empty piece is never
+// 0): bit h = some column of the tiles that part h densifies holds entries there (one part = bit 0 below 24 tiles; at
+// 24 / 32 tiles a workgroup densifies only the tiles its tile rows meet, panels_body).  A block looks at 256 panels x 32
+// columns = two tiles: neighbouring threads, neighbouring panels.
+// (Round 5, found by the soak: with ONE bit for all parts a panel could enter a workgroup's pipeline without an entry
+// in any of ITS tiles, so nothing was noted in sSafe for it and the lanes without an entry went on reading entry 0 of
+// the matrix -- whose row then lay in the panel being filled: x[0] in every column of that row, x[0]^2 added to column
+// pairs that share no row.  Now a panel only enters where it holds entries of the workgroup's own tiles.)
+__device__ __forceinline__ uint32_t xp_parts_of_tile(int tile, int nt, int split) {
+    if (split <= 1) return 1u;
+    const int nw = nt / split, wl = nw + nt / 2;
+    uint32_t bits = 0;
+    for (int h = 0; h < split; ++h) {
+        int d = tile - h * nw;
+        if (d < 0) d += nt;
+        if (d < wl) bits |= 1u << h;
+    }
+    return bits;
+}
+
 __global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __restrict__ Te, int32_t ncol, int64_t npanels,
-                                                           uint32_t* __restrict__ has_words) {
+                                                           int32_t nt, int32_t split, uint32_t* __restrict__ has_words) {
     const int64_t P = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int c0 = blockIdx.y * 32, c1 = c0 + 32 < ncol ? c0 + 32 : ncol;
-    int any = 0;
+    uint32_t bits = 0;
     if (P < npanels)
-        for (int c = c0; c < c1; ++c) any |= Te[(int64_t)c * npanels + P];
+        for (int half = 0; half < 2; ++half) {
+            const int c0 = blockIdx.y * 32 + 16 * half, c1 = c0 + 16 < ncol ? c0 + 16 : ncol;
+            int any = 0;
+            for (int c = c0; c < c1; ++c) any |= Te[(int64_t)c * npanels + P];
+            if (any != 0) bits |= xp_parts_of_tile(c0 >> 4, nt, split);
+        }
     // four panels' bytes share a word of has[]: the lanes of a quad put theirs together, one atomic per word
-    uint32_t word = (any != 0 ? 1u : 0u) << (8 * (threadIdx.x & 3));
+    uint32_t word = bits << (8 * (threadIdx.x & 3));
     word |= __shfl_xor(word, 1, 64);
     word |= __shfl_xor(word, 2, 64);
     if ((threadIdx.x & 3) == 0 && word != 0 && P < npanels) atomicOr(&has_words[P >> 2], word);
@@ -1017,8 +1039,10 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // Only panels that hold entries enter the pipeline (has[], written with the tables).  "The next one" is asked for a
     // phase ahead with a vector load (hq), so that the common case -- the next panel holds entries too -- never waits;
     // a gap is walked with one exposed load per empty panel, a tenth of what multiplying it would cost.
+    // (has[P]: bit h = panel P holds entries of the tiles part h densifies; one part: bit 0)
+    auto holds = [&](int64_t P) { return ((int32_t)has[P] >> (LOCAL ? part : 0)) & 1; };
     auto next_panel = [&](int64_t P) {   // the first panel at or after P that holds entries (wave-uniform; P1 if none)
-        while (P < P1 && __builtin_amdgcn_readfirstlane((int)has[P]) == 0) ++P;
+        while (P < P1 && __builtin_amdgcn_readfirstlane(holds(P)) == 0) ++P;
         return P;
     };
     // ---- the first panel into buffer 0, the second one requested, the third one's cells of the tables requested
@@ -1048,7 +1072,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     }
     int64_t Pnn = Pn < P1 ? next_panel(Pn + 1) : P1;
     load_T(Pnn);
-    int32_t hq = Pnn + 1 < P1 ? (int32_t)has[Pnn + 1] : 1;
+    int32_t hq = Pnn + 1 < P1 ? (int32_t)has[Pnn + 1] : 0xff;   // (the byte as loaded: looked at a phase later)
     xp_lds_barrier();         // (everybody has read sT once more)
     int b = 0, q = 0;         // q: where this phase notes an entry of the panel whose cells it puts into sT (the other one: of the panel before)
     while (Pc < P1) {
@@ -1057,9 +1081,9 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
         const int o = b ^ 1;
         put_T(q, Pnn);        // (sT and sSafe[q] were last read before the barrier that ended the previous phase)
         int64_t Pnnn = Pnn + 1 < P1 ? Pnn + 1 : P1;
-        if (Pnnn < P1 && __builtin_amdgcn_readfirstlane(hq) == 0) Pnnn = next_panel(Pnnn + 1);
+        if (Pnnn < P1 && ((__builtin_amdgcn_readfirstlane(hq) >> (LOCAL ? part : 0)) & 1) == 0) Pnnn = next_panel(Pnnn + 1);
         load_T(Pnnn);
-        hq = Pnnn + 1 < P1 ? (int32_t)has[Pnnn + 1] : 1;
+        hq = Pnnn + 1 < P1 ? (int32_t)has[Pnnn + 1] : 0xff;
         const int32_t r0n = Pn < P1 ? (int32_t)(Pn * PR) : -2 * PR;   // (no next panel: no row is within PR of that)
         // Group g: its MFMAs, and a share of everything else -- the groups of the first two k-steps zero the other
         // buffer, 16 later ones move one round of entries each.  (sched_barrier: the compiler keeps this order.  All of
@@ -1403,7 +1427,8 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
                 hipLaunchKernelGGL(xp_panel_table_kernel, dim3((unsigned)xparts, (unsigned)want_y), dim3(256), 0, stream,
                                    d_i, d_p, L.panel_rows == 16 ? 4 : 5, ncol, nnz, L.npanels, Ts, Te);
             hipLaunchKernelGGL(xp_panel_has_kernel, dim3((unsigned)((L.npanels + 255) / 256), (unsigned)((ncol + 31) / 32)),
-                               dim3(256), 0, stream, (const int32_t*)Te, ncol, L.npanels, (uint32_t*)has);
+                               dim3(256), 0, stream, (const int32_t*)Te, ncol, L.npanels, L.ntiles,
+                               L.ntiles == 32 ? 4 : (L.ntiles == 24 ? 3 : 1), (uint32_t*)has);   // (the SPLIT of RSP_XP_LAUNCH below)
 #define RSP_XP_LAUNCH(NT, NW, PR, SPLIT, WIDE, M)                                                                       \
     hipLaunchKernelGGL((crossprod_panels_kernel<NT, NW, PR, SPLIT, WIDE, M>), dim3((unsigned)L.ngroups * SPLIT),        \
                        dim3(NW * 64), 0, stream, d_x, d_i, (const int32_t*)Ts, (const int32_t*)Te, (const uint8_t*)has, \

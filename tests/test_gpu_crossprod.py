@@ -279,6 +279,44 @@ def test_crossprod_panel_table_form_gaps_ragged_end_and_round3_kernel_agree(torc
         os.environ.pop("RSP_CROSSPROD_TALL_ALWAYS", None)
 
 
+@pytest.mark.parametrize("ncol,order", [
+    (257, "tail-first"),      # 24 tiles, three workgroups per panel range: part 2 densifies tiles 16..23 and 0..11
+    (512, "head-late"),       # 32 tiles, four workgroups: part 1 densifies tiles 8..31 -- column 0 is not among them
+    (300, "tail-first"), (400, "head-late")])
+def test_crossprod_wide_forms_columns_in_disjoint_row_windows(torch_cuda, ncol, order):
+    """Round 5 (found by tools/soak_crossprod_tall.py, 257 columns): at 24 / 32 tiles a workgroup densifies only the tiles its
+    tile rows meet, and a panel that held entries of OTHER tiles only entered its pipeline without leaving an entry for
+    the lanes that have none to read -- they went on reading entry 0 of the matrix, and when that entry's row lay in the panel
+    being filled, x[0] stood in every column of that row: x[0]^2 in column pairs that share no row.  Every column dense in a
+    row window of its own, the windows in an order that puts column 0's first row behind a long run of panels in which a
+    workgroup finds nothing of its own tiles: every off-diagonal element is exactly zero."""
+    import os
+    torch = torch_cuda
+    length = 4100
+    if order == "tail-first":          # columns 192.. first (tiles 12..15: not densified by part 2 of 24 tiles), then 0, 1, ...
+        seq = list(range(192, min(ncol, 256))) + list(range(0, 192)) + list(range(256, ncol))
+    else:                              # columns 1..127 first (tiles 0..7: not densified by part 1 of 32 tiles), then 0, then the rest
+        seq = list(range(1, 128)) + [0] + list(range(128, ncol))
+    assert sorted(seq) == list(range(ncol))
+    start = np.empty(ncol, dtype=np.int64)
+    start[np.array(seq)] = np.arange(ncol, dtype=np.int64) * length + 5        # (windows do not start on a panel edge)
+    nrow = ncol * length + 40
+    i = (start[:, None] + np.arange(length)[None, :]).reshape(-1).astype(np.int32)
+    p = (np.arange(ncol + 1, dtype=np.int64) * length).astype(np.int32)
+    x = np.random.default_rng(ncol).standard_normal(i.size) * 300.0
+    os.environ["RSP_CROSSPROD_TALL_ALWAYS"] = "1"     # (no two columns share a row: the cost model would take the exact form)
+    try:
+        assert capi.crossprod_form(nrow, ncol, x.size) == "tall"
+        xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+        got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy()
+    finally:
+        os.environ.pop("RSP_CROSSPROD_TALL_ALWAYS", None)
+    diag = np.array([np.dot(x[p[c]:p[c + 1]], x[p[c]:p[c + 1]]) for c in range(ncol)])
+    off = got - np.diag(np.diag(got))
+    assert not off.any(), (int(np.count_nonzero(off)), float(np.abs(off).max()), np.argwhere(off)[:4].tolist())
+    assert np.all(np.abs(np.diag(got) - diag) <= 1e-12 * diag)
+
+
 @pytest.mark.parametrize("ncol", [256, 180, 112, 330])
 def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda, ncol):
     """16 / 12 / 8 column tiles: the panel-table kernel looks at its sums, not at every value: a NaN made by a structural zero

@@ -2,9 +2,11 @@
 """Soak of crossprod's tall (f64 MFMA) form on one GPU: random matrices of 1..256 columns whose average
 column length puts them on that form, with columns of very different lengths (some empty), rows spread over
 the whole matrix, clustered into a few 64-row panels, or shared by all columns; against the oracle's merges
-within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric.
+within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric; a quarter of the cases hold infinities / NaNs (round 5):
+the exact kernels that stand by behind the tall form's flag answer, equal to the oracle entry for entry.
 
     python3 tools/soak_crossprod_tall.py [seconds] [seed] [mincol]
+    python3 tools/soak_crossprod_tall.py 0 seed mincol case [dump.npz]        (replay one case of a seed)
 
 mincol (default 1): the smallest number of columns drawn; 193 keeps every case on the panel-table kernel of
 16 column tiles, 257 on its 24- and 32-tile forms (257..512 columns, 16-row panels).  The cost model is bypassed (RSP_CROSSPROD_TALL_ALWAYS=1): every case takes the tall form.
@@ -18,7 +20,8 @@ import oracle
 from rcppsparse_amd import capi
 
 
-def one(rng, case, mincol=1):
+def make(rng, mincol=1):
+    """one random case: everything drawn here, nothing computed (so that a case can be replayed by its number)"""
     ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, 129, 160, 192, 193, 256, int(rng.integers(1, 257))]))
     if ncol < mincol:
         top = 512 if mincol > 256 else 256
@@ -60,11 +63,26 @@ def one(rng, case, mincol=1):
     i = np.concatenate(cols).astype(np.int32)
     p = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
     x = rng.standard_normal(i.size) * np.exp(rng.uniform(-20, 20))
+    nonfinite = i.size > 0 and rng.random() < 0.25
+    if nonfinite:          # the tall form raises its flag and the exact kernels, which stood by, produce the reference's result
+        x[rng.integers(0, i.size, int(rng.integers(1, 4)))] = rng.choice([np.inf, -np.inf, np.nan])
+    return x, i, p, nrow, ncol, kind, nonfinite
+
+
+def one(rng, case, mincol=1, dump=None):
+    x, i, p, nrow, ncol, kind, nonfinite = make(rng, mincol)
+    if dump:
+        np.savez(dump, x=x, i=i, p=p, nrow=nrow)
     ref = oracle.crossprod(x, i, p)
-    scale = oracle.crossprod(np.abs(x), i, p)
     xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
     got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
     again = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    if nonfinite:
+        ok = np.array_equal(got, ref, equal_nan=True) and np.array_equal(again, ref, equal_nan=True)
+        if not ok:
+            print(f"FAIL case {case} (non-finite values): {nrow}x{ncol} nnz {i.size} kind {kind}", flush=True)
+        return ok
+    scale = oracle.crossprod(np.abs(x), i, p)
     ok = (got.tobytes() == again.tobytes() and np.array_equal(got, got.T)
           and bool(np.all(np.abs(got - ref) <= 1e-12 * scale)) and bool(np.all(got[scale == 0] == 0)))
     if not ok:
@@ -79,6 +97,13 @@ def main():
     mincol = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     capi.load()
     rng = np.random.default_rng(seed)
+    if len(sys.argv) > 4:                      # replay ONE case of this seed: [seconds] seed mincol case [dump.npz]
+        case = int(sys.argv[4])
+        for _ in range(case):
+            make(rng, mincol)
+        ok = one(rng, case, mincol, dump=sys.argv[5] if len(sys.argv) > 5 else None)
+        print(f"soak_crossprod_tall: case {case} of seed {seed}, mincol {mincol}: {'ok' if ok else 'FAILED'}", flush=True)
+        sys.exit(0 if ok else 1)
     t0, n, bad, last = time.time(), 0, 0, time.time()
     while time.time() - t0 < secs:
         bad += not one(rng, n, mincol)
