@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak of crossprod's tall (f64 MFMA) form on one GPU: random matrices of 1..256 columns whose average
 column length puts them on that form, with columns of very different lengths (some empty), rows spread over
-the whole matrix, clustered into a few 64-row panels, or shared by all columns; against the oracle's merges
+the whole matrix, clustered into a few 64-row panels, shared by all columns, or (from 97 columns on) striped -- every
+panel holding entries of a few column tiles only; against the oracle's merges
 within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric; a quarter of the cases hold infinities / NaNs (round 5):
 the exact kernels that stand by behind the tall form's flag answer, equal to the oracle entry for entry.
 
@@ -20,6 +21,47 @@ import oracle
 from rcppsparse_amd import capi
 
 
+def striped(rng, ncol):
+    """kind 4 (round 5, after the has[] defect): panel by panel of 16 / 32 rows, entries in the columns of zero to three
+    column tiles drawn at random, runs of empty panels between them, and the matrix's first entry somewhere in the
+    middle of the rows -- every workgroup of a panel range keeps meeting panels that hold nothing of its own tiles."""
+    ph = 16 if ncol > 256 else 32
+    ntile = (ncol + 15) // 16
+    fill = float(rng.uniform(0.5, 0.95))
+    per_panel = 1.5 / ntile * ph * fill                                # entries per column and panel, on average
+    npanels = int(4300 / per_panel * 1.7 * rng.uniform(1.0, 1.5)) + 8     # (about 38 % of the panels fall into gaps)
+    nrow = npanels * ph - int(rng.integers(0, ph))                     # (the last panel partial)
+    rows_of = [[] for _ in range(ncol)]
+    P = 0
+    while P < npanels:
+        if rng.random() < 0.02:
+            P += int(rng.integers(1, 60))                             # a gap
+            continue
+        for t in rng.choice(ntile, size=int(rng.integers(0, 4)), replace=False):
+            for c in range(16 * t, min(16 * t + 16, ncol)):
+                r = P * ph + np.flatnonzero(rng.random(ph) < fill)
+                rows_of[c].append(r[r < nrow])
+        P += 1
+    # column 0 starts late: its first row (entry 0 of the matrix) lies well inside the rows
+    cut = int(nrow * rng.uniform(0.2, 0.8))
+    cols = [np.concatenate(r) if r else np.zeros(0, np.int64) for r in rows_of]
+    cols[0] = cols[0][cols[0] >= cut]
+    lens = np.array([len(c) for c in cols], dtype=np.int64)
+    short = 4097 * ncol - int(lens.sum())
+    if short > 0:                                                      # keep the average on the tall side: one dense stretch in the longest column
+        c = int(np.argmax(lens))
+        extra = np.setdiff1d(np.arange(nrow), cols[c])[:short]
+        cols[c] = np.sort(np.concatenate([cols[c], extra]))
+        lens[c] = len(cols[c])
+    i = np.concatenate(cols).astype(np.int32)
+    p = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    x = rng.standard_normal(i.size) * np.exp(rng.uniform(-20, 20))
+    nonfinite = rng.random() < 0.15
+    if nonfinite:
+        x[rng.integers(0, i.size, int(rng.integers(1, 4)))] = rng.choice([np.inf, -np.inf, np.nan])
+    return x, i, p, nrow, ncol, 4, nonfinite
+
+
 def make(rng, mincol=1):
     """one random case: everything drawn here, nothing computed (so that a case can be replayed by its number)"""
     ncol = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 48, 64, 65, 80, 96, 97, 128, 129, 160, 192, 193, 256, int(rng.integers(1, 257))]))
@@ -29,7 +71,9 @@ def make(rng, mincol=1):
     mean_len = int(rng.integers(4096, 40000)) if ncol > 40 else int(rng.integers(4096, 90000))
     if ncol > 256:
         mean_len = int(rng.integers(4096, 6000))                      # (the oracle's merges: ncol^2 x length)
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5)) if ncol > 96 else int(rng.integers(0, 4))
+    if kind == 4:
+        return striped(rng, ncol)
     lens = rng.integers(0, 2 * mean_len, ncol)
     if ncol > 2 and kind != 3:
         lens[rng.integers(0, ncol, max(1, ncol // 8))] = 0          # some empty columns
