@@ -140,7 +140,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(const int32_t*
     }
 }
 
-constexpr int64_t kScanSelfTiles = 8192;   // (33.5 million counts: the last block reads 32 KB of totals)
+constexpr int64_t kScanSelfTiles = 2048;   // (8.4 million counts: the last block reads 8 KB of totals, eight loads per thread;
+                                           // at 8192 tiles the blocks' own sums would cost what the one-block pass does)
 
 }  // namespace
 

@@ -409,8 +409,9 @@ def test_hand_written_exclusive_scan_of_the_count_tables(torch_cuda, n):
 
 
 def test_exclusive_scan_above_the_self_prefix_limit(torch_cuda):
-    """scan.hip, round 5: up to 8192 tiles of 4096 counts every block of the last pass adds up the totals before it for
-    itself; beyond that the one-block pass over the totals is back.  One size on the far side of the limit."""
+    """scan.hip, round 5: up to 2048 tiles of 4096 counts every block of the last pass adds up the totals before it for
+    itself; beyond that the one-block pass over the totals is back (the sizes above 8.4 million of the test above take it
+    too).  One size well on the far side of the limit, in place and out of place."""
     torch = torch_cuda
     n = 4096 * 8193 + 11
     host = np.random.default_rng(5).integers(0, 40, size=n, dtype=np.int32)
