@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of crossprod's tall (f64 MFMA) form on one GPU: random matrices of 1..256 columns whose average
 column length puts them on that form, with columns of very different lengths (some empty), rows spread over
-the whole matrix, clustered into a few 64-row panels, shared by all columns, or (from 97 columns on) striped -- every
+the whole matrix, clustered into a few 64-row panels, shared by all columns, or (from 16 columns on) striped -- every
 panel holding entries of a few column tiles only; against the oracle's merges
 within 1e-12 * sum|x1 x2| per entry, bit-stable, symmetric; a quarter of the cases hold infinities / NaNs (round 5):
 the exact kernels that stand by behind the tall form's flag answer, equal to the oracle entry for entry.
@@ -25,10 +25,11 @@ def striped(rng, ncol):
     """kind 4 (round 5, after the has[] defect): panel by panel of 16 / 32 rows, entries in the columns of zero to three
     column tiles drawn at random, runs of empty panels between them, and the matrix's first entry somewhere in the
     middle of the rows -- every workgroup of a panel range keeps meeting panels that hold nothing of its own tiles."""
-    ph = 16 if ncol > 256 else 32
+    ph = 16 if ncol > 256 else (32 if ncol > 96 else 64)            # (the panel heights of the three kernels)
     ntile = (ncol + 15) // 16
     fill = float(rng.uniform(0.5, 0.95))
-    per_panel = 1.5 / ntile * ph * fill                                # entries per column and panel, on average
+    kmax = min(3, ntile)
+    per_panel = 0.5 * kmax / ntile * ph * fill                         # entries per column and panel, on average
     npanels = int(4300 / per_panel * 1.7 * rng.uniform(1.0, 1.5)) + 8     # (about 38 % of the panels fall into gaps)
     nrow = npanels * ph - int(rng.integers(0, ph))                     # (the last panel partial)
     rows_of = [[] for _ in range(ncol)]
@@ -37,7 +38,7 @@ def striped(rng, ncol):
         if rng.random() < 0.02:
             P += int(rng.integers(1, 60))                             # a gap
             continue
-        for t in rng.choice(ntile, size=int(rng.integers(0, 4)), replace=False):
+        for t in rng.choice(ntile, size=int(rng.integers(0, kmax + 1)), replace=False):
             for c in range(16 * t, min(16 * t + 16, ncol)):
                 r = P * ph + np.flatnonzero(rng.random(ph) < fill)
                 rows_of[c].append(r[r < nrow])
@@ -71,7 +72,7 @@ def make(rng, mincol=1):
     mean_len = int(rng.integers(4096, 40000)) if ncol > 40 else int(rng.integers(4096, 90000))
     if ncol > 256:
         mean_len = int(rng.integers(4096, 6000))                      # (the oracle's merges: ncol^2 x length)
-    kind = int(rng.integers(0, 5)) if ncol > 96 else int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5)) if ncol >= 16 else int(rng.integers(0, 4))
     if kind == 4:
         return striped(rng, ncol)
     lens = rng.integers(0, 2 * mean_len, ncol)
