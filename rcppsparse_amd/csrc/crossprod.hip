@@ -827,20 +827,21 @@ __global__ __launch_bounds__(256) void xp_panel_table_kernel(const int32_t* __re
 // in any of ITS tiles, so nothing was noted in sSafe for it and the lanes without an entry went on reading entry 0 of
 // the matrix -- whose row then lay in the panel being filled: x[0] in every column of that row, x[0]^2 added to column
 // pairs that share no row.  Now a panel only enters where it holds entries of the workgroup's own tiles.)
-__device__ __forceinline__ uint32_t xp_parts_of_tile(int tile, int nt, int split) {
+__device__ __forceinline__ uint32_t xp_parts_of_tile(int tile, int rt, int split) {   // rt: the matrix's real column tiles (panels_body: RT)
     if (split <= 1) return 1u;
-    const int nw = nt / split, wl = nw + nt / 2;
+    const int nwr = (rt + split - 1) / split, need = nwr + rt / 2;
     uint32_t bits = 0;
     for (int h = 0; h < split; ++h) {
-        int d = tile - h * nw;
-        if (d < 0) d += nt;
-        if (d < wl) bits |= 1u << h;
+        int d = tile - h * nwr;
+        if (d < 0) d += rt;
+        if (d < need) bits |= 1u << h;
     }
     return bits;
 }
 
 __global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __restrict__ Te, int32_t ncol, int64_t npanels,
-                                                           int32_t nt, int32_t split, uint32_t* __restrict__ has_words) {
+                                                           int32_t /* padded tiles: not needed */, int32_t split,
+                                                           uint32_t* __restrict__ has_words) {
     const int64_t P = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t bits = 0;
     if (P < npanels)
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __rest
             const int c0 = blockIdx.y * 32 + 16 * half, c1 = c0 + 16 < ncol ? c0 + 16 : ncol;
             int any = 0;
             for (int c = c0; c < c1; ++c) any |= Te[(int64_t)c * npanels + P];
-            if (any != 0) bits |= xp_parts_of_tile(c0 >> 4, nt, split);
+            if (any != 0) bits |= xp_parts_of_tile(c0 >> 4, (ncol + 15) >> 4, split);
         }
     // four panels' bytes share a word of has[]: the lanes of a quad put theirs together, one atomic per word
     uint32_t word = bits << (8 * (threadIdx.x & 3));
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256) void xp_panel_has_kernel(const int32_t* __rest
 typedef double xp_v2f64 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double xp_lds_f64;   // (LDS pointers as such: handed on as generic pointers they
 typedef __attribute__((address_space(3))) int32_t xp_lds_i32;  // become FLAT accesses, which queue behind the global loads)
-template <int NT, int NW, int PR, int SPLIT, bool WIDE, int MODE>
+template <int NT, int NW, int PR, int SPLIT, bool WIDE, int MODE, int NAX>
 __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_lds_i32* __restrict__ sT,
                                             xp_lds_i32* __restrict__ sSafe, xp_lds_f64* __restrict__ sStray,
                                             const uint8_t* __restrict__ has,
@@ -889,28 +890,38 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     constexpr int W = WL * 16, W1 = W + kPanPad, NTH = NW * 64, CPI = 64 / PR, RND = W / (CPI * NW);
     constexpr bool TWO = NW * 2 == NT && SPLIT == 1;   // two tile rows per wavefront (16 tiles) or one
     static_assert(TWO || NW * SPLIT == NT, "a wavefront owns one or two whole tile rows; SPLIT workgroups share a range of panels");
-    constexpr int KS = PR / 4, NA = NT / 2 + 1;        // k-steps per panel; pairs of a tile row below NT / 2 (one more than of the others)
+    // NAX (24 / 32 tiles only, else NT / 2 + 1): pairs of a tile row when the matrix has FEWER column tiles than the kernel was
+    // laid out for -- RT = ceil(ncol / 16) real tiles, NAX = RT / 2 + 1.  The tile rows then meet each other modulo RT, every
+    // wavefront multiplies NAX pairs instead of NT / 2 + 1 (257 columns: 9 instead of 13), the workgroups of a panel range
+    // share the RT real tile rows (NWR each; the wavefronts beyond multiply what they find and store nothing) and densify
+    // NWR + RT / 2 tiles.  RT = NT: exactly the kernel of the full width.
+    static_assert(NAX == NT / 2 + 1 || SPLIT > 1, "fewer pairs per tile row: the 24 / 32-tile forms only");
+    constexpr int KS = PR / 4, NA = NAX;               // k-steps per panel; pairs of a tile row below RT / 2 (one more than of the others when RT is even)
     constexpr int NPW = TWO ? NT + 1 : NA;             // pairs per wavefront (one row: the last only if the row is below NT / 2)
     constexpr int kBufDoubles = PR * W1;
     constexpr int TC = (2 * W + NTH - 1) / NTH;        // cells of the tables per thread and panel (1; 2 at 32 tiles)
     static_assert(RND * CPI * NW == W && (PR == 32 || PR == 16), "every column in exactly one round");
     const int tid = threadIdx.x, lane = tid & 63, sub = lane / PR, l = lane % PR;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int trow = TWO ? wave : part * NW + wave;    // this wavefront's (first) tile row
-    const int t0 = LOCAL ? part * NW : 0;              // (LOCAL: the workgroup's first tile row = local tile 0)
+    const int RT = LOCAL ? (ncol + 15) >> 4 : NT;      // real column tiles (LOCAL: the launcher picks NAX = RT / 2 + 1)
+    const int NWR = LOCAL ? (RT + SPLIT - 1) / SPLIT : NW;   // tile rows per workgroup of a panel range
+    const int trow = TWO ? wave : part * NWR + wave;   // this wavefront's (first) tile row
+    const int t0 = LOCAL ? part * NWR : 0;             // (LOCAL: the workgroup's first tile row = local tile 0)
+    const bool live = !LOCAL || (wave < NWR && trow < RT);   // (a wavefront without a tile row of its own stores nothing)
+    const int need = NWR + RT / 2;                     // (LOCAL: local tiles 0 .. need - 1 are met by some tile row)
     static_assert(!LOCAL || !TWO, "local tile order is for one tile row per wavefront");
     xp_v4f64 acc[NPW];
 #pragma unroll
     for (int s = 0; s < NPW; ++s) acc[s] = xp_v4f64{0.0, 0.0, 0.0, 0.0};
     // (wave-uniform) tile of pair s on the A side and on the B side; whether this wavefront has a pair s at all
-    auto wrap = [&](int t) { return t >= NT ? t - NT : t; };
+    auto wrap = [&](int t) { return t >= RT ? t - RT : t; };
     auto tile_a = [&](int s) { return TWO && s >= NA ? trow + NW : trow; };
     auto tile_b = [&](int s) { return wrap(TWO && s >= NA ? trow + NW + (s - NA) : trow + s); };
     // where these tiles stand in the panel buffer (LOCAL: wave + s never reaches WL, nothing wraps)
     auto lds_tile_a = [&](int s) { return LOCAL ? wave : tile_a(s); };
     auto lds_tile_b = [&](int s) { return LOCAL ? wave + s : tile_b(s); };
     static_assert(!LOCAL || (NW - 1) + (NT / 2) < WL, "every pair's B tile lies inside the densified tiles");
-    auto has_pair = [&](int s) { return TWO || s < NA - 1 || trow < NT / 2; };
+    auto has_pair = [&](int s) { return TWO || s < NA - 1 || (RT & 1) != 0 || trow < RT / 2; };   // (RT odd: every row meets (RT + 1) / 2 tiles)
 
     auto zero_part = [&](int b, int m0, int m1) {   // 16-byte units tid + m * NTH, m0 <= m < m1
         auto* z = (__attribute__((address_space(3))) xp_v2f64*)(panel + b * kBufDoubles);
@@ -931,8 +942,9 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     int32_t treg[TC];
     auto global_col = [&](int col) {   // column of the matrix that stands at (local) column `col` of the panel buffer
         if (!LOCAL) return col;
+        if ((col >> 4) >= need) return 0x7fffffff;     // (a tile no tile row of this workgroup meets: no column)
         const int g = col + 16 * t0;
-        return g >= 16 * NT ? g - 16 * NT : g;
+        return g >= 16 * RT ? g - 16 * RT : g;
     };
     auto cell_of = [&](int k, bool& have, int& col, const int32_t*& tab) {   // cell tid + k NTH of {Ts[0..W), Te[0..W)}
         const int idx = tid + k * NTH;
@@ -1140,7 +1152,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     // pair (I <= J) number q; lane: element (row, col) of the tile A_side x B_side: col = lane & 15, row = (lane >> 4) + 4 r
 #pragma unroll
     for (int s = 0; s < NPW; ++s) {
-        if (!has_pair(s)) continue;
+        if (!has_pair(s) || !live) continue;
         const int ta = tile_a(s), tb = tile_b(s);
         const bool wraps = tb < ta;              // computed C(ta, tb) = transpose of pair (tb, ta)
         const int I = wraps ? tb : ta, J = wraps ? ta : tb;
@@ -1154,7 +1166,7 @@ __device__ __forceinline__ void panels_body(xp_lds_f64* __restrict__ panel, xp_l
     }
 }
 
-template <int NT, int NW, int PR, int SPLIT, bool WIDE, int MODE = 0>   // (MODE, measurements only: 1 = no MFMAs, 2 = no entries moved)
+template <int NT, int NW, int PR, int SPLIT, bool WIDE, int MODE = 0, int NAX = NT / 2 + 1>   // (MODE, measurements only: 1 = no MFMAs, 2 = no entries moved; NAX: panels_body)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NT >= 16 ? 2 : (NT == 12 ? 3 : 4), NT >= 16 ? 2 : (NT == 12 ? 3 : 4))))
 void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __restrict__ ri,
                              const int32_t* __restrict__ Ts, const int32_t* __restrict__ Te,
@@ -1187,7 +1199,8 @@ void crossprod_panels_kernel(const double* __restrict__ x, const int32_t* __rest
     // (One instruction stream for all wavefronts, the wavefront's number in a register.  A stream per wavefront, with
     // every LDS offset a constant, saves 136 vector instructions per panel and was slower; so were two streams that
     // multiply and move in opposite order on the two wavefronts of a SIMD.)
-    panels_body<NT, NW, PR, SPLIT, WIDE, MODE>((xp_lds_f64*)panel, (xp_lds_i32*)sT, (xp_lds_i32*)sSafe, (xp_lds_f64*)sStray, has, x,
+    if (SPLIT > 1 && ((ncol + 15) >> 4) / 2 + 1 != NAX) return;   // (not the instantiation for this width: the launcher's mistake, nothing is touched)
+    panels_body<NT, NW, PR, SPLIT, WIDE, MODE, NAX>((xp_lds_f64*)panel, (xp_lds_i32*)sT, (xp_lds_i32*)sSafe, (xp_lds_f64*)sStray, has, x,
                                                ri, Ts, Te, ncol, npanels, P0, P1, part, nonfinite, mine);
 }
 
@@ -1429,10 +1442,20 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             hipLaunchKernelGGL(xp_panel_has_kernel, dim3((unsigned)((L.npanels + 255) / 256), (unsigned)((ncol + 31) / 32)),
                                dim3(256), 0, stream, (const int32_t*)Te, ncol, L.npanels, L.ntiles,
                                L.ntiles == 32 ? 4 : (L.ntiles == 24 ? 3 : 1), (uint32_t*)has);   // (the SPLIT of RSP_XP_LAUNCH below)
-#define RSP_XP_LAUNCH(NT, NW, PR, SPLIT, WIDE, M)                                                                       \
-    hipLaunchKernelGGL((crossprod_panels_kernel<NT, NW, PR, SPLIT, WIDE, M>), dim3((unsigned)L.ngroups * SPLIT),        \
+#define RSP_XP_LAUNCH_N(NT, NW, PR, SPLIT, WIDE, M, NAX)                                                                \
+    hipLaunchKernelGGL((crossprod_panels_kernel<NT, NW, PR, SPLIT, WIDE, M, NAX>), dim3((unsigned)L.ngroups * SPLIT),   \
                        dim3(NW * 64), 0, stream, d_x, d_i, (const int32_t*)Ts, (const int32_t*)Te, (const uint8_t*)has, \
                        ncol, L.npanels, L.panels_per_group, flag, partial)
+#define RSP_XP_LAUNCH(NT, NW, PR, SPLIT, WIDE, M) RSP_XP_LAUNCH_N(NT, NW, PR, SPLIT, WIDE, M, NT / 2 + 1)
+// 24 / 32 tiles: the instantiation for the matrix's REAL tile count RT (NAX = RT / 2 + 1 pairs per tile row; panels_body)
+#define RSP_XP_LAUNCH_WIDE(NT, SPLIT, WIDE)                                                                            \
+    switch (((ncol + 15) / 16) / 2 + 1) {                                                                              \
+        case NT / 2 - 3: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 - 3); break;                                 \
+        case NT / 2 - 2: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 - 2); break;                                 \
+        case NT / 2 - 1: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 - 1); break;                                 \
+        case NT / 2: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2); break;                                         \
+        default: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 + 1); break;                                         \
+    }
             const bool wide = nnz >= (1ll << 29);   // (byte offsets of x beyond 32 bits)
             int mode = 0;
 #ifdef RSP_XP_MODES   // (a measurement build: RSP_XP_PANELS_MODE = 1 no MFMAs, 2 no entries moved, 3 neither; 16 tiles only)
@@ -1443,12 +1466,10 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
             if (mode == 3) RSP_XP_LAUNCH(16, 8, 32, 1, false, 3);
 #endif
             if (mode == 0) {
-                if (L.ntiles == 32) {
-                    if (wide) RSP_XP_LAUNCH(32, 8, 16, 4, true, 0);
-                    else RSP_XP_LAUNCH(32, 8, 16, 4, false, 0);
-                } else if (L.ntiles == 24) {
-                    if (wide) RSP_XP_LAUNCH(24, 8, 16, 3, true, 0);
-                    else RSP_XP_LAUNCH(24, 8, 16, 3, false, 0);
+                if (L.ntiles == 32) {          // (25 .. 32 real tiles: 13 .. 17 pairs per tile row)
+                    if (wide) { RSP_XP_LAUNCH_WIDE(32, 4, true) } else { RSP_XP_LAUNCH_WIDE(32, 4, false) }
+                } else if (L.ntiles == 24) {   // (17 .. 24 real tiles: 9 .. 13 pairs per tile row)
+                    if (wide) { RSP_XP_LAUNCH_WIDE(24, 3, true) } else { RSP_XP_LAUNCH_WIDE(24, 3, false) }
                 } else if (L.ntiles == 16) {
                     if (wide) RSP_XP_LAUNCH(16, 8, 32, 1, true, 0);
                     else RSP_XP_LAUNCH(16, 8, 32, 1, false, 0);
@@ -1460,7 +1481,9 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
                     else RSP_XP_LAUNCH(8, 8, 32, 1, false, 0);
                 }
             }
+#undef RSP_XP_LAUNCH_WIDE
 #undef RSP_XP_LAUNCH
+#undef RSP_XP_LAUNCH_N
         } else
         switch (L.ntiles) {
             case 1: launch_tall<1, 4>(L, d_x, d_i, d_p, nrow, ncol, nnz, flag, partial, stream); break;
