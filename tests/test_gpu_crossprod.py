@@ -279,6 +279,26 @@ def test_crossprod_panel_table_form_gaps_ragged_end_and_round3_kernel_agree(torc
         os.environ.pop("RSP_CROSSPROD_TALL_ALWAYS", None)
 
 
+@pytest.mark.parametrize("ncol", [285, 410, 440, 460, 490])
+def test_crossprod_wide_forms_at_every_real_tile_count(torch_cuda, ncol):
+    """Round 5: the 24 / 32-tile kernels are instantiated per REAL tile count (18 / 26, 28, 29, 31 tiles here; 17, 19,
+    21, 23-25 and 32 are met by the shapes above, the rest by tools/soak_crossprod_tall.py): pairs per tile row = tiles / 2 + 1, tile rows meeting modulo the real
+    count, even and odd counts.  Against the oracle within the tall form's tolerance, the same bits twice, symmetric."""
+    torch = torch_cuda
+    nrow = 43_000
+    m = synth.rsparsematrix(nrow, ncol, density=0.1, seed=ncol, kind=0)
+    x, i, p = m["x"], m["i"], m["p"]
+    assert capi.crossprod_form(nrow, ncol, x.size) == "tall"
+    ref = oracle.crossprod(x, i, p)
+    scale = oracle.crossprod(np.abs(x), i, p)
+    xt, it, pt = torch.from_numpy(x).cuda(), torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda()
+    got = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    again = capi.crossprod_device(xt, it, pt, nrow).cpu().numpy().T
+    assert got.tobytes() == again.tobytes()
+    assert np.array_equal(got, got.T)
+    assert np.all(np.abs(got - ref) <= 1e-12 * scale), float(np.max(np.abs(got - ref) / np.maximum(scale, 1e-300)))
+
+
 @pytest.mark.parametrize("ncol,order", [
     (257, "tail-first"),      # 24 tiles, three workgroups per panel range: part 2 densifies tiles 16..23 and 0..11
     (512, "head-late"),       # 32 tiles, four workgroups: part 1 densifies tiles 8..31 -- column 0 is not among them
