@@ -1328,8 +1328,13 @@ static bool tall_pays(int32_t nrow, int32_t ncol, int64_t nnz) {
     // profiles/r04_crossprod_panels.json, r04_form_edges_crossprod.json; round 5, local tile order: x 384 3.3 / 3.5 ms,
     // x 512 5.5 ms, profiles/r05_crossprod_wide.json)
     const int nt = tall_tiles(ncol);
+    // (24 / 32 tiles: one instantiation per REAL tile count rt, rt / 2 + 1 pairs per tile row instead of nt / 2 + 1 -- the
+    // multiply-adds are 64 % of the kernel's time at full width: 257 / 320 / 385 / 448 columns 0.80 / 0.87 / 0.85 / 0.90 of
+    // the full width's time, profiles/r05_crossprod_widths.json)
+    const int rt = (ncol + 15) / 16;
+    const double partial = nt >= 24 ? 0.36 + 0.64 * (double)(rt / 2 + 1) / (double)(nt / 2 + 1) : 1.0;
     if (panel_table_tiles(nt))
-        t_tall = 0.09 + rows * width * width / (nt == 32 ? 4.8e10 : (nt == 24 ? 4.8e10 : (nt == 16 ? 6.0e10 : (nt == 12 ? 5.2e10 : 4.5e10)))) + (nt == 32 ? 0.0 : 2.7e-9 * (double)nnz);
+        t_tall = 0.09 + partial * rows * width * width / (nt == 32 ? 4.8e10 : (nt == 24 ? 4.8e10 : (nt == 16 ? 6.0e10 : (nt == 12 ? 5.2e10 : 4.5e10)))) + (nt == 32 ? 0.0 : 2.7e-9 * (double)nnz);
     return t_tall <= t_exact;
 }
 

@@ -328,6 +328,8 @@ def sweep_crossprod(quick):
              (1_000_000, 128, 6_000), (1_000_000, 100, 5_000), (250_000, 128, 4_096), (4_000_000, 128, 20_000),
              (1_000_000, 512, 4_096), (1_000_000, 512, 12_000), (1_000_000, 512, 20_000), (1_000_000, 384, 8_000), (1_000_000, 384, 14_000),
              (250_000, 400, 4_096), (4_000_000, 320, 30_000), (100_000, 512, 4_096),
+             # (widths between the tile counts: the 24 / 32-tile kernels per real tile count, round 5)
+             (1_000_000, 272, 8_000), (1_000_000, 272, 14_000), (1_000_000, 300, 10_000), (1_000_000, 420, 12_000), (1_000_000, 420, 20_000), (250_000, 288, 5_000),
              (1_000_000, 128, 4_096), (1_000_000, 128, 10_000), (1_000_000, 64, 4_096), (100_000, 256, 4_096),
              (4_000_000, 200, 8_000), (4_000_000, 200, 60_000)] if not quick else [(300_000, 64, 4_096)]
     for nrow, ncol, per_col in cases:
