@@ -8,7 +8,9 @@
 // Two kernels in the reference's accumulation order (bit-identical results), and two for the tall
 // matrices the routine is meant for, where that order is a serial walk of every column (see "tall form"
 // below: dense rank-k updates on the matrix cores, results within the floating-point tolerance --
-// crossprod_tall_kernel up to 96 columns, crossprod_panels_kernel from 97 to 256):
+// crossprod_tall_kernel up to 96 columns, crossprod_panels_kernel from 97 to 512: 8 / 12 / 16 column tiles with one
+// workgroup per range of row panels, 24 / 32 tiles with three / four that share a range and one instantiation per real
+// tile count):
 //
 //  * crossprod_rows_kernel (used when the caller provides a workspace).  The row-major form of
 //    A is built first (integer row histogram, exclusive scan, cursor fill; the order of the
