@@ -366,7 +366,7 @@ def test_crossprod_panel_table_form_steps_aside_for_nonfinite_values(torch_cuda,
         assert np.array_equal(via_handle, ref, equal_nan=True)
 
 
-@pytest.mark.parametrize("ncol", [256, 180, 112, 500])
+@pytest.mark.parametrize("ncol", [256, 180, 112, 500, 290, 420])   # (290, 420: the 24 / 32-tile kernels at a partial width)
 def test_crossprod_panel_table_form_is_memory_safe_on_invalid_matrices(torch_cuda, ncol):
     """Not a dgCMatrix -- rows that do not ascend, rows outside the matrix, column offsets that go backwards or
     beyond nnz: the result means nothing, but the call returns, reads and writes nothing out of bounds (the entries
