@@ -64,6 +64,24 @@ def test_scipy_cross_check(seed):
     assert np.all(np.abs(got - red) <= 1e-13 * scale)
 
 
+@pytest.mark.parametrize("seed,shape,density", [(21, (300, 40), 0.2), (22, (2000, 130), 0.05), (23, (64, 70), 0.6), (24, (500, 9), 0.0)])
+def test_crossprod_restatement_against_scipy(seed, shape, density):
+    """oracle.crossprod (the reference's sorted merges, RcppSparse.h:159-194) against SciPy's t(A) %*% A: the same numbers up
+    to the order of the adds (1e-13 of sum |x1 x2|), exactly symmetric, exactly zero where two columns share no row.  (GPU
+    tests of the wide matrix-core forms use SciPy's product directly where the merges would take seconds per case.)"""
+    nrow, ncol = shape
+    m = synth.rsparsematrix(nrow, ncol, density=density, seed=seed)
+    x, i, p = m["x"], m["i"], m["p"]
+    got = oracle.crossprod(x, i, p)
+    A = sp.csc_matrix((x, i, p), shape=shape)
+    B = sp.csc_matrix((np.abs(x), i, p), shape=shape)
+    ref = np.asarray((A.T @ A).todense())
+    scale = np.asarray((B.T @ B).todense())
+    assert got.shape == (ncol, ncol) and np.array_equal(got, got.T)
+    assert np.all(np.abs(got - ref) <= 1e-13 * scale)
+    assert np.all(got[scale == 0] == 0)
+
+
 def test_empty_columns_are_positive_zero():
     g = load_golden("stored_zeros")
     s = oracle.column_sums(g["x"], g["p"])
