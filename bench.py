@@ -135,6 +135,18 @@ GLOSSARY = {
                     "whole-matrix parity",
     "parity": "EVERY column of the gathered result against the oracle (1-thread C restatement of the reference loop), after "
               "the timed region: |gpu - ref| <= 1e-12 x sum|x| per column; empty columns exactly +0.0",
+    "config.parallelism=threads": "ONE process, N shards through rsp_mcsc_column_sums (the resident multi-GPU handle: per shard a stream, "
+                                  "an output, a plan; per handle one page-locked result vector and parked worker threads; nothing is "
+                                  "created per call).  `value` = K synchronous calls back to back, gather d2h (every shard copies its "
+                                  "slice over its own host link), result left in the page-locked vector; THREE such regions, the "
+                                  "median one is `value` (config.regions_ms lists all three).  roofline.threads_<gather>_"
+                                  "<dest>_ms: ms per call of the other combinations -- gather d2h | stores | rccl (ncclCommInitAll, "
+                                  "grouped send / recv to shard 0's device, one D2H; needs a device per shard) | none (slices stay on "
+                                  "the devices: launch + wait only); dest pinned (the handle's vector) | pageable (a malloc'ed vector: "
+                                  "what an R NumericVector is).  threads_last_enqueue_us: host clock from a call's entry to the return "
+                                  "of the last shard's launch; config.devices_distinct false = a rehearsal on fewer cards than shards",
+    "roofline.threads_*": "--parallelism ranks at N > 1: the figures of a `--parallelism threads` CHILD run over the same devices after "
+                          "the ranks have finished (threads_value = its `value`); threads_error instead if the child failed",
     "cpu_baseline": "the oracle (kind port: restatement of reference src/example.cpp:26-32), 1 thread, on this box's host on "
                     "a bounded prefix of the same matrix, rank 0, at every N; all_cores_value: the same loop under an OpenMP "
                     "parallel-for over the columns (NOT the reference's behaviour)",
@@ -204,6 +216,15 @@ def parse_args(argv=None):
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: still create the RCCL communicator and run the gatherv in every "
                          "call (rehearsal of the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--parallelism", default="ranks", choices=["ranks", "threads"],
+                    help="ranks (default): one process per GPU, the RCCL gatherv between them.  threads: ONE process drives all "
+                         "N shards through the resident multi-GPU handle (rsp_mcsc_*: what an R session -- one process -- reaches; "
+                         "shard k on device k %% device_count, so a 1-GPU box rehearses it with every shard on its one card); "
+                         "no torchrun, same JSON line with config.parallelism 'threads'")
+    ap.add_argument("--threads-figure", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1, --parallelism ranks: after the ranks have finished, rank 0 runs `--parallelism threads` over the "
+                         "same devices as a CHILD process (a timeout around it; its failure costs the line nothing) and adds its "
+                         "figures to the line as roofline.threads_*.  auto = on a real multi-GPU run (rendezvous nccl)")
     ap.add_argument("--verbose", action="store_true", help="add the glossary of the line's keys to the line (`notes`)")
     ap.add_argument("--explain", action="store_true", help="print the glossary of the line's keys and exit")
     return ap.parse_args(argv)
@@ -882,6 +903,160 @@ def main_rowsums(args):
         print(json.dumps(out), flush=True)
 
 
+def main_threads(args):
+    """--parallelism threads: ONE process, the resident multi-GPU handle (rsp_mcsc_*, csrc/multigpu.cpp) over N column-range
+    shards.  Same line, same metric; a call is synchronous (it returns when the whole vector is in host memory)."""
+    import numpy as np
+    import torch
+    from rcppsparse_amd import capi, sharded
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    capi.load()
+    capi.set_tuning(args.chunk_rows)
+    G = max(1, args.gpus)
+    ndev = torch.cuda.device_count()
+    devices = [k % ndev for k in range(G)]
+    distinct = len(set(devices)) == G
+    nrow, ncol, nnz, shape, p = build_offsets(args.workload, args.nnz)
+    shards = [sharded.make_shard(p, k, G, balance=args.partition) for k in range(G)]
+    xs, ps = [], []
+    for k, sh in enumerate(shards):
+        with torch.cuda.device(devices[k]):
+            xt = torch.empty(max(sh.nnz, 2), dtype=torch.float64, device=f"cuda:{devices[k]}")[:sh.nnz]
+            if sh.nnz:
+                capi.gen_values_device(xt, SEED, sh.x0, args.kind)
+            xs.append(xt)
+            ps.append(torch.from_numpy(sh.p_local).to(f"cuda:{devices[k]}"))
+            torch.cuda.synchronize()
+    h = capi.MultiDeviceCSC.wrap_device(xs, ps, nrow)
+    forms = [h.shard_info(k)["form"] for k in range(G)]
+    kernel_ms = [h.shard_kernel_ms(k, reps=max(3, args.steps)) if shards[k].nnz else 0.0 for k in range(G)]
+    pinned, pageable = h.result_buffer(), np.empty(ncol, dtype=np.float64)
+    launch = h.config()["launch"]
+
+    def run(gather, dest, steps, warmup, nregions=N_REGIONS_SMALL):
+        """ms per call (median of `nregions` regions of `steps` synchronous calls back to back), ms per call of every region,
+        median host time until the last shard's launch had been issued."""
+        h.set_gather(gather)
+        out = pinned if dest == "pinned" else pageable
+        for _ in range(warmup):
+            h.column_sums(out=out)
+        regions, enq = [], []
+        for _ in range(nregions):
+            per_call = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                t1 = time.perf_counter()
+                h.column_sums(out=out)
+                per_call.append(time.perf_counter() - t1)
+                enq.append(max(h.last_call_stamps()["enqueued_us"]))
+            regions.append((time.perf_counter() - t0) / steps * 1e3)
+            if os.environ.get("RSP_BENCH_DEBUG"):
+                print(f"[threads] {gather}/{dest}: " + " ".join(f"{t * 1e6:.0f}" for t in per_call), file=sys.stderr, flush=True)
+        return sorted(regions)[len(regions) // 2], regions, sorted(enq)[len(enq) // 2]
+
+    # `value`: gather d2h, result in the page-locked vector; three regions, the median one counts (one call in a few
+    # hundred stalls for milliseconds somewhere below the library -- the host runtime or the box's CPU quota --, and K = 20
+    # calls of ~0.2 ms cannot average that away: the same protocol as the small single-GPU workloads)
+    ms_value, regions_ms, last_enq = run("d2h", "pinned", args.steps, args.warmup)
+    got = np.array(pinned, copy=True)
+    parity = parity_whole_matrix(got, p, args.kind)
+    if not parity_ok(parity):
+        raise SystemExit(f"parity check failed (threads, {args.workload}): {json.dumps(parity)}")
+    figures = {"d2h_pinned_ms": ms_value, "last_enqueue_us": last_enq}
+    combos = [("d2h", "pageable"), ("stores", "pinned"), ("none", "pinned")]
+    if distinct:
+        combos.append(("rccl", "pinned"))
+    for gather, dest in combos:
+        try:
+            ms, _, _ = run(gather, dest, args.steps, args.warmup)
+            figures[f"{gather}_{dest}_ms"] = ms
+            if gather != "none" and np.asarray(pinned if dest == "pinned" else pageable).tobytes() != got.tobytes():
+                figures[f"{gather}_{dest}_bits_differ"] = True
+        except capi.RspError as e:
+            figures[f"{gather}_{dest}_error"] = str(e)[:120]
+    rccl = {}
+    try:
+        rccl = capi.rccl_info()
+    except Exception as e:   # noqa: BLE001
+        rccl = {"error": str(e)[:80]}
+    h.set_gather("d2h")
+    # the other launch mode by the protocol of `value` (the default comes from the shard count)
+    other = "serial" if launch == "workers" else "workers"
+    if G > 1:
+        h.set_launch(other)
+        figures[f"{other}_d2h_pinned_ms"], _, figures[f"{other}_last_enqueue_us"] = run("d2h", "pinned", args.steps, args.warmup)
+        h.set_launch(launch)
+    h.close()
+
+    algo = 8 * shards[0].nnz + 4 * (shards[0].ncol + 1) + 8 * shards[0].ncol
+    achieved = algo / (kernel_ms[0] * 1e-3) / 1e9 if kernel_ms[0] > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None, "kernel": "the shards' planned launches (config.shards[].form), shard 0 timed alone with HIP events",
+            "kernel_ms": kernel_ms[0], "kernel_ms_max_over_shards": max(kernel_ms), "algorithmic_bytes_per_launch": algo,
+            "call_minus_slowest_kernel_us": ms_value * 1e3 - max(kernel_ms) * 1e3}
+    for k, v in figures.items():
+        roof["threads_" + k] = v
+    cfg = {"workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, values kind {args.kind}, seed {SEED}",
+           "parallelism": "threads", "devices": ndev, "devices_distinct": distinct, "launch": launch, "gather": "d2h",
+           "result": "page-locked host vector", "partition": args.partition, "regions_ms": regions_ms,
+           "shard_imbalance_max_over_mean": sharded.imbalance(p, shards[0].bounds),
+           "rccl_version": rccl.get("version"), "rccl_library": rccl.get("library"),
+           "shards": [{"shard": k, "device": devices[k], "c0": sh.c0, "c1": sh.c1, "nnz": sh.nnz, "kernel_ms": kernel_ms[k],
+                       "form": forms[k]} for k, sh in enumerate(shards)]}
+    line = {"metric": "columnSums nnz/s + achieved HBM GB/s vs roofline, 1e9-nnz CSC at 1/2/4/8 GPUs",
+            "value": nnz / (ms_value * 1e-3), "unit": "nnz/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_value, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": sig(cfg), "roofline": sig(roof), "parity": sig(parity)}
+    line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(p, args.kind)
+    if args.verbose:
+        line["notes"] = GLOSSARY
+    print(json.dumps(line), flush=True)
+
+
+THREADS_CHILD_KEYS = ("threads_d2h_pinned_ms", "threads_d2h_pageable_ms", "threads_stores_pinned_ms", "threads_none_pinned_ms",
+                      "threads_rccl_pinned_ms", "threads_last_enqueue_us", "threads_serial_d2h_pinned_ms",
+                      "threads_workers_d2h_pinned_ms", "threads_rccl_pinned_error", "call_minus_slowest_kernel_us",
+                      "kernel_ms_max_over_shards")
+
+
+def threads_child_figures(args, timeout_s=300):
+    """`--parallelism threads` over the same devices as a CHILD process (the ranks of this job have finished their work; a
+    child cannot take this process down with it): {threads_*: ...} for the line, or {threads_error: why}."""
+    import signal
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                        "MASTER_ADDR", "MASTER_PORT", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE") and not k.startswith("TORCHELASTIC_")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--parallelism", "threads", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--workload", args.workload, "--kind", str(args.kind), "--partition", args.partition,
+           "--no-cpu-baseline"] + (["--nnz", str(args.nnz)] if args.nnz else [])
+    t0 = time.perf_counter()
+    try:
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            out, err = pr.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)      # (the group this call started, nothing else)
+            pr.communicate()
+            return {"threads_error": f"the child did not finish in {timeout_s} s"}
+    except OSError as e:
+        return {"threads_error": f"the child could not be started: {e}"[:160]}
+    if pr.returncode != 0:
+        return {"threads_error": f"exit {pr.returncode}: {err.decode(errors='replace')[-160:]}"}
+    try:
+        line = json.loads([ln for ln in out.decode().splitlines() if ln.startswith("{")][-1])
+    except (IndexError, ValueError):
+        return {"threads_error": "the child printed no line"}
+    res = {"threads_value": line["value"], "threads_ms_per_step": line["ms_per_step"],
+           "threads_launch": line["config"].get("launch"), "threads_devices_distinct": line["config"].get("devices_distinct"),
+           "threads_parity_err": line["parity"]["max_abs_err_over_l1"], "threads_seconds": time.perf_counter() - t0}
+    for k in THREADS_CHILD_KEYS:
+        if k in line["roofline"]:
+            res[k if k.startswith("threads_") else "threads_" + k] = line["roofline"][k]
+    return res
+
+
 def make_communicator(env, counts, displs, recv, shard_ncol):
     """The C-ABI communicator (rsp_comm_*), checked with a trial gatherv of a known pattern.  If it
     cannot be created or delivers wrong data on any rank, EVERY rank switches to the same gatherv
@@ -1246,6 +1421,10 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
             if "value" in s:
                 for f in ("value", "ms_per_step", "imbalance", "kernel_ms_max", "gather_ms_max", "parity_err"):
                     roof[f"{k}_{f}"] = s[f]
+    th = extras.get("threads")
+    if th:
+        roof.update(th)
+    rccl = extras.get("rccl") or {}
     cfg = {
         "workload": f"{H['workload']}: {H['nrow']}x{H['ncol']} CSC dgCMatrix, nnz={H['nnz']}, {H['shape']} nnz/column, "
                     f"values kind {args.kind}, seed {SEED}",
@@ -1259,6 +1438,7 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         "x_copies_rotated": H["ncopies"],
         "gather": H["gather_name"],
         "gather_fell_back_to_torch_distributed": H["fell_back"],
+        "rccl_version": rccl.get("version"), "rccl_library": rccl.get("library"),
         "regions_ms": H["regions_ms"],
         "host_stall_suspected": bool(not use_comm and ms_per_step > 1.5 * H["kernel_ms"]),
         "planned": None if plan is None else {k: v for k, v in plan.items() if k != "kernel"},
@@ -1306,6 +1486,8 @@ def main(argv=None):
         for k, v in GLOSSARY.items():
             print(f"{k}\n    {v}")
         return
+    if args.parallelism == "threads":
+        return main_threads(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
@@ -1409,10 +1591,22 @@ def main(argv=None):
     if comm is not None:
         torch.cuda.synchronize()
         comm.close()
+    if rank == 0 and (world > 1 or args.force_comm):
+        try:
+            extras["rccl"] = capi.rccl_info()
+        except Exception as e:   # noqa: BLE001
+            extras["rccl"] = {"error": str(e)[:80]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        want_threads = args.threads_figure == "on" or (args.threads_figure == "auto" and world > 1 and not rehearsal
+                                                       and args.workload == "c3" and not args.planned)
+        if want_threads:
+            # the ranks are done (the process group is gone); what an R session -- ONE process -- gets out of the same devices
+            H["x0_for_ceiling"] = None
+            torch.cuda.empty_cache()
+            extras["threads"] = threads_child_figures(args)
         line = assemble_line(args, H, extras, devices=torch.cuda.device_count(), rehearsal=rehearsal,
                              comm_rehearsal=comm_rehearsal)
         print(json.dumps(line), flush=True)

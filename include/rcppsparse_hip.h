@@ -95,17 +95,65 @@ int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol,
                                int ndevices);
 
 /*
- * Upload once, sum many, over several GPUs from one process (what an R session would
- * hold): the columns are cut as above, every range becomes a resident shard on its
- * device, and rsp_mcsc_column_sums runs all shards concurrently, each copying its
- * slice straight into `sums`.  `devices` as for rsp_column_sums_host_multi.
+ * Upload once, sum many, over several GPUs from ONE process -- the multi-GPU path an R session reaches (the reference's
+ * .Call runs on the R main thread, src/RcppExports.cpp:16-24): the columns are cut as above (SURVEY.md 8e:
+ * bounds[k] = lower_bound(p, k * nnz / G)), every range becomes a resident shard on its device, and
+ * rsp_mcsc_column_sums runs all shards side by side and lands every slice in `sums`.  `devices` as for
+ * rsp_column_sums_host_multi.
+ *
+ * A call creates NOTHING (round 6; before, G - 1 threads were started and joined per call): the handle keeps per shard
+ * a stream, an output and a plan, and per handle one page-locked vector of ncol doubles, parked worker threads and,
+ * for the RCCL gather, the communicators of one ncclCommInitAll.  Two independent choices, both per handle:
+ *   launch  RSP_LAUNCH_SERIAL   the calling thread enqueues shard after shard, then waits for them in order;
+ *           RSP_LAUNCH_WORKERS  shard 0 on the calling thread, shard k on its own thread, which stays parked between
+ *                               calls (futex; it spins for RSP_MCSC_SPIN_US microseconds, default 50, after a call so
+ *                               that calls in a loop find it awake): enqueues, waits and the copies into `sums` overlap.
+ *                               Default from 3 shards on (RSP_MCSC_LAUNCH=serial|workers in the environment overrides).
+ *   gather  RSP_GATHER_D2H      (default) every shard copies its slice over ITS device's host link into the
+ *                               page-locked vector;
+ *           RSP_GATHER_RCCL     the slices travel to shard 0's device in one group of ncclSend / ncclRecv over xGMI
+ *                               (communicators from ncclCommInitAll, made when the mode is first selected; one DEVICE
+ *                               per shard, RCCL refuses duplicates), then ONE copy of the whole vector to the host;
+ *           RSP_GATHER_STORES   the kernels take the page-locked vector as their output: no copy command at all.
+ * Every combination returns the bits of the per-shard device calls (the same launches over the same data).
+ * `sums` may be rsp_mcsc_result_buffer(handle) -- the page-locked vector itself, ncol doubles, valid until the next
+ * call on the handle or its release: then nothing is copied on the host at all.
  */
 typedef struct rsp_mcsc *rsp_mcsc_t;
+#define RSP_GATHER_D2H     0
+#define RSP_GATHER_RCCL    1
+#define RSP_GATHER_STORES  2
+#define RSP_GATHER_NONE    3   /* MEASUREMENT ONLY: the slices stay on the devices, `sums` is not written; the call
+                                  returns when every shard's stream has drained (launch + wait cost without a transfer) */
+#define RSP_LAUNCH_SERIAL  0
+#define RSP_LAUNCH_WORKERS 1
 int rsp_mcsc_upload(const double *x, const int32_t *p, int32_t nrow, int32_t ncol,
                     int64_t nnz, const int *devices, int ndevices, rsp_mcsc_t *handle);
 int rsp_mcsc_column_sums(rsp_mcsc_t handle, double *sums);
 /* Matrix::colMeans (RcppSparse.h:145-150) on the shards: sums divided by Dim[0]. */
 int rsp_mcsc_column_means(rsp_mcsc_t handle, double *means);
+int rsp_mcsc_set_gather(rsp_mcsc_t handle, int mode);
+int rsp_mcsc_set_launch(rsp_mcsc_t handle, int mode);
+/* info4 = { gather, launch, worker threads alive, communicators made } */
+int rsp_mcsc_config(rsp_mcsc_t handle, int32_t *info4);
+double *rsp_mcsc_result_buffer(rsp_mcsc_t handle);
+/*
+ * The same handle over shards that ALREADY live in the devices' HBM (a caller that produced x / p on the GPUs, bench.py):
+ * shard k = columns [sum of shard_ncol[0..k), ...) with its entries d_x[k] (16-byte aligned), its rebased offsets
+ * d_p[k] (shard_ncol[k] + 1 values from 0 to shard_nnz[k]) and optionally its row indices d_i[k] (d_i may be NULL), all
+ * on devices[k].  Nothing is copied and nothing of the caller's is ever freed; the memory must outlive the handle.
+ * Every shard's offsets are inspected on its device (rsp_column_sums_plan_create_device, waited for), so calls take
+ * their final form from the first one on.
+ */
+int rsp_mcsc_wrap_device(int nshards, const int *devices, const double *const *d_x,
+                         const int32_t *const *d_i, const int32_t *const *d_p,
+                         const int32_t *shard_ncol, const int64_t *shard_nnz, int32_t nrow,
+                         rsp_mcsc_t *handle);
+/* Measurement: host clock of the LAST column-sum call, microseconds from its entry: us[0] = the whole call, then per
+ * shard { enqueue begun, enqueue returned, stream drained, slice copied out }; capacity >= 1 + 4 * shards. */
+int rsp_mcsc_last_call_stamps(rsp_mcsc_t handle, double *us, int capacity);
+/* Measurement: mean device milliseconds of ONE shard's column-sum launches alone (HIP events on its stream). */
+int rsp_mcsc_shard_kernel_ms(rsp_mcsc_t handle, int32_t shard, int reps, float *ms);
 /* The same handle with the row indices kept on the devices (i[] cut like x[]), for the row-wise entries:
  * Matrix::rowSums / rowMeans (RcppSparse.h:138-156).  Every shard sums the rows of its own columns
  * (rsp_csc_row_sums), the partial vectors come back over the shards' own host links and are added on the host
@@ -450,6 +498,9 @@ int rsp_rebase_offsets(const int32_t *p, int32_t c0, int32_t c1, int32_t *p_loca
 typedef struct rsp_comm *rsp_comm_t;
 
 int rsp_comm_unique_id(void *id_bytes);
+/* Which RCCL this process runs: *version = ncclGetVersion (e.g. 22606), library_path = the file "librccl*" is mapped
+ * from (/proc/self/maps; "" if not found).  Either output may be NULL. */
+int rsp_rccl_info(int *version, char *library_path, size_t capacity);
 int rsp_comm_init(const void *id_bytes, int nranks, int rank, int device,
                   rsp_comm_t *comm);
 /*

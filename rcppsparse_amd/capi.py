@@ -52,7 +52,11 @@ EXPORTED_SYMBOLS = (
     "rsp_host_barrier_create", "rsp_host_barrier_wait", "rsp_host_barrier_destroy",
     "rsp_crossprod_form", "rsp_debug_exclusive_scan_device",
     "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
+    "rsp_mcsc_set_gather", "rsp_mcsc_set_launch", "rsp_mcsc_config", "rsp_mcsc_result_buffer", "rsp_mcsc_wrap_device",
+    "rsp_mcsc_last_call_stamps", "rsp_mcsc_shard_kernel_ms", "rsp_rccl_info",
 )
+GATHER_MODES = {"d2h": 0, "rccl": 1, "stores": 2, "none": 3}
+LAUNCH_MODES = {"serial": 0, "workers": 1}
 
 
 class RspError(RuntimeError):
@@ -103,6 +107,15 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_mcsc_row_sums.argtypes = [vp, dp]
     L.rsp_mcsc_row_means.argtypes = [vp, dp]
     L.rsp_mcsc_free.argtypes = [vp]
+    L.rsp_mcsc_set_gather.argtypes = [vp, c.c_int]
+    L.rsp_mcsc_set_launch.argtypes = [vp, c.c_int]
+    L.rsp_mcsc_config.argtypes = [vp, ip]
+    L.rsp_mcsc_result_buffer.argtypes = [vp]
+    L.rsp_mcsc_result_buffer.restype = dp
+    L.rsp_mcsc_wrap_device.argtypes = [c.c_int, c.POINTER(c.c_int), c.POINTER(vp), c.POINTER(vp), c.POINTER(vp), ip,
+                                       c.POINTER(i64), i32, c.POINTER(vp)]
+    L.rsp_mcsc_last_call_stamps.argtypes = [vp, dp, c.c_int]
+    L.rsp_mcsc_shard_kernel_ms.argtypes = [vp, i32, c.c_int, c.POINTER(c.c_float)]
     L.rsp_csc_upload.argtypes = [dp, ip, ip, i32, i32, i64, c.c_int, c.POINTER(vp)]
     L.rsp_csc_column_sums.argtypes = [vp, dp]
     L.rsp_csc_column_means.argtypes = [vp, dp]
@@ -150,6 +163,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_partition_columns.argtypes = [ip, i32, i32, ip]
     L.rsp_rebase_offsets.argtypes = [ip, i32, i32, ip]
     L.rsp_comm_unique_id.argtypes = [vp]
+    L.rsp_rccl_info.argtypes = [c.POINTER(c.c_int), c.c_char_p, c.c_size_t]
     L.rsp_comm_init.argtypes = [vp, c.c_int, c.c_int, c.c_int, c.POINTER(vp)]
     L.rsp_comm_gatherv.argtypes = [vp, vp, i64, vp, c.POINTER(i64), c.POINTER(i64), c.c_int, vp]
     L.rsp_comm_destroy.argtypes = [vp]
@@ -315,16 +329,76 @@ class MultiDeviceCSC:
             _check(load().rsp_mcsc_upload_csc(_dp(x), _ip(i), _ip(p), self.nrow, self.ncol, x.size, arr, n,
                                               ctypes.byref(self._h)))
 
+    @classmethod
+    def wrap_device(cls, x_ts, p_ts, nrow: int, i_ts=None):
+        """The handle over shards that already live in the devices' HBM (rsp_mcsc_wrap_device): x_ts[k] / p_ts[k] are
+        torch tensors on shard k's device (float64 entries, int32 rebased offsets), i_ts optionally the row indices.
+        Nothing is copied; the tensors are kept alive by the object."""
+        self = cls.__new__(cls)
+        G = len(x_ts)
+        self._keep = (list(x_ts), list(p_ts), None if i_ts is None else list(i_ts))
+        self.nrow = int(nrow)
+        ncols = [int(pt.numel()) - 1 for pt in p_ts]
+        self.ncol = int(sum(ncols))
+        self._h = ctypes.c_void_p()
+        vps = ctypes.c_void_p * G
+        devs = (ctypes.c_int * G)(*[int(xt.device.index or 0) for xt in x_ts])
+        dx = vps(*[xt.data_ptr() for xt in x_ts])
+        dpp = vps(*[pt.data_ptr() for pt in p_ts])
+        di = None if i_ts is None else vps(*[it.data_ptr() for it in i_ts])
+        nc = (ctypes.c_int32 * G)(*ncols)
+        nz = (ctypes.c_int64 * G)(*[int(xt.numel()) for xt in x_ts])
+        _check(load().rsp_mcsc_wrap_device(G, devs, dx, di, dpp, nc, nz, self.nrow, ctypes.byref(self._h)))
+        return self
+
     def _out(self, fn, n):
         out = np.empty(n, dtype=np.float64)
         _check(fn(self._h, _dp(out)))
         return out
 
-    def column_sums(self) -> np.ndarray:
-        return self._out(load().rsp_mcsc_column_sums, self.ncol)
+    def column_sums(self, out=None) -> np.ndarray:
+        """out: a float64 vector of ncol entries to fill (a fresh one otherwise); `self.result_buffer()` = no host copy."""
+        if out is None:
+            return self._out(load().rsp_mcsc_column_sums, self.ncol)
+        _check(load().rsp_mcsc_column_sums(self._h, _dp(out)))
+        return out
 
     def column_means(self) -> np.ndarray:
         return self._out(load().rsp_mcsc_column_means, self.ncol)
+
+    def set_gather(self, mode: str) -> None:
+        """'d2h' (default) | 'rccl' | 'stores' (rsp_mcsc_set_gather)."""
+        _check(load().rsp_mcsc_set_gather(self._h, GATHER_MODES[mode]))
+
+    def set_launch(self, mode: str) -> None:
+        """'serial' | 'workers' (rsp_mcsc_set_launch)."""
+        _check(load().rsp_mcsc_set_launch(self._h, LAUNCH_MODES[mode]))
+
+    def config(self) -> dict:
+        out = np.zeros(4, dtype=np.int32)
+        _check(load().rsp_mcsc_config(self._h, _ip(out)))
+        inv_g = {v: k for k, v in GATHER_MODES.items()}
+        inv_l = {v: k for k, v in LAUNCH_MODES.items()}
+        return {"gather": inv_g[int(out[0])], "launch": inv_l[int(out[1])], "workers": int(out[2]), "comms": int(out[3])}
+
+    def result_buffer(self) -> np.ndarray:
+        """The handle's page-locked result vector as a numpy view (valid until the next call or close)."""
+        ptr = load().rsp_mcsc_result_buffer(self._h)
+        return np.ctypeslib.as_array(ptr, shape=(max(self.ncol, 1),))[:self.ncol]
+
+    def last_call_stamps(self) -> dict:
+        """Host clock of the last column-sum call in microseconds from its entry (rsp_mcsc_last_call_stamps)."""
+        G = self.dims()[2]
+        us = np.zeros(1 + 4 * G, dtype=np.float64)
+        _check(load().rsp_mcsc_last_call_stamps(self._h, _dp(us), us.size))
+        per = us[1:].reshape(G, 4)
+        return {"call_us": float(us[0]), "begin_us": per[:, 0].tolist(), "enqueued_us": per[:, 1].tolist(),
+                "done_us": per[:, 2].tolist(), "copied_us": per[:, 3].tolist()}
+
+    def shard_kernel_ms(self, k: int, reps: int = 20) -> float:
+        ms = ctypes.c_float(0.0)
+        _check(load().rsp_mcsc_shard_kernel_ms(self._h, int(k), int(reps), ctypes.byref(ms)))
+        return float(ms.value)
 
     def row_sums(self) -> np.ndarray:
         return self._out(load().rsp_mcsc_row_sums, self.nrow)
@@ -775,6 +849,14 @@ def rebase_offsets(p, c0: int, c1: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------- RCCL
+def rccl_info() -> dict:
+    """{"version": ncclGetVersion of the RCCL this process runs, "library": the file it is mapped from} (rsp_rccl_info)."""
+    v = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(512)
+    _check(load().rsp_rccl_info(ctypes.byref(v), buf, 512))
+    return {"version": int(v.value), "library": buf.value.decode("utf-8", "replace")}
+
+
 def comm_unique_id() -> bytes:
     buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
     _check(load().rsp_comm_unique_id(buf))

@@ -379,6 +379,7 @@ struct rsp_csc {
     int32_t rows_unsorted;
     bool row_ready;
     bool plan_bypass;        // rsp_csc_set_planned(h, 0): the general kernels also where the upload's plan applies (A/B)
+    bool borrowed;           // x / i / p belong to the caller (rsp::csc_wrap_device): never freed here
 };
 
 extern "C" {
@@ -1242,9 +1243,9 @@ int rsp_csc_free(rsp_csc_t h) {
     if (!h) return RSP_OK;
     DeviceGuard on(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->d_x) (void)hipFree(h->d_x);
-    if (h->d_i) (void)hipFree(h->d_i);
-    if (h->d_p) (void)hipFree(h->d_p);
+    if (h->d_x && !h->borrowed) (void)hipFree(h->d_x);
+    if (h->d_i && !h->borrowed) (void)hipFree(h->d_i);
+    if (h->d_p && !h->borrowed) (void)hipFree(h->d_p);
     if (h->d_out) (void)hipFree(h->d_out);
     if (h->d_ws) (void)hipFree(h->d_ws);
     if (h->d_row_persist) (void)hipFree(h->d_row_persist);
@@ -1358,22 +1359,92 @@ int rsp_csc_upload(const double* x, const int32_t* i, const int32_t* p, int32_t 
     return csc_upload(x, i, p, nrow, ncol, nnz, device, true, handle);
 }
 
+// the handle's column sums (means) enqueued on its own stream into `d_out` (the handle's device is current): nothing waits
+static int csc_enqueue(rsp_csc_t h, double* d_out, bool means) {
+    if (h->plan && h->plan->snapped && !h->plan_bypass)
+        return planned_enqueue(h->plan, h->d_x, h->d_p, d_out, h->d_ws, h->ws_bytes, means ? (double)h->nrow : 1.0, means,
+                               h->stream);
+    return enqueue(h->d_x, h->d_p, h->ncol, h->nnz, d_out, h->d_ws, h->ws_bytes, means ? (double)h->nrow : 1.0, means,
+                   h->stream);
+}
+
 static int csc_run(rsp_csc_t h, double* host_out, bool means) {
     if (!h || !host_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
     DeviceGuard on(h->device);
     HIP_TRY(on.error());
     if (h->ncol == 0) return RSP_OK;
-    if (h->plan && h->plan->snapped && !h->plan_bypass) {
-        if (int rc = planned_enqueue(h->plan, h->d_x, h->d_p, h->d_out, h->d_ws, h->ws_bytes,
-                                     means ? (double)h->nrow : 1.0, means, h->stream))
-            return rc;
-    } else if (int rc = enqueue(h->d_x, h->d_p, h->ncol, h->nnz, h->d_out, h->d_ws, h->ws_bytes,
-                                means ? (double)h->nrow : 1.0, means, h->stream))
-        return rc;
+    if (int rc = csc_enqueue(h, h->d_out, means)) return rc;
     HIP_TRY(hipMemcpyAsync(host_out, h->d_out, (size_t)h->ncol * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return RSP_OK;
 }
+
+}  // extern "C"
+namespace rsp {
+// ---- what multigpu.cpp needs of a resident shard (the struct stays private to this file) ----
+int csc_view(rsp_csc_t h, CscView* v) {
+    if (!h || !v) return fail(RSP_ERR_BAD_ARG, "null handle");
+    v->device = h->device;
+    v->nrow = h->nrow;
+    v->ncol = h->ncol;
+    v->nnz = h->nnz;
+    v->d_out = h->d_out;
+    v->stream = h->stream;
+    return RSP_OK;
+}
+
+int csc_enqueue_columns(rsp_csc_t h, bool means, double* d_out) {
+    if (!h) return fail(RSP_ERR_BAD_ARG, "null handle");
+    if (h->ncol == 0) return RSP_OK;
+    return csc_enqueue(h, d_out ? d_out : h->d_out, means);
+}
+
+// A shard over device memory the CALLER owns (x, p and optionally i already in the HBM of `device`): nothing is copied,
+// nothing of the caller's is ever freed; the handle adds its own stream, output, workspace and a device-made plan
+// (inspected on the handle's stream and waited for, so that every later call takes its final form).
+int csc_wrap_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol, int64_t nnz,
+                    int device, rsp_csc_t* handle) {
+    if (!handle) return fail(RSP_ERR_BAD_ARG, "handle is null");
+    *handle = nullptr;
+    if (int rc = check_sizes(ncol, nnz)) return rc;
+    if (nrow < 0) return fail(RSP_ERR_BAD_ARG, "nrow is negative");
+    if (!d_p || (nnz > 0 && !d_x)) return fail(RSP_ERR_BAD_ARG, "d_x or d_p is null");
+    if (((uintptr_t)d_x & 15) != 0) return fail(RSP_ERR_BAD_ARG, "d_x must be 16-byte aligned");
+    if (int rc = require_device(device)) return rc;
+    DeviceGuard on(device);
+    HIP_TRY(on.error());
+    rsp_csc* h = new (std::nothrow) rsp_csc();
+    if (!h) return fail(RSP_ERR_ALLOC, "out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    h->nrow = nrow;
+    h->ncol = ncol;
+    h->nnz = nnz;
+    h->borrowed = true;
+    h->d_x = const_cast<double*>(d_x);
+    h->d_i = const_cast<int32_t*>(d_i);
+    h->d_p = const_cast<int32_t*>(d_p);
+    h->ws_bytes = rsp_column_sums_workspace_bytes(ncol, nnz);
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_out, ncol ? (size_t)ncol * 8 : 8);
+    if (e == hipSuccess) e = hipMalloc(&h->d_ws, h->ws_bytes);
+    if (e != hipSuccess) {
+        rsp_csc_free(h);
+        return fail(RSP_ERR_HIP, "wrapping the device shard failed: %s", hipGetErrorString(e));
+    }
+    rsp_colsums_plan* planned = nullptr;
+    if (ncol > 0 && nnz > 0 && rsp_column_sums_plan_create_device(d_p, ncol, nnz, h->stream, &planned) == RSP_OK) {
+        if (plan_poll(planned, nullptr, true) != RSP_OK) {
+            rsp_column_sums_plan_destroy(planned);
+            planned = nullptr;
+        }
+    }
+    h->plan = planned;
+    *handle = h;
+    return RSP_OK;
+}
+}  // namespace rsp
+extern "C" {
 
 int rsp_csc_column_sums(rsp_csc_t h, double* sums) { return csc_run(h, sums, false); }
 

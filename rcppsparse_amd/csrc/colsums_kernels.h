@@ -105,6 +105,25 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 int column_sums_general(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
                         size_t ws_bytes, hipStream_t stream);
 
+// ---- what multigpu.cpp sees of a resident shard (struct rsp_csc is private to capi.hip) ----
+struct CscView {
+    int device;
+    int32_t nrow, ncol;
+    int64_t nnz;
+    double* d_out;        // the handle's own output, ncol doubles in its device's HBM
+    hipStream_t stream;   // the handle's own non-blocking stream
+};
+}  // namespace rsp
+struct rsp_csc;
+namespace rsp {
+int csc_view(rsp_csc* h, CscView* v);
+// column sums (means) of the shard enqueued on ITS stream into d_out (nullptr: its own output); the shard's device must be
+// the calling thread's current one; nothing waits
+int csc_enqueue_columns(rsp_csc* h, bool means, double* d_out);
+// a shard over x / i / p that already live in `device`'s HBM and stay the caller's (never copied, never freed)
+int csc_wrap_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol, int64_t nnz,
+                    int device, rsp_csc** handle);
+
 // ---- device-side inspector (inspect_device.hip): the plans of inspect.hpp for offsets that live in HBM ----
 constexpr int kInspectMaxBlocksColumns = 1024;   // blocks of the pass over p[] (grid-stride): one partial record each
 constexpr int kInspectMaxBlocksChunks = 256;     // blocks of the pass over the lean chunks

@@ -7,14 +7,17 @@
 #include <rccl/rccl.h>
 
 #include <fcntl.h>
+#include <linux/futex.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -193,17 +196,359 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
     return fail(RSP_ERR_ALLOC, "out of host memory in rsp_column_sums_host_multi");
 }
 
-// ---- resident matrix spread over several GPUs: upload once, sum many (f2) ----------------------
+}  // extern "C"
+
+// ---- resident matrix spread over several GPUs: upload once, sum many (f2) --------------------------
+// This is the multi-GPU path an R session reaches: ONE process (reference src/RcppExports.cpp:16-24 runs on the R main
+// thread), G devices.  A shard of C4 (1.25e8 entries) sums in ~150 us, and ">= 6x at 8 GPUs" leaves ~50 us for
+// everything else, so nothing per call may cost what a thread creation, a stream creation or an allocation costs.
+// The handle therefore keeps, per shard: the resident rsp_csc (its own stream, output and plan), and per handle: ONE
+// page-locked host vector of ncol doubles that every shard's slice lands in, optionally G - 1 worker threads that stay
+// parked between calls (each with its shard's device current for good), and -- for the RCCL gather -- the communicators
+// of one ncclCommInitAll.  A call is, per shard: enqueue the column-sum launches, enqueue the slice's way home, wait for
+// the shard's stream, copy the slice into the caller's vector.
+//   launch  serial  : the calling thread walks the shards (set device, enqueue) and then waits for them in order;
+//           workers : shard 0 on the calling thread, shard k on its parked thread -- enqueues, waits and the copies
+//                     into the caller's (pageable) vector all run side by side.  A worker spins for a short while
+//                     after a call (RSP_MCSC_SPIN_US, default 50) so that calls in a loop find it awake, then sleeps
+//                     on a futex: an idle R session burns nothing.
+//   gather  D2H     : hipMemcpyAsync of every slice over its own device's host link into the page-locked vector;
+//           RCCL    : grouped ncclSend / ncclRecv of the slices to shard 0's device over xGMI (the collective
+//                     BASELINE.json's north_star names), then one D2H of the whole vector;
+//           STORES  : the kernels take the page-locked vector (+ the shard's first column) as their output: no copy
+//                     command at all, the result stores travel over the host link as they are made.
+// All of them give the bits of the per-shard device calls: the same launches on the same data.
+namespace {
+
+inline double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
+inline void futex_wait(std::atomic<uint32_t>* word, uint32_t expected) {
+    (void)syscall(SYS_futex, (uint32_t*)word, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake_all(std::atomic<uint32_t>* word) {
+    (void)syscall(SYS_futex, (uint32_t*)word, FUTEX_WAKE_PRIVATE, INT32_MAX, nullptr, nullptr, 0);
+}
+static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+
+int spin_us_setting() {
+    static const int v = [] {
+        const char* s = getenv("RSP_MCSC_SPIN_US");
+        const int n = (s && s[0]) ? atoi(s) : 50;
+        return n < 0 ? 0 : n;
+    }();
+    return v;
+}
+
+// Threads that outlive the calls: worker j (1-based shard index) runs fn(ctx, j) whenever the owner bumps the
+// generation; the owner runs fn(ctx, 0) itself and then waits for `pending` to drain.
+class ShardWorkers {
+public:
+    using Fn = void (*)(void* ctx, int shard);
+    ShardWorkers() = default;
+    ShardWorkers(const ShardWorkers&) = delete;
+    ShardWorkers& operator=(const ShardWorkers&) = delete;
+    ~ShardWorkers() { stop(); }
+
+    // one thread per entry of `devices` (the device of shards 1 .. n); false: no threads to be had (nothing left running)
+    bool start(const std::vector<int>& devices) noexcept {
+        try {
+            devices_ = devices;
+            threads_.reserve(devices.size());
+            for (size_t j = 0; j < devices.size(); ++j) threads_.emplace_back([this, j] { loop((int)j + 1); });
+            return true;
+        } catch (...) {
+            stop();
+            return false;
+        }
+    }
+    int size() const { return (int)threads_.size(); }
+
+    void run(Fn fn, void* ctx) noexcept {
+        fn_ = fn;
+        ctx_ = ctx;
+        pending_.store((uint32_t)threads_.size(), std::memory_order_relaxed);
+        generation_.fetch_add(1, std::memory_order_seq_cst);
+        if (parked_.load(std::memory_order_seq_cst) > 0) futex_wake_all(&generation_);
+        fn(ctx, 0);
+        unsigned spins = 0;
+        while (pending_.load(std::memory_order_acquire) != 0) {
+            if ((++spins & 0xfff) == 0) std::this_thread::yield();   // (fewer cores than shards: let a worker run)
+            else cpu_relax();
+        }
+    }
+
+private:
+    void stop() noexcept {
+        if (threads_.empty()) return;
+        quit_.store(true, std::memory_order_release);
+        generation_.fetch_add(1, std::memory_order_seq_cst);
+        futex_wake_all(&generation_);
+        for (auto& t : threads_)
+            if (t.joinable()) t.join();
+        threads_.clear();
+    }
+
+    void loop(int shard) noexcept {
+        (void)hipSetDevice(devices_[(size_t)shard - 1]);   // a thread's current device stays: set once, not per call
+        uint32_t seen = 0;
+        const double spin_us = (double)spin_us_setting();
+        for (;;) {
+            uint32_t g;
+            double t0 = now_us();
+            unsigned spins = 0;
+            while ((g = generation_.load(std::memory_order_acquire)) == seen) {
+                if ((++spins & 63) == 0 && now_us() - t0 >= spin_us) {
+                    parked_.fetch_add(1, std::memory_order_seq_cst);
+                    futex_wait(&generation_, seen);   // (returns at once if the generation has moved meanwhile)
+                    parked_.fetch_sub(1, std::memory_order_seq_cst);
+                    t0 = now_us();
+                } else {
+                    cpu_relax();
+                }
+            }
+            seen = g;
+            if (quit_.load(std::memory_order_acquire)) return;
+            fn_(ctx_, shard);
+            pending_.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+
+    std::vector<std::thread> threads_;
+    std::vector<int> devices_;
+    Fn fn_ = nullptr;
+    void* ctx_ = nullptr;
+    alignas(64) std::atomic<uint32_t> generation_{0};
+    alignas(64) std::atomic<uint32_t> pending_{0};
+    alignas(64) std::atomic<int> parked_{0};
+    std::atomic<bool> quit_{false};
+};
+
+struct ShardState {
+    rsp::CscView view;        // device, stream, own output of the resident shard
+    hipEvent_t done = nullptr;   // recorded behind the shard's last command of a call (no timing: as light as an event gets)
+    int status = RSP_OK;
+    char message[256] = "";
+    double t_begin = 0, t_enqueued = 0, t_done = 0, t_copied = 0;   // host clock of the last call, microseconds
+};
+
+}  // namespace
+
 struct rsp_mcsc {
     std::vector<rsp_csc_t> shards;
     std::vector<int32_t> bounds;   // column range of shard k: [bounds[k], bounds[k+1])
-    int32_t nrow, ncol;
-    bool has_rows;                 // uploaded with i[]: the row-wise entries are available
+    std::vector<int> devices;
+    int32_t nrow = 0, ncol = 0;
+    bool has_rows = false;         // uploaded with i[]: the row-wise entries are available
+    // what a column-sum call needs, made once
+    std::vector<ShardState> st;
+    double* h_result = nullptr;    // page-locked, ncol doubles: every shard's slice lands here
+    double* d_result_view = nullptr;   // the same memory as the devices address it (RSP_GATHER_STORES)
+    int gather = RSP_GATHER_D2H;
+    int launch = RSP_LAUNCH_SERIAL;
+    ShardWorkers* workers = nullptr;   // made on the first call that wants them
+    bool workers_failed = false;
+    std::vector<ncclComm_t> comms;     // RSP_GATHER_RCCL: one ncclCommInitAll over the shards' devices
+    double* d_gathered = nullptr;      // ... and the gathered vector on shard 0's device
+    double t_call_begin = 0, t_call_end = 0;
 };
+
+namespace {
+
+void shard_fail(ShardState& s, int code, const char* what, const char* detail) noexcept {
+    if (s.status != RSP_OK) return;
+    s.status = code;
+    snprintf(s.message, sizeof(s.message), "%s: %s", what, detail ? detail : "");
+}
+
+struct ColumnCall {
+    rsp_mcsc* h;
+    double* sums;
+    bool means;
+};
+
+// shard k, step 1: the column-sum launches on the shard's own stream (its device current)
+void shard_launch(ColumnCall* c, int k) noexcept {
+    rsp_mcsc* h = c->h;
+    ShardState& s = h->st[(size_t)k];
+    s.status = RSP_OK;
+    s.t_begin = now_us();
+    const int32_t c0 = h->bounds[(size_t)k], nc = h->bounds[(size_t)k + 1] - c0;
+    if (nc > 0) {
+        double* d_out = nullptr;   // the shard's own output
+        if (h->gather == RSP_GATHER_STORES) d_out = h->d_result_view + c0;
+        else if (h->gather == RSP_GATHER_RCCL && k == 0) d_out = h->d_gathered + c0;   // shard 0's slice is in place
+        const int rc = rsp::csc_enqueue_columns(h->shards[(size_t)k], c->means, d_out);
+        if (rc != RSP_OK) shard_fail(s, rc, "column sums", rsp_last_error());
+    }
+    s.t_enqueued = now_us();
+}
+
+// step 2: the slice's way to the page-locked vector, behind the launches on the same stream
+void shard_send(ColumnCall* c, int k) noexcept {
+    rsp_mcsc* h = c->h;
+    ShardState& s = h->st[(size_t)k];
+    const int32_t c0 = h->bounds[(size_t)k], nc = h->bounds[(size_t)k + 1] - c0;
+    if (nc > 0 && s.status == RSP_OK && h->gather == RSP_GATHER_D2H) {
+        const hipError_t e = hipMemcpyAsync(h->h_result + c0, s.view.d_out, (size_t)nc * 8, hipMemcpyDeviceToHost, s.view.stream);
+        if (e != hipSuccess) shard_fail(s, RSP_ERR_HIP, "D2H of the slice", hipGetErrorString(e));
+    }
+    if (nc > 0) {
+        const hipError_t e = hipEventRecord(s.done, s.view.stream);
+        if (e != hipSuccess) shard_fail(s, RSP_ERR_HIP, "hipEventRecord", hipGetErrorString(e));
+    }
+}
+
+// step 3: has the shard's event passed?  (A look costs a fraction of a microsecond; hipStreamSynchronize on a stream that
+// has ALREADY drained costs ~9 us on this runtime -- eight of them in a row were most of a call, profiles/r06_mcsc_overhead.md.)
+// true: the shard is done with (its slice handed to the caller, or its failure recorded).
+bool shard_poll(ColumnCall* c, int k) noexcept {
+    rsp_mcsc* h = c->h;
+    ShardState& s = h->st[(size_t)k];
+    const int32_t c0 = h->bounds[(size_t)k], nc = h->bounds[(size_t)k + 1] - c0;
+    if (nc > 0) {
+        const hipError_t q = s.status == RSP_OK ? hipEventQuery(s.done) : hipErrorUnknown;
+        if (q == hipErrorNotReady) return false;
+        if (q != hipSuccess) {
+            (void)hipGetLastError();
+            if (s.status == RSP_OK) shard_fail(s, RSP_ERR_HIP, "waiting for the shard", hipGetErrorString(q));
+            (void)hipStreamSynchronize(s.view.stream);   // nothing of a failed call stays in flight
+        }
+    }
+    s.t_done = now_us();
+    if (nc > 0 && s.status == RSP_OK && c->sums != h->h_result && h->gather != RSP_GATHER_NONE)
+        memcpy(c->sums + c0, h->h_result + c0, (size_t)nc * 8);
+    s.t_copied = now_us();
+    return true;
+}
+
+void shard_whole(void* ctx, int k) noexcept {
+    shard_launch((ColumnCall*)ctx, k);
+    shard_send((ColumnCall*)ctx, k);
+    while (!shard_poll((ColumnCall*)ctx, k)) cpu_relax();
+}
+void shard_copy_only(void* ctx, int k) noexcept {   // RCCL gather: the whole vector is in h_result; the slices go out side by side
+    ColumnCall* c = (ColumnCall*)ctx;
+    rsp_mcsc* h = c->h;
+    const int32_t c0 = h->bounds[(size_t)k], nc = h->bounds[(size_t)k + 1] - c0;
+    if (nc > 0 && c->sums != h->h_result) memcpy(c->sums + c0, h->h_result + c0, (size_t)nc * 8);
+    h->st[(size_t)k].t_copied = now_us();
+}
+
+bool ensure_workers(rsp_mcsc* h) noexcept {
+    if (h->workers) return true;
+    if (h->workers_failed || h->shards.size() < 2) return false;
+    ShardWorkers* w = new (std::nothrow) ShardWorkers();
+    std::vector<int> devs;
+    try {
+        devs.assign(h->devices.begin() + 1, h->devices.end());
+    } catch (...) {
+        delete w;
+        w = nullptr;
+    }
+    if (!w || !w->start(devs)) {
+        delete w;
+        h->workers_failed = true;   // (no threads to be had: the calling thread does the work, now and later)
+        return false;
+    }
+    h->workers = w;
+    return true;
+}
+
+void mcsc_release_rccl(rsp_mcsc* h) noexcept {
+    for (size_t k = 0; k < h->comms.size(); ++k)
+        if (h->comms[k]) {
+            (void)hipSetDevice(h->devices[k]);
+            (void)ncclCommDestroy(h->comms[k]);
+        }
+    h->comms.clear();
+    if (h->d_gathered) {
+        (void)hipSetDevice(h->devices[0]);
+        (void)hipFree(h->d_gathered);
+        h->d_gathered = nullptr;
+    }
+}
+
+int default_launch(int nshards) {
+    const char* s = getenv("RSP_MCSC_LAUNCH");
+    if (s && !strcmp(s, "serial")) return RSP_LAUNCH_SERIAL;
+    if (s && !strcmp(s, "workers")) return RSP_LAUNCH_WORKERS;
+    // measured (profiles/r06_mcsc_overhead.json): from three shards on, eight enqueues one after the other cost the
+    // last shard more than a parked thread's wake-up does
+    return nshards >= 3 ? RSP_LAUNCH_WORKERS : RSP_LAUNCH_SERIAL;
+}
+
+// the per-handle state of the column-sum calls, once the shards exist (h->shards, bounds, devices filled)
+int mcsc_prepare_on_devices(rsp_mcsc* h);
+int mcsc_prepare(rsp_mcsc* h) {   // (leaves the calling thread's current device as it found it)
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    const int rc = mcsc_prepare_on_devices(h);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+int mcsc_prepare_on_devices(rsp_mcsc* h) {
+    const size_t G = h->shards.size();
+    try {
+        h->st.assign(G, ShardState());
+    } catch (...) {
+        return fail(RSP_ERR_ALLOC, "out of host memory");
+    }
+    for (size_t k = 0; k < G; ++k) {
+        if (int rc = rsp::csc_view(h->shards[k], &h->st[k].view)) return rc;
+        hipError_t e = hipSetDevice(h->devices[k]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->st[k].done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            h->st[k].done = nullptr;
+            return fail(RSP_ERR_HIP, "event of shard %zu: %s", k, hipGetErrorString(e));
+        }
+    }
+    const size_t bytes = h->ncol > 0 ? (size_t)h->ncol * 8 : 8;
+    // portable: page-locked for EVERY device of the process (each shard's copy engine writes its own slice)
+    hipError_t e = hipHostMalloc((void**)&h->h_result, bytes, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        h->h_result = nullptr;
+        return fail(RSP_ERR_ALLOC, "page-locked result vector (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    void* dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, h->h_result, 0) == hipSuccess) h->d_result_view = (double*)dv;
+    else (void)hipGetLastError();
+    h->gather = RSP_GATHER_D2H;
+    h->launch = default_launch((int)G);
+    return RSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int rsp_mcsc_free(rsp_mcsc_t h) {
     if (!h) return RSP_OK;
-    for (rsp_csc_t s : h->shards) rsp_csc_free(s);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    delete h->workers;   // (joins the parked threads)
+    h->workers = nullptr;
+    for (rsp_csc_t s : h->shards) rsp_csc_free(s);   // waits for each shard's stream
+    for (ShardState& s : h->st)
+        if (s.done) (void)hipEventDestroy(s.done);
+    mcsc_release_rccl(h);
+    if (h->h_result) (void)hipHostFree(h->h_result);
+    if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
     return RSP_OK;
 }
@@ -232,13 +577,15 @@ static int mcsc_upload(const double* x, const int32_t* i, const int32_t* p, int3
         h->nrow = nrow;
         h->ncol = ncol;
         h->has_rows = i != nullptr || nnz == 0;
+        h->devices = devs;
         h->bounds.assign((size_t)G + 1, 0);
         h->shards.assign((size_t)G, nullptr);
         if (int rc = rsp_partition_columns(p, ncol, G, h->bounds.data())) {
             delete h;
             return rc;
         }
-        // one host thread per shard: every shard goes over its own GPU's host link
+        // one host thread per shard: every shard goes over its own GPU's host link (an upload is milliseconds to
+        // seconds of copying: the threads of this ONE call are noise beside it)
         std::vector<int> status((size_t)G, RSP_OK);
         std::vector<std::string> message((size_t)G);
         auto work = [&](int k) noexcept {
@@ -264,6 +611,10 @@ static int mcsc_upload(const double* x, const int32_t* i, const int32_t* p, int3
                 rsp_mcsc_free(h);
                 return rc;
             }
+        if (int rc = mcsc_prepare(h)) {
+            rsp_mcsc_free(h);
+            return rc;
+        }
     } catch (...) {
         if (h) rsp_mcsc_free(h);
         return fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_upload");
@@ -283,32 +634,281 @@ int rsp_mcsc_upload_csc(const double* x, const int32_t* i, const int32_t* p, int
     return mcsc_upload(x, i, p, nrow, ncol, nnz, devices, ndevices, handle);
 }
 
-static int mcsc_columns(rsp_mcsc_t h, double* sums, bool means) try {
-    if (!h || (h->ncol > 0 && !sums)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
-    const int G = (int)h->shards.size();
-    std::vector<int> status((size_t)G, RSP_OK);
-    std::vector<std::string> message((size_t)G);
-    auto work = [&](int k) noexcept {
-        if (h->bounds[k + 1] == h->bounds[k]) return;
-        status[k] = means ? rsp_csc_column_means(h->shards[k], sums + h->bounds[k])   // (every shard knows Dim[0])
-                          : rsp_csc_column_sums(h->shards[k], sums + h->bounds[k]);    // slice lands in place
-        if (status[k] != RSP_OK) {
-            try {
-                message[k] = rsp_last_error();
-            } catch (...) {
+int rsp_mcsc_wrap_device(int nshards, const int* devices, const double* const* d_x, const int32_t* const* d_i,
+                         const int32_t* const* d_p, const int32_t* shard_ncol, const int64_t* shard_nnz, int32_t nrow,
+                         rsp_mcsc_t* handle) {
+    if (!handle) return fail(RSP_ERR_BAD_ARG, "handle is null");
+    *handle = nullptr;
+    if (nshards <= 0 || !devices || !d_x || !d_p || !shard_ncol || !shard_nnz || nrow < 0)
+        return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_mcsc_wrap_device");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    rsp_mcsc* h = nullptr;
+    int rc = RSP_OK;
+    try {
+        h = new rsp_mcsc();
+        h->nrow = nrow;
+        h->devices.assign(devices, devices + nshards);
+        h->bounds.assign((size_t)nshards + 1, 0);
+        h->shards.assign((size_t)nshards, nullptr);
+        h->has_rows = d_i != nullptr;
+        int64_t total = 0;
+        for (int k = 0; k < nshards && rc == RSP_OK; ++k) {
+            if (shard_ncol[k] < 0 || shard_nnz[k] < 0) rc = fail(RSP_ERR_BAD_ARG, "shard %d: negative size", k);
+            total += shard_ncol[k];
+            if (rc == RSP_OK && total > INT32_MAX - 65537) rc = fail(RSP_ERR_BAD_ARG, "too many columns");
+            h->bounds[(size_t)k + 1] = (int32_t)total;
+            if (d_i && shard_nnz[k] > 0 && !d_i[k]) h->has_rows = false;
+        }
+        h->ncol = (int32_t)total;
+        for (int k = 0; k < nshards && rc == RSP_OK; ++k) {
+            rc = rsp::csc_wrap_device(d_x[k], (d_i && h->has_rows) ? d_i[k] : nullptr, d_p[k], nrow, shard_ncol[k],
+                                      shard_nnz[k], devices[k], &h->shards[(size_t)k]);
+            if (rc != RSP_OK) {
+                char text[400];
+                snprintf(text, sizeof(text), "%s", rsp_last_error());
+                rc = fail(rc, "shard %d on device %d: %s", k, devices[k], text);
             }
         }
-    };
-    if (!run_shards(G, work)) return fail(RSP_ERR_ALLOC, "out of host memory or threads while summing the shards");
-    for (int k = 0; k < G; ++k)
-        if (status[k] != RSP_OK) return fail(status[k], "shard %d: %s", k, message[k].c_str());
+        if (rc == RSP_OK) rc = mcsc_prepare(h);
+    } catch (...) {
+        rc = fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_wrap_device");
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (rc != RSP_OK) {
+        char text[400];
+        snprintf(text, sizeof(text), "%s", rsp_last_error());
+        if (h) rsp_mcsc_free(h);
+        return fail(rc, "%s", text);
+    }
+    *handle = h;
     return RSP_OK;
-} catch (...) {
-    return fail(RSP_ERR_ALLOC, "out of host memory in rsp_mcsc_column_sums");
+}
+
+// RSP_GATHER_RCCL: the communicators of ONE ncclCommInitAll over the shards' devices ("single process,
+// G devices") and the gathered vector on shard 0's device, made when the mode is first selected.
+static int mcsc_make_rccl(rsp_mcsc* h) {
+    if (!h->comms.empty()) return RSP_OK;
+    const int G = (int)h->shards.size();
+    for (int a = 0; a < G; ++a)
+        for (int b = a + 1; b < G; ++b)
+            if (h->devices[(size_t)a] == h->devices[(size_t)b])
+                return fail(RSP_ERR_BAD_ARG, "the RCCL gather needs one DEVICE per shard (shards %d and %d share device %d): "
+                                             "RCCL refuses two ranks of a communicator on one device", a, b, h->devices[(size_t)a]);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    int rc = RSP_OK;
+    try {
+        h->comms.assign((size_t)G, nullptr);
+    } catch (...) {
+        return fail(RSP_ERR_ALLOC, "out of host memory");
+    }
+    const ncclResult_t r = ncclCommInitAll(h->comms.data(), G, h->devices.data());
+    if (r != ncclSuccess) {
+        h->comms.clear();
+        rc = fail(RSP_ERR_RCCL, "ncclCommInitAll over %d devices: %s", G, ncclGetErrorString(r));
+    }
+    if (rc == RSP_OK) {
+        hipError_t e = hipSetDevice(h->devices[0]);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->d_gathered, h->ncol > 0 ? (size_t)h->ncol * 8 : 8);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_gathered = nullptr;
+            mcsc_release_rccl(h);
+            rc = fail(RSP_ERR_HIP, "gathered vector on device %d: %s", h->devices[0], hipGetErrorString(e));
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+
+int rsp_mcsc_set_gather(rsp_mcsc_t h, int mode) {
+    if (!h) return fail(RSP_ERR_BAD_ARG, "null handle");
+    if (mode == RSP_GATHER_RCCL) {
+        if (int rc = mcsc_make_rccl(h)) return rc;
+    } else if (mode == RSP_GATHER_STORES) {
+        if (!h->d_result_view) return fail(RSP_ERR_HIP, "the page-locked result vector has no device address on this system");
+    } else if (mode != RSP_GATHER_D2H && mode != RSP_GATHER_NONE) {
+        return fail(RSP_ERR_BAD_ARG, "unknown gather mode %d", mode);
+    }
+    h->gather = mode;
+    return RSP_OK;
+}
+
+int rsp_mcsc_set_launch(rsp_mcsc_t h, int mode) {
+    if (!h) return fail(RSP_ERR_BAD_ARG, "null handle");
+    if (mode != RSP_LAUNCH_SERIAL && mode != RSP_LAUNCH_WORKERS) return fail(RSP_ERR_BAD_ARG, "unknown launch mode %d", mode);
+    h->launch = mode;
+    return RSP_OK;
+}
+
+int rsp_mcsc_config(rsp_mcsc_t h, int32_t* info4) {
+    if (!h || !info4) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    info4[0] = h->gather;
+    info4[1] = h->launch;
+    info4[2] = h->workers ? h->workers->size() : 0;
+    info4[3] = (int32_t)h->comms.size();
+    return RSP_OK;
+}
+
+double* rsp_mcsc_result_buffer(rsp_mcsc_t h) { return h ? h->h_result : nullptr; }
+
+static int mcsc_columns(rsp_mcsc_t h, double* sums, bool means) {
+    if (!h || (h->ncol > 0 && !sums)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    const int G = (int)h->shards.size();
+    h->t_call_begin = now_us();
+    if (h->ncol == 0) {
+        h->t_call_end = h->t_call_begin;
+        return RSP_OK;
+    }
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    ColumnCall call{h, sums, means};
+    int rc = RSP_OK;
+    if (h->gather == RSP_GATHER_RCCL) {
+        // the launches, then ONE group of sends and receives (a group is issued by one thread), then one copy home
+        for (int k = 0; k < G; ++k) {
+            const hipError_t e = hipSetDevice(h->devices[(size_t)k]);
+            if (e != hipSuccess) shard_fail(h->st[(size_t)k], RSP_ERR_HIP, "hipSetDevice", hipGetErrorString(e));
+            shard_launch(&call, k);
+        }
+        bool ok = true;
+        for (int k = 0; k < G; ++k) ok = ok && h->st[(size_t)k].status == RSP_OK;
+        ncclResult_t r = ok && G > 1 ? ncclGroupStart() : ncclSuccess;
+        if (ok && G > 1 && r == ncclSuccess) {
+            for (int k = 1; k < G && r == ncclSuccess; ++k) {
+                const int32_t c0 = h->bounds[(size_t)k], nc = h->bounds[(size_t)k + 1] - c0;
+                if (nc <= 0) continue;
+                r = ncclSend(h->st[(size_t)k].view.d_out, (size_t)nc, ncclDouble, 0, h->comms[(size_t)k], h->st[(size_t)k].view.stream);
+                if (r == ncclSuccess)
+                    r = ncclRecv(h->d_gathered + c0, (size_t)nc, ncclDouble, k, h->comms[0], h->st[0].view.stream);
+            }
+            const ncclResult_t r2 = ncclGroupEnd();
+            if (r == ncclSuccess) r = r2;
+        }
+        if (r != ncclSuccess) rc = fail(RSP_ERR_RCCL, "gatherv of the slices: %s", ncclGetErrorString(r));
+        hipError_t e = hipSetDevice(h->devices[0]);
+        // (shard 0 may own no column at all: its stream still carries the receives)
+        if (e == hipSuccess && ok && rc == RSP_OK)
+            e = hipMemcpyAsync(h->h_result, h->d_gathered, (size_t)h->ncol * 8, hipMemcpyDeviceToHost, h->st[0].view.stream);
+        for (int k = 0; k < G; ++k) {   // every stream drained before the call returns, whatever went wrong
+            (void)hipSetDevice(h->devices[(size_t)k]);
+            const hipError_t w = hipStreamSynchronize(h->st[(size_t)k].view.stream);
+            if (w != hipSuccess && e == hipSuccess) e = w;
+            h->st[(size_t)k].t_done = now_us();
+        }
+        if (e != hipSuccess && rc == RSP_OK) rc = fail(RSP_ERR_HIP, "RCCL gather: %s", hipGetErrorString(e));
+        if (rc == RSP_OK && ok) {
+            if (h->launch == RSP_LAUNCH_WORKERS && ensure_workers(h)) h->workers->run(shard_copy_only, &call);
+            else for (int k = 0; k < G; ++k) shard_copy_only(&call, k);
+        }
+    } else if (h->launch == RSP_LAUNCH_WORKERS && G > 1 && ensure_workers(h)) {
+        const hipError_t e = hipSetDevice(h->devices[0]);   // shard 0 is this thread's
+        if (e != hipSuccess) rc = fail(RSP_ERR_HIP, "hipSetDevice(%d): %s", h->devices[0], hipGetErrorString(e));
+        else h->workers->run(shard_whole, &call);
+    } else {
+        // every shard's kernels first (a device starts working ~3 us after the one before it), the copy commands in a
+        // second pass while the kernels run, then the waits in shard order
+        for (int k = 0; k < G; ++k) {
+            const hipError_t e = hipSetDevice(h->devices[(size_t)k]);
+            if (e != hipSuccess) shard_fail(h->st[(size_t)k], RSP_ERR_HIP, "hipSetDevice", hipGetErrorString(e));
+            shard_launch(&call, k);
+        }
+        for (int k = 0; k < G; ++k) {
+            (void)hipSetDevice(h->devices[(size_t)k]);
+            shard_send(&call, k);
+        }
+        // the shards in the order they finish: one thread looks at the events in turn
+        uint64_t pending = 0;   // (more than 64 shards: the tail is waited for in order afterwards)
+        for (int k = 0; k < G && k < 64; ++k) pending |= (uint64_t)1 << k;
+        int current = h->devices[(size_t)G - 1];
+        while (pending) {
+            for (int k = 0; k < G && k < 64; ++k) {
+                if (!((pending >> k) & 1)) continue;
+                if (h->devices[(size_t)k] != current) {
+                    current = h->devices[(size_t)k];
+                    (void)hipSetDevice(current);
+                }
+                if (shard_poll(&call, k)) pending &= ~((uint64_t)1 << k);
+            }
+            if (pending) cpu_relax();
+        }
+        for (int k = 64; k < G; ++k) {
+            (void)hipSetDevice(h->devices[(size_t)k]);
+            while (!shard_poll(&call, k)) cpu_relax();
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    h->t_call_end = now_us();
+    if (rc != RSP_OK) return rc;
+    for (int k = 0; k < G; ++k)
+        if (h->st[(size_t)k].status != RSP_OK)
+            return fail(h->st[(size_t)k].status, "shard %d on device %d: %s", k, h->devices[(size_t)k], h->st[(size_t)k].message);
+    return RSP_OK;
 }
 
 int rsp_mcsc_column_sums(rsp_mcsc_t h, double* sums) { return mcsc_columns(h, sums, false); }
 int rsp_mcsc_column_means(rsp_mcsc_t h, double* means) { return mcsc_columns(h, means, true); }
+
+// Measurement: the host clock of the LAST column-sum call on this handle, microseconds from the call's entry:
+// us[0] = the whole call; then per shard { enqueue begun, enqueue returned, stream drained, slice copied out }.
+int rsp_mcsc_last_call_stamps(rsp_mcsc_t h, double* us, int capacity) {
+    if (!h || !us) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    const int G = (int)h->shards.size();
+    if (capacity < 1 + 4 * G) return fail(RSP_ERR_BAD_ARG, "room for %d values needed", 1 + 4 * G);
+    us[0] = h->t_call_end - h->t_call_begin;
+    for (int k = 0; k < G; ++k) {
+        const ShardState& s = h->st[(size_t)k];
+        us[1 + 4 * k + 0] = s.t_begin - h->t_call_begin;
+        us[1 + 4 * k + 1] = s.t_enqueued - h->t_call_begin;
+        us[1 + 4 * k + 2] = s.t_done - h->t_call_begin;
+        us[1 + 4 * k + 3] = s.t_copied - h->t_call_begin;
+    }
+    return RSP_OK;
+}
+
+// Measurement: mean device time of ONE shard's column-sum launches alone (HIP events on the shard's stream, `reps`
+// calls back to back after one untimed call) -- what the call's wall time is compared with.
+int rsp_mcsc_shard_kernel_ms(rsp_mcsc_t h, int32_t shard, int reps, float* ms) {
+    if (!h || !ms || reps <= 0) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_mcsc_shard_kernel_ms");
+    if (shard < 0 || shard >= (int32_t)h->shards.size()) return fail(RSP_ERR_BAD_ARG, "shard %d out of range", shard);
+    *ms = 0.0f;
+    if (h->bounds[(size_t)shard + 1] == h->bounds[(size_t)shard]) return RSP_OK;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    const ShardState& s = h->st[(size_t)shard];
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = RSP_OK;
+    hipError_t e = hipSetDevice(h->devices[(size_t)shard]);
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    if (e == hipSuccess) rc = rsp::csc_enqueue_columns(h->shards[(size_t)shard], false, nullptr);
+    if (e == hipSuccess && rc == RSP_OK) e = hipEventRecord(a, s.view.stream);
+    for (int r = 0; r < reps && e == hipSuccess && rc == RSP_OK; ++r) rc = rsp::csc_enqueue_columns(h->shards[(size_t)shard], false, nullptr);
+    if (e == hipSuccess && rc == RSP_OK) e = hipEventRecord(b, s.view.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.view.stream);
+    float total = 0.0f;
+    if (e == hipSuccess && rc == RSP_OK) e = hipEventElapsedTime(&total, a, b);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (rc != RSP_OK) return rc;
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "timing shard %d: %s", shard, hipGetErrorString(e));
+    *ms = total / (float)reps;
+    return RSP_OK;
+}
 
 // Matrix::rowSums / rowMeans (reference RcppSparse.h:138-156) of the resident shards: every shard's partial row
 // sums come back over its own device's link into a host vector, and the host adds the vectors in SHARD order
@@ -383,6 +983,38 @@ int rsp_mcsc_shard_info(rsp_mcsc_t h, int32_t shard, int32_t* info4) {
     return RSP_OK;
 }
 int rsp_mcsc_row_means(rsp_mcsc_t h, double* means) { return mcsc_rows(h, means, true); }
+
+// Which RCCL this process really runs: the version the loaded library reports and the file it was mapped from.  The
+// library is linked against librccl.so by soname; which file answers is the loader's choice (a process that imported torch
+// first gets torch's bundled copy) -- a multi-GPU number should say which one produced it.
+int rsp_rccl_info(int* version, char* library_path, size_t capacity) {
+    if (version) {
+        int v = 0;
+        const ncclResult_t r = ncclGetVersion(&v);
+        if (r != ncclSuccess) return fail(RSP_ERR_RCCL, "ncclGetVersion: %s", ncclGetErrorString(r));
+        *version = v;
+    }
+    if (library_path && capacity > 0) {
+        library_path[0] = '\0';
+        FILE* f = fopen("/proc/self/maps", "r");
+        if (f) {
+            char line[1024];
+            while (fgets(line, sizeof(line), f)) {
+                const char* hit = strstr(line, "librccl");
+                if (!hit) continue;
+                const char* path = strchr(line, '/');
+                if (!path) continue;
+                size_t n = strcspn(path, "\n");
+                if (n >= capacity) n = capacity - 1;
+                memcpy(library_path, path, n);
+                library_path[n] = '\0';
+                break;
+            }
+            fclose(f);
+        }
+    }
+    return RSP_OK;
+}
 
 int rsp_comm_unique_id(void* id_bytes) {
     if (!id_bytes) return fail(RSP_ERR_BAD_ARG, "id_bytes is null");
