@@ -426,7 +426,7 @@ def traffic_child(args):
     ws = capi.alloc_workspace(ncol, nnz, "cuda")
     run = capi.prepared_column_sums(x, pt, out, ws)
     run()
-    capi.column_sums_device_form(pt, nnz, wait=True)     # the entry plans for itself: count the form it settles on
+    capi.column_sums_device_settle(pt, nnz)     # the entry plans for itself: count the form it settles on
     for _ in range(max(1, args.steps)):
         run()
     torch.cuda.synchronize()
@@ -561,7 +561,7 @@ def also_record(torch, capi, spec, args, dev, dev_index, stream, traffic_now=Fal
     auto_form = None
     if plan is None:
         # the plan-free entry plans for itself (include/rcppsparse_hip.h): wait until it has settled on a form, then warm that
-        auto_form = capi.column_sums_device_form(pt, nnz, wait=True)
+        auto_form = capi.column_sums_device_settle(pt, nnz, stream=stream)
         for k in range(max(args.warmup, ncopies)):
             launches[k % ncopies]()
     mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
@@ -1207,7 +1207,8 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
         # rsp_column_sums_device plans for itself: every rank waits until ITS entry has settled on a form (outside every timed
         # region: the inspection is ~23 us of device time behind the first call), then warms that form.  (The same number of
         # steps on every rank, whatever its shard holds: a step with a gather is a collective.)
-        my_form = form_code.get(capi.column_sums_device_form(pt, shard.nnz, wait=True), 0) if shard.nnz > 0 else 0
+        # (rsp_column_sums_device_settle: from here on every call of this rank takes ONE form -- bit-stable run to run)
+        my_form = form_code.get(capi.column_sums_device_settle(pt, shard.nnz, stream=s_main), 0) if shard.nnz > 0 else 0
         for _ in range(args.warmup):
             driver.step(recv)
     else:

@@ -216,27 +216,40 @@ int rsp_csc_free(rsp_csc_t handle);
  * streams (two workspaces) lets one call fill the chip while the previous one
  * drains (bench.py does this for the 1/8 shards of the multi-GPU runs: -15 %).
  *
- * These two entries PLAN FOR THEMSELVES (matrices of at least 2^20 entries).  The first call on
- * (device, d_p, ncol, nnz) runs the general kernels and enqueues a device-side inspection of d_p behind them on
- * `stream` (rsp_column_sums_plan_create_device: ~23 us for 1e6 columns; nothing waits).  Once the host has seen its
- * result -- an event query per call -- later calls with the same key take the form it selects: lean (every column
- * short: ONE launch, every column bit-identical to the reference loop; BASELINE config 2: 0.51 -> ~0.7 of the
- * HBM roofline) or columns (every column long: one launch); other matrices stay on the general kernels.  The
- * caller promises NOTHING about d_p between calls: the kernels of this path check every column's offsets against
- * the p[] of the call they run in, sum a column whose offsets have changed straight from x (clamped to [0, nnz]),
- * and make the library inspect again -- never a wrong sum, only a slower call.  Up to 16 keys are remembered per
- * process; a 17th is planned only once a remembered one has gone unused for 64 calls, and forgetting that one
- * waits for the device (the ONE case in which these entries synchronise: launches in flight may still read its
- * images); rsp_release_cached() forgets them all (it waits for the device too).  Consequences: the first calls
- * and the later ones agree within the documented tolerance, not bit for bit, and which call is the first planned
- * one depends on timing.  A call on a CAPTURING stream always records the general kernels (a graph outlives the
- * call, the library's plan images do not belong to it): to put the planned form into a graph, make the plan
- * yourself (rsp_column_sums_plan_create_device, rsp_column_sums_plan_wait) and capture
- * rsp_column_sums_planned_device -- the plan's lifetime is then yours.  RSP_AUTO_PLAN=0 in the
- * environment (or rsp_debug_set("auto_plan", 0)) keeps every call on the general kernels, bit-stable from the first
- * call; explicit plans (below) and handles choose their form once, at creation / upload.
+ * These two entries PLAN FOR THEMSELVES (matrices of at least 2^20 entries; round 6 rules).  The FIRST call on
+ * (device, d_p, ncol, nnz) runs the general kernels and only notes the key (no allocation, nothing else enqueued: a
+ * caller that shows fresh offsets in every call never pays for a plan).  The SECOND call runs the general kernels too
+ * and enqueues a device-side inspection of d_p behind them on `stream` (rsp_column_sums_plan_create_device: ~23 us for
+ * 1e6 columns; its memory is allocated in this call, once per key).  Once the host has seen the result -- one load of a
+ * page-locked word per call: no event query, never a wait -- later calls with the same key take the form it selects:
+ * lean (every column short: ONE launch, every column bit-identical to the reference loop; BASELINE config 2: 0.51 ->
+ * ~0.7 of the HBM roofline) or columns (every column long: one launch); other matrices stay on the general kernels.
+ * The caller promises NOTHING about d_p between calls: the kernels of this path check every column's offsets against
+ * the p[] of the call they run in, sum a column whose offsets have changed straight from x (clamped to [0, nnz]), and
+ * make the library retire that plan and inspect again -- never a wrong sum, only a slower call.
+ * NOTHING IN THESE ENTRIES EVER WAITS FOR THE DEVICE.  A retired plan's image is freed when an event recorded on every
+ * stream it was launched on has completed (looked at only while something is retired); a key keeps at most 2 retired
+ * images (beyond that it stays on the general kernels until one is freed), so HBM use is bounded whatever the caller
+ * does with d_p.  Up to 16 keys are remembered per process; keys that never got a plan make room first, a planned key
+ * only after 64 calls without a use (its plan is retired, not waited for).  One plan is launched on up to 6 different
+ * streams; calls on further streams take the general kernels.  rsp_release_cached() forgets everything (it DOES wait).
+ * BIT STABILITY: every form is deterministic, but the general kernels and a planned form agree within
+ * the documented tolerance, not bit for bit, and WHICH call is the first planned one depends on when the inspection's
+ * result is seen.  rsp_column_sums_device_settle(d_p, ncol, nnz, stream) removes that: it makes the key's plan now if
+ * there is none (inspection enqueued on `stream`), WAITS for its result and returns the form -- 0 general kernels,
+ * 2 lean, 3 columns, -1 no usable device.  From its return on, every call with that key takes that one form and
+ * returns identical bits run to run, for as long as d_p holds the same offsets and the key stays among the remembered
+ * ones (tests/test_gpu_autoplan.py::test_bit_stable_run_to_run_under_the_defaults).  Without it the guarantee starts
+ * at the first call after rsp_column_sums_device_form(.., wait = 1) has returned >= 0.
+ * A call on a CAPTURING stream always records the general kernels (a graph outlives the call, the library's plan images
+ * do not belong to it): to put the planned form into a graph, make the plan yourself
+ * (rsp_column_sums_plan_create_device, rsp_column_sums_plan_wait) and capture rsp_column_sums_planned_device -- the
+ * plan's lifetime is then yours.  RSP_AUTO_PLAN=0 in the environment (or rsp_debug_set("auto_plan", 0)) keeps every
+ * call on the general kernels, bit-stable from the first call; explicit plans (below) and handles choose their form
+ * once, at creation / upload.
  * rsp_column_sums_device_form: the form calls with that key take now -- 0 general kernels, 2 lean, 3 columns,
- * -1 not known (yet); wait != 0 blocks until the inspection's result has been seen (measurements).
+ * -1 not known (yet: no plan has been made, or its result has not been seen); wait != 0 blocks until the result of an
+ * inspection that has been enqueued is seen (it does not make a plan: that is settle's job).
  */
 size_t rsp_column_sums_workspace_bytes(int32_t ncol, int64_t nnz);
 int rsp_column_sums_device(const double *d_x, const int32_t *d_p, int32_t ncol,
@@ -249,6 +262,7 @@ int rsp_column_means_device(const double *d_x, const int32_t *d_p, int32_t nrow,
                             void *d_workspace, size_t workspace_bytes,
                             void *stream);
 int rsp_column_sums_device_form(const int32_t *d_p, int32_t ncol, int64_t nnz, int wait);
+int rsp_column_sums_device_settle(const int32_t *d_p, int32_t ncol, int64_t nnz, void *stream);
 /*
  * Inspector-executor form for callers that can show p[] to the host once (a resident matrix summed many
  * times; rsp_csc_upload does this by itself, the one-shot rsp_column_sums_host does not: it sums once).  The inspector walks the chunk
@@ -593,6 +607,8 @@ int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
  *   "row_slices"      row-restricted sums: 0 never the slice-major form, 1 where faster (default), 2 wherever possible
  *   "auto_plan"       rsp_column_sums_device / rsp_column_means_device plan for themselves (1, default) or never (0)
  *   "auto_min_nnz"    ... for matrices of at least this many entries (default 2^20; tests lower it to 1)
+ *   read-only (rsp_debug_get): "auto_plans_made" / "auto_plans_freed" -- plans those entries have made / freed since the
+ *                     process started; "auto_plans_retired" -- retired images still waiting for their events
  * An unknown key is RSP_ERR_BAD_ARG.  rsp_debug_get reads the value in force (environment and defaults resolved).
  * Threads: the knobs are atomics -- setting one while another thread is inside a call is safe and takes effect for
  * calls (plans, handles) that start afterwards; two libraries' worth of callers in one process share them, which is

@@ -54,6 +54,7 @@ EXPORTED_SYMBOLS = (
     "rsp_csc_dims", "rsp_csc_column_form", "rsp_csc_set_planned", "rsp_mcsc_dims", "rsp_mcsc_shard_info",
     "rsp_mcsc_set_gather", "rsp_mcsc_set_launch", "rsp_mcsc_config", "rsp_mcsc_result_buffer", "rsp_mcsc_wrap_device",
     "rsp_mcsc_last_call_stamps", "rsp_mcsc_shard_kernel_ms", "rsp_rccl_info",
+    "rsp_column_sums_device_settle",
 )
 GATHER_MODES = {"d2h": 0, "rccl": 1, "stores": 2, "none": 3}
 LAUNCH_MODES = {"serial": 0, "workers": 1}
@@ -145,6 +146,7 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_debug_set.argtypes = [c.c_char_p, c.c_int]
     L.rsp_debug_get.argtypes = [c.c_char_p, c.POINTER(c.c_int)]
     L.rsp_column_sums_device_form.argtypes = [vp, i32, i64, c.c_int]
+    L.rsp_column_sums_device_settle.argtypes = [vp, i32, i64, vp]
     L.rsp_csc_row_form.argtypes = [c.c_void_p]
     L.rsp_column_sums_in_rows_form.argtypes = [i32, i32, i64, c.c_size_t]
     L.rsp_column_sums_in_rows_workspace_bytes.argtypes = [i32, i32, i64]
@@ -237,6 +239,14 @@ def column_sums_device_form(p_t, nnz: int, wait: bool = False) -> str:
     """The form plan-free calls on these offsets take now (rsp_column_sums_device_form): 'general', 'lean', 'columns', or
     'unknown' (no call with this key yet, or the inspection's result has not been seen; wait=True blocks for it)."""
     r = int(load().rsp_column_sums_device_form(p_t.data_ptr(), p_t.numel() - 1, int(nnz), int(bool(wait))))
+    return {0: "general", 2: "lean", 3: "columns"}.get(r, "unknown")
+
+
+def column_sums_device_settle(p_t, nnz: int, stream=None) -> str:
+    """Makes the plan-free entry's plan for these offsets now (if there is none), waits for the inspection and returns the
+    form every later call with this key takes: 'general', 'lean' or 'columns' (rsp_column_sums_device_settle).  From here on
+    calls with the key are bit-identical run to run."""
+    r = int(load().rsp_column_sums_device_settle(p_t.data_ptr(), p_t.numel() - 1, int(nnz), _stream_ptr(stream)))
     return {0: "general", 2: "lean", 3: "columns"}.get(r, "unknown")
 
 

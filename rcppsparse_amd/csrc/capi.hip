@@ -417,6 +417,7 @@ int rsp_plan_describe(int64_t nnz, int32_t* plan4) {
 namespace {
 int clamp012(int v) { return v <= 0 ? 0 : (v >= 2 ? 2 : 1); }
 int auto_plan_setting();
+int auto_counter(int which);
 std::atomic<int> g_auto_plan{-1};   // "auto_plan": 0 / 1; -1 = RSP_AUTO_PLAN from the environment, else 1
 std::atomic<int> g_auto_min_nnz{1 << 20};   // "auto_min_nnz": calls below it never plan for themselves (tests lower it)
 }  // namespace
@@ -468,6 +469,9 @@ int rsp_debug_get(const char* key, int* value) {
     else if (k == "row_slices") *value = row_slices_setting();
     else if (k == "auto_plan") *value = auto_plan_setting();
     else if (k == "auto_min_nnz") *value = g_auto_min_nnz.load(std::memory_order_relaxed);
+    else if (k == "auto_plans_made") *value = auto_counter(0);       // read-only: plans the plan-free entries have made ...
+    else if (k == "auto_plans_freed") *value = auto_counter(1);      // ... freed again ...
+    else if (k == "auto_plans_retired") *value = auto_counter(2);    // ... and retired images waiting for their events right now
     else return fail(RSP_ERR_BAD_ARG, "unknown knob '%s'", key);
     return RSP_OK;
 }
@@ -730,9 +734,10 @@ static int plan_poll(rsp_colsums_plan* pl, hipStream_t stream, bool block) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
         if (cs != hipStreamCaptureStatusNone) return RSP_OK;
-        const hipError_t q = hipEventQuery(pl->ev_end);
-        if (q == hipErrorNotReady) return RSP_OK;
-        if (q != hipSuccess) return fail(RSP_ERR_HIP, "plan inspection failed: %s", hipGetErrorString(q));
+        // the last inspection kernel writes `ready` into the page-locked record behind the statistics (a system-scope
+        // release): looking costs one load, touches no runtime state (an event query could disturb a global-mode stream
+        // capture of another thread) and cannot fail
+        if (__atomic_load_n(&pl->h_stats->ready, __ATOMIC_ACQUIRE) != rsp::inspect::kStatsReady) return RSP_OK;
     } else {
         HIP_TRY(hipEventSynchronize(pl->ev_end));
     }
@@ -767,6 +772,7 @@ int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t
     if (e == hipSuccess) e = hipEventCreate(&pl->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev_end);
     hipStream_t s = (hipStream_t)stream;
+    if (e == hipSuccess) pl->h_stats->ready = 0;
     if (e == hipSuccess) e = hipEventRecord(pl->ev_begin, s);
     // (the last kernel writes the statistics straight into the page-locked host record: no copy, no memset)
     if (e == hipSuccess) e = rsp::launch_inspect_device(d_p, ncol, (int32_t)nnz, pl->lp, pl->dl, pl->d_mem, pl->h_stats, s);
@@ -848,46 +854,105 @@ int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
 // ---- the plan-free device entries plan for themselves --------------------------------------------------------
 // rsp_column_sums_device / rsp_column_means_device are what a caller with device pointers uses when it knows
 // nothing about plans (BASELINE config 2 through them: 0.46-0.51 of the HBM roofline on the general kernels, 0.70
-// through a plan).  The library therefore remembers the offsets it has been shown: the FIRST call on (device, d_p,
-// ncol, nnz) runs the general kernels and enqueues the device-side inspection of d_p BEHIND them on the caller's
-// stream (23 us for 1e6 columns, nothing waits); once the host has seen the statistics (an event query per call,
-// never a wait) calls with that key take the form they select -- lean (every column short: one launch, the
-// reference's bits) or columns (every column long: one launch); matrices with neither keep the general kernels and
-// cost nothing further.
+// through a plan).  The library therefore remembers the offsets it has been shown.
+//   * The FIRST call on (device, d_p, ncol, nnz) runs the general kernels and only notes the key (a table entry: no
+//     allocation, nothing enqueued) -- a caller that shows fresh offsets in every call never pays for a plan.
+//   * The SECOND call runs the general kernels too and enqueues the device-side inspection of d_p BEHIND them on the
+//     caller's stream (23 us for 1e6 columns; its image and page-locked record are allocated here, outside the table's lock).
+//   * Once the host has seen the statistics (the kernels write a `ready` word into the page-locked record: one load per
+//     call, no event query, never a wait) calls with that key take the form they select -- lean (every column short: one
+//     launch, the reference's bits) or columns (every column long: one launch); matrices with neither keep the general
+//     kernels and cost nothing further.  rsp_column_sums_device_settle does all of that at once and WAITS: from its
+//     return on every call with the key takes the same form -- bit-identical results run to run.
 // Nobody has promised that d_p still holds the offsets that were inspected.  The kernels of this path do not rest
 // on it: the lean kernel compares every column's image offsets with the p[] of THIS call and sums a column that
-// differs straight from x; the columns kernel reads p[] itself.  Both clamp to [0, nnz] and raise a page-locked
-// `stale` word, and a call that finds it raised inspects again (a fresh image; the old one is kept until
-// rsp_release_cached, a launch of an earlier call on another stream may still be reading it) -- after kAutoMaxStrikes
-// such rounds without kAutoForgive clean planned calls in between the key stays on the general kernels.  So: never a wrong sum, whatever the caller does with d_p.
+// differs straight from x; the columns kernel reads p[] itself.  Both clamp to [0, nnz] and raise the plan's OWN
+// page-locked `stale` word; a call that finds it raised answers with the general kernels, RETIRES the plan and
+// inspects again.  So: never a wrong sum, whatever the caller does with d_p.
+// A retired plan's image may still be read by launches in flight.  Every plan remembers the streams it was launched
+// on; retiring it records an event on the retiring call's stream at once, and the other streams get theirs at their
+// next call through these entries; when every such event has completed the image is freed (looked at only while
+// something is retired).  Nothing here ever waits for the device, and HBM use is bounded: at most kAutoMaxRetiredPerKey
+// retired images per key (a key that has them all outstanding stays on the general kernels until one is freed) and
+// kAutoMaxRetired per process.  After kAutoMaxStrikes stale rounds without kAutoForgive clean planned calls in
+// between the key stays on the general kernels for good.
+// The table's mutex is held for the bookkeeping only: allocations, the inspection's enqueue and the column-sum
+// launches themselves run outside it (a plan in use is pinned by a counter).
 // A call on a CAPTURING stream records the general kernels and touches none of this: a graph outlives the call, the
 // images belong to the library.
-// What this costs a caller: results of the first calls (general kernels) and of later ones (planned form) agree
-// within the documented tolerance, not bit for bit, and the call at which the form changes depends on when the
-// statistics arrive.  rsp_debug_set("auto_plan", 0) / RSP_AUTO_PLAN=0 keeps every call on the general kernels
-// (bit-stable from the first call); explicit plans and handles are as deterministic as before; the one-shot host
-// entry never plans (it sees new offsets at the same address in every call).
 namespace {
 constexpr int kAutoMaxEntries = 16;
 constexpr int kAutoMaxStrikes = 4;
-constexpr int kAutoForgive = 64;
+constexpr int kAutoForgive = 32;         // clean planned calls that wipe a key's strikes (a caller rewriting p[] every ~70 calls stays planned)
+constexpr int kAutoMaxStreams = 6;         // streams one plan is launched on; a further stream's calls take the general kernels
+constexpr int kAutoMaxRetiredPerKey = 2;
+constexpr int kAutoMaxRetired = 24;
+constexpr uint64_t kAutoIdleTicks = 64;    // a PLANNED entry makes room for a new key only after this many calls without a use
 // (calls below 2^20 entries -- g_auto_min_nnz, "auto_min_nnz" -- are launch-bound either way: two launches against one)
+
+// One inspection's result with everything whose lifetime is tied to it.
+struct AutoPlan {
+    rsp_colsums_plan* plan = nullptr;
+    int device = -1;
+    int32_t* h_stale = nullptr;            // this plan's own word (page-locked pool): raised by a kernel that found p[] changed
+    hipStream_t streams[kAutoMaxStreams];  // streams it has been launched on ...
+    int nstreams = 0;
+    int pins = 0;                          // launches being issued right now (outside the lock)
+    // retired:
+    bool retired = false;
+    bool awaiting[kAutoMaxStreams];        // ... of which these still owe an event
+    hipEvent_t fences[kAutoMaxStreams + 1];
+    int nfences = 0;
+    struct AutoEntry* owner = nullptr;     // its key's entry while that exists (counts the key's retired images)
+};
+
 struct AutoEntry {
     int device = -1;
     const int32_t* d_p = nullptr;
     int32_t ncol = 0;
     int64_t nnz = 0;
-    rsp_colsums_plan* plan = nullptr;   // device-made; nullptr: dead (stays on the general kernels)
-    int32_t* h_stale = nullptr;         // page-locked: raised by a kernel that found p[] changed under the plan
+    int sightings = 0;
+    AutoPlan* cur = nullptr;               // nullptr: none (yet, or given up)
+    bool planning = false;                 // a thread is allocating / enqueueing the inspection outside the lock
+    bool dead = false;                     // stays on the general kernels for good
+    bool want_plan = false;                // a stale round could not inspect again (retired images outstanding): try later
+    int nretired = 0;                      // this key's retired images not freed yet
     uint64_t last_use = 0;
     int strikes = 0;
-    int clean = 0;                      // planned calls since the last stale round: kAutoForgive of them wipe the strikes
-    int last_form = 0;                  // form of the most recent call with this key (rsp_column_sums_device_form)
-    std::vector<rsp_colsums_plan*> retired;
+    int clean = 0;                         // planned calls since the last stale round: kAutoForgive of them wipe the strikes
+    int last_form = 0;                     // form of the most recent call with this key (rsp_column_sums_device_form)
 };
 std::mutex g_auto_mu;
-std::vector<AutoEntry> g_auto;
+std::vector<AutoEntry*> g_auto;            // (pointers: an entry's address survives the table's growth while a thread plans for it)
+std::vector<AutoPlan*> g_auto_retired;
 uint64_t g_auto_tick = 0;
+std::atomic<int> g_auto_made{0}, g_auto_freed{0};   // plans made / freed since the process started (rsp_debug_get: soak runs)
+
+// page-locked stale words: 4 bytes each, handed out from whole pages that are never unmapped before
+// rsp_release_cached (a word goes back to the free list only when its plan is freed, i.e. when no launch can write it)
+std::vector<int32_t*> g_stale_pages, g_stale_free;
+int32_t* stale_word_take() {   // caller holds g_auto_mu
+    if (g_stale_free.empty()) {
+        int32_t* page = nullptr;
+        if (hipHostMalloc((void**)&page, 4096, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipHostMalloc((void**)&page, 4096, hipHostMallocPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+        }
+        try {
+            g_stale_pages.push_back(page);
+            for (int k = 0; k < 1024; k += 16) g_stale_free.push_back(page + k);   // one word per 64-byte line
+        } catch (...) {
+            return nullptr;
+        }
+    }
+    int32_t* w = g_stale_free.back();
+    g_stale_free.pop_back();
+    *(volatile int32_t*)w = 0;
+    return w;
+}
 
 int auto_plan_setting() {
     int v = g_auto_plan.load(std::memory_order_relaxed);
@@ -901,24 +966,112 @@ int auto_plan_setting() {
     return v;
 }
 
-void auto_entry_release(AutoEntry& e) {   // caller holds g_auto_mu; the device has been synchronised
-    DeviceGuard on(e.device);
-    if (e.plan) rsp_column_sums_plan_destroy(e.plan);
-    for (rsp_colsums_plan* r : e.retired) rsp_column_sums_plan_destroy(r);
-    if (e.h_stale) (void)hipHostFree(e.h_stale);
-    e.plan = nullptr;
-    e.retired.clear();
-    e.h_stale = nullptr;
+// frees a plan nothing can read any more (caller holds g_auto_mu)
+void auto_plan_free(AutoPlan* ap) {
+    DeviceGuard on(ap->device);
+    if (ap->plan) rsp_column_sums_plan_destroy(ap->plan);
+    for (int k = 0; k < ap->nfences; ++k) (void)hipEventDestroy(ap->fences[k]);
+    if (ap->h_stale) {
+        try {
+            g_stale_free.push_back(ap->h_stale);
+        } catch (...) {   // (the word is simply not handed out again)
+        }
+    }
+    if (ap->owner) --ap->owner->nretired;
+    g_auto_freed.fetch_add(1, std::memory_order_relaxed);
+    delete ap;
 }
 
-void auto_release_all() {
-    std::lock_guard<std::mutex> lock(g_auto_mu);
-    for (AutoEntry& e : g_auto) {
-        DeviceGuard on(e.device);
-        (void)hipDeviceSynchronize();   // launches that read an image may still be in flight on any stream
-        auto_entry_release(e);
+// a retired plan owes an event on `stream` if it was launched there (caller holds g_auto_mu, the plan's device is current)
+void auto_fence(AutoPlan* ap, hipStream_t stream) {
+    for (int k = 0; k < ap->nstreams; ++k) {
+        if (ap->streams[k] != stream || !ap->awaiting[k]) continue;
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, stream) == hipSuccess) {
+            ap->fences[ap->nfences++] = ev;
+            ap->awaiting[k] = false;
+        } else {
+            (void)hipGetLastError();
+            if (ev) (void)hipEventDestroy(ev);   // (it keeps owing: the image stays until rsp_release_cached)
+        }
     }
+}
+
+void auto_retire(AutoPlan* ap, AutoEntry* owner, hipStream_t stream) {   // caller holds g_auto_mu; ap's device is current
+    ap->retired = true;
+    ap->owner = owner;
+    if (owner) ++owner->nretired;
+    for (int k = 0; k < ap->nstreams; ++k) ap->awaiting[k] = true;
+    auto_fence(ap, stream);
+    try {
+        g_auto_retired.push_back(ap);
+    } catch (...) {   // (no room to remember it: it is leaked rather than freed under a launch)
+    }
+}
+
+// every call: streams that owe a retired plan an event pay now; plans nobody can read any more are freed.  Only looks at
+// events while something is retired (rare), never waits.
+void auto_collect(int device, hipStream_t stream) {   // caller holds g_auto_mu; `device` is current
+    for (size_t k = 0; k < g_auto_retired.size();) {
+        AutoPlan* ap = g_auto_retired[k];
+        bool done = ap->pins == 0;
+        if (ap->device == device) auto_fence(ap, stream);
+        for (int j = 0; j < ap->nstreams && done; ++j) done = !ap->awaiting[j];
+        if (done && ap->device != device) done = false;   // (its events belong to another device: that device's calls look)
+        for (int j = 0; j < ap->nfences && done; ++j) {
+            const hipError_t q = hipEventQuery(ap->fences[j]);
+            if (q != hipSuccess) {
+                if (q != hipErrorNotReady) (void)hipGetLastError();
+                done = q != hipErrorNotReady;   // (an event that cannot be asked any more holds nothing up)
+            }
+        }
+        if (done) {
+            auto_plan_free(ap);
+            g_auto_retired[k] = g_auto_retired.back();
+            g_auto_retired.pop_back();
+        } else {
+            ++k;
+        }
+    }
+}
+
+int auto_counter(int which) {
+    if (which == 0) return g_auto_made.load(std::memory_order_relaxed);
+    if (which == 1) return g_auto_freed.load(std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lock(g_auto_mu);
+    return (int)g_auto_retired.size();
+}
+
+void auto_release_all() {   // rsp_release_cached: the one place that waits for the devices
+    std::lock_guard<std::mutex> lock(g_auto_mu);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) {
+        (void)hipGetLastError();
+        ndev = 0;
+    }
+    {
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        for (int d = 0; d < ndev; ++d)
+            if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();   // launches that read an image may be in flight on any stream
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    for (AutoEntry* e : g_auto) {
+        if (e->cur) {
+            e->cur->owner = nullptr;
+            auto_plan_free(e->cur);
+        }
+    }
+    for (AutoPlan* ap : g_auto_retired) {
+        ap->owner = nullptr;
+        auto_plan_free(ap);
+    }
+    for (AutoEntry* e : g_auto) delete e;
     g_auto.clear();
+    g_auto_retired.clear();
+    g_stale_free.clear();
+    for (int32_t* page : g_stale_pages) (void)hipHostFree(page);
+    g_stale_pages.clear();
 }
 }  // namespace
 
@@ -973,14 +1126,65 @@ int rsp_column_sums_planned_device(rsp_colsums_plan_t plan, const double* d_x, c
                            (hipStream_t)stream);
 }
 
-static int auto_inspect(AutoEntry& e, hipStream_t stream) {   // caller holds g_auto_mu; enqueues behind what is on `stream`
-    rsp_colsums_plan* pl = nullptr;
-    if (rsp_column_sums_plan_create_device(e.d_p, e.ncol, e.nnz, stream, &pl) != RSP_OK) {
-        e.plan = nullptr;   // (no memory for an image: this key stays on the general kernels; not an error of the call)
-        return RSP_OK;
+// Makes the plan of a key: allocates, enqueues the inspection behind what is on `stream` (outside the table's lock).
+// nullptr: no memory for it (the key then stays on the general kernels; not an error of the call).
+static AutoPlan* auto_make_plan(int device, const int32_t* d_p, int32_t ncol, int64_t nnz, hipStream_t stream, int32_t* h_stale) {
+    AutoPlan* ap = new (std::nothrow) AutoPlan();
+    if (!ap) return nullptr;
+    ap->device = device;
+    ap->h_stale = h_stale;
+    if (rsp_column_sums_plan_create_device(d_p, ncol, nnz, stream, &ap->plan) != RSP_OK) {
+        delete ap;
+        return nullptr;
     }
-    e.plan = pl;
-    return RSP_OK;
+    g_auto_made.fetch_add(1, std::memory_order_relaxed);
+    return ap;
+}
+
+static AutoEntry* auto_find(int device, const int32_t* d_p, int32_t ncol, int64_t nnz) {   // caller holds g_auto_mu
+    for (AutoEntry* c : g_auto)
+        if (c->device == device && c->d_p == d_p && c->ncol == ncol && c->nnz == nnz) return c;
+    return nullptr;
+}
+
+// A place in the table for a new key, or nullptr (everything in use).  Entries that never got a plan go first (they hold
+// nothing); a planned one only after kAutoIdleTicks calls without a use -- its plan is retired, never waited for.
+static AutoEntry* auto_new_entry(int device, const int32_t* d_p, int32_t ncol, int64_t nnz, hipStream_t stream) {   // caller holds g_auto_mu
+    if ((int)g_auto.size() >= kAutoMaxEntries) {
+        size_t victim = g_auto.size();
+        for (size_t k = 0; k < g_auto.size(); ++k) {
+            AutoEntry* c = g_auto[k];
+            if (c->planning || c->nretired > 0) continue;
+            const bool bare = c->cur == nullptr;
+            if (!bare && (g_auto_tick - c->last_use < kAutoIdleTicks || (int)g_auto_retired.size() >= kAutoMaxRetired)) continue;
+            if (victim == g_auto.size()) { victim = k; continue; }
+            AutoEntry* v = g_auto[victim];
+            const bool vbare = v->cur == nullptr;
+            if ((bare && !vbare) || (bare == vbare && c->last_use < v->last_use)) victim = k;
+        }
+        if (victim == g_auto.size()) return nullptr;
+        AutoEntry* v = g_auto[victim];
+        if (v->cur) {
+            DeviceGuard on(v->cur->device);
+            auto_retire(v->cur, nullptr, v->cur->device == device ? stream : nullptr);
+        }
+        delete v;
+        g_auto[victim] = g_auto.back();
+        g_auto.pop_back();
+    }
+    AutoEntry* ne = new (std::nothrow) AutoEntry();
+    if (!ne) return nullptr;
+    ne->device = device;
+    ne->d_p = d_p;
+    ne->ncol = ncol;
+    ne->nnz = nnz;
+    try {
+        g_auto.push_back(ne);
+    } catch (...) {
+        delete ne;
+        return nullptr;
+    }
+    return ne;
 }
 
 static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
@@ -992,93 +1196,145 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
     HIP_TRY(hipGetDevice(&device));
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
-    const bool capturing = cs != hipStreamCaptureStatusNone;
     // A capture records the general kernels, whatever is known about these offsets: a graph outlives this call, and the
-    // images of the entry's own plans belong to the library (an eviction or rsp_release_cached would leave the graph a
-    // dangling pointer).  A caller that wants the planned form in a graph makes the plan itself and owns its lifetime.
-    if (capturing) return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
-    std::lock_guard<std::mutex> lock(g_auto_mu);
-    ++g_auto_tick;
-    AutoEntry* e = nullptr;
-    for (AutoEntry& c : g_auto)
-        if (c.device == device && c.d_p == d_p && c.ncol == ncol && c.nnz == nnz) e = &c;
-    if (!e) {
-        // the general kernels answer this call; the inspection goes behind them (a capture records no inspection)
-        if (int rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream)) return rc;
-        if ((int)g_auto.size() >= kAutoMaxEntries) {
-            // full: the entry that has gone unused longest makes room -- if it has been idle for a while (its images may
-            // still be read by launches in flight: the device is waited for, which is why this is kept rare)
-            size_t victim = 0;
-            for (size_t k = 1; k < g_auto.size(); ++k)
-                if (g_auto[k].last_use < g_auto[victim].last_use) victim = k;
-            if (g_auto_tick - g_auto[victim].last_use < 64) return RSP_OK;   // everything in use: this key stays unplanned
-            {
-                DeviceGuard on(g_auto[victim].device);
-                (void)hipDeviceSynchronize();
-                auto_entry_release(g_auto[victim]);
+    // images of the entry's own plans belong to the library (a retirement would leave the graph a dangling pointer).
+    // A caller that wants the planned form in a graph makes the plan itself and owns its lifetime.
+    if (cs != hipStreamCaptureStatusNone) return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
+
+    // ---- bookkeeping under the lock: which form, and what else this call has to do ----
+    enum { kGeneral, kLean, kColumns } form = kGeneral;
+    AutoPlan* use = nullptr;       // pinned: launched below, outside the lock
+    AutoEntry* plan_for = nullptr; // this call makes the key's plan (behind its own general launch)
+    int32_t* new_stale = nullptr;
+    rsp_colsums_plan snap{};       // what the launch needs of the plan (copied: the entry may move on meanwhile)
+    {
+        std::lock_guard<std::mutex> lock(g_auto_mu);
+        ++g_auto_tick;
+        if (!g_auto_retired.empty()) auto_collect(device, stream);
+        AutoEntry* e = auto_find(device, d_p, ncol, nnz);
+        if (!e) e = auto_new_entry(device, d_p, ncol, nnz, stream);   // first sighting: the key is noted, nothing else
+        if (e) {
+            e->last_use = g_auto_tick;
+            ++e->sightings;
+            AutoPlan* ap = e->cur;
+            if (ap && *(volatile int32_t*)ap->h_stale != 0) {
+                // a kernel found p[] changed under the plan: this call on the general kernels, the plan retired (launches in
+                // flight may still read its image), a fresh inspection behind this call
+                auto_retire(ap, e, stream);
+                e->cur = nullptr;
+                ap = nullptr;
+                e->last_form = 0;
+                e->clean = 0;
+                if (++e->strikes >= kAutoMaxStrikes) e->dead = true;
+                e->want_plan = !e->dead;
             }
-            g_auto.erase(g_auto.begin() + (long)victim);
-        }
-        AutoEntry ne;
-        ne.device = device;
-        ne.d_p = d_p;
-        ne.ncol = ncol;
-        ne.nnz = nnz;
-        ne.last_use = g_auto_tick;
-        // (coherent: a kernel's store has to reach the host's next look without a synchronisation in between)
-        if (hipHostMalloc((void**)&ne.h_stale, sizeof(int32_t), hipHostMallocCoherent) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipHostMalloc((void**)&ne.h_stale, sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
-                (void)hipGetLastError();
-                return RSP_OK;
+            if (ap && !ap->plan->known) (void)plan_poll(ap->plan, stream, false);
+            if (ap && ap->plan->known && (ap->plan->lean || ap->plan->columns)) {
+                int slot = -1;
+                for (int k = 0; k < ap->nstreams; ++k)
+                    if (ap->streams[k] == stream) slot = k;
+                if (slot < 0 && ap->nstreams < kAutoMaxStreams) {
+                    slot = ap->nstreams++;
+                    ap->streams[slot] = stream;
+                }
+                if (slot >= 0) {   // (a seventh stream on one plan: the general kernels answer its calls)
+                    use = ap;
+                    ++ap->pins;
+                    snap = *ap->plan;
+                    form = ap->plan->lean ? kLean : kColumns;
+                    if (++e->clean >= kAutoForgive) e->strikes = 0;
+                }
+            }
+            e->last_form = form == kLean ? 2 : (form == kColumns ? 3 : 0);
+            const bool wants = !e->cur && !e->dead && !e->planning && (e->sightings >= 2 || e->want_plan);
+            if (wants && e->nretired < kAutoMaxRetiredPerKey && (new_stale = stale_word_take()) != nullptr) {
+                e->planning = true;
+                plan_for = e;
             }
         }
-        *ne.h_stale = 0;
-        auto_inspect(ne, stream);
-        if (!ne.plan) {
-            (void)hipHostFree(ne.h_stale);
-            return RSP_OK;
-        }
-        g_auto.push_back(ne);
-        return RSP_OK;
     }
-    e->last_use = g_auto_tick;
-    rsp_colsums_plan* pl = e->plan;
-    if (pl && *(volatile int32_t*)e->h_stale != 0) {
-        // a kernel found p[] changed under the plan: this call on the general kernels, a fresh inspection behind it
-        // (into a NEW image: a launch of an earlier call may still be reading the old one)
-        if (int rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream)) return rc;
-        e->last_form = 0;
-        e->clean = 0;
-        (void)plan_poll(pl, stream, false);
-        e->retired.push_back(pl);
-        e->plan = nullptr;
-        *(volatile int32_t*)e->h_stale = 0;
-        if (++e->strikes < kAutoMaxStrikes) auto_inspect(*e, stream);
-        return RSP_OK;
-    }
-    if (pl && !pl->known) {
-        if (int rc = plan_poll(pl, stream, false)) return rc;
-    }
-    if (pl && pl->known && pl->lean) {
-        HIP_TRY(rsp::launch_column_sums_lean(d_x, (int32_t)nnz, pl->d_lean_hdr, pl->d_lean_offs, pl->lean_stride_dwords,
-                                             pl->lean_chunks, pl->lean_rows, d_out, divisor, means, stream, d_p, ncol,
-                                             e->h_stale));
-        e->last_form = 2;
-        if (++e->clean >= kAutoForgive) e->strikes = 0;
-        return RSP_OK;
-    }
-    if (pl && pl->known && pl->columns) {
+
+    // ---- the launches, outside the lock ----
+    int rc = RSP_OK;
+    hipError_t le = hipSuccess;
+    if (form == kLean) {
+        le = rsp::launch_column_sums_lean(d_x, (int32_t)nnz, snap.d_lean_hdr, snap.d_lean_offs, snap.lean_stride_dwords,
+                                          snap.lean_chunks, snap.lean_rows, d_out, divisor, means, stream, d_p, ncol, use->h_stale);
+    } else if (form == kColumns) {
         // lengths the choice of the form rested on, with room: a column outside [min / 4, 4 max] says the matrix has changed
-        const int32_t lo = pl->columns_min / 4, hi = pl->columns_max > rsp::kColumnsMaxLen / 4 ? rsp::kColumnsMaxLen : 4 * pl->columns_max;
-        HIP_TRY(rsp::launch_column_sums_columns(d_x, d_p, ncol, pl->columns_waves, d_out, divisor, means, stream, (int32_t)nnz,
-                                                lo, hi, e->h_stale));
-        e->last_form = 3;
-        if (++e->clean >= kAutoForgive) e->strikes = 0;
-        return RSP_OK;
+        const int32_t lo = snap.columns_min / 4, hi = snap.columns_max > rsp::kColumnsMaxLen / 4 ? rsp::kColumnsMaxLen : 4 * snap.columns_max;
+        le = rsp::launch_column_sums_columns(d_x, d_p, ncol, snap.columns_waves, d_out, divisor, means, stream, (int32_t)nnz, lo, hi,
+                                             use->h_stale);
+    } else {
+        rc = enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
     }
-    e->last_form = 0;
-    return enqueue(d_x, d_p, ncol, nnz, d_out, d_ws, ws_bytes, divisor, means, stream);
+    if (le != hipSuccess) rc = fail(RSP_ERR_HIP, "planned column-sum launch failed: %s", hipGetErrorString(le));
+    AutoPlan* made = nullptr;
+    if (plan_for && rc == RSP_OK) made = auto_make_plan(device, d_p, ncol, nnz, stream, new_stale);
+
+    // ---- and the lock once more, only if something has to be put back ----
+    if (use || plan_for) {
+        std::lock_guard<std::mutex> lock(g_auto_mu);
+        if (use) {
+            --use->pins;
+            if (use->retired) auto_fence(use, stream);   // retired while this launch was being issued: its event comes now
+        }
+        if (plan_for) {
+            plan_for->planning = false;
+            plan_for->want_plan = false;
+            if (made) plan_for->cur = made;
+            else {
+                try {
+                    g_stale_free.push_back(new_stale);
+                } catch (...) {
+                }
+                if (rc == RSP_OK) plan_for->dead = true;   // no memory for an image: the general kernels for good
+            }
+        }
+    }
+    return rc;
+}
+
+int rsp_column_sums_device_settle(const int32_t* d_p, int32_t ncol, int64_t nnz, void* stream) {
+    if (!d_p || ncol <= 0 || nnz < 0) return -1;
+    if (auto_plan_setting() == 0 || nnz < (int64_t)g_auto_min_nnz.load(std::memory_order_relaxed) || nnz > INT32_MAX) return 0;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    AutoEntry* plan_for = nullptr;
+    int32_t* new_stale = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_auto_mu);
+        ++g_auto_tick;
+        AutoEntry* e = auto_find(device, d_p, ncol, nnz);
+        if (!e) e = auto_new_entry(device, d_p, ncol, nnz, s);
+        if (!e) return 0;   // the table is full of keys in use: this one stays on the general kernels (until one goes idle)
+        e->last_use = g_auto_tick;
+        if (e->dead) return 0;
+        if (!e->cur && !e->planning && e->nretired < kAutoMaxRetiredPerKey && (new_stale = stale_word_take()) != nullptr) {
+            e->planning = true;
+            plan_for = e;
+        }
+    }
+    if (plan_for) {
+        AutoPlan* made = auto_make_plan(device, d_p, ncol, nnz, s, new_stale);
+        std::lock_guard<std::mutex> lock(g_auto_mu);
+        plan_for->planning = false;
+        plan_for->want_plan = false;
+        plan_for->sightings = plan_for->sightings < 2 ? 2 : plan_for->sightings;
+        if (made) plan_for->cur = made;
+        else {
+            try {
+                g_stale_free.push_back(new_stale);
+            } catch (...) {
+            }
+            plan_for->dead = true;
+        }
+    }
+    return rsp_column_sums_device_form(d_p, ncol, nnz, 1);
 }
 
 int rsp_column_sums_device_form(const int32_t* d_p, int32_t ncol, int64_t nnz, int wait) {
@@ -1087,16 +1343,43 @@ int rsp_column_sums_device_form(const int32_t* d_p, int32_t ncol, int64_t nnz, i
         (void)hipGetLastError();
         return -1;
     }
-    std::lock_guard<std::mutex> lock(g_auto_mu);
-    for (AutoEntry& c : g_auto)
-        if (c.device == device && c.d_p == d_p && c.ncol == ncol && c.nnz == nnz) {
-            if (!c.plan) return 0;                               // given up on: the general kernels
-            if (!c.plan->known) {
-                if (plan_poll(c.plan, nullptr, wait != 0) != RSP_OK || !c.plan->known) return -1;
+    for (int attempt = 0;; ++attempt) {
+        rsp_colsums_plan* pl = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_auto_mu);
+            AutoEntry* c = auto_find(device, d_p, ncol, nnz);
+            if (!c) return -1;
+            if (c->dead) return 0;                                   // given up on: the general kernels
+            if (!c->cur) {
+                if (!(c->planning && wait && attempt < 2000)) return -1;   // (another thread is making the plan right now)
+            } else {
+                pl = c->cur->plan;
+                if (!pl->known) (void)plan_poll(pl, nullptr, false);
+                if (pl->known) return pl->lean ? 2 : (pl->columns ? 3 : 0);   // (a snapped plan is not taken here: general kernels)
+                if (!wait) return -1;
+                ++c->cur->pins;   // (the plan cannot go away while this thread waits for its inspection)
             }
-            return c.plan->lean ? 2 : (c.plan->columns ? 3 : 0);   // (a snapped plan is not taken here: general kernels)
         }
-    return -1;
+        if (!pl) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            continue;
+        }
+        const hipError_t e = hipEventSynchronize(pl->ev_end);
+        std::lock_guard<std::mutex> lock(g_auto_mu);
+        AutoEntry* c = auto_find(device, d_p, ncol, nnz);
+        AutoPlan* holder = nullptr;
+        if (c && c->cur && c->cur->plan == pl) holder = c->cur;
+        for (AutoPlan* ap : g_auto_retired)
+            if (ap->plan == pl) holder = ap;
+        if (holder) --holder->pins;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        if (!holder || holder->retired) continue;   // retired meanwhile: look again
+        if (!pl->known) plan_finalize(pl);
+        return pl->lean ? 2 : (pl->columns ? 3 : 0);
+    }
 }
 
 int rsp_column_reduce_device(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, int op,

@@ -84,8 +84,10 @@ struct Stats {              // what the choice of form rests on; every word a fl
     int32_t inv_min_len;    // INT_MAX - the shortest column
     int32_t lean_bad;       // lean form: a column reaches more than a row past its chunk, or a chunk has more columns than the image has room for
     int32_t lean_widest;    // lean form: most columns starting in one chunk
-    int32_t pad[2];
+    int32_t ready;          // device-made plans: kStatsReady once every word above has landed (written last, behind a system-scope fence)
+    int32_t pad;
 };
+constexpr int32_t kStatsReady = 0x5253504b;
 constexpr int kSpanWrites = 4;   // chunks one column start writes at most (more means a column longer than a chunk: that plan is never used)
 
 // What the lean kernel can hold (colsums_kernels.h): elements per row of x, longest column, most columns per chunk.

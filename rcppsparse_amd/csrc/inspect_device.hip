@@ -192,6 +192,10 @@ __global__ __launch_bounds__(kInspectThreads) void inspect_finish_kernel(const i
         r.lean_bad = st[4];
         r.lean_widest = st[5];
         *out = r;
+        // the host may look at the page-locked record at any moment (capi.hip plan_poll: no event query, no wait): the
+        // ready word goes out only after the statistics have
+        __threadfence_system();
+        __hip_atomic_store(&out->ready, inspect::kStatsReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -21,17 +21,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(autouse=True, scope="session")
-def _plan_free_entry_stays_on_the_general_kernels():
-    """rsp_column_sums_device plans for itself by default (include/rcppsparse_hip.h): after a call or two with the same
-    offsets it takes the lean / columns form.  The parity tests of this suite were written about the kernels they name --
-    many compare two plan-free calls bit for bit -- so the process default here is "auto_plan" OFF; the entry's own
-    planning has its module (tests/test_gpu_autoplan.py switches it on) and bench.py's child processes run with the
-    library's default (on)."""
-    from rcppsparse_amd import capi
-    capi.load()
-    capi.set_auto_plan(False)
-    yield
+# The suite runs under the LIBRARY'S DEFAULTS (round 6): rsp_column_sums_device plans for itself
+# (include/rcppsparse_hip.h) exactly as it does for a caller who sets nothing.  Tests that are about the general kernels
+# pin capi.set_auto_plan(False) themselves (the `launch_mode` fixture's "general" leg, tools/edge_sweep.py), and put the
+# default back.  Nothing here loads the library: a pure-CPU test (oracle, host mirror, mock Rcpp) must not need it.
 
 
 def golden_names():

@@ -1,8 +1,9 @@
-"""-m gpu: the plan-free device entries plan for themselves (round 5).
+"""-m gpu: the plan-free device entries plan for themselves (round 5; round 6: plan on the second sighting, nothing ever
+waits for the device, retired images are freed behind events, HBM use is bounded, rsp_column_sums_device_settle).
 
 rsp_column_sums_device / rsp_column_means_device (include/rcppsparse_hip.h) remember the offsets they are shown: the
-first call with (device, d_p, ncol, nnz) runs the general kernels and enqueues a device-side inspection of d_p behind
-them; once the host has seen its result, calls with that key take the lean form (every column short: one launch, the
+first call with (device, d_p, ncol, nnz) runs the general kernels and notes the key, the second enqueues a device-side
+inspection of d_p behind them; once the host has seen its result, calls with that key take the lean form (every column short: one launch, the
 reference's bits) or the columns form (every column long).  The caller promises nothing about d_p between calls, so
 the kernels of this path check every column's offsets against the p[] of the call they run in -- what these tests are
 mostly about: offsets changed in place under an adopted plan, captured calls replayed over changed offsets, two
@@ -26,11 +27,10 @@ def torch_auto():
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked tests need a GPU: the HIP path has no CPU fallback")
     capi.load()
-    capi.set_auto_plan(True)          # (the suite's default is off: tests/conftest.py)
+    assert capi.debug_get("auto_plan") == 1      # the library's default, which the whole suite runs under
     capi.release_cached()
     yield torch
     capi.release_cached()
-    capi.set_auto_plan(False)
 
 
 def check(got, x, p, exact=False):
@@ -55,9 +55,9 @@ def short_matrix(ncol, mean, seed):
 
 
 def settled(torch, xt, pt, out, ws, stream=None):
-    """calls until the entry has settled on a form for these offsets; returns the form"""
+    """a first call (general kernels), rsp_column_sums_device_settle, a call in the settled form; returns the form"""
     capi.column_sums_device(xt, pt, out, ws, stream=stream)
-    form = capi.column_sums_device_form(pt, xt.numel(), wait=True)
+    form = capi.column_sums_device_settle(pt, xt.numel(), stream=stream)
     capi.column_sums_device(xt, pt, out, ws, stream=stream)
     torch.cuda.synchronize()
     return form
@@ -72,9 +72,18 @@ def test_c2_shaped_calls_settle_on_the_lean_form_with_the_references_bits(torch_
     out = torch.empty(len(p) - 1, dtype=torch.float64, device="cuda")
     ws = capi.alloc_workspace(len(p) - 1, nnz)
     assert capi.column_sums_device_form(pt, nnz) == "unknown"                  # never seen
+    warm_p, warm_x = short_matrix(300_000, 10, seed=99)                        # (code objects, torch's staging pools: warm)
+    capi.column_sums_device(torch.from_numpy(warm_x).cuda(), torch.from_numpy(warm_p).cuda()).cpu()
+    torch.cuda.synchronize()
+    made0 = capi.debug_get("auto_plans_made")
+    free0 = torch.cuda.mem_get_info()[0]
     capi.column_sums_device(xt, pt, out, ws)
     first = out.cpu().numpy()
-    check(first, x, p)                                                         # the general kernels answered the first call
+    check(first, x, p)                                                         # the general kernels answered the first call ...
+    assert capi.column_sums_device_form(pt, nnz, wait=True) == "unknown"       # ... which only NOTED the key: no plan,
+    assert torch.cuda.mem_get_info()[0] == free0 and capi.debug_get("auto_plans_made") == made0   # no allocation
+    capi.column_sums_device(xt, pt, out, ws)                                   # second sighting: general kernels + the inspection
+    assert out.cpu().numpy().tobytes() == first.tobytes()
     assert capi.column_sums_device_form(pt, nnz, wait=True) == "lean"
     capi.column_sums_device(xt, pt, out, ws)
     check(out.cpu().numpy(), x, p, exact=True)                                 # lean: every column in the reference's order
@@ -134,7 +143,7 @@ def test_offsets_changed_in_place_under_an_adopted_plan_never_give_wrong_sums(to
             out.fill_(-1.0)
             capi.column_sums_device(xt, pt, out, ws)
             check(out.cpu().numpy(), x, q)
-        form = capi.column_sums_device_form(pt, nnz, wait=True)
+        form = capi.column_sums_device_settle(pt, nnz)
         assert form in ("lean", "general", "columns")
         out.fill_(-1.0)
         capi.column_sums_device(xt, pt, out, ws)
@@ -240,7 +249,7 @@ def test_long_columns_settle_on_the_columns_form_and_notice_a_different_matrix(t
         out.fill_(-1.0)
         capi.column_sums_device(xt, pt, out, ws)
         check(out.cpu().numpy(), x, q)
-    assert capi.column_sums_device_form(pt, nnz, wait=True) in ("general", "columns")
+    assert capi.column_sums_device_settle(pt, nnz) in ("general", "columns")
     capi.column_sums_device(xt, pt, out, ws)
     check(out.cpu().numpy(), x, q)
 
@@ -349,7 +358,7 @@ def test_fuzz_adopted_forms_against_the_oracle(torch_auto, seed):
     ws = capi.alloc_workspace(ncol, nnz)
     capi.column_sums_device(xt, pt, out, ws)
     check(out.cpu().numpy(), x, p)
-    form = capi.column_sums_device_form(pt, nnz, wait=True)
+    form = capi.column_sums_device_settle(pt, nnz)
     assert form in ("lean", "columns", "general")
     if kind == 3:
         assert form == "general"
@@ -399,9 +408,9 @@ def test_the_entrys_own_lean_plan_at_the_int32_limit(torch_auto):
     assert int(pt[-1]) == nnz and int(pt[-2]) == (ncol - 1) * per
     out = torch.empty(ncol, dtype=torch.float64, device="cuda")
     ws = capi.alloc_workspace(ncol, nnz)
-    capi.column_sums_device(xt, pt, out, ws)                              # the general kernels + the inspection behind them
+    capi.column_sums_device(xt, pt, out, ws)                              # the general kernels
     assert out.cpu().numpy().tobytes() == (want + 0.0).tobytes()
-    assert capi.column_sums_device_form(pt, nnz, wait=True) == "lean"
+    assert capi.column_sums_device_settle(pt, nnz) == "lean"              # the inspection of 860 MB of offsets, waited for
     out.fill_(-1.0)
     capi.column_sums_device(xt, pt, out, ws)
     assert out.cpu().numpy().tobytes() == (want + 0.0).tobytes()
@@ -439,7 +448,8 @@ def test_auto_plan_off_keeps_every_call_on_the_general_kernels(torch_auto):
 
 
 def test_more_keys_than_the_library_remembers(torch_auto):
-    """16 keys are remembered; further matrices are summed by the general kernels until an old key has gone unused."""
+    """16 keys are remembered.  Keys that never got a plan make room first (they hold nothing); a PLANNED key only after 64
+    calls without a use, and then its plan is retired behind an event -- nothing waits for the device."""
     torch = torch_auto
     capi.release_cached()
     keep = []
@@ -447,12 +457,154 @@ def test_more_keys_than_the_library_remembers(torch_auto):
         p, x = short_matrix(110_000, 10, seed=30 + k)
         xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
         keep.append((p, x, xt, pt))
-        out = capi.column_sums_device(xt, pt)
-        check(out.cpu().numpy(), x, p)
     torch.cuda.synchronize()
+    for p, x, xt, pt in keep:                                             # two sightings each: the first 16 get their plan,
+        for _ in range(2):                                                # the other four find the table full of keys in use
+            check(capi.column_sums_device(xt, pt).cpu().numpy(), x, p)
     forms = [capi.column_sums_device_form(pt, len(x), wait=True) for p, x, xt, pt in keep]
-    assert forms[:16] == ["lean"] * 16 and set(forms[16:]) <= {"unknown", "lean"}
+    assert forms[:16] == ["lean"] * 16 and forms[16:] == ["unknown"] * 4
     for p, x, xt, pt in keep:
-        check(capi.column_sums_device(xt, pt).cpu().numpy(), x, p)
+        check(capi.column_sums_device(xt, pt).cpu().numpy(), x, p, exact=None)
+    # key 0 used 70 more times: the other fifteen have gone idle, and key 16 now takes the place of the longest-idle one
+    p0, x0, xt0, pt0 = keep[0]
+    for _ in range(70):
+        capi.column_sums_device(xt0, pt0)
+    p16, x16, xt16, pt16 = keep[16]
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(2):
+        check(capi.column_sums_device(xt16, pt16).cpu().numpy(), x16, p16)
+    assert capi.column_sums_device_form(pt16, len(x16), wait=True) == "lean"
+    assert capi.column_sums_device_form(keep[1][3], len(keep[1][1])) == "unknown"     # key 1 made room ...
+    assert capi.column_sums_device_form(pt0, len(x0)) == "lean"                          # ... key 0, in use, did not
+    torch.cuda.synchronize()
+    check(capi.column_sums_device(xt16, pt16).cpu().numpy(), x16, p16, exact=True)      # (this call frees key 1's retired image)
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < 2**22                             # one image came, one went
     capi.release_cached()
     assert capi.column_sums_device_form(keep[0][3], len(keep[0][1])) == "unknown"
+
+
+def test_a_stream_of_fresh_keys_allocates_nothing_and_never_waits(torch_auto):
+    """fresh offsets in every call (a new p buffer per batch) must not cost an allocation, an inspection or
+    a device synchronisation.  200 unique keys, one call each: free HBM does not move, and a deliberately slow kernel
+    queued on another stream is still running when the calls have returned (nothing waited for the device)."""
+    torch = torch_auto
+    capi.release_cached()
+    p, x = short_matrix(120_000, 10, seed=60)
+    nnz, ncol = int(p[-1]), len(p) - 1
+    xt = torch.from_numpy(x).cuda()
+    pts = [torch.from_numpy(p).cuda() for _ in range(200)]               # 200 different addresses: 200 keys
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        big.add_(1.0)                                                      # (its code object loaded before anything is measured)
+    torch.cuda.synchronize()
+    free0, made0 = torch.cuda.mem_get_info()[0], capi.debug_get("auto_plans_made")
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            big.add_(1.0)                                                  # ~40 x 2 GB of traffic: several milliseconds
+        done = torch.cuda.Event()
+        done.record(side)
+    for pt in pts:
+        capi.column_sums_device(xt, pt, out, ws)
+    still_running = not done.query()
+    torch.cuda.synchronize()
+    assert capi.debug_get("auto_plans_made") == made0 and abs(torch.cuda.mem_get_info()[0] - free0) <= 2**22
+    assert still_running, "the calls outlasted several milliseconds of queued work: something waited for the device"
+    check(out.cpu().numpy(), x, p)
+
+
+def test_rewriting_the_offsets_in_place_keeps_hbm_bounded_and_the_key_planned(torch_auto):
+    """VERDICT round 5, next 4 / ADVICE: a caller that rewrites p[] in place every ~70 calls used to leak one image per
+    rewrite.  600 rewrites x 70 calls on one stream: every rewrite retires a plan; its image is freed once the event
+    recorded behind the retiring call has completed; free HBM stays within two images of the start, and the key is still
+    planned at the end (32 clean calls forgive the strike)."""
+    torch = torch_auto
+    capi.release_cached()
+    ncol = 150_000
+    pa, x = short_matrix(ncol, 10, seed=70)
+    nnz = int(pa[-1])
+    rng = np.random.default_rng(71)
+    pb = synth.offsets_from_counts(np.minimum(rng.multinomial(nnz, np.full(ncol, 1.0 / ncol)), 64).astype(np.int64))
+    if int(pb[-1]) != nnz:                                                 # (the clamp to 64 moved entries: spread the rest)
+        pb = pa.copy()
+        pb[1:-1] = np.minimum(pb[1:-1] + 1, pb[2:])
+    qa, qb = torch.from_numpy(pa).cuda(), torch.from_numpy(np.ascontiguousarray(pb, dtype=np.int32)).cuda()
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(pa).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    capi.column_sums_device(xt, pt, out, ws)
+    assert capi.column_sums_device_settle(pt, nnz) == "lean"
+    image = torch.cuda.mem_get_info()[0]
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    made0 = capi.debug_get("auto_plans_made")
+    for r in range(600):
+        pt.copy_(qb if r % 2 == 0 else qa)                                 # in place, on the calls' stream ...
+        torch.cuda.synchronize()                                           # ... and waited for, as a synchronous caller (R) does
+        for _ in range(70):
+            capi.column_sums_device(xt, pt, out, ws)
+        if r % 100 == 99:
+            torch.cuda.synchronize()
+            check(out.cpu().numpy(), x, pb if r % 2 == 0 else pa)
+            assert abs(torch.cuda.mem_get_info()[0] - free0) <= 3 * 2**21, (r, free0 - torch.cuda.mem_get_info()[0])
+    torch.cuda.synchronize()
+    assert capi.column_sums_device_settle(pt, nnz) == "lean"              # not given up on
+    capi.column_sums_device(xt, pt, out, ws)
+    check(out.cpu().numpy(), x, pa, exact=True)
+    assert capi.debug_get("auto_plans_made") - made0 >= 300               # (the key really was re-planned all along)
+    assert capi.debug_get("auto_plans_retired") <= 2
+    del image
+
+
+def test_a_deep_queue_behind_one_in_place_update_costs_one_strike_not_the_key(torch_auto):
+    """with ONE stale word shared by a key's plans, launches of the old image that were already queued raised
+    it again after the host had reset it, and a single legitimate update could use up every strike.  Every plan now has its
+    own word: 200 calls queued without a synchronisation right behind an update retire ONE plan, and the key is lean again."""
+    torch = torch_auto
+    capi.release_cached()
+    ncol = 200_000
+    pa, x = short_matrix(ncol, 9, seed=80)
+    nnz = int(pa[-1])
+    pb = pa.copy()
+    inner = np.flatnonzero((pa[1:-1] > pa[:-2]) & (pa[1:-1] < pa[2:]))[::7] + 1
+    pb[inner] -= 1                                                         # thousands of boundaries moved by one entry
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(pa).cuda()
+    qb = torch.from_numpy(pb).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    capi.column_sums_device(xt, pt, out, ws)
+    assert capi.column_sums_device_settle(pt, nnz) == "lean"
+    for rnd in range(6):                                                   # six updates: more than kAutoMaxStrikes, were they double-counted
+        pt.copy_(qb if rnd % 2 == 0 else torch.from_numpy(pa).cuda())
+        for _ in range(200):
+            capi.column_sums_device(xt, pt, out, ws)                       # (no synchronisation: a deep queue)
+        torch.cuda.synchronize()
+        check(out.cpu().numpy(), x, pb if rnd % 2 == 0 else pa)
+    assert capi.column_sums_device_form(pt, nnz, wait=True) == "lean"
+    capi.column_sums_device(xt, pt, out, ws)
+    check(out.cpu().numpy(), x, pa, exact=True)
+
+
+def test_bit_stable_run_to_run_under_the_defaults(torch_auto):
+    """include/rcppsparse_hip.h: from the return of rsp_column_sums_device_settle on, every call with the key returns the
+    same bits -- two streams, sums and means, fifty calls."""
+    torch = torch_auto
+    capi.release_cached()
+    p, x = short_matrix(260_000, 12, seed=90)
+    nnz, ncol = int(p[-1]), len(p) - 1
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+    assert capi.column_sums_device_settle(pt, nnz) == "lean"              # (no call before it: settle makes the plan itself)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    wss = [capi.alloc_workspace(ncol, nnz) for _ in streams]
+    outs = [torch.empty(ncol, dtype=torch.float64, device="cuda") for _ in streams]
+    want = oracle.column_sums(x, p).tobytes()
+    for k in range(50):
+        j = k % 2
+        capi.column_sums_device(xt, pt, outs[j], wss[j], stream=streams[j])
+        if k % 10 >= 8:
+            streams[j].synchronize()
+            assert outs[j].cpu().numpy().tobytes() == want
+    torch.cuda.synchronize()
+    assert capi.column_sums_device(xt, pt, nrow_for_means=777).cpu().numpy().tobytes() == (oracle.column_sums(x, p) / 777).tobytes()

@@ -70,6 +70,8 @@ def launch_mode(request):
     _MODE["launch"] = request.param
     capi.load()
     capi.set_lean(2 if request.param != "planned_no_lean" else 0)   # (2: the lean form wherever it applies -- it would otherwise take only means <= 60)
+    if request.param == "general":
+        capi.set_auto_plan(False)   # this leg is ABOUT the general kernels: the entry must not plan for itself here
     if request.param == "auto":
         # round 5: the plan-free entry as it behaves by DEFAULT -- planning for itself -- with the size it starts at lowered
         # from 2^20 entries to 1, so that every matrix of these tests goes through its own plan and its validating kernels
@@ -77,7 +79,7 @@ def launch_mode(request):
         capi.debug_set("auto_min_nnz", 1)
     yield request.param
     capi.set_lean(1)
-    capi.set_auto_plan(False)
+    capi.set_auto_plan(True)        # the library's default
     capi.debug_set("auto_min_nnz", 1 << 20)
     capi.release_cached()
     _MODE["launch"] = "general"
@@ -104,11 +106,11 @@ def dev_colsums(torch, x, p, **kw):
         plan.close()
         return out.cpu().numpy()
     if _MODE["launch"] == "auto" and not kw:
-        # first call: the general kernels + the inspection behind them; once its result has been seen the entry's own plan
-        # (lean / columns where they apply) answers, bit-stable from then on
+        # first call: the general kernels (the key is only noted); rsp_column_sums_device_settle then makes the entry's own
+        # plan and waits for it: lean / columns where they apply, bit-stable from then on
         capi.release_cached()                               # (16 keys are remembered: every matrix of the suite gets its own plan)
         first = capi.column_sums_device(xt, pt)
-        form = capi.column_sums_device_form(pt, xt.numel(), wait=True) if xt.numel() > 0 and pt.numel() > 1 else "general"
+        form = capi.column_sums_device_settle(pt, xt.numel()) if xt.numel() > 0 and pt.numel() > 1 else "general"
         PLANS_SEEN["auto_" + form] = PLANS_SEEN.get("auto_" + form, 0) + 1
         out = capi.column_sums_device(xt, pt)
         again = capi.column_sums_device(xt, pt)
@@ -431,14 +433,35 @@ def test_na_real_comes_back_as_na_like_the_reference(torch_cuda, form):
 
 
 def test_bit_stable_run_to_run(torch_cuda):
+    """"GPU result must be bit-identical run-to-run" -- under the library's DEFAULTS (the plan-free entry plans
+    for itself).  The contract of include/rcppsparse_hip.h: a key's first two calls take the general kernels (identical
+    bits); rsp_column_sums_device_settle fixes the key's form, and from its return on every call returns the same bits --
+    checked on a matrix of each kind: short columns (lean), long similar columns (columns), Zipf (general kernels)."""
     torch = torch_cuda
-    counts = synth.zipf_counts(5000, 2_000_000, seed=1, nrow=300_000)
-    p = synth.offsets_from_counts(counts)
-    x = synth.gen_values(int(p[-1]), seed=2, kind=0)
-    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
-    first = capi.column_sums_device(xt, pt).cpu().numpy().tobytes()
-    for _ in range(5):
-        assert capi.column_sums_device(xt, pt).cpu().numpy().tobytes() == first
+    assert capi.debug_get("auto_plan") == 1
+    capi.release_cached()
+    rng = np.random.default_rng(5)
+    mats = {
+        "lean": synth.offsets_from_counts(np.minimum(rng.poisson(9, size=200_000), 64).astype(np.int64)),
+        "columns": synth.offsets_from_counts(rng.integers(3000, 5000, size=500).astype(np.int64)),
+        "general": synth.offsets_from_counts(synth.zipf_counts(5000, 2_000_000, seed=1, nrow=300_000)),
+    }
+    for want, p in mats.items():
+        nnz = int(p[-1])
+        assert nnz >= 2**20
+        x = synth.gen_values(nnz, seed=2, kind=0)
+        xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+        a = capi.column_sums_device(xt, pt).cpu().numpy()
+        b = capi.column_sums_device(xt, pt).cpu().numpy()
+        assert a.tobytes() == b.tobytes()                                  # the first two calls: the general kernels
+        assert capi.column_sums_device_settle(pt, nnz) == want
+        first = capi.column_sums_device(xt, pt).cpu().numpy()
+        for _ in range(5):
+            assert capi.column_sums_device(xt, pt).cpu().numpy().tobytes() == first.tobytes(), want
+        assert_parity(first, x, p)
+        if want == "general":
+            assert first.tobytes() == a.tobytes()
+    capi.release_cached()
 
 
 def test_device_generator_matches_oracle_bits(torch_cuda):
@@ -570,7 +593,7 @@ def test_c3_c5_integer_valued_entries_sum_exactly_in_every_form(torch_cuda, shap
         n = min(100_000_000, nnz - s0)
         xt[s0:s0 + n] = _small_integers(torch.arange(s0, s0 + n, dtype=torch.int64, device="cuda")).double()
     pt = torch.from_numpy(p).cuda()
-    # (1) the general kernels (this suite keeps the plan-free entry from planning for itself: tests/conftest.py)
+    # (1) the general kernels (a key's first call always takes them)
     got = capi.column_sums_device(xt, pt).cpu().numpy()
     assert got.tobytes() == (want + 0.0).tobytes(), int(np.count_nonzero(got != want))
     # (2) a caller's plan, whatever form it takes for this matrix
@@ -589,14 +612,13 @@ def test_c3_c5_integer_valued_entries_sum_exactly_in_every_form(torch_cuda, shap
             ws = capi.alloc_workspace(sh.ncol, sh.nnz)
             capi.column_sums_device(xs, ps, out, ws)
             assert out.cpu().numpy().tobytes() == got[sh.c0:sh.c1].tobytes(), (shape, r, "first call")
-            forms.append(capi.column_sums_device_form(ps, sh.nnz, wait=True))
+            forms.append(capi.column_sums_device_settle(ps, sh.nnz))
             out.fill_(-1.0)
             capi.column_sums_device(xs, ps, out, ws)
             assert out.cpu().numpy().tobytes() == got[sh.c0:sh.c1].tobytes(), (shape, r, forms[-1])
         if shape == "uniform":
             assert forms == ["columns"] * 8
     finally:
-        capi.set_auto_plan(False)
         capi.release_cached()
 
 

@@ -49,7 +49,7 @@ with torch.cuda.stream(stream):
     for _ in range(50):
         f()
     torch.cuda.synchronize()
-    res["form_of_the_entrys_own_plan"] = capi.column_sums_device_form(pt, nnz, wait=True)
+    res["form_of_the_entrys_own_plan"] = capi.column_sums_device_settle(pt, nnz, stream=stream)
     res["plan_free_entry_own_plan"] = loop(f)
     capi.set_auto_plan(False)
     res["plan_free_entry_planning_off_two_launches"] = loop(f)

@@ -74,7 +74,71 @@ def random_offsets(rng, ncol, nnz):
     return p, name
 
 
+def rewrites(n_rewrites, calls_between=70, deep_queue=False):
+    """p[] rewritten IN PLACE every `calls_between` calls (32 clean planned calls forgive a stale
+    round, so the key is re-planned every time): before round 6 every rewrite left one plan image behind for good.  Free
+    HBM (hipMemGetInfo) must stay within ONE image of where it stood after the first plan, the sums right, the key planned.
+    The caller waits for its update before it goes on (what a synchronous caller like R does).  deep_queue: it does not --
+    the host then runs hundreds of calls ahead of the device, every new plan is stale before its statistics arrive, and
+    after four such rounds the key rightly stays on the general kernels; memory must stay bounded all the same."""
+    capi.load()
+    capi.release_cached()
+    ncol, mean = 1_000_000, 10                     # BASELINE config 2's shape: a lean image of ~2.7 MB
+    rng = np.random.default_rng(7)
+    pa = synth.offsets_from_counts(np.minimum(rng.poisson(mean, size=ncol), 64).astype(np.int64))
+    nnz = int(pa[-1])
+    pb = pa.copy()
+    inner = np.flatnonzero((pa[1:-1] > pa[:-2]) & (pa[1:-1] < pa[2:]))[::5] + 1
+    pb[inner] -= 1
+    x = synth.gen_values(nnz, seed=7, kind=0)
+    xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(pa).cuda()
+    qa, qb = torch.from_numpy(pa).cuda(), torch.from_numpy(pb).cuda()
+    out = torch.empty(ncol, dtype=torch.float64, device="cuda")
+    ws = capi.alloc_workspace(ncol, nnz)
+    refs = {0: (oracle.column_sums(x, pa), oracle.column_abs_sums(x, pa)), 1: (oracle.column_sums(x, pb), oracle.column_abs_sums(x, pb))}
+    torch.cuda.synchronize()
+    free_before_plan = torch.cuda.mem_get_info()[0]
+    capi.column_sums_device(xt, pt, out, ws)
+    assert capi.column_sums_device_settle(pt, nnz) == "lean"
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    image = free_before_plan - free0
+    low = free0
+    t0 = last_note = time.time()
+    for r in range(n_rewrites):
+        which = (r + 1) % 2
+        pt.copy_(qb if which else qa)
+        if not deep_queue:
+            torch.cuda.synchronize()
+        for _ in range(calls_between):
+            capi.column_sums_device(xt, pt, out, ws)
+        if r % 250 == 249 or r == n_rewrites - 1:
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            ref, scale = refs[which]
+            assert np.all(np.abs(got - ref) <= 1e-12 * scale), r
+            free = torch.cuda.mem_get_info()[0]
+            low = min(low, free)
+            if free0 - free > max(image, 1 << 20) + (1 << 21):
+                print(json.dumps({"FAILED": "HBM use grows", "rewrite": r, "free_at_start": free0, "free_now": free, "image_bytes": image}))
+                sys.exit(1)
+        if time.time() - last_note > 60:
+            last_note = time.time()
+            print(f"[soak_auto_plan] rewrite {r} of {n_rewrites}", file=sys.stderr, flush=True)
+    form = capi.column_sums_device_settle(pt, nnz)
+    torch.cuda.synchronize()
+    capi.column_sums_device(xt, pt, out, ws)          # (a call collects what has been retired)
+    print(json.dumps({"rewrites": n_rewrites, "deep_queue": deep_queue, "plans_made": capi.debug_get("auto_plans_made"),
+                      "plans_freed": capi.debug_get("auto_plans_freed"), "plans_retired_now": capi.debug_get("auto_plans_retired"), "calls_between": calls_between, "calls": n_rewrites * calls_between,
+                      "seconds": round(time.time() - t0, 1), "image_bytes": int(image), "free_at_start": int(free0),
+                      "lowest_free_seen": int(low), "most_extra_bytes_held": int(free0 - low), "form_at_the_end": form,
+                      "mismatches": 0}))
+    assert deep_queue or form == "lean"
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] in ("rewrites", "rewrites-deep"):
+        return rewrites(int(sys.argv[2]) if len(sys.argv) > 2 else 10_000, deep_queue=sys.argv[1] == "rewrites-deep")
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
@@ -107,7 +171,7 @@ def main():
         ref, scale = s["ref"]
         for k in range(int(rng.integers(1, 5))):
             if rng.random() < 0.3:
-                capi.column_sums_device_form(s["pt"], s["nnz"], wait=True)    # sometimes let the inspection's result arrive first
+                capi.column_sums_device_settle(s["pt"], s["nnz"])    # sometimes make the plan now and let its result arrive first
             s["out"].fill_(-3.0)
             capi.column_sums_device(s["xt"], s["pt"], s["out"], s["ws"])
             form = capi.column_sums_device_form(s["pt"], s["nnz"])
