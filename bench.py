@@ -101,6 +101,11 @@ GLOSSARY = {
     "direct_gather": "N > 1: every rank's kernels store into rank 0's result buffer (mapped with hipIpcOpenMemHandle) at the "
                      "rank's displacement; per call: launch, wait for the own stream, cross a shared-memory barrier; "
                      "NOT the protocol of `value`",
+    "host_gather": "N > 1: every rank copies its slice (hipMemcpyAsync behind its kernels) over its own host link into ONE page-locked "
+                   "vector in POSIX shared memory that all rank processes map; per call: launch, the copy, wait for the own stream, "
+                   "cross a shared-memory barrier -- the root then holds the whole vector in HOST memory; NOT the protocol of `value`",
+    "config.peer_probe": "what the throw-away child processes saw before direct_gather was allowed between different devices: "
+                         "passed | same device | no peer access | failed: ...",
     "roofline.achieved": "algorithmic bytes of one launch (8 B/nnz + 12 B/column, SURVEY.md 8d; i[] is never read) of rank 0's "
                          "shard / roofline.kernel_ms",
     "roofline.kernel_ms": "mean device time of the kernels of one call, HIP events on the launch stream.  kernel_timing = "
@@ -195,8 +200,17 @@ def parse_args(argv=None):
     ap.add_argument("--no-planned-shards", action="store_true", help="N > 1: skip the separate planned_shards figure")
     ap.add_argument("--direct-gather", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: the separate direct_gather figure (the ranks' kernels store into rank 0's result buffer, mapped "
-                         "with hipIpc).  auto = in the --rendezvous gloo rehearsal only: between DIFFERENT devices a kernel that "
-                         "writes through a mapping the driver does not honour faults, and a fault ends the whole job")
+                         "with hipIpc).  auto = in the --rendezvous gloo rehearsal always; between DIFFERENT devices only after a "
+                         "PROBE has passed: rank 0 starts a child process (and that a second one) which does exactly this between "
+                         "rank 0's and rank 1's device -- hipDeviceCanAccessPeer, an IPC-mapped buffer, one kernel storing through "
+                         "the mapping from the other process, the values read back -- so that a mapping the driver does not honour "
+                         "takes a throw-away process down, not the job (config.peer_probe says what it saw)")
+    ap.add_argument("--host-gather", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: the separate host_gather figure (SURVEY.md section 5's other comparator: every rank copies its slice "
+                         "over its own host link into ONE page-locked vector in shared memory; per call: kernels, the copy, a wait "
+                         "for the own stream, a host barrier).  auto = on")
+    ap.add_argument("--peer-probe", nargs=2, type=int, metavar=("OWNER", "WRITER"), help=argparse.SUPPRESS)
+    ap.add_argument("--peer-probe-writer", nargs=2, metavar=("HANDLE_HEX", "WRITER"), help=argparse.SUPPRESS)
     ap.add_argument("--also", default="auto",
                     help="N = 1: more single-GPU workloads measured after the headline one, OUTSIDE its timed region "
                          "(never part of `value`).  auto = every other single-GPU BASELINE configuration and its planned form "
@@ -749,6 +763,159 @@ def direct_gather_figure(ctx):
     return fig
 
 
+PROBE_N = 4096
+
+
+def peer_probe_writer(args):
+    """Grandchild of the probe: a SECOND process on the writer's device maps the owner's buffer (hipIpcOpenMemHandle) and lets
+    the column-sum kernels store PROBE_N results through the mapping -- exactly what a rank does in direct_gather."""
+    import numpy as np
+    import torch
+    from rcppsparse_amd import capi
+    handle, writer = bytes.fromhex(args.peer_probe_writer[0]), int(args.peer_probe_writer[1])
+    capi.load()
+    torch.cuda.set_device(writer)
+    shared = capi.SharedResult(PROBE_N, handle=handle)
+
+    class Out:
+        def data_ptr(self):
+            return shared.ptr
+    x = torch.arange(1, PROBE_N + 1, dtype=torch.float64, device=f"cuda:{writer}")
+    pt = torch.arange(0, PROBE_N + 1, dtype=torch.int32, device=f"cuda:{writer}")      # one entry per column: sums = 1 .. n
+    ws = capi.alloc_workspace(PROBE_N, PROBE_N, f"cuda:{writer}")
+    capi.prepared_column_sums(x, pt, Out(), ws)()
+    torch.cuda.synchronize()
+    shared.close()
+    del np
+    return 0
+
+
+def peer_probe(args):
+    """The probe's child process: owns a small IPC-exported buffer on OWNER's device, has a second process store into it from
+    WRITER's device, reads it back.  Exit code 0 and ONE line on stdout: passed | same device | no peer access | failed: why."""
+    import numpy as np
+    import torch
+    from rcppsparse_amd import capi
+    owner, writer = args.peer_probe
+    if owner == writer:
+        print("same device")
+        return 0
+    capi.load()
+    try:
+        if not (capi.device_can_access_peer(writer, owner) and capi.device_can_access_peer(owner, writer)):
+            print("no peer access")
+            return 0
+        torch.cuda.set_device(owner)
+        shared = capi.SharedResult(PROBE_N)
+        env = dict(os.environ)
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--peer-probe-writer", shared.handle.hex(), str(writer)],
+                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90)
+        if pr.returncode != 0:
+            print(f"failed: the writing process exited with {pr.returncode}: {pr.stderr.decode(errors='replace')[-120:]}".replace("\n", " "))
+            return 0
+        got = shared.read()
+        shared.close()
+        if np.array_equal(got, np.arange(1, PROBE_N + 1, dtype=np.float64)):
+            print("passed")
+        else:
+            print(f"failed: {int(np.count_nonzero(got != np.arange(1, PROBE_N + 1)))} of {PROBE_N} values did not arrive")
+    except subprocess.TimeoutExpired:
+        print("failed: the writing process did not finish in 90 s")
+    except Exception as e:   # noqa: BLE001
+        print(f"failed: {e}"[:160].replace("\n", " "))
+    return 0
+
+
+def run_peer_probe(owner, writer, timeout_s=150, command=None):
+    """Starts the probe as a child process of its own session and returns its one-line verdict.  A child that dies (a fault
+    ends the process that owns the queue), hangs or prints nothing is a failed probe -- never an exception here."""
+    import signal
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                        "MASTER_ADDR", "MASTER_PORT", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE") and not k.startswith("TORCHELASTIC_")}
+    cmd = command or [sys.executable, os.path.abspath(__file__), "--peer-probe", str(owner), str(writer)]
+    try:
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            out, err = pr.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)      # (the group this call started, nothing else)
+            pr.communicate()
+            return f"failed: the probe did not finish in {timeout_s} s"
+    except OSError as e:
+        return f"failed: the probe could not be started: {e}"[:160]
+    if pr.returncode != 0:
+        return f"failed: the probe exited with {pr.returncode}: {err.decode(errors='replace')[-100:]}".replace("\n", " ")[:200]
+    lines = [ln.strip() for ln in out.decode(errors="replace").splitlines() if ln.strip()]
+    verdicts = [ln for ln in lines if ln.startswith(("passed", "same device", "no peer access", "failed"))]
+    return verdicts[-1][:200] if verdicts else "failed: the probe printed no verdict"
+
+
+def host_gather_figure(ctx):
+    """N > 1, separate key: SURVEY.md section 5's other comparator -- per-GPU D2H into disjoint slices of ONE pinned buffer.
+    The buffer lives in POSIX shared memory, every rank maps and page-locks it; per call a rank launches its kernels, copies
+    its slice behind them (its own host link), waits for its stream and crosses a host barrier.  Never `value`."""
+    torch, dist, capi = ctx["torch"], ctx["dist"], ctx["capi"]
+    args, world, rank = ctx["args"], ctx["world"], ctx["rank"]
+    ncol, displs, s_main, shard = ctx["ncol"], ctx["displs"], ctx["s_main"], ctx["shard"]
+    note, vec, barrier = None, None, None
+    try:
+        box = [None]
+        if rank == 0:
+            box = [f"/rsp_bench_host_{os.getpid()}"]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        if rank == 0:
+            vec = capi.SharedHostVector(box[0], ncol, create=True)
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            vec = capi.SharedHostVector(box[0], ncol, create=False)
+        barrier = capi.HostBarrier(box[0] + "_b", world, rank)
+        ok = torch.tensor([1.0], device=ctx["stat_dev"])
+    except Exception as e:   # noqa: BLE001
+        note = f"not measured: {e}"[:160]
+        ok = torch.tensor([0.0], device=ctx["stat_dev"])
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok[0]) == 0.0:
+        notes = [None] * world
+        if world > 1:
+            dist.all_gather_object(notes, note)
+        if vec is not None:
+            vec.close()
+        return {"value": None, "note": ([n for n in notes if n] or [note])[0]} if rank == 0 else None
+    out = torch.empty(max(shard.ncol, 1), dtype=torch.float64, device=ctx["dev"])[:shard.ncol]
+    launches = [capi.prepared_column_sums(xk, ctx["pt"], out, ctx["ws_main"], stream=s_main) for xk in ctx["xs"]]
+    n = [0]
+
+    def step():
+        launches[n[0] % len(launches)]()
+        n[0] += 1
+        vec.copy_from_device(out, int(displs[rank]), stream=s_main)
+        s_main.synchronize()                      # this rank's slice is in the shared vector ...
+        barrier.wait()                            # ... and after the barrier every rank's is
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_steps(torch, dist, world, ctx["stat_dev"], ctx["fence"], args.steps, step)
+    n[0] = 0
+    step()
+    fig = None
+    if rank == 0:
+        par = parity_whole_matrix(vec.array.copy(), ctx["p"], args.kind)
+        fig = sig({"value": ctx["nnz"] * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                   "parity_err": par["max_abs_err_over_l1"], "bad_columns": par["columns_out_of_tolerance"]})
+    barrier.wait()
+    barrier.close()
+    if rank != 0:
+        vec.close()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        vec.close()
+    return fig
+
+
 def main_rowsums(args):
     """bench.py --op rowsums: Matrix::rowSums (reference RcppSparse.h:138-144) over column-range shards.  A step = every rank
     sums the rows of its own columns (rsp_row_sums_device: nrow doubles) and the partial vectors are reduced IN RANK ORDER to
@@ -1293,7 +1460,7 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
             del prepared, launches, outs, wss
 
     # ------------------------------------------------------------------ N > 1: two more separate figures
-    planned_shards = direct_gather = None
+    planned_shards = direct_gather = host_gather = None
     if full and world > 1:
         ctx = {"torch": torch, "dist": dist, "capi": capi, "sharded": sharded, "args": args, "rank": rank, "world": world,
                "dev": dev, "dev_index": dev_index, "stat_dev": stat_dev, "shard": shard, "counts": counts, "displs": displs,
@@ -1301,8 +1468,26 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
                "use_comm": use_comm, "out_main": out_main, "ws_main": ws_main, "new_gather": new_gather}
         if plan is None and not args.no_planned_shards:
             planned_shards = planned_shards_figure(ctx)
-        if args.direct_gather == "on" or (args.direct_gather == "auto" and rehearsal):
+        peer_probe_verdict = None
+        want_direct = args.direct_gather == "on" or (args.direct_gather == "auto" and rehearsal)
+        if args.direct_gather == "auto" and not rehearsal:
+            # between different devices: only after throw-away processes have done the same thing and lived (rank 0 asks,
+            # everybody hears the answer)
+            box = [None]
+            gathered = [None] * world
+            dist.all_gather_object(gathered, dev_index)
+            if rank == 0:
+                box = [run_peer_probe(gathered[0], gathered[1])]
+            dist.broadcast_object_list(box, src=0)
+            peer_probe_verdict = box[0]
+            want_direct = peer_probe_verdict == "passed"
+        if want_direct:
             direct_gather = direct_gather_figure(ctx)
+        elif peer_probe_verdict is not None and rank == 0:
+            direct_gather = {"value": None, "note": f"not measured: peer probe: {peer_probe_verdict}"[:160]}
+        env["peer_probe"] = peer_probe_verdict
+        if args.host_gather != "off":
+            host_gather = host_gather_figure(ctx)
 
     stats = torch.tensor([elapsed, kernel_ms, gather_ms, lat_med], dtype=torch.float64, device=stat_dev)
     # what every rank owned and measured (rank order), so the line shows the whole partition
@@ -1345,7 +1530,8 @@ def run_sharded_workload(env, name, partition, full, nnz_override=0):
                         for r, t in enumerate(per_rank)],
              "form": PLAN_FORMS[int(my_form)], "auto_plan": capi.debug_get("auto_plan"),
              "parity": parity, "lat_med": lat_med, "lat_min": lat_min, "lat_med_max": lat_med_max,
-             "pipelined": pipe, "planned_shards": planned_shards, "direct_gather": direct_gather,
+             "pipelined": pipe, "planned_shards": planned_shards, "direct_gather": direct_gather, "host_gather": host_gather,
+             "peer_probe": env.get("peer_probe"),
              "plan": (None if plan is None else
                       {"form": PLAN_FORMS[plan.form], "snapped": plan.snapped, "plan_ms": plan.inspect_ms, "chunks": plan.nchunks,
                        "entries_per_chunk": plan.chunk_elems, "max_skip": plan.max_skip,
@@ -1425,6 +1611,11 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
     th = extras.get("threads")
     if th:
         roof.update(th)
+    for name in ("planned_shards", "direct_gather", "host_gather", "pipelined"):
+        fig = H.get(name)
+        if fig and fig.get("value") is not None:
+            roof[name + "_value"] = fig["value"]
+            roof[name + "_ms_per_step"] = fig["ms_per_step"]
     rccl = extras.get("rccl") or {}
     cfg = {
         "workload": f"{H['workload']}: {H['nrow']}x{H['ncol']} CSC dgCMatrix, nnz={H['nnz']}, {H['shape']} nnz/column, "
@@ -1440,6 +1631,7 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         "gather": H["gather_name"],
         "gather_fell_back_to_torch_distributed": H["fell_back"],
         "rccl_version": rccl.get("version"), "rccl_library": rccl.get("library"),
+        "peer_probe": H.get("peer_probe"),
         "regions_ms": H["regions_ms"],
         "host_stall_suspected": bool(not use_comm and ms_per_step > 1.5 * H["kernel_ms"]),
         "planned": None if plan is None else {k: v for k, v in plan.items() if k != "kernel"},
@@ -1466,6 +1658,7 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         "pipelined": H["pipelined"],
         "planned_shards": H["planned_shards"],
         "direct_gather": H["direct_gather"],
+        "host_gather": H.get("host_gather"),
         "roofline": sig(roof),
         "parity": sig(H["parity"]),
     }
@@ -1487,6 +1680,10 @@ def main(argv=None):
         for k, v in GLOSSARY.items():
             print(f"{k}\n    {v}")
         return
+    if args.peer_probe_writer:
+        sys.exit(peer_probe_writer(args))
+    if args.peer_probe:
+        sys.exit(peer_probe(args))
     if args.parallelism == "threads":
         return main_threads(args)
     if args.gpus > 1 and "RANK" not in os.environ:

@@ -566,6 +566,20 @@ int rsp_shared_result_open(const void *handle_bytes, void **d_ptr);
 /* the gathered vector (or a part of it) into host memory -- the one D2H copy into the NumericVector; waits for `stream` */
 int rsp_shared_result_read(const void *d_ptr, size_t offset_bytes, void *host, size_t bytes, void *stream);
 int rsp_shared_result_close(void *d_ptr, int owner);
+/*
+ * The other comparator ("per-GPU D2H into disjoint slices of one pinned buffer"): ONE vector in POSIX
+ * shared memory, mapped by every rank process and page-locked there (hipHostRegister), so that each rank's copy engine
+ * writes the rank's slice straight into memory the root process reads -- over the rank's own host link, no xGMI hop, no
+ * RCCL.  Per call: the rank's kernels, rsp_copy_to_host_async of its slice behind them, a wait for the own stream, one
+ * host barrier; the root then holds the whole vector in HOST memory.  name: "/something", the same on every rank; the
+ * creating rank passes create != 0, the others wait up to 30 s for it.  rsp_shared_host_close(ptr, bytes, name) also
+ * unlinks the name (the creator), NULL just unmaps.
+ */
+int rsp_shared_host_open(const char *name, size_t bytes, int create, void **host_ptr);
+int rsp_shared_host_close(void *host_ptr, size_t bytes, const char *unlink_name);
+int rsp_copy_to_host_async(const double *d_src, double *host_dst, int64_t n, void *stream);
+/* hipDeviceCanAccessPeer (1 for device == peer): bench.py asks before it lets kernels store across devices. */
+int rsp_device_can_access_peer(int device, int peer, int *can);
 typedef struct rsp_host_barrier *rsp_host_barrier_t;
 /* name: a POSIX shared-memory name ("/something", the same on every rank); rank 0 creates it, the others wait for it */
 int rsp_host_barrier_create(const char *name, int nranks, int rank, rsp_host_barrier_t *barrier);

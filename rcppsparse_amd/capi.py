@@ -55,6 +55,7 @@ EXPORTED_SYMBOLS = (
     "rsp_mcsc_set_gather", "rsp_mcsc_set_launch", "rsp_mcsc_config", "rsp_mcsc_result_buffer", "rsp_mcsc_wrap_device",
     "rsp_mcsc_last_call_stamps", "rsp_mcsc_shard_kernel_ms", "rsp_rccl_info",
     "rsp_column_sums_device_settle",
+    "rsp_shared_host_open", "rsp_shared_host_close", "rsp_copy_to_host_async", "rsp_device_can_access_peer",
 )
 GATHER_MODES = {"d2h": 0, "rccl": 1, "stores": 2, "none": 3}
 LAUNCH_MODES = {"serial": 0, "workers": 1}
@@ -177,6 +178,10 @@ def load(build: bool = True) -> ctypes.CDLL:
     L.rsp_shared_result_open.argtypes = [vp, c.POINTER(vp)]
     L.rsp_shared_result_close.argtypes = [vp, c.c_int]
     L.rsp_shared_result_read.argtypes = [vp, c.c_size_t, vp, c.c_size_t, vp]
+    L.rsp_shared_host_open.argtypes = [c.c_char_p, c.c_size_t, c.c_int, c.POINTER(vp)]
+    L.rsp_shared_host_close.argtypes = [vp, c.c_size_t, c.c_char_p]
+    L.rsp_copy_to_host_async.argtypes = [vp, vp, i64, vp]
+    L.rsp_device_can_access_peer.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_int)]
     L.rsp_host_barrier_create.argtypes = [c.c_char_p, c.c_int, c.c_int, c.POINTER(vp)]
     L.rsp_host_barrier_wait.argtypes = [vp, c.c_double]
     L.rsp_host_barrier_destroy.argtypes = [vp]
@@ -963,6 +968,35 @@ class SharedResult:
         if self._p:
             load().rsp_shared_result_close(self._p, int(self.owner))
             self._p = ctypes.c_void_p()
+
+
+class SharedHostVector:
+    """n doubles in POSIX shared memory, mapped and page-locked in this process (rsp_shared_host_open): the rank processes'
+    copy engines write their slices into it, the root reads the whole (`array`)."""
+
+    def __init__(self, name: str, n: int, create: bool):
+        self.name, self.n, self.bytes, self.create = name, int(n), max(8, 8 * int(n)), bool(create)
+        p = ctypes.c_void_p()
+        _check(load().rsp_shared_host_open(name.encode(), self.bytes, int(self.create), ctypes.byref(p)))
+        self.ptr = int(p.value)
+        self.array = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), shape=(max(self.n, 1),))[:self.n]
+
+    def copy_from_device(self, src_t, offset: int, stream=None) -> None:
+        """enqueue: src_t (float64, device) -> vector[offset : offset + len] on `stream`"""
+        _check(load().rsp_copy_to_host_async(src_t.data_ptr(), ctypes.c_void_p(self.ptr + 8 * int(offset)), int(src_t.numel()),
+                                             _stream_ptr(stream)))
+
+    def close(self) -> None:
+        if getattr(self, "ptr", 0):
+            self.array = None
+            load().rsp_shared_host_close(ctypes.c_void_p(self.ptr), self.bytes, self.name.encode() if self.create else None)
+            self.ptr = 0
+
+
+def device_can_access_peer(device: int, peer: int) -> bool:
+    can = ctypes.c_int(0)
+    _check(load().rsp_device_can_access_peer(int(device), int(peer), ctypes.byref(can)))
+    return bool(can.value)
 
 
 class HostBarrier:

@@ -1232,6 +1232,88 @@ int rsp_shared_result_close(void* d_ptr, int owner) {
     return RSP_OK;
 }
 
+// ---- host-memory gather: one page-locked vector shared by the rank processes -------------------------------------
+// SURVEY.md section 5's other comparator: "per-GPU D2H into disjoint slices of one pinned buffer".  The vector lives in
+// POSIX shared memory; every rank maps it and page-locks ITS mapping (hipHostRegister), so its copy engine writes the
+// rank's slice straight into memory the root process reads -- over the rank's own host link, no xGMI hop, no RCCL.
+// After the ranks' stream waits and one host barrier the root holds the complete vector in HOST memory (where an R
+// NumericVector has to end up anyway).
+int rsp_shared_host_open(const char* name, size_t bytes, int create, void** host_ptr) {
+    if (!name || name[0] != '/' || !host_ptr || bytes == 0)
+        return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_shared_host_open (name must start with '/')");
+    *host_ptr = nullptr;
+    const size_t mapped = (bytes + 4095) & ~(size_t)4095;
+    int fd = -1;
+    if (create) {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)mapped) != 0) {
+            close(fd);
+            (void)shm_unlink(name);
+            fd = -1;
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= mapped) break;
+            if (fd >= 0) close(fd);
+            fd = -1;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    if (fd < 0) return fail(RSP_ERR_ALLOC, "shared memory %s could not be %s", name, create ? "created" : "opened");
+    void* m = mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(RSP_ERR_ALLOC, "mmap of %s failed", name);
+    const hipError_t e = hipHostRegister(m, mapped, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        munmap(m, mapped);
+        if (create) (void)shm_unlink(name);
+        return fail(RSP_ERR_HIP, "hipHostRegister of the shared vector: %s", hipGetErrorString(e));
+    }
+    *host_ptr = m;
+    return RSP_OK;
+}
+
+int rsp_shared_host_close(void* host_ptr, size_t bytes, const char* unlink_name) {
+    if (!host_ptr) return RSP_OK;
+    const size_t mapped = (bytes + 4095) & ~(size_t)4095;
+    const hipError_t e = hipHostUnregister(host_ptr);
+    if (e != hipSuccess) (void)hipGetLastError();
+    munmap(host_ptr, mapped);
+    if (unlink_name) (void)shm_unlink(unlink_name);
+    return RSP_OK;
+}
+
+// enqueue only: n doubles from device memory into (page-locked) host memory on `stream`
+int rsp_copy_to_host_async(const double* d_src, double* host_dst, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!d_src || !host_dst))) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_copy_to_host_async");
+    if (n == 0) return RSP_OK;
+    const hipError_t e = hipMemcpyAsync(host_dst, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(RSP_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
+    return RSP_OK;
+}
+
+// hipDeviceCanAccessPeer, for the probe bench.py runs in a child process before it lets kernels store across devices
+int rsp_device_can_access_peer(int device, int peer, int* can) {
+    if (!can) return fail(RSP_ERR_BAD_ARG, "can is null");
+    *can = 0;
+    if (device == peer) {
+        *can = 1;
+        return RSP_OK;
+    }
+    const hipError_t e = hipDeviceCanAccessPeer(can, device, peer);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RSP_ERR_HIP, "hipDeviceCanAccessPeer(%d, %d): %s", device, peer, hipGetErrorString(e));
+    }
+    return RSP_OK;
+}
+
 // A barrier between the rank PROCESSES of one node through a page of POSIX shared memory: sense-reversing, spinning
 // on the host (the ranks are about to consume each other's results: they have nothing else to do), a microsecond or
 // two per crossing, with a timeout instead of a hang when a rank has died.

@@ -38,6 +38,8 @@ def _head(world, nnz=1_000_000_000, ncol=1_000_000, rehearsal=False, small=False
             "planned_shards": None if world == 1 else {"value": 4.1e12, "ms_per_step": 0.244, "forms_by_rank": ["columns"] * world,
                                                        "plan_ms_rank0": 1.93, "parity_err": 4.4e-16, "bad_columns": 0},
             "direct_gather": None if world == 1 else {"value": 3.9e12, "ms_per_step": 0.256, "parity_err": 4.4e-16, "bad_columns": 0},
+            "host_gather": None if world == 1 else {"value": 3.6e12, "ms_per_step": 0.278, "parity_err": 4.4e-16, "bad_columns": 0},
+            "peer_probe": None if world == 1 or rehearsal else "passed",
             "plan": None, "gather_name": "rsp_comm_gatherv (C ABI, RCCL)" if use_comm else None, "fell_back": False,
             "x0_for_ceiling": None}
 
@@ -114,8 +116,28 @@ def test_n_rank_line_fits_and_lists_every_shard(world):
     assert line["also_sharded"]["c5_cols"]["kernel_ms_by_rank"] == [0.29] * world
     assert line["cpu_baseline"]["kind"] == "port"                       # rank 0 at every N
     assert line["n_gpus"] == world and line["scaling"] == "strong"
-    real = bench.assemble_line(_args("--gpus", str(world)), _head(world), {"cpu_baseline": CPU}, devices=world)
+    threads = {"threads_value": 4.4e12, "threads_ms_per_step": 0.2271234, "threads_launch": "workers", "threads_devices_distinct": True,
+               "threads_parity_err": 4.6e-16, "threads_seconds": 31.2, "threads_d2h_pinned_ms": 0.2271234,
+               "threads_d2h_pageable_ms": 0.2561234, "threads_stores_pinned_ms": 0.2391234, "threads_none_pinned_ms": 0.1791234,
+               "threads_rccl_pinned_ms": 0.2931234, "threads_last_enqueue_us": 11.71234, "threads_serial_d2h_pinned_ms": 0.2461234,
+               "threads_call_minus_slowest_kernel_us": 74.31234, "threads_kernel_ms_max_over_shards": 0.1521234}
+    real = bench.assemble_line(_args("--gpus", str(world)), _head(world),
+                               {"cpu_baseline": CPU, "also_sharded": sharded, "threads": threads,
+                                "rccl": {"version": 22606, "library": "/usr/local/lib/python3.10/dist-packages/torch/lib/librccl.so"}},
+                               devices=world)
     assert real["config"]["parallelism"] == "ranges+rccl" and "comm_refused_on_ranks" not in real["config"]
+    # round 6: everything the driver's first real N > 1 run can tell, as flat scalars, and still under the 8 KiB tail
+    assert len(json.dumps(real)) < bench.LINE_BYTES_MAX, len(json.dumps(real))
+    assert real["config"]["rccl_version"] == 22606 and real["config"]["rccl_library"].endswith("librccl.so")
+    assert real["config"]["peer_probe"] == "passed"
+    rr = real["roofline"]
+    for k in ("threads_value", "threads_d2h_pinned_ms", "threads_rccl_pinned_ms", "threads_last_enqueue_us",
+              "direct_gather_value", "host_gather_value", "planned_shards_value", "pipelined_value", "host_gather_ms_per_step"):
+        assert isinstance(rr[k], float), k
+    assert real["host_gather"]["value"] == 3.6e12 and rr["threads_launch"] == "workers"
+    assert all(not isinstance(v, (dict, list)) for v in rr.values())
+    failed = bench.assemble_line(_args("--gpus", str(world)), _head(world), {"threads": {"threads_error": "exit 1: boom"}}, devices=world)
+    assert failed["roofline"]["threads_error"] == "exit 1: boom" and "threads_value" not in failed["roofline"]
 
 
 def test_small_headline_reports_its_regions_and_flags_a_host_stall():
@@ -140,3 +162,30 @@ def test_median_region_and_rounding_helpers():
 def test_verbose_line_carries_the_glossary():
     line = bench.assemble_line(_args("--verbose"), _head(1), {})
     assert set(line["notes"]) == set(bench.GLOSSARY)
+
+
+def test_peer_probe_runner_turns_every_failure_into_a_verdict(tmp_path):
+    """bench.run_peer_probe starts throw-away processes before kernels are allowed to store across devices (direct_gather on a
+    real multi-GPU node).  Whatever happens to the child -- it dies on a signal as a process does whose queue faulted, it exits
+    non-zero, it hangs, it prints nothing -- the runner returns a 'failed: ...' verdict and never raises; a child that says
+    'passed' / 'same device' / 'no peer access' is believed."""
+    import sys
+    py = sys.executable
+    assert bench.run_peer_probe(0, 1, command=[py, "-c", "print('passed')"]) == "passed"
+    assert bench.run_peer_probe(0, 0, command=[py, "-c", "print('noise'); print('same device')"]) == "same device"
+    assert bench.run_peer_probe(0, 1, command=[py, "-c", "print('no peer access')"]) == "no peer access"
+    v = bench.run_peer_probe(0, 1, command=[py, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGSEGV)"])
+    assert v.startswith("failed: the probe exited with")
+    v = bench.run_peer_probe(0, 1, command=[py, "-c", "import sys; sys.stderr.write('Memory access fault by GPU node-2'); sys.exit(134)"])
+    assert v.startswith("failed: the probe exited with 134") and "Memory access fault" in v
+    v = bench.run_peer_probe(0, 1, timeout_s=1, command=[py, "-c", "import time; time.sleep(30)"])
+    assert v == "failed: the probe did not finish in 1 s"
+    assert bench.run_peer_probe(0, 1, command=[py, "-c", "pass"]) == "failed: the probe printed no verdict"
+    assert bench.run_peer_probe(0, 1, command=[str(tmp_path / "no_such_program")]).startswith("failed: the probe could not be started")
+    # and the line says what was seen instead of measuring
+    H = _head(2)
+    H["direct_gather"] = {"value": None, "note": "not measured: peer probe: no peer access"}
+    H["peer_probe"] = "no peer access"
+    line = bench.assemble_line(_args("--gpus", "2"), H, {}, devices=2)
+    assert line["config"]["peer_probe"] == "no peer access" and "direct_gather_value" not in line["roofline"]
+    assert line["direct_gather"]["note"].endswith("no peer access")

@@ -213,6 +213,14 @@ def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload,
     dg = d["direct_gather"]
     assert dg["value"] is not None, dg                                # the ranks mapped rank 0's buffer (hipIpc) ...
     assert dg["bad_columns"] == 0 and dg["parity_err"] <= RTOL        # ... and wrote into it
+    # round 6: SURVEY section 5's other comparator -- every rank's copy engine writes its slice into ONE page-locked vector in
+    # shared memory; whole-matrix parity of what the root then reads from HOST memory; and the flat scalars of all of them
+    hg = d["host_gather"]
+    assert hg["value"] is not None, hg
+    assert hg["bad_columns"] == 0 and hg["parity_err"] <= RTOL
+    for name in ("planned_shards", "direct_gather", "host_gather", "pipelined"):
+        assert roof[name + "_value"] == d[name]["value"] and roof[name + "_ms_per_step"] == d[name]["ms_per_step"]
+    assert cfg["peer_probe"] is None                                  # (the rehearsal shares one device: nothing to probe)
     # --try-comm: the C-ABI communicator's multi-rank bootstrap ran between the rank processes (unique id
     # from rank 0, rsp_comm_init everywhere) and RCCL refused the shared device on EVERY rank, cleanly
     assert cfg["comm_refused_on_ranks"] == world and "comm_rehearsal_unexpected" not in cfg, cfg
@@ -524,3 +532,50 @@ def test_bench_child_process_planned_vignette(torch_cuda):
     assert par["columns_checked"] == "all" and par["ncol"] == 1000 and par["columns_out_of_tolerance"] == 0
     assert par["max_abs_err_over_l1"] <= 1e-12
     assert 0.3 < d["roofline"]["frac"] < 1.0
+
+
+def test_peer_probe_child_on_one_device_says_not_applicable(torch_cuda):
+    """bench.py's probe before direct_gather between different devices, on the one device this box
+    has: the child process starts, sees owner == writer and reports 'same device' -- the branch a 1-GPU box can reach.  The
+    writer grandchild is exercised too, against a buffer this process exports (two processes, one device: the IPC path that
+    test_direct_write_gather_between_two_processes_sharing_the_gpu covers end to end)."""
+    import bench
+    assert bench.run_peer_probe(0, 0) == "same device"
+    assert capi.device_can_access_peer(0, 0) is True
+    shared = capi.SharedResult(bench.PROBE_N)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--peer-probe-writer", shared.handle.hex(), "0"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(shared.read(), np.arange(1, bench.PROBE_N + 1, dtype=np.float64))
+    shared.close()
+
+
+@pytest.mark.parametrize("gpus,workload", [(1, "tinyu"), (4, "tinyu"), (8, "c4shard")])
+def test_bench_parallelism_threads_line(torch_cuda, gpus, workload):
+    """`bench.py --parallelism threads`: ONE process drives N shards through the resident multi-GPU handle (rsp_mcsc_*) -- the
+    multi-GPU path an R session reaches.  Same line, whole-matrix parity, every gather / launch
+    combination as a flat scalar; on this box every shard shares the one device (config.devices_distinct false)."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--parallelism", "threads", "--gpus", str(gpus), "--workload", workload, "--steps", "6", "--warmup", "2")
+    assert d["_line_bytes"] < 8000
+    cfg, roof = d["config"], d["roofline"]
+    assert d["n_gpus"] == gpus and cfg["parallelism"] == "threads" and cfg["devices_distinct"] is (gpus == 1)
+    assert cfg["launch"] == ("workers" if gpus >= 3 else "serial") and cfg["gather"] == "d2h"
+    assert len(cfg["shards"]) == gpus and cfg["shards"][0]["c0"] == 0 and all(s["device"] == 0 for s in cfg["shards"])
+    assert cfg["rccl_version"] > 20000 and "librccl" in cfg["rccl_library"]
+    par = d["parity"]
+    assert par["columns_out_of_tolerance"] == 0 and par["max_abs_err_over_l1"] <= RTOL and par["columns_checked"] == "all"
+    assert len(cfg["regions_ms"]) == 3 and d["ms_per_step"] == pytest.approx(sorted(cfg["regions_ms"])[1])
+    nnz = sum(s["nnz"] for s in cfg["shards"])
+    assert d["value"] == pytest.approx(nnz / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    for k in ("threads_d2h_pinned_ms", "threads_d2h_pageable_ms", "threads_stores_pinned_ms", "threads_none_pinned_ms",
+              "threads_last_enqueue_us", "call_minus_slowest_kernel_us"):
+        assert isinstance(roof[k], float), k
+    assert not any(k.endswith("_bits_differ") for k in roof)          # every gather returned the bits of `value`'s run
+    if gpus == 1:
+        assert roof["threads_rccl_pinned_ms"] > 0                     # ncclCommInitAll over one device, one D2H
+    else:
+        assert "threads_rccl_pinned_ms" not in roof                   # (RCCL refuses two ranks on one device: not tried)
+        assert roof["threads_serial_d2h_pinned_ms" if cfg["launch"] == "workers" else "threads_workers_d2h_pinned_ms"] > 0
+    if workload == "c4shard":
+        assert all(s["form"] == "columns" for s in cfg["shards"]) and 0.2 < roof["frac"] < 1.0
