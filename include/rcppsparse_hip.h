@@ -621,6 +621,9 @@ int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
  *   "row_slices"      row-restricted sums: 0 never the slice-major form, 1 where faster (default), 2 wherever possible
  *   "auto_plan"       rsp_column_sums_device / rsp_column_means_device plan for themselves (1, default) or never (0)
  *   "auto_min_nnz"    ... for matrices of at least this many entries (default 2^20; tests lower it to 1)
+ *   "fold_fixup"      plain calls that are one round of waves: 1 = the fix-up runs inside the main launch (the last workgroup to
+ *                     finish does it), 0 (default) = as a second launch.  Same bits; the folded form measured SLOWER (BASELINE
+ *                     config 2: 37.0 against 22.5 us, profiles/DEAD_ENDS.md) and exists for that A/B
  *   read-only (rsp_debug_get): "auto_plans_made" / "auto_plans_freed" -- plans those entries have made / freed since the
  *                     process started; "auto_plans_retired" -- retired images still waiting for their events
  * An unknown key is RSP_ERR_BAD_ARG.  rsp_debug_get reads the value in force (environment and defaults resolved).

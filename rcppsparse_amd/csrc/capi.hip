@@ -308,6 +308,63 @@ int require_device(int device) {
     return RSP_OK;
 }
 
+// ---- the folded fix-up's ticket words (colsums_kernels.hip FOLD): one per (device, launching stream) ----
+// A short plain call runs its fix-up inside the main launch; the workgroups count themselves through a device word that
+// must be zero when the kernel starts and is zero again when it ends.  Calls on ONE stream run one after the other, so a
+// word per stream is enough and two calls can never meet in one; streams beyond kFoldStreams (and capturing streams: a
+// graph could be replayed beside another call of its stream's word) take the two-launch form.
+// MEASURED AND LEFT OFF (profiles/DEAD_ENDS.md, round 6): C2 through the folded form 37.0 us against 22.5 us in two launches --
+// the last workgroup walks ~3900 records with device-scope loads, sixteen dependent passes of ~1.4 us, which costs more
+// than the gap between two dependent kernels (4.9 us) ever did.  The form stays selectable for the A/B (tools/ab_c2_fold.sh)
+// and is held to the two-launch bits by tests/test_gpu_parity.py::test_folded_fixup_gives_the_two_launch_bits.
+std::atomic<int> g_fold_fixup{-1};   // "fold_fixup": 0 (default) never, 1 short plain calls; -1 = RSP_FOLD_FIXUP from the environment
+constexpr int kFoldStreams = 64;
+struct FoldSlot {
+    int device;
+    hipStream_t stream;
+    uint32_t* word;
+};
+std::mutex g_fold_mu;
+FoldSlot g_fold_slots[kFoldStreams];
+int g_fold_used = 0;
+
+int fold_fixup_setting() {
+    int v = g_fold_fixup.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static const int env = [] {
+            const char* s = getenv("RSP_FOLD_FIXUP");
+            return (s && s[0]) ? (atoi(s) != 0 ? 1 : 0) : 0;
+        }();
+        v = env;
+    }
+    return v;
+}
+
+uint32_t* fold_ticket_for(hipStream_t stream) {   // nullptr: this call takes the two-launch form
+    if (fold_fixup_setting() == 0) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_fold_mu);
+    for (int k = 0; k < g_fold_used; ++k)
+        if (g_fold_slots[k].device == device && g_fold_slots[k].stream == stream) return g_fold_slots[k].word;
+    if (g_fold_used >= kFoldStreams) return nullptr;
+    int on_device = 0;   // (the words live in a __device__ array of each device's copy of the code object)
+    for (int k = 0; k < g_fold_used; ++k) on_device += g_fold_slots[k].device == device;
+    uint32_t* word = nullptr;
+    if (rsp::fold_ticket_address(on_device, &word) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    g_fold_slots[g_fold_used++] = FoldSlot{device, stream, word};
+    return word;
+}
+
 int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out,
             void* d_ws, size_t ws_bytes, double divisor, bool means, hipStream_t stream,
             int op = rsp::kOpSum, const int32_t* d_i = nullptr, const uint32_t* d_bitmap = nullptr,
@@ -322,8 +379,10 @@ int enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, do
     const size_t need = rsp::workspace_bytes_for(plan.nchunks);
     if (nnz > 0 && (!d_ws || ws_bytes < need))
         return fail(RSP_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+    uint32_t* fold = nullptr;
+    if (plan.short_pipeline && op == rsp::kOpSum && plan.variant == 0 && nnz > 0) fold = fold_ticket_for(stream);
     HIP_TRY(rsp::launch_column_sums(d_x, d_p, ncol, (int32_t)nnz, d_out, plan, d_ws, divisor, means,
-                                    stream, op, d_i, d_bitmap, bitmap_words, nullptr, d_run_if));
+                                    stream, op, d_i, d_bitmap, bitmap_words, nullptr, d_run_if, fold));
     return RSP_OK;
 }
 
@@ -446,6 +505,8 @@ int rsp_debug_set(const char* key, int value) {
         g_row_slices.store(clamp012(value), std::memory_order_relaxed);
     } else if (k == "auto_plan") {      // the plan-free device entries plan for themselves (1, default) or never (0)
         g_auto_plan.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+    } else if (k == "fold_fixup") {     // short plain calls run their fix-up inside the main launch (1) or as a second launch (0, default: faster)
+        g_fold_fixup.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
     } else if (k == "auto_min_nnz") {   // ... for matrices of at least this many entries (default 2^20; the parity suite lowers it to 1)
         g_auto_min_nnz.store(value < 1 ? 1 : value, std::memory_order_relaxed);
     } else {
@@ -469,6 +530,7 @@ int rsp_debug_get(const char* key, int* value) {
     else if (k == "row_slices") *value = row_slices_setting();
     else if (k == "auto_plan") *value = auto_plan_setting();
     else if (k == "auto_min_nnz") *value = g_auto_min_nnz.load(std::memory_order_relaxed);
+    else if (k == "fold_fixup") *value = fold_fixup_setting();
     else if (k == "auto_plans_made") *value = auto_counter(0);       // read-only: plans the plan-free entries have made ...
     else if (k == "auto_plans_freed") *value = auto_counter(1);      // ... freed again ...
     else if (k == "auto_plans_retired") *value = auto_counter(2);    // ... and retired images waiting for their events right now

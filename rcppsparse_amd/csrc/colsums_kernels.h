@@ -99,7 +99,10 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double divisor, bool means, hipStream_t stream, int op = kOpSum,
                               const int32_t* rows_i = nullptr, const uint32_t* row_bitmap = nullptr,
                               int32_t bitmap_words = 0, const int2* plan_rec = nullptr,
-                              const int32_t* run_if = nullptr);
+                              const int32_t* run_if = nullptr, uint32_t* fold_ticket = nullptr);
+// fold_ticket: a zeroed device word owned by the launching stream (fold_ticket_address): a plain column-sum call that is one
+// round of waves (plan.short_pipeline) then runs its fix-up inside the main launch -- ONE kernel -- with identical bits
+hipError_t fold_ticket_address(int slot, uint32_t** out);
 
 // rsp_column_sums_device without the entry's own planning (capi.hip): the library's one-shot paths use it
 int column_sums_general(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,

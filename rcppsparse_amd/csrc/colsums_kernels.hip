@@ -571,16 +571,22 @@ __device__ __forceinline__ void process_row(double v0, double v1, int rs, int la
 // records are there) and one wave reduction.  No column search (four dependent round trips before the first
 // add in a short call), no carries, no fix-up launch.  The grid loads start immediately, before the records
 // have arrived.
+template <class P, bool COHERENT>
+__device__ __forceinline__ void fixup_chunk(int w, int lane, int32_t ncol, int32_t nchunks, double* __restrict__ out,
+                                            const double* carry_head, const double* carry_tail, const int4* carry_info,
+                                            double divisor);
+
 template <int BATCH_ROWS, bool MEANS, int AUX, int WPG = kWavesPerWG, int OP = kOpSum, bool LDSMAP = false,
-          bool PLANNED = false>
+          bool PLANNED = false, bool FOLD = false>
 __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ p, int32_t ncol, int32_t nnz,
     ChunkMap cmap, int32_t nchunks, double* __restrict__ out,
     double* __restrict__ carry_head, double* __restrict__ carry_tail,
     int4* __restrict__ carry_info, double divisor, const int32_t* __restrict__ rows_i,
     const uint32_t* __restrict__ row_bitmap, int32_t bitmap_words, const int2* __restrict__ plan_rec = nullptr,
-    const int32_t* __restrict__ run_if = nullptr) {
+    const int32_t* __restrict__ run_if = nullptr, uint32_t* __restrict__ ticket = nullptr) {
     static_assert(BATCH_ROWS % kGroupRows == 0, "batch must be whole groups");
+    static_assert(!(FOLD && PLANNED), "a planned launch has no carries to fix up");
     typedef Policy<MEANS, OP> P;
     constexpr bool MASKED = (OP == kOpMaskedIn || OP == kOpMaskedOut);
     // row-restricted sums: the slice-major form (colsums_rowslices.hip) ran instead unless its guard said otherwise
@@ -597,7 +603,9 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         for (int k = threadIdx.x; k < bitmap_words; k += WPG * 64) s_bitmap[k] = row_bitmap[k];
         __syncthreads();
     }
-    if (w >= nchunks) return;
+    // (FOLD: a wavefront without a chunk -- the last workgroup may have some -- still meets the others at the barriers below)
+    if (!FOLD && w >= nchunks) return;
+    if (w < nchunks) {
     int32_t* win = s_win[wave_in_wg];
     double* stage = s_stage[wave_in_wg];
     // the general row path's histogram shares the staging area of the dense path: a wave is in one
@@ -844,6 +852,38 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
         carry_info[w] = make_int4(c0, st.ccur - c0, ts, (int64_t)p_c0 == cmap.start(ts) ? 1 : 0);
     }
     RSP_STAMP(6);
+    }   // (w < nchunks)
+    if (FOLD) {
+        // Calls that are one round of waves (C2: 22 us in all): the fix-up as a second launch costs ~5 us, most of it the
+        // gap between two dependent kernels.  Here the workgroup that finishes LAST runs it.  A device-scope fence per
+        // wavefront (write back this XCD's L2) cost more than the launch it saves -- 111 us against 22.6, profiles/
+        // r06_fold_fixup.md -- so the carries are made visible the cheap way: lane 0 stores its three records once more as
+        // device-scope atomic stores (written through to memory, no cache maintenance), waits for them, the workgroup takes
+        // a ticket, and the holder of the last ticket reads every record with device-scope loads.  The adds are those of
+        // colsums_fixup_kernel in the same order (fixup_chunk): identical bits.  The ticket word belongs to the launching
+        // stream (capi.hip) and is back at zero when the kernel ends.
+        __shared__ int s_last;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (a record may have been stored by another lane of this wavefront)
+        if (w < nchunks && lane == 0) {
+            const double h = carry_head[w], t = carry_tail[w];
+            const int4 inf = carry_info[w];
+            __hip_atomic_store(&carry_head[w], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&carry_tail[w], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* q = reinterpret_cast<unsigned long long*>(&carry_info[w]);
+            __hip_atomic_store(&q[0], ((unsigned long long)(uint32_t)inf.y << 32) | (uint32_t)inf.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&q[1], ((unsigned long long)(uint32_t)inf.w << 32) | (uint32_t)inf.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the stores above have completed: s_waitcnt, no cache write-back)
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1 : 0;
+        __syncthreads();
+        if (s_last) {
+            for (int base = 0; base < nchunks; base += WPG * 64)
+                fixup_chunk<P, true>(base + (int)threadIdx.x, lane, ncol, nchunks, out, carry_head, carry_tail, carry_info, divisor);
+            if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -859,32 +899,42 @@ __global__ __launch_bounds__(WPG * 64) void colsums_chunks_kernel(
 // longer than 64 chunks (a giant column) is summed by the whole wavefront with a fixed
 // lane-strided assignment and a fixed DPP tree, so one 1e9-long column costs
 // microseconds instead of a serial walk.  Deterministic.
-template <bool MEANS, int OP = kOpSum>
-__global__ __launch_bounds__(256) void colsums_fixup_kernel(
-    int32_t ncol, int32_t nchunks, double* __restrict__ out, const double* __restrict__ carry_head,
-    const double* __restrict__ carry_tail, const int4* __restrict__ carry_info, double divisor,
-    const int32_t* __restrict__ run_if = nullptr) {
-    typedef Policy<MEANS, OP> P;
-    if (run_if != nullptr && *run_if == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+// COHERENT (the folded form: the records were written by other workgroups of the SAME launch): device-scope loads.
+template <bool COHERENT>
+__device__ __forceinline__ double carry_load(const double* q) {
+    return COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+}
+template <bool COHERENT>
+__device__ __forceinline__ int4 carry_load(const int4* q) {
+    if (!COHERENT) return *q;
+    const unsigned long long* u = reinterpret_cast<const unsigned long long*>(q);
+    const unsigned long long a = __hip_atomic_load(&u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(&u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_int4((int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)(uint32_t)b, (int)(uint32_t)(b >> 32));
+}
+
+template <class P, bool COHERENT>
+__device__ __forceinline__ void fixup_chunk(int w, int lane, int32_t ncol, int32_t nchunks, double* __restrict__ out,
+                                            const double* carry_head, const double* carry_tail, const int4* carry_info,
+                                            double divisor) {
+    // (called by whole wavefronts: the giant-column path below is wave-cooperative; lanes with w >= nchunks idle)
     bool need = false;
     int c = 0, ts = 0;
     double first = P::id(), head_w = P::id();
     if (w < nchunks) {
-        const int4 inf = carry_info[w];                       // three independent loads
-        head_w = carry_head[w];
-        const double tail_prev = w > 0 ? carry_tail[w - 1] : P::id();
+        const int4 inf = carry_load<COHERENT>(&carry_info[w]);                       // three independent loads
+        head_w = carry_load<COHERENT>(&carry_head[w]);
+        const double tail_prev = w > 0 ? carry_load<COHERENT>(&carry_tail[w - 1]) : P::id();
         c = inf.x;
         ts = inf.z;
         // a column ends in chunk w and it started in an earlier chunk
         need = inf.y != 0 && c < ncol && ts < w;
-        if (need) first = inf.w ? carry_head[ts] : (ts == w - 1 ? tail_prev : carry_tail[ts]);
+        if (need) first = inf.w ? carry_load<COHERENT>(&carry_head[ts]) : (ts == w - 1 ? tail_prev : carry_load<COHERENT>(&carry_tail[ts]));
     }
     const int span = w - ts;
     if (need && span <= 64) {
         double acc = first;
-        for (int t = ts + 1; t < w; ++t) acc = P::comb(acc, carry_head[t]);
+        for (int t = ts + 1; t < w; ++t) acc = P::comb(acc, carry_load<COHERENT>(&carry_head[t]));
         out[c] = P::finish(P::comb(acc, head_w), divisor);
     }
     // giant columns: whole wave per column, one after the other
@@ -901,7 +951,7 @@ __global__ __launch_bounds__(256) void colsums_fixup_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = t0 + 64 * u;
-                h[u] = (t <= wl) ? carry_head[t] : P::id();
+                h[u] = (t <= wl) ? carry_load<COHERENT>(&carry_head[t]) : P::id();
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = P::comb(acc, h[u]);
@@ -909,6 +959,28 @@ __global__ __launch_bounds__(256) void colsums_fixup_kernel(
         const double total = P::comb(readlane_f64(first, l), wave_allreduce<P>(acc));
         if (lane == l) out[c] = P::finish(total, divisor);
     }
+}
+
+template <bool MEANS, int OP = kOpSum>
+__global__ __launch_bounds__(256) void colsums_fixup_kernel(
+    int32_t ncol, int32_t nchunks, double* __restrict__ out, const double* __restrict__ carry_head,
+    const double* __restrict__ carry_tail, const int4* __restrict__ carry_info, double divisor,
+    const int32_t* __restrict__ run_if = nullptr) {
+    typedef Policy<MEANS, OP> P;
+    if (run_if != nullptr && *run_if == 0) return;
+    fixup_chunk<P, false>((int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(threadIdx.x & 63), ncol, nchunks, out, carry_head,
+                   carry_tail, carry_info, divisor);
+}
+
+// ticket words of the folded fix-up (one per launching stream: capi.hip hands them out); zero between launches
+constexpr int kFoldSlots = 64;
+__device__ uint32_t g_fold_tickets[kFoldSlots];
+hipError_t fold_ticket_address(int slot, uint32_t** out) {
+    void* base = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&base, HIP_SYMBOL(g_fold_tickets));
+    if (e != hipSuccess) return e;
+    *out = (uint32_t*)base + (slot < 0 ? 0 : slot % kFoldSlots);
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------
@@ -1030,7 +1102,7 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
                               double* d_out, const LaunchPlan& plan, void* d_workspace,
                               double divisor, bool means, hipStream_t stream, int op,
                               const int32_t* rows_i, const uint32_t* row_bitmap, int32_t bitmap_words,
-                              const int2* plan_rec, const int32_t* run_if) {
+                              const int2* plan_rec, const int32_t* run_if, uint32_t* fold_ticket) {
     if (ncol <= 0) return hipSuccess;
     if (op == kOpCount) {   // nnz per column: offsets only, x is not read
         hipLaunchKernelGGL(colsums_count_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, d_p, d_out, ncol);
@@ -1144,6 +1216,18 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
         RSP_LAUNCH_OP(kOpMax);
     } else if (op == kOpMin) {
         RSP_LAUNCH_OP(kOpMin);
+    } else
+    if (fold_ticket != nullptr && plan.short_pipeline && plan.variant == 0 && op == kOpSum) {
+        // one launch: the last workgroup to finish runs the fix-up (FOLD)
+        if (means)
+            hipLaunchKernelGGL((colsums_chunks_kernel<4, true, kLoadAux, kWavesPerWG, kOpSum, false, false, true>), grid, block, 0,
+                               stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out, carry_head, carry_tail, carry_info, divisor,
+                               rows_i, row_bitmap, bitmap_words, (const int2*)nullptr, (const int32_t*)nullptr, fold_ticket);
+        else
+            hipLaunchKernelGGL((colsums_chunks_kernel<4, false, kLoadAux, kWavesPerWG, kOpSum, false, false, true>), grid, block, 0,
+                               stream, d_x, d_p, ncol, nnz, cmap, plan.nchunks, d_out, carry_head, carry_tail, carry_info, divisor,
+                               rows_i, row_bitmap, bitmap_words, (const int2*)nullptr, (const int32_t*)nullptr, fold_ticket);
+        return hipGetLastError();
     } else
     switch (plan.variant) {   // 0 = production; the rest are A/B builds (rsp_set_experiment)
         case 1: RSP_LAUNCH_K(colsums_chunks_kernel, 16, kLoadAux); break;   // 16 rows in flight

@@ -464,6 +464,43 @@ def test_bit_stable_run_to_run(torch_cuda):
     capi.release_cached()
 
 
+def test_folded_fixup_gives_the_two_launch_bits(torch_cuda):
+    """rsp_debug_set("fold_fixup", 1): a plain call that is one round of waves runs its fix-up inside the main launch (the last
+    workgroup to finish).  Measured slower than the second launch and therefore off by default
+    (profiles/DEAD_ENDS.md) -- but it must stay RIGHT: identical bits on short, long, giant and empty columns, sums and means,
+    two streams, and the ticket word back at zero (a second call on the same stream works)."""
+    torch = torch_cuda
+    capi.set_auto_plan(False)
+    rng = np.random.default_rng(3)
+    mats = [np.minimum(rng.poisson(10, size=300_000), 64).astype(np.int64),                 # C2's shape
+            synth.zipf_counts(20_000, 3_000_000, seed=4, nrow=400_000),                    # giant + short
+            np.where(rng.random(50_000) < 0.1, rng.integers(1, 900, size=50_000), 0).astype(np.int64),
+            np.array([0, 0, 5_000_000, 0, 3], dtype=np.int64)]                             # one column over thousands of chunks
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    try:
+        for counts in mats:
+            p = synth.offsets_from_counts(counts)
+            x = synth.gen_values(int(p[-1]), seed=9, kind=0)
+            xt, pt = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
+            assert capi.plan_describe(len(x))["nchunks"] > 1
+            capi.debug_set("fold_fixup", 0)
+            want = capi.column_sums_device(xt, pt).cpu().numpy()
+            want_means = capi.column_sums_device(xt, pt, nrow_for_means=321).cpu().numpy()
+            assert_parity(want, x, p)
+            capi.debug_set("fold_fixup", 1)
+            for rnd in range(3):
+                for s_ in streams:
+                    with torch.cuda.stream(s_):
+                        got = capi.column_sums_device(xt, pt)
+                        got_means = capi.column_sums_device(xt, pt, nrow_for_means=321)
+                    s_.synchronize()
+                    assert got.cpu().numpy().tobytes() == want.tobytes(), (len(counts), rnd)
+                    assert got_means.cpu().numpy().tobytes() == want_means.tobytes()
+    finally:
+        capi.debug_set("fold_fixup", 0)
+        capi.set_auto_plan(True)
+
+
 def test_device_generator_matches_oracle_bits(torch_cuda):
     torch = torch_cuda
     for kind in (0, 1):
