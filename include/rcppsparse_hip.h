@@ -193,7 +193,10 @@ int rsp_csc_column_means(rsp_csc_t handle, double *means);
 int rsp_csc_dims(rsp_csc_t handle, int32_t *nrow, int32_t *ncol, int64_t *nnz);
 /* The upload inspects p[] once -- on a host thread beside the copies, or (65536 columns and more; round 5) on the
  * device behind the copy of p[], where it costs microseconds instead of milliseconds -- and freezes the result in the
- * handle: which form the
+ * handle.  The two inspectors select the same form: where the device-made lean image (sized before the offsets are
+ * seen) has no room for a matrix's densest chunk, the upload inspects that matrix again on the host (round 6), so a
+ * matrix of short columns gets the lean form -- every column bit-identical to the reference loop -- on either side of
+ * 65536 columns.  (rsp_mcsc_wrap_device, whose offsets never visit the host, keeps the device-made plan.)  Which form the
  * handle's column sums take -- 0 general kernels, 1 snapped, 2 lean, 3 columns (rsp_column_sums_plan_info).
  * The settings in force AT UPLOAD decide (RSP_LEAN, RSP_COLUMNS_FORM, the chunking knobs: rsp_debug_set);
  * changing them later does not touch existing handles.  rsp_csc_set_planned(h, 0) sends the handle's

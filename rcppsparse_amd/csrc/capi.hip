@@ -1683,6 +1683,23 @@ static int csc_upload(const double* x, const int32_t* i, const int32_t* p, int32
         rsp_column_sums_plan_destroy(planned);
         planned = nullptr;
     }
+    // The device-made lean image is sized BEFORE the offsets are seen (3 x the mean number of columns per chunk + 16, at
+    // least 126).  A matrix of short columns with one denser chunk does not fit it and would take the snapped / general
+    // kernels here -- within tolerance -- although the host inspector gives it the lean form and with it the reference's
+    // bits, as it does below 65536 columns.  With every column <= 64 entries `lean_bad` can only mean
+    // "more columns in a chunk than the image has room for" (no such column reaches a row past its chunk): then p[], which is
+    // in host memory right here, is inspected again by the host inspector, whose image has the room the matrix needs.
+    if (e == hipSuccess && device_inspect && planned && planned->known && !planned->lean && planned->dl.try_lean &&
+        planned->h_stats && !planned->h_stats->invalid && planned->h_stats->lean_bad &&
+        planned->h_stats->max_len <= rsp::kLeanMaxColumn && planned->h_stats->lean_widest <= rsp::kLeanMaxColumns) {
+        rsp_colsums_plan* by_host = nullptr;
+        if (plan_make(p, ncol, nnz, device, &by_host) == RSP_OK && by_host && by_host->lean) {
+            rsp_column_sums_plan_destroy(planned);
+            planned = by_host;
+        } else if (by_host) {
+            rsp_column_sums_plan_destroy(by_host);
+        }
+    }
     const double t_copied = ms_since();
     if (inspector_started) inspector.join();
     if (timing)

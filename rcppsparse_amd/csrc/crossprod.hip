@@ -1461,7 +1461,11 @@ hipError_t launch_crossprod_rows(const double* d_x, const int32_t* d_i, const in
         case NT / 2 - 2: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 - 2); break;                                 \
         case NT / 2 - 1: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 - 1); break;                                 \
         case NT / 2: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2); break;                                         \
-        default: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 + 1); break;                                         \
+        case NT / 2 + 1: RSP_XP_LAUNCH_N(NT, 8, 16, SPLIT, WIDE, 0, NT / 2 + 1); break;                                 \
+        /* a tile count this layout was not planned for (a change to tall_tiles without one here): REFUSE.  The kernel  \
+           returns without writing its partial sums when NAX does not fit the width, and the reduce behind it would     \
+           then hand out whatever the workspace held -- with RSP_OK */                                  \
+        default: return hipErrorInvalidValue;                                                                            \
     }
             const bool wide = nnz >= (1ll << 29);   // (byte offsets of x beyond 32 bits)
             int mode = 0;

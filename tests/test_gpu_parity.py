@@ -464,6 +464,26 @@ def test_bit_stable_run_to_run(torch_cuda):
     capi.release_cached()
 
 
+def test_handle_with_a_dense_chunk_gets_the_lean_form_on_both_sides_of_65536_columns(torch_cuda):
+    """handles of >= 65536 columns are inspected on the device, whose lean image is sized before the offsets
+    are seen (3 x the mean columns per chunk + 16); a matrix of short columns with ONE denser chunk used to fall to the
+    snapped / general kernels there (tolerance) while the same matrix below 65536 columns took the lean form (the reference's
+    bits).  The upload now inspects such a matrix again on the host: lean, bit-identical to the reference loop, either side."""
+    rng = np.random.default_rng(12)
+    for ncol in (60_000, 70_000):
+        counts = np.minimum(rng.poisson(20, size=ncol), 64).astype(np.int64)
+        counts[30_000:31_000] = 1                                          # a thousand one-entry columns: one crowded chunk
+        p = synth.offsets_from_counts(counts)
+        x = synth.gen_values(int(p[-1]), seed=13, kind=0)
+        h = capi.DeviceCSC(x, p, (100_000, ncol))
+        try:
+            assert h.column_form() == "lean", (ncol, h.column_form())
+            got = h.column_sums()
+        finally:
+            h.close()
+        assert got.tobytes() == oracle.column_sums(x, p).tobytes(), ncol
+
+
 def test_folded_fixup_gives_the_two_launch_bits(torch_cuda):
     """rsp_debug_set("fold_fixup", 1): a plain call that is one round of waves runs its fix-up inside the main launch (the last
     workgroup to finish).  Measured slower than the second launch and therefore off by default
