@@ -149,8 +149,9 @@ def test_bench_line_measures_its_own_ceiling_traffic_and_more_workloads(torch_cu
                                                      ("tiny", 3, 4_000_000, 40_000),
                                                      ("c3", 4, 1_000_000_000, 1_000_000)])
 def test_bench_n_ranks_share_the_gpu_with_real_hip_compute(torch_cuda, workload, world, nnz, ncol):
-    """`bench.py --gpus N --rendezvous gloo`: bench.py starts N ranks under torch.distributed.run
-    (fresh child processes; nothing here re-executes a process that has touched the GPU), every
+    """`bench.py --gpus N --rendezvous gloo`: bench.py starts the N ranks ITSELF as fresh child processes with the
+    environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: torchrun's own agent
+    would hold a seventh context on a pool that allows six; nothing here re-executes a process that has touched the GPU), every
     rank generates ITS column range of the matrix in HBM at shard.x0 and sums it through
     rsp_column_sums_device, the slices are gathered to rank 0 (as host copies over gloo: RCCL
     refuses two ranks on one device) and rank 0 checks EVERY column of the gathered result against
