@@ -142,10 +142,11 @@ GLOSSARY = {
               "the timed region: |gpu - ref| <= 1e-12 x sum|x| per column; empty columns exactly +0.0",
     "config.parallelism=threads": "ONE process, N shards through rsp_mcsc_column_sums (the resident multi-GPU handle: per shard a stream, "
                                   "an output, a plan; per handle one page-locked result vector and parked worker threads; nothing is "
-                                  "created per call).  `value` = K synchronous calls back to back, gather d2h (every shard copies its "
-                                  "slice over its own host link), result left in the page-locked vector; THREE such regions, the "
+                                  "created per call).  `value` = K synchronous calls back to back, the handle's default gather (config.gather: "
+                                  "blit = a copy kernel per slice with a device per shard, d2h = the runtime's copy command where "
+                                  "shards share a device; either way every slice over its own host link), result left in the page-locked vector; THREE such regions, the "
                                   "median one is `value` (config.regions_ms lists all three).  roofline.threads_<gather>_"
-                                  "<dest>_ms: ms per call of the other combinations -- gather d2h | stores | rccl (ncclCommInitAll, "
+                                  "<dest>_ms: ms per call of the other combinations -- gather d2h | blit | stores | rccl (ncclCommInitAll, "
                                   "grouped send / recv to shard 0's device, one D2H; needs a device per shard) | none (slices stay on "
                                   "the devices: launch + wait only); dest pinned (the handle's vector) | pageable (a malloc'ed vector: "
                                   "what an R NumericVector is).  threads_last_enqueue_us: host clock from a call's entry to the return "
@@ -1123,16 +1124,18 @@ def main_threads(args):
                 print(f"[threads] {gather}/{dest}: " + " ".join(f"{t * 1e6:.0f}" for t in per_call), file=sys.stderr, flush=True)
         return sorted(regions)[len(regions) // 2], regions, sorted(enq)[len(enq) // 2]
 
-    # `value`: gather d2h, result in the page-locked vector; three regions, the median one counts (one call in a few
+    # `value`: the handle's default gather (blit with a device per shard, d2h where shards share one), result in the
+    # page-locked vector; three regions, the median one counts (one call in a few
     # hundred stalls for milliseconds somewhere below the library -- the host runtime or the box's CPU quota --, and K = 20
     # calls of ~0.2 ms cannot average that away: the same protocol as the small single-GPU workloads)
-    ms_value, regions_ms, last_enq = run("d2h", "pinned", args.steps, args.warmup)
+    gather0 = h.config()["gather"]
+    ms_value, regions_ms, last_enq = run(gather0, "pinned", args.steps, args.warmup)
     got = np.array(pinned, copy=True)
     parity = parity_whole_matrix(got, p, args.kind)
     if not parity_ok(parity):
         raise SystemExit(f"parity check failed (threads, {args.workload}): {json.dumps(parity)}")
-    figures = {"d2h_pinned_ms": ms_value, "last_enqueue_us": last_enq}
-    combos = [("d2h", "pageable"), ("stores", "pinned"), ("none", "pinned")]
+    figures = {f"{gather0}_pinned_ms": ms_value, "last_enqueue_us": last_enq}
+    combos = [("blit" if gather0 == "d2h" else "d2h", "pinned"), (gather0, "pageable"), ("stores", "pinned"), ("none", "pinned")]
     if distinct:
         combos.append(("rccl", "pinned"))
     for gather, dest in combos:
@@ -1148,12 +1151,12 @@ def main_threads(args):
         rccl = capi.rccl_info()
     except Exception as e:   # noqa: BLE001
         rccl = {"error": str(e)[:80]}
-    h.set_gather("d2h")
+    h.set_gather(gather0)
     # the other launch mode by the protocol of `value` (the default comes from the shard count)
     other = "serial" if launch == "workers" else "workers"
     if G > 1:
         h.set_launch(other)
-        figures[f"{other}_d2h_pinned_ms"], _, figures[f"{other}_last_enqueue_us"] = run("d2h", "pinned", args.steps, args.warmup)
+        figures[f"{other}_{gather0}_pinned_ms"], _, figures[f"{other}_last_enqueue_us"] = run(gather0, "pinned", args.steps, args.warmup)
         h.set_launch(launch)
     h.close()
 
@@ -1166,7 +1169,7 @@ def main_threads(args):
     for k, v in figures.items():
         roof["threads_" + k] = v
     cfg = {"workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, values kind {args.kind}, seed {SEED}",
-           "parallelism": "threads", "devices": ndev, "devices_distinct": distinct, "launch": launch, "gather": "d2h",
+           "parallelism": "threads", "devices": ndev, "devices_distinct": distinct, "launch": launch, "gather": gather0,
            "result": "page-locked host vector", "partition": args.partition, "regions_ms": regions_ms,
            "shard_imbalance_max_over_mean": sharded.imbalance(p, shards[0].bounds),
            "rccl_version": rccl.get("version"), "rccl_library": rccl.get("library"),
@@ -1182,9 +1185,10 @@ def main_threads(args):
     print(json.dumps(line), flush=True)
 
 
-THREADS_CHILD_KEYS = ("threads_d2h_pinned_ms", "threads_d2h_pageable_ms", "threads_stores_pinned_ms", "threads_none_pinned_ms",
-                      "threads_rccl_pinned_ms", "threads_last_enqueue_us", "threads_serial_d2h_pinned_ms",
-                      "threads_workers_d2h_pinned_ms", "threads_rccl_pinned_error", "call_minus_slowest_kernel_us",
+THREADS_CHILD_KEYS = ("threads_d2h_pinned_ms", "threads_blit_pinned_ms", "threads_d2h_pageable_ms", "threads_blit_pageable_ms",
+                      "threads_stores_pinned_ms", "threads_none_pinned_ms", "threads_rccl_pinned_ms", "threads_last_enqueue_us",
+                      "threads_serial_d2h_pinned_ms", "threads_workers_d2h_pinned_ms", "threads_serial_blit_pinned_ms",
+                      "threads_workers_blit_pinned_ms", "threads_rccl_pinned_error", "call_minus_slowest_kernel_us",
                       "kernel_ms_max_over_shards")
 
 
@@ -1216,7 +1220,7 @@ def threads_child_figures(args, timeout_s=300):
     except (IndexError, ValueError):
         return {"threads_error": "the child printed no line"}
     res = {"threads_value": line["value"], "threads_ms_per_step": line["ms_per_step"],
-           "threads_launch": line["config"].get("launch"), "threads_devices_distinct": line["config"].get("devices_distinct"),
+           "threads_launch": line["config"].get("launch"), "threads_gather": line["config"].get("gather"), "threads_devices_distinct": line["config"].get("devices_distinct"),
            "threads_parity_err": line["parity"]["max_abs_err_over_l1"], "threads_seconds": time.perf_counter() - t0}
     for k in THREADS_CHILD_KEYS:
         if k in line["roofline"]:

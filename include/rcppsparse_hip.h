@@ -109,8 +109,12 @@ int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol,
  *                               calls (futex; it spins for RSP_MCSC_SPIN_US microseconds, default 50, after a call so
  *                               that calls in a loop find it awake): enqueues, waits and the copies into `sums` overlap.
  *                               Default from 3 shards on (RSP_MCSC_LAUNCH=serial|workers in the environment overrides).
- *   gather  RSP_GATHER_D2H      (default) every shard copies its slice over ITS device's host link into the
- *                               page-locked vector;
+ *   gather  RSP_GATHER_D2H      every shard copies its slice over ITS device's host link into the page-locked vector
+ *                               (hipMemcpyAsync; the default where shards share a device);
+ *           RSP_GATHER_BLIT     the same trip by a copy kernel of the library behind the shard's kernels: it starts a few
+ *                               microseconds after them, where the runtime's copy command needs ~20 us before its first
+ *                               byte moves (1 MB slice: 19 against 36 us).  The default with a device per shard
+ *                               (RSP_MCSC_GATHER=d2h|blit in the environment overrides);
  *           RSP_GATHER_RCCL     the slices travel to shard 0's device in one group of ncclSend / ncclRecv over xGMI
  *                               (communicators from ncclCommInitAll, made when the mode is first selected; one DEVICE
  *                               per shard, RCCL refuses duplicates), then ONE copy of the whole vector to the host;
@@ -123,6 +127,8 @@ typedef struct rsp_mcsc *rsp_mcsc_t;
 #define RSP_GATHER_D2H     0
 #define RSP_GATHER_RCCL    1
 #define RSP_GATHER_STORES  2
+#define RSP_GATHER_BLIT    4   /* a copy KERNEL of the library writes the slice into the page-locked vector behind the shard's
+                                  kernels (instead of the runtime's copy command, which needs ~20 us before its first byte moves) */
 #define RSP_GATHER_NONE    3   /* MEASUREMENT ONLY: the slices stay on the devices, `sums` is not written; the call
                                   returns when every shard's stream has drained (launch + wait cost without a transfer) */
 #define RSP_LAUNCH_SERIAL  0

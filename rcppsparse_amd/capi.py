@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = (
     "rsp_column_sums_device_settle",
     "rsp_shared_host_open", "rsp_shared_host_close", "rsp_copy_to_host_async", "rsp_device_can_access_peer",
 )
-GATHER_MODES = {"d2h": 0, "rccl": 1, "stores": 2, "none": 3}
+GATHER_MODES = {"d2h": 0, "rccl": 1, "stores": 2, "none": 3, "blit": 4}
 LAUNCH_MODES = {"serial": 0, "workers": 1}
 
 

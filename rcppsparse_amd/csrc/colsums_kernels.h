@@ -103,6 +103,8 @@ hipError_t launch_column_sums(const double* d_x, const int32_t* d_p, int32_t nco
 // fold_ticket: a zeroed device word owned by the launching stream (fold_ticket_address): a plain column-sum call that is one
 // round of waves (plan.short_pipeline) then runs its fix-up inside the main launch -- ONE kernel -- with identical bits
 hipError_t fold_ticket_address(int slot, uint32_t** out);
+// n doubles from HBM into page-locked host memory (its device address) by a kernel, enqueued on `stream`
+hipError_t launch_copy_f64(const double* d_src, double* dst, int64_t n, hipStream_t stream);
 
 // rsp_column_sums_device without the entry's own planning (capi.hip): the library's one-shot paths use it
 int column_sums_general(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,

@@ -972,6 +972,28 @@ __global__ __launch_bounds__(256) void colsums_fixup_kernel(
                    carry_tail, carry_info, divisor);
 }
 
+// n doubles from HBM into (page-locked, device-visible) host memory by a kernel: 16 bytes per lane, a wavefront writes 1 KiB of
+// consecutive bytes per instruction, so the host link sees full-size writes.  The single-process multi-GPU call uses it for
+// a shard's slice (multigpu.cpp RSP_GATHER_BLIT): behind the shard's kernels on the same stream it starts a few
+// microseconds after them, where the runtime's copy command needs ~20 us before its first byte moves.
+__global__ __launch_bounds__(256) void copy_f64_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+    const int64_t pairs = n >> 1;
+    const d2* s2 = reinterpret_cast<const d2*>(src);
+    d2* t2 = reinterpret_cast<d2*>(dst);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * blockDim.x) t2[k] = s2[k];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+hipError_t launch_copy_f64(const double* d_src, double* dst, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if ((((uintptr_t)d_src | (uintptr_t)dst) & 15) != 0) {   // (a slice that starts on an odd column: the copy command does it)
+        return hipMemcpyAsync(dst, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, stream);
+    }
+    const int64_t want = (n / 2 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
+    hipLaunchKernelGGL(copy_f64_kernel, dim3(blocks), dim3(256), 0, stream, d_src, dst, n);
+    return hipGetLastError();
+}
+
 // ticket words of the folded fix-up (one per launching stream: capi.hip hands them out); zero between launches
 constexpr int kFoldSlots = 64;
 __device__ uint32_t g_fold_tickets[kFoldSlots];

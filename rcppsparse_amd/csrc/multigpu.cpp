@@ -213,6 +213,7 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
 //                     after a call (RSP_MCSC_SPIN_US, default 50) so that calls in a loop find it awake, then sleeps
 //                     on a futex: an idle R session burns nothing.
 //   gather  D2H     : hipMemcpyAsync of every slice over its own device's host link into the page-locked vector;
+//           BLIT    : the same trip by a copy kernel of the library behind the shard's kernels (default with a device per shard);
 //           RCCL    : grouped ncclSend / ncclRecv of the slices to shard 0's device over xGMI (the collective
 //                     BASELINE.json's north_star names), then one D2H of the whole vector;
 //           STORES  : the kernels take the page-locked vector (+ the shard's first column) as their output: no copy
@@ -400,6 +401,10 @@ void shard_send(ColumnCall* c, int k) noexcept {
         const hipError_t e = hipMemcpyAsync(h->h_result + c0, s.view.d_out, (size_t)nc * 8, hipMemcpyDeviceToHost, s.view.stream);
         if (e != hipSuccess) shard_fail(s, RSP_ERR_HIP, "D2H of the slice", hipGetErrorString(e));
     }
+    if (nc > 0 && s.status == RSP_OK && h->gather == RSP_GATHER_BLIT) {
+        const hipError_t e = rsp::launch_copy_f64(s.view.d_out, h->d_result_view + c0, nc, s.view.stream);
+        if (e != hipSuccess) shard_fail(s, RSP_ERR_HIP, "copy kernel of the slice", hipGetErrorString(e));
+    }
     if (nc > 0) {
         const hipError_t e = hipEventRecord(s.done, s.view.stream);
         if (e != hipSuccess) shard_fail(s, RSP_ERR_HIP, "hipEventRecord", hipGetErrorString(e));
@@ -525,7 +530,18 @@ int mcsc_prepare_on_devices(rsp_mcsc* h) {
     void* dv = nullptr;
     if (hipHostGetDevicePointer(&dv, h->h_result, 0) == hipSuccess) h->d_result_view = (double*)dv;
     else (void)hipGetLastError();
-    h->gather = RSP_GATHER_D2H;
+    // default gather: with a DEVICE per shard a copy kernel behind the shard's kernels brings the slice home (1 MB: 19 us
+    // against 36 us for the runtime's copy command, profiles/r06_mcsc_overhead.md section 4); shards that share a device
+    // share its CUs and its one host link, where the copy command is no worse
+    bool distinct = h->d_result_view != nullptr;
+    for (size_t a = 0; a < G && distinct; ++a)
+        for (size_t b = a + 1; b < G; ++b)
+            if (h->devices[a] == h->devices[b]) distinct = false;
+    if (const char* g = getenv("RSP_MCSC_GATHER")) {
+        if (!strcmp(g, "d2h")) distinct = false;
+        else if (!strcmp(g, "blit") && h->d_result_view) distinct = true;
+    }
+    h->gather = distinct ? RSP_GATHER_BLIT : RSP_GATHER_D2H;
     h->launch = default_launch((int)G);
     return RSP_OK;
 }
@@ -732,7 +748,7 @@ int rsp_mcsc_set_gather(rsp_mcsc_t h, int mode) {
     if (!h) return fail(RSP_ERR_BAD_ARG, "null handle");
     if (mode == RSP_GATHER_RCCL) {
         if (int rc = mcsc_make_rccl(h)) return rc;
-    } else if (mode == RSP_GATHER_STORES) {
+    } else if (mode == RSP_GATHER_STORES || mode == RSP_GATHER_BLIT) {
         if (!h->d_result_view) return fail(RSP_ERR_HIP, "the page-locked result vector has no device address on this system");
     } else if (mode != RSP_GATHER_D2H && mode != RSP_GATHER_NONE) {
         return fail(RSP_ERR_BAD_ARG, "unknown gather mode %d", mode);

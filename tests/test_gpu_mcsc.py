@@ -59,10 +59,11 @@ def test_every_launch_and_gather_gives_the_per_shard_bits(torch_cuda, G):
     h = capi.MultiDeviceCSC(x, p, (nrow, ncol), devices=[0] * G)
     try:
         cfg = h.config()
-        assert cfg["gather"] == "d2h" and cfg["launch"] == ("workers" if G >= 3 else "serial")
+        # (a device per shard -- here: the single shard -- gets the copy kernel, shards sharing a device the copy command)
+        assert cfg["gather"] == ("blit" if G == 1 else "d2h") and cfg["launch"] == ("workers" if G >= 3 else "serial")
         seen = {}
         for launch in ("serial", "workers"):
-            for gather in ("d2h", "stores"):
+            for gather in ("d2h", "blit", "stores"):
                 h.set_launch(launch)
                 h.set_gather(gather)
                 got = h.column_sums()
@@ -98,7 +99,7 @@ def test_rccl_gather_over_comm_init_all_one_device(torch_cuda):
         got = h.column_sums()
         assert got.tobytes() == want.tobytes()
         assert h.column_means().tobytes() == (want / nrow).tobytes()
-        h.set_gather("d2h")
+        h.set_gather("blit")
         assert h.column_sums().tobytes() == want.tobytes()
     finally:
         h.close()
@@ -154,7 +155,7 @@ def test_empty_shards_and_empty_matrix(torch_cuda):
     for launch in ("serial", "workers"):
         h = capi.MultiDeviceCSC(x, p, (5, 4), devices=[0] * 6)
         h.set_launch(launch)
-        for gather in ("d2h", "stores"):
+        for gather in ("d2h", "blit", "stores"):
             h.set_gather(gather)
             assert h.column_sums().tolist() == [0.0, 7.0, 0.0, 0.0]
         h.close()

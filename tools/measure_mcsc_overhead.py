@@ -68,7 +68,7 @@ def main():
         pageable = np.empty(ncol, dtype=np.float64)
         want = None
         for launch in (("serial",) if G == 1 else ("serial", "workers")):
-            for gather in ("none", "d2h", "stores"):
+            for gather in ("none", "d2h", "blit", "stores"):
                 h.set_launch(launch)
                 h.set_gather(gather)
                 for dest in (("nocopy",) if gather == "none" else ("pageable", "nocopy")):
