@@ -579,7 +579,8 @@ int rsp_shared_result_close(void *d_ptr, int owner);
  * The other comparator ("per-GPU D2H into disjoint slices of one pinned buffer"): ONE vector in POSIX
  * shared memory, mapped by every rank process and page-locked there (hipHostRegister), so that each rank's copy engine
  * writes the rank's slice straight into memory the root process reads -- over the rank's own host link, no xGMI hop, no
- * RCCL.  Per call: the rank's kernels, rsp_copy_to_host_async of its slice behind them, a wait for the own stream, one
+ * RCCL.  Per call: the rank's kernels, rsp_copy_to_host_async of its slice behind them (a copy kernel of the library where
+ * the device can address the destination, the runtime's copy command otherwise), a wait for the own stream, one
  * host barrier; the root then holds the whole vector in HOST memory.  name: "/something", the same on every rank; the
  * creating rank passes create != 0, the others wait up to 30 s for it.  rsp_shared_host_close(ptr, bytes, name) also
  * unlinks the name (the creator), NULL just unmaps.

@@ -1309,7 +1309,16 @@ int rsp_shared_host_close(void* host_ptr, size_t bytes, const char* unlink_name)
 int rsp_copy_to_host_async(const double* d_src, double* host_dst, int64_t n, void* stream) {
     if (n < 0 || (n > 0 && (!d_src || !host_dst))) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_copy_to_host_async");
     if (n == 0) return RSP_OK;
-    const hipError_t e = hipMemcpyAsync(host_dst, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    // page-locked memory the device can address: the copy KERNEL (it starts a few microseconds behind the kernels in front
+    // of it; the runtime's copy command needs ~20 us before its first byte moves -- profiles/r06_mcsc_overhead.md section 3)
+    void* dv = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dv, host_dst, 0);
+    if (e == hipSuccess && dv) {
+        e = rsp::launch_copy_f64(d_src, (double*)dv, n, (hipStream_t)stream);
+    } else {
+        (void)hipGetLastError();
+        e = hipMemcpyAsync(host_dst, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail(RSP_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
     return RSP_OK;
 }
