@@ -236,10 +236,12 @@ int rsp_csc_free(rsp_csc_t handle);
  * The caller promises NOTHING about d_p between calls: the kernels of this path check every column's offsets against
  * the p[] of the call they run in, sum a column whose offsets have changed straight from x (clamped to [0, nnz]), and
  * make the library retire that plan and inspect again -- never a wrong sum, only a slower call.
- * NOTHING IN THESE ENTRIES EVER WAITS FOR THE DEVICE.  A retired plan's image is freed when an event recorded on every
- * stream it was launched on has completed (looked at only while something is retired); a key keeps at most 2 retired
- * images (beyond that it stays on the general kernels until one is freed), so HBM use is bounded whatever the caller
- * does with d_p.  Up to 16 keys are remembered per process; keys that never got a plan make room first, a planned key
+ * NOTHING IN THESE ENTRIES WAITS FOR THE DEVICE.  A retired plan's image is given up when an event recorded on every
+ * stream it was launched on has completed (looked at only while something is retired) -- given up, not freed: on this
+ * runtime hipFree and hipHostFree drain every stream of the device first, so the allocation goes to a pool of at most 8
+ * and the next plan that fits takes it (a re-inspection of the same key always fits; only a 9th dead image of a size
+ * nobody asks for again is really freed, and that free waits).  A key keeps at most 2 retired images (beyond that it
+ * stays on the general kernels until one is given up), so HBM use is bounded whatever the caller does with d_p.  Up to 16 keys are remembered per process; keys that never got a plan make room first, a planned key
  * only after 64 calls without a use (its plan is retired, not waited for).  One plan is launched on up to 6 different
  * streams; calls on further streams take the general kernels.  rsp_release_cached() forgets everything (it DOES wait).
  * BIT STABILITY: every form is deterministic, but the general kernels and a planned form agree within
@@ -634,8 +636,9 @@ int rsp_gen_row_indices_device(int32_t *d_i, const int32_t *d_p, int32_t nrow,
  *   "fold_fixup"      plain calls that are one round of waves: 1 = the fix-up runs inside the main launch (the last workgroup to
  *                     finish does it), 0 (default) = as a second launch.  Same bits; the folded form measured SLOWER (BASELINE
  *                     config 2: 37.0 against 22.5 us, profiles/DEAD_ENDS.md) and exists for that A/B
- *   read-only (rsp_debug_get): "auto_plans_made" / "auto_plans_freed" -- plans those entries have made / freed since the
- *                     process started; "auto_plans_retired" -- retired images still waiting for their events
+ *   read-only (rsp_debug_get): "auto_plans_made" / "auto_plans_freed" -- plans those entries have made / given up since the
+ *                     process started; "auto_plans_retired" -- retired images still waiting for their events;
+ *                     "auto_plans_recycled" -- plans that took a recycled allocation instead of a new one
  * An unknown key is RSP_ERR_BAD_ARG.  rsp_debug_get reads the value in force (environment and defaults resolved).
  * Threads: the knobs are atomics -- setting one while another thread is inside a call is safe and takes effect for
  * calls (plans, handles) that start afterwards; two libraries' worth of callers in one process share them, which is

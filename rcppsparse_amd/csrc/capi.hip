@@ -411,6 +411,7 @@ struct rsp_colsums_plan {
     // kernels, afterwards the form they select.  d_rec / d_lean_hdr then point into d_mem.
     bool device_built, known;
     void* d_mem;
+    size_t d_mem_bytes;      // capacity of d_mem (a recycled allocation may be larger than dl.bytes)
     rsp::DeviceInspectLayout dl;
     rsp::PlanStats* h_stats;
     hipEvent_t ev_begin, ev_end;
@@ -533,7 +534,8 @@ int rsp_debug_get(const char* key, int* value) {
     else if (k == "fold_fixup") *value = fold_fixup_setting();
     else if (k == "auto_plans_made") *value = auto_counter(0);       // read-only: plans the plan-free entries have made ...
     else if (k == "auto_plans_freed") *value = auto_counter(1);      // ... freed again ...
-    else if (k == "auto_plans_retired") *value = auto_counter(2);    // ... and retired images waiting for their events right now
+    else if (k == "auto_plans_retired") *value = auto_counter(2);    // ... retired images waiting for their events right now ...
+    else if (k == "auto_plans_recycled") *value = auto_counter(3);   // ... and plans that took a recycled allocation instead of a new one
     else return fail(RSP_ERR_BAD_ARG, "unknown knob '%s'", key);
     return RSP_OK;
 }
@@ -807,8 +809,19 @@ static int plan_poll(rsp_colsums_plan* pl, hipStream_t stream, bool block) {
     return RSP_OK;
 }
 
-int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t nnz, void* stream,
-                                       rsp_colsums_plan_t* plan) {
+// What a device-made plan holds of the runtime: freeing any of it WAITS FOR THE DEVICE on this runtime (hipFree,
+// hipHostFree and hipFreeAsync of a hipMalloc'ed block all drain every stream first: 21 ms behind 21 ms of queued
+// work, tools/microbench notes in profiles/r06_README.md), so the plan-free entries never free -- they recycle.
+struct PlanResources {
+    int device = -1;
+    void* d_mem = nullptr;
+    size_t d_mem_bytes = 0;
+    rsp::PlanStats* h_stats = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+static int plan_create_device_impl(const int32_t* d_p, int32_t ncol, int64_t nnz, hipStream_t s, PlanResources* reuse,
+                                   rsp_colsums_plan_t* plan) {
     if (!plan) return fail(RSP_ERR_BAD_ARG, "plan is null");
     *plan = nullptr;
     if (int rc = check_sizes(ncol, nnz)) return rc;
@@ -829,11 +842,22 @@ int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t
     pl->lp = make_plan(nnz, true);
     pl->device_built = true;
     pl->dl = device_plan_layout(ncol, nnz, pl->lp);
-    hipError_t e = hipMalloc(&pl->d_mem, pl->dl.bytes);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&pl->h_stats, sizeof(rsp::PlanStats), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreate(&pl->ev_begin);
-    if (e == hipSuccess) e = hipEventCreate(&pl->ev_end);
-    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (reuse && reuse->device == device && reuse->d_mem && reuse->d_mem_bytes >= pl->dl.bytes && reuse->h_stats &&
+        reuse->ev_begin && reuse->ev_end) {
+        pl->d_mem = reuse->d_mem;
+        pl->d_mem_bytes = reuse->d_mem_bytes;
+        pl->h_stats = reuse->h_stats;
+        pl->ev_begin = reuse->ev_begin;
+        pl->ev_end = reuse->ev_end;
+        *reuse = PlanResources();   // (taken)
+    } else {
+        e = hipMalloc(&pl->d_mem, pl->dl.bytes);
+        if (e == hipSuccess) pl->d_mem_bytes = pl->dl.bytes;
+        if (e == hipSuccess) e = hipHostMalloc((void**)&pl->h_stats, sizeof(rsp::PlanStats), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreate(&pl->ev_begin);
+        if (e == hipSuccess) e = hipEventCreate(&pl->ev_end);
+    }
     if (e == hipSuccess) pl->h_stats->ready = 0;
     if (e == hipSuccess) e = hipEventRecord(pl->ev_begin, s);
     // (the last kernel writes the statistics straight into the page-locked host record: no copy, no memset)
@@ -849,6 +873,39 @@ int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t
     pl->inspect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *plan = pl;
     return RSP_OK;
+}
+
+int rsp_column_sums_plan_create_device(const int32_t* d_p, int32_t ncol, int64_t nnz, void* stream,
+                                       rsp_colsums_plan_t* plan) {
+    return plan_create_device_impl(d_p, ncol, nnz, (hipStream_t)stream, nullptr, plan);
+}
+
+// takes a device-made plan apart WITHOUT freeing anything of the runtime's: what it held comes back for the next plan
+static PlanResources plan_strip(rsp_colsums_plan* pl) {
+    PlanResources r;
+    if (pl->device_built) {
+        r.device = pl->device;
+        r.d_mem = pl->d_mem;
+        r.d_mem_bytes = pl->d_mem_bytes;
+        r.h_stats = pl->h_stats;
+        r.ev_begin = pl->ev_begin;
+        r.ev_end = pl->ev_end;
+        pl->d_mem = nullptr;
+        pl->h_stats = nullptr;
+        pl->ev_begin = pl->ev_end = nullptr;
+    }
+    delete pl;
+    return r;
+}
+
+static void plan_resources_free(PlanResources& r) {   // WAITS for the device (rsp_release_cached only, and a pool that overflows)
+    if (r.device < 0) return;
+    DeviceGuard on(r.device);
+    if (r.d_mem) (void)hipFree(r.d_mem);
+    if (r.h_stats) (void)hipHostFree(r.h_stats);
+    if (r.ev_begin) (void)hipEventDestroy(r.ev_begin);
+    if (r.ev_end) (void)hipEventDestroy(r.ev_end);
+    r = PlanResources();
 }
 
 int rsp_column_sums_plan_ready(rsp_colsums_plan_t plan) {
@@ -989,6 +1046,13 @@ std::vector<AutoEntry*> g_auto;            // (pointers: an entry's address surv
 std::vector<AutoPlan*> g_auto_retired;
 uint64_t g_auto_tick = 0;
 std::atomic<int> g_auto_made{0}, g_auto_freed{0};   // plans made / freed since the process started (rsp_debug_get: soak runs)
+std::atomic<int> g_auto_recycled{0};                // ... of the made ones, how many took a recycled allocation
+// what freed plans held of the runtime, waiting for the next plan that fits (same device, at least as many bytes): a
+// re-inspection of the same key always fits.  Bounded: kAutoPoolMax sets; a further one replaces the oldest, which IS freed
+// there and then (the one place where a call of these entries can wait for the device; it takes more than kAutoPoolMax
+// dead images of sizes nobody asks for again)
+constexpr size_t kAutoPoolMax = 8;
+std::vector<PlanResources> g_plan_pool;
 
 // page-locked stale words: 4 bytes each, handed out from whole pages that are never unmapped before
 // rsp_release_cached (a word goes back to the free list only when its plan is freed, i.e. when no launch can write it)
@@ -1028,10 +1092,27 @@ int auto_plan_setting() {
     return v;
 }
 
-// frees a plan nothing can read any more (caller holds g_auto_mu)
-void auto_plan_free(AutoPlan* ap) {
+// a plan nothing can read any more (caller holds g_auto_mu): its allocations go to the pool, NOTHING is freed (freeing
+// device or page-locked memory waits for every stream of the device on this runtime)
+void auto_plan_free(AutoPlan* ap, bool really_free = false) {
     DeviceGuard on(ap->device);
-    if (ap->plan) rsp_column_sums_plan_destroy(ap->plan);
+    if (ap->plan) {
+        PlanResources r = plan_strip(ap->plan);
+        ap->plan = nullptr;
+        if (really_free) {
+            plan_resources_free(r);
+        } else if (r.device >= 0) {
+            try {
+                if (g_plan_pool.size() >= kAutoPoolMax) {
+                    plan_resources_free(g_plan_pool.front());
+                    g_plan_pool.erase(g_plan_pool.begin());
+                }
+                g_plan_pool.push_back(r);
+            } catch (...) {
+                plan_resources_free(r);
+            }
+        }
+    }
     for (int k = 0; k < ap->nfences; ++k) (void)hipEventDestroy(ap->fences[k]);
     if (ap->h_stale) {
         try {
@@ -1100,6 +1181,7 @@ void auto_collect(int device, hipStream_t stream) {   // caller holds g_auto_mu;
 int auto_counter(int which) {
     if (which == 0) return g_auto_made.load(std::memory_order_relaxed);
     if (which == 1) return g_auto_freed.load(std::memory_order_relaxed);
+    if (which == 3) return g_auto_recycled.load(std::memory_order_relaxed);
     std::lock_guard<std::mutex> lock(g_auto_mu);
     return (int)g_auto_retired.size();
 }
@@ -1121,13 +1203,15 @@ void auto_release_all() {   // rsp_release_cached: the one place that waits for 
     for (AutoEntry* e : g_auto) {
         if (e->cur) {
             e->cur->owner = nullptr;
-            auto_plan_free(e->cur);
+            auto_plan_free(e->cur, true);
         }
     }
     for (AutoPlan* ap : g_auto_retired) {
         ap->owner = nullptr;
-        auto_plan_free(ap);
+        auto_plan_free(ap, true);
     }
+    for (PlanResources& r : g_plan_pool) plan_resources_free(r);
+    g_plan_pool.clear();
     for (AutoEntry* e : g_auto) delete e;
     g_auto.clear();
     g_auto_retired.clear();
@@ -1195,11 +1279,42 @@ static AutoPlan* auto_make_plan(int device, const int32_t* d_p, int32_t ncol, in
     if (!ap) return nullptr;
     ap->device = device;
     ap->h_stale = h_stale;
-    if (rsp_column_sums_plan_create_device(d_p, ncol, nnz, stream, &ap->plan) != RSP_OK) {
+    // a recycled allocation that fits (the smallest such), taken out of the pool under the lock
+    PlanResources reuse;
+    {
+        const size_t need = device_plan_layout(ncol, nnz, make_plan(nnz, true)).bytes;
+        std::lock_guard<std::mutex> lock(g_auto_mu);
+        size_t best = g_plan_pool.size();
+        for (size_t k = 0; k < g_plan_pool.size(); ++k)
+            if (g_plan_pool[k].device == device && g_plan_pool[k].d_mem_bytes >= need &&
+                (best == g_plan_pool.size() || g_plan_pool[k].d_mem_bytes < g_plan_pool[best].d_mem_bytes))
+                best = k;
+        if (best < g_plan_pool.size()) {
+            reuse = g_plan_pool[best];
+            g_plan_pool.erase(g_plan_pool.begin() + (long)best);
+        }
+    }
+    const bool recycled = reuse.device >= 0;
+    if (plan_create_device_impl(d_p, ncol, nnz, stream, recycled ? &reuse : nullptr, &ap->plan) != RSP_OK) {
+        if (reuse.device >= 0) {   // (not taken after all: back into the pool)
+            std::lock_guard<std::mutex> lock(g_auto_mu);
+            try {
+                g_plan_pool.push_back(reuse);
+            } catch (...) {
+            }
+        }
         delete ap;
         return nullptr;
     }
+    if (reuse.device >= 0) {   // (offered but not used -- cannot happen after the fit test above; kept safe)
+        std::lock_guard<std::mutex> lock(g_auto_mu);
+        try {
+            g_plan_pool.push_back(reuse);
+        } catch (...) {
+        }
+    }
     g_auto_made.fetch_add(1, std::memory_order_relaxed);
+    if (recycled) g_auto_recycled.fetch_add(1, std::memory_order_relaxed);
     return ap;
 }
 

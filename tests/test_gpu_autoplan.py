@@ -555,7 +555,30 @@ def test_rewriting_the_offsets_in_place_keeps_hbm_bounded_and_the_key_planned(to
     check(out.cpu().numpy(), x, pa, exact=True)
     assert capi.debug_get("auto_plans_made") - made0 >= 300               # (the key really was re-planned all along)
     assert capi.debug_get("auto_plans_retired") <= 2
-    del image
+    assert capi.debug_get("auto_plans_recycled") >= 290                   # ... out of recycled allocations: nothing was freed
+    # and none of it waits for the device: freeing device or page-locked memory drains EVERY stream on this runtime (21 ms
+    # behind 21 ms of queued work), so retired plans' allocations are recycled, never freed, inside a call.  Two more
+    # rewrite cycles with a slow kernel queued on another stream: it is still running when the cycles' calls have returned.
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        big.add_(1.0)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            big.add_(1.0)
+        done = torch.cuda.Event()
+        done.record(side)
+    for r in range(2):
+        pt.copy_(qb if r % 2 == 0 else qa)
+        torch.cuda.current_stream().synchronize()                          # (the caller waits for ITS stream only)
+        for _ in range(70):
+            capi.column_sums_device(xt, pt, out, ws)
+        torch.cuda.current_stream().synchronize()
+    assert not done.query(), "a call waited for the device (something was freed inside it)"
+    torch.cuda.synchronize()
+    check(out.cpu().numpy(), x, pa, exact=None)
+    del image, big
 
 
 def test_a_deep_queue_behind_one_in_place_update_costs_one_strike_not_the_key(torch_auto):

@@ -129,7 +129,7 @@ def rewrites(n_rewrites, calls_between=70, deep_queue=False):
     torch.cuda.synchronize()
     capi.column_sums_device(xt, pt, out, ws)          # (a call collects what has been retired)
     print(json.dumps({"rewrites": n_rewrites, "deep_queue": deep_queue, "plans_made": capi.debug_get("auto_plans_made"),
-                      "plans_freed": capi.debug_get("auto_plans_freed"), "plans_retired_now": capi.debug_get("auto_plans_retired"), "calls_between": calls_between, "calls": n_rewrites * calls_between,
+                      "plans_freed": capi.debug_get("auto_plans_freed"), "plans_from_recycled_allocations": capi.debug_get("auto_plans_recycled"), "plans_retired_now": capi.debug_get("auto_plans_retired"), "calls_between": calls_between, "calls": n_rewrites * calls_between,
                       "seconds": round(time.time() - t0, 1), "image_bytes": int(image), "free_at_start": int(free0),
                       "lowest_free_seen": int(low), "most_extra_bytes_held": int(free0 - low), "form_at_the_end": form,
                       "mismatches": 0}))
