@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "librcppsparse_hip.so")
 HOST_SEAM_PATH = os.path.join(_HERE, "librcppsparse_host.so")
-_SOURCES = ["colsums_kernels.hip", "colsums_rowslices.hip", "inspect_device.hip", "scan.hip", "colsums_kernels.h", "inspect.hpp", "rowsums.hip", "crossprod.hip", "capi.hip", "multigpu.cpp", "Makefile",
+_SOURCES = ["colsums_kernels.hip", "colsums_rowslices.hip", "inspect_device.hip", "scan.hip", "colsums_kernels.h", "inspect.hpp", "shard_workers.hpp", "rowsums.hip", "crossprod.hip", "capi.hip", "multigpu.cpp", "Makefile",
             os.path.join("..", "..", "include", "rcppsparse_hip.h")]
 
 
