@@ -428,7 +428,8 @@ int rsp_debug_read_ceiling_device(const double *d_x, int64_t nnz, double *d_sink
  * first regrouped by block of 16384 rows in ONE partition pass (up to 1.36e7 rows), by
  * coarse block of 2 / 4 / 8 such blocks (up to 1.09e8 rows; every row block then picks
  * its entries out of its coarse block's), or in two passes (more rows still), with a
- * workspace of 12 B/nnz (two passes: 24 B/nnz; up to 6 % more where the regrouped copy
+ * workspace of 10 B/nnz where the row blocks themselves are the regrouping's buckets (up to 1.36e7 rows: the copy keeps a
+ * row as its 16 bits inside the block; round 6), else 12 B/nnz (two passes: 24 B/nnz; up to 6 % more where the regrouped copy
  * is padded to whole 16-entry groups) + up to 64 B/row + a count table of at most 64 MB.  The handle variants (the handle must have been uploaded with i[]) build
  * that regrouped copy on first use and keep it: repeated calls only accumulate
  * (12 B/nnz); the device variants regroup in the caller's workspace on every call.

@@ -205,6 +205,7 @@ struct RowSumsLayout {
     bool aligned;           // the pass writes whole groups of 8 entries only; regions padded with entries of no row
     int64_t slots;          // capacity of the regrouped copy in entries (nnz, or nnz + the padding)
     bool direct;   // up to 4 row blocks: no regrouping, the accumulate pass reads the caller's x / i
+    bool rows16;   // the regrouped copy keeps a row as 16 bits RELATIVE TO ITS ROW BLOCK (0xffff: no row): one-level regrouping by the row blocks themselves, where a region belongs to one block -- 10 instead of 12 B per entry written by the partition pass and read by every accumulate pass (round 6)
     int64_t super_elems;
 };
 hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, bool keep_row_form, RowSumsLayout* L);

@@ -193,9 +193,16 @@ hipError_t plan_row_sums(int32_t nrow, int64_t nnz, size_t colsums_ws_bytes, boo
     L->aligned = queue_allowed && L->mode == 2 && !L->direct && L->ncoarse >= kQueueMinBlocks &&
                  L->ncoarse <= kQueueMaxBlocks && padded <= 0x7fffffffll;
     L->slots = L->aligned ? padded : nnz;
+    // one-level regrouping by the row blocks themselves: every region of the copy belongs to ONE block, so a row is kept
+    // as its 14 bits inside the block (0xffff: an entry of no row) -- 2 bytes instead of 4 (RSP_ROWS16=0: A/B)
+    static const bool rows16_allowed = [] {
+        const char* e = getenv("RSP_ROWS16");
+        return !(e && atoi(e) == 0);
+    }();
+    L->rows16 = rows16_allowed && L->mode == 2 && !L->direct && L->sub == 0 && kPartShift <= 15;
     if (!L->direct) {
         L->vals_off = off;  off = align_up(off + (size_t)L->slots * 8, 256);       // x grouped by row block
-        L->rows_off = off;  off = align_up(off + (size_t)L->slots * 4, 256);       // their row indices
+        L->rows_off = off;  off = align_up(off + (size_t)L->slots * (L->rows16 ? 2 : 4), 256);   // their row indices
     }
     L->boff_off = off;  off = align_up(off + ((size_t)L->ncoarse + 1) * 4, 256);   // first slot of every (coarse) block
     L->partial_off = off;                                                          // sums per (part, row)
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift,
     int32_t nblocks, int64_t super_elems, int32_t nsuper, const int32_t* __restrict__ first_slot,
     double* __restrict__ px, int32_t* __restrict__ pr, const int32_t* __restrict__ seg, int32_t row_base,
-    const int32_t* __restrict__ run_if, int32_t pad_group) {
+    const int32_t* __restrict__ run_if, int32_t pad_group, uint16_t* __restrict__ pr16 = nullptr) {
     // (standing by for the queue form: runs only if the histogram pass found the row indices too clustered for it, and
     // then fills every region up to whole groups with entries of no row, as the queue form's layout expects)
     if (run_if && *run_if == 0) return;
@@ -425,7 +432,8 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
                 const int b = ((uint32_t)rr - (uint32_t)row_base) >> shift;
                 const int32_t dest = cursor[b] + (base + j - tstart[b]);
                 px[dest] = stage_x[j];
-                pr[dest] = rr;
+                if (pr16) pr16[dest] = (uint16_t)((uint32_t)rr & ((1u << shift) - 1u));   // (every staged entry has a row)
+                else pr[dest] = rr;
             }
             lds_barrier();
         };
@@ -445,7 +453,8 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
             if (over)
                 for (int32_t d = cur; d < cur - over + pad_group; ++d) {
                     px[d] = 0.0;
-                    pr[d] = -1;
+                    if (pr16) pr16[d] = 0xffffu;
+                    else pr[d] = -1;
                 }
         }
     }
@@ -467,7 +476,8 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_kernel(
 __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_queue_kernel(
     const double* __restrict__ x, const int32_t* __restrict__ ri, int64_t nnz, int32_t nrow, int32_t shift,
     int32_t nblocks, int64_t super_elems, int32_t nsuper, const int32_t* __restrict__ first_slot,
-    double* __restrict__ px, int32_t* __restrict__ pr, const int32_t* __restrict__ skew_flag) {
+    double* __restrict__ px, int32_t* __restrict__ pr, const int32_t* __restrict__ skew_flag,
+    uint16_t* __restrict__ pr16 = nullptr) {
     if (*skew_flag != 0) return;   // clustered row indices: the staged form (standing by on the same table) does the pass
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double* qx = (double*)s_raw;                                        // nblocks x kQueueGroup
@@ -575,7 +585,8 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_queue_kernel
                 if (fill + tcount[b] - rr * G >= G) {
                     const int32_t dest = cur - fill + rr * G + l;
                     px[dest] = qx[item];
-                    pr[dest] = qr[item];
+                    if (pr16) pr16[dest] = (uint16_t)((uint32_t)qr[item] & ((1u << shift) - 1u));   // (a full group holds entries with rows only)
+                    else pr[dest] = qr[item];
                 }
             }
             lds_barrier();
@@ -594,7 +605,8 @@ __global__ __launch_bounds__(kPartThreads) void rows_tile_partition_queue_kernel
         if (fill > 0) {
             const int32_t dest = cur - fill + l;
             px[dest] = l < fill ? qx[item] : 0.0;
-            pr[dest] = l < fill ? qr[item] : -1;
+            if (pr16) pr16[dest] = l < fill ? (uint16_t)((uint32_t)qr[item] & ((1u << shift) - 1u)) : (uint16_t)0xffffu;
+            else pr[dest] = l < fill ? qr[item] : -1;
         }
     }
 }
@@ -622,11 +634,11 @@ __global__ void rows_tile_offsets_kernel(const int32_t* __restrict__ first_slot,
 //    which is the read of the 12 GB.)
 //    nsplit == 1: sums (or means) straight to `out`.  Otherwise each part's sums go to part_out + part * nrow
 //    and rows_combine_parts_kernel adds the parts up.
-template <bool MEANS>
+template <bool MEANS, bool R16 = false>   // R16: the copy's rows are 16-bit, block-local (RowSumsLayout::rows16)
 __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
     const double* __restrict__ px, const int32_t* __restrict__ pr, const int32_t* __restrict__ boff,
     int64_t direct_nnz, int32_t nrow, int32_t shift, int32_t sub, int32_t nsplit, double* __restrict__ out,
-    double* __restrict__ part_out, double divisor) {
+    double* __restrict__ part_out, double divisor, const uint16_t* __restrict__ pr16 = nullptr) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double* sums = (double*)s_raw;                          // 1 << shift
@@ -678,9 +690,14 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
         double gv[kAccDepth];
         auto fetch = [&](int d, int32_t step) {   // unconditional loads from clamped addresses: exact wait counts
             const int64_t j = (int64_t)u0 + (int64_t)step * kAccStagers + stid;
-            const int32_t t = __builtin_nontemporal_load(pr + (j <= last ? j : last));
+            // (rows16: the block-local row of a region that belongs to block b alone; 0xffff = an entry of no row)
+            // (R16: the block-local row of a region that belongs to block b alone, 0xffff = an entry of no row; the staging
+            // wavefronts are as busy as the adding one -- no instruction to spare for rebuilding a global row here)
+            int32_t t;
+            if (R16) t = (int32_t)__builtin_nontemporal_load(pr16 + (j <= last ? j : last));
+            else t = __builtin_nontemporal_load(pr + (j <= last ? j : last));
             gv[d] = __builtin_nontemporal_load(px + (j <= last ? j : last));
-            gr[d] = j <= last ? t : -1;
+            gr[d] = j <= last ? t : (R16 ? 0xffff : -1);
         };
         if (nrounds > 0) {
 #pragma unroll
@@ -693,8 +710,8 @@ __global__ __launch_bounds__(kAccThreads) void rows_tile_accumulate_kernel(
                 // Its instruction stream is the pass's critical path (one extra branch per entry there: 2.8 -> 6.6 ms),
                 // so slots past the end, other blocks' entries (direct form) and invalid row indices are turned into
                 // "+0.0 to a spare slot" HERE, and the adder adds unconditionally.
-                const bool mine = (uint32_t)gr[d] < (uint32_t)nrow && (gr[d] >> shift) == b;
-                st_r[(d & 1) * kAccStagers + stid] = mine ? (gr[d] & mask) * 8 : (rows_here + (stid & 63)) * 8;   // (a spare slot per adder lane)
+                const bool mine = R16 ? gr[d] != 0xffff : ((uint32_t)gr[d] < (uint32_t)nrow && (gr[d] >> shift) == b);
+                st_r[(d & 1) * kAccStagers + stid] = mine ? (R16 ? gr[d] : (gr[d] & mask)) * 8 : (rows_here + (stid & 63)) * 8;   // (a spare slot per adder lane)
                 st_x[(d & 1) * kAccStagers + stid] = mine ? gv[d] : 0.0;
                 fetch(d, (q + 1) * kAccDepth + d);
                 lds_barrier();
@@ -821,7 +838,8 @@ hipError_t launch_add_partials(const double* parts, int32_t nparts, int64_t stri
 static hipError_t partition_pass(const double* src_x, const int32_t* src_i, int64_t nnz, int32_t nrow_here, int32_t shift,
                                  int32_t nblocks, const RowSumsLayout& L, int32_t* table, void* temp, double* dst_x,
                                  int32_t* dst_i, int32_t* boff, const int32_t* seg, int32_t row_base, int32_t close,
-                                 hipStream_t stream, bool queue = false) {
+                                 hipStream_t stream, bool queue = false, bool rows16 = false) {
+    uint16_t* dst_i16 = rows16 ? (uint16_t*)dst_i : nullptr;
     const size_t table_entries = (size_t)L.nsuper * (size_t)nblocks + 1;
     hipError_t e = hipMemsetAsync(table + (table_entries - 1), 0, 8, stream);   // the slot that receives the total, and the flag behind it
     if (e != hipSuccess) return e;
@@ -852,14 +870,14 @@ static hipError_t partition_pass(const double* src_x, const int32_t* src_i, int6
         if (queue) {   // (one-level regrouping only: no segment, rows from 0); the staged form stands by for clustered rows
             hipLaunchKernelGGL(rows_tile_partition_queue_kernel, dim3(L.nsuper), dim3(kPartThreads), part_lds, stream,
                                src_x, src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i,
-                               flag);
+                               flag, dst_i16);
             hipLaunchKernelGGL(rows_tile_partition_kernel, dim3(L.nsuper), dim3(kPartThreads), stage_lds, stream, src_x,
                                src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i, seg,
-                               row_base, flag, kQueueGroup);
+                               row_base, flag, kQueueGroup, dst_i16);
         } else {
             hipLaunchKernelGGL(rows_tile_partition_kernel, dim3(L.nsuper), dim3(kPartThreads), part_lds, stream, src_x,
                                src_i, nnz, nrow_here, shift, nblocks, L.super_elems, L.nsuper, table, dst_x, dst_i, seg,
-                               row_base, (const int32_t*)nullptr, 1);
+                               row_base, (const int32_t*)nullptr, 1, dst_i16);
         }
         e = hipGetLastError();
     }
@@ -877,7 +895,7 @@ hipError_t launch_row_build(const double* d_x, const int32_t* d_i, int32_t nrow,
     void* temp = (char*)scratch + L.temp_off;
     if (L.mode == 2)
         return partition_pass(d_x, d_i, nnz, nrow, L.shift + L.sub, L.ncoarse, L, table, temp, px, pr, boff, nullptr, 0, 1,
-                              stream, L.aligned);
+                              stream, L.aligned, L.rows16);
     // two levels: by bucket into the intermediate copy, then every bucket by its blocks into the final one
     double* mx = (double*)((char*)scratch + L.mid_vals_off);
     int32_t* mr = (int32_t*)((char*)scratch + L.mid_rows_off);
@@ -928,19 +946,28 @@ hipError_t launch_row_reduce(const double* d_x, const int32_t* d_i, int32_t nrow
     const double* px = direct ? d_x : (const double*)((char*)persist + L.vals_off);
     const int32_t* pr = direct ? d_i : (const int32_t*)((char*)persist + L.rows_off);
     const int32_t* boff = (const int32_t*)((char*)persist + L.boff_off);
+    const uint16_t* pr16 = (!direct && L.rows16) ? (const uint16_t*)pr : nullptr;
     const size_t acc_lds = ((size_t)8 << L.shift) + 64 * 8 + (size_t)2 * kAccStagers * 12;
-    static DynamicLdsLimit acc_limit_means, acc_limit_sums;
+    static DynamicLdsLimit acc_limit_means, acc_limit_sums, acc_limit_means16, acc_limit_sums16;
     hipError_t e = acc_limit_means.ensure((const void*)rows_tile_accumulate_kernel<true>, (int)acc_lds);
     if (e == hipSuccess) e = acc_limit_sums.ensure((const void*)rows_tile_accumulate_kernel<false>, (int)acc_lds);
+    if (e == hipSuccess) e = acc_limit_means16.ensure((const void*)rows_tile_accumulate_kernel<true, true>, (int)acc_lds);
+    if (e == hipSuccess) e = acc_limit_sums16.ensure((const void*)rows_tile_accumulate_kernel<false, true>, (int)acc_lds);
     if (e != hipSuccess) return e;
     double* parts = (double*)((char*)persist + L.partial_off);
     const dim3 grid((unsigned)L.nblocks * (unsigned)L.nsplit);
-    if (means)
+    if (pr16 && means)
+        hipLaunchKernelGGL((rows_tile_accumulate_kernel<true, true>), grid, dim3(kAccThreads), acc_lds, stream, px, pr,
+                           boff, (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor, pr16);
+    else if (pr16)
+        hipLaunchKernelGGL((rows_tile_accumulate_kernel<false, true>), grid, dim3(kAccThreads), acc_lds, stream, px, pr,
+                           boff, (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor, pr16);
+    else if (means)
         hipLaunchKernelGGL(rows_tile_accumulate_kernel<true>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
-                           boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor);
+                           boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor, pr16);
     else
         hipLaunchKernelGGL(rows_tile_accumulate_kernel<false>, grid, dim3(kAccThreads), acc_lds, stream, px, pr,
-                           boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor);
+                           boff, direct ? nnz : (int64_t)-1, nrow, L.shift, L.sub, L.nsplit, d_out, parts, divisor, pr16);
     e = hipGetLastError();
     if (e != hipSuccess || L.nsplit <= 1) return e;
     return launch_rows_combine(parts, nrow, L.nsplit, d_out, divisor, means, stream);
