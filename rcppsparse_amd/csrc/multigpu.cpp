@@ -206,9 +206,11 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
 // The handle therefore keeps, per shard: the resident rsp_csc (its own stream, output and plan), and per handle: ONE
 // page-locked host vector of ncol doubles that every shard's slice lands in, optionally G - 1 worker threads that stay
 // parked between calls (each with its shard's device current for good), and -- for the RCCL gather -- the communicators
-// of one ncclCommInitAll.  A call is, per shard: enqueue the column-sum launches, enqueue the slice's way home, wait for
-// the shard's stream, copy the slice into the caller's vector.
-//   launch  serial  : the calling thread walks the shards (set device, enqueue) and then waits for them in order;
+// of one ncclCommInitAll.  A call is, per shard: enqueue the column-sum launches, enqueue the slice's way home and an
+// event behind it, poll that event (hipStreamSynchronize costs ~9 us even on a drained stream), copy the slice into the
+// caller's vector.
+//   launch  serial  : the calling thread issues every shard's kernels, then every shard's copy command + event, and
+//                     then polls the events in turn (the shards are handed to the caller in the order they finish);
 //           workers : shard 0 on the calling thread, shard k on its parked thread -- enqueues, waits and the copies
 //                     into the caller's (pageable) vector all run side by side.  A worker spins for a short while
 //                     after a call (RSP_MCSC_SPIN_US, default 50) so that calls in a loop find it awake, then sleeps
@@ -247,7 +249,7 @@ struct rsp_mcsc {
     // what a column-sum call needs, made once
     std::vector<ShardState> st;
     double* h_result = nullptr;    // page-locked, ncol doubles: every shard's slice lands here
-    double* d_result_view = nullptr;   // the same memory as the devices address it (RSP_GATHER_STORES)
+    double* d_result_view = nullptr;   // the same memory as the devices address it (RSP_GATHER_BLIT / _STORES)
     int gather = RSP_GATHER_D2H;
     int launch = RSP_LAUNCH_SERIAL;
     ShardWorkers* workers = nullptr;   // made on the first call that wants them
