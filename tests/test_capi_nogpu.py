@@ -304,3 +304,41 @@ print("ok", rank)
         b.wait(0.3)
     assert "timed out" in str(e.value)
     b.close()
+
+
+def test_round6_entries_check_their_arguments_without_a_device():
+    """The entries round 6 added -- the single-process multi-GPU handle's knobs, rsp_mcsc_wrap_device, the plan-free entry's
+    settle, the shared host vector, the RCCL / peer queries -- refuse bad arguments (or answer) before any device is
+    touched, and the read-only counters of the plan cache are there."""
+    L = capi.load()
+    null = ctypes.c_void_p()
+    info = np.zeros(4, dtype=np.int32)
+    assert L.rsp_mcsc_set_gather(null, 0) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_mcsc_set_launch(null, 0) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_mcsc_config(null, info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) == capi.RSP_ERR_BAD_ARG
+    assert not L.rsp_mcsc_result_buffer(null)                                # NULL for a null handle
+    us = np.zeros(8)
+    assert L.rsp_mcsc_last_call_stamps(null, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 8) == capi.RSP_ERR_BAD_ARG
+    ms = ctypes.c_float(0)
+    assert L.rsp_mcsc_shard_kernel_ms(null, 0, 3, ctypes.byref(ms)) == capi.RSP_ERR_BAD_ARG
+    h = ctypes.c_void_p()
+    assert L.rsp_mcsc_wrap_device(0, None, None, None, None, None, None, 5, ctypes.byref(h)) == capi.RSP_ERR_BAD_ARG
+    assert not h.value
+    assert L.rsp_column_sums_device_settle(None, 10, 100, None) == -1       # no offsets: nothing to settle
+    assert L.rsp_column_sums_device_settle(ctypes.c_void_p(4096), 0, 0, None) == -1
+    hp = ctypes.c_void_p()
+    assert L.rsp_shared_host_open(b"no-leading-slash", 64, 1, ctypes.byref(hp)) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_shared_host_open(b"/rsp_test_zero", 0, 1, ctypes.byref(hp)) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_shared_host_close(None, 64, None) == capi.RSP_OK            # closing nothing is fine
+    assert L.rsp_copy_to_host_async(None, None, -1, None) == capi.RSP_ERR_BAD_ARG
+    assert L.rsp_copy_to_host_async(None, None, 0, None) == capi.RSP_OK
+    can = ctypes.c_int(-1)
+    assert L.rsp_device_can_access_peer(3, 3, ctypes.byref(can)) == capi.RSP_OK and can.value == 1   # a device reaches itself
+    assert L.rsp_device_can_access_peer(0, 1, None) == capi.RSP_ERR_BAD_ARG
+    inf = capi.rccl_info()                                                   # which RCCL this process runs: answered without a device
+    assert inf["version"] > 20000 and "rccl" in inf["library"]
+    for key in ("auto_plans_made", "auto_plans_freed", "auto_plans_retired", "auto_plans_recycled", "fold_fixup"):
+        assert capi.debug_get(key) >= 0
+    assert capi.debug_get("fold_fixup") == 0 and capi.debug_get("auto_plan") == 1      # the defaults
+    with pytest.raises(capi.RspError):
+        capi.debug_set("auto_plans_made", 3)                                 # read-only
