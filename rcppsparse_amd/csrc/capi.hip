@@ -1054,11 +1054,29 @@ std::atomic<int> g_auto_recycled{0};                // ... of the made ones, how
 constexpr size_t kAutoPoolMax = 8;
 std::vector<PlanResources> g_plan_pool;
 
+// Another thread of the process may be capturing a stream in GLOBAL mode, which an allocation, an event query or a page-lock
+// on ANY thread invalidates.  The few such calls these entries make -- once per key for its plan, and while
+// something is retired -- run with THIS thread's capture mode relaxed: they touch nothing a capture could record.
+struct RelaxedCaptureMode {
+    hipStreamCaptureMode prev = hipStreamCaptureModeRelaxed;
+    bool ok = false;
+    RelaxedCaptureMode() {
+        ok = hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    ~RelaxedCaptureMode() {
+        if (ok && hipThreadExchangeStreamCaptureMode(&prev) != hipSuccess) (void)hipGetLastError();
+    }
+    RelaxedCaptureMode(const RelaxedCaptureMode&) = delete;
+    RelaxedCaptureMode& operator=(const RelaxedCaptureMode&) = delete;
+};
+
 // page-locked stale words: 4 bytes each, handed out from whole pages that are never unmapped before
 // rsp_release_cached (a word goes back to the free list only when its plan is freed, i.e. when no launch can write it)
 std::vector<int32_t*> g_stale_pages, g_stale_free;
 int32_t* stale_word_take() {   // caller holds g_auto_mu
     if (g_stale_free.empty()) {
+        RelaxedCaptureMode relaxed;
         int32_t* page = nullptr;
         if (hipHostMalloc((void**)&page, 4096, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
             (void)hipGetLastError();
@@ -1141,6 +1159,7 @@ void auto_fence(AutoPlan* ap, hipStream_t stream) {
 }
 
 void auto_retire(AutoPlan* ap, AutoEntry* owner, hipStream_t stream) {   // caller holds g_auto_mu; ap's device is current
+    RelaxedCaptureMode relaxed;
     ap->retired = true;
     ap->owner = owner;
     if (owner) ++owner->nretired;
@@ -1155,6 +1174,7 @@ void auto_retire(AutoPlan* ap, AutoEntry* owner, hipStream_t stream) {   // call
 // every call: streams that owe a retired plan an event pay now; plans nobody can read any more are freed.  Only looks at
 // events while something is retired (rare), never waits.
 void auto_collect(int device, hipStream_t stream) {   // caller holds g_auto_mu; `device` is current
+    RelaxedCaptureMode relaxed;
     for (size_t k = 0; k < g_auto_retired.size();) {
         AutoPlan* ap = g_auto_retired[k];
         bool done = ap->pins == 0;
@@ -1295,6 +1315,7 @@ static AutoPlan* auto_make_plan(int device, const int32_t* d_p, int32_t ncol, in
         }
     }
     const bool recycled = reuse.device >= 0;
+    RelaxedCaptureMode relaxed;   // (a new plan allocates; a recycled one only records events)
     if (plan_create_device_impl(d_p, ncol, nnz, stream, recycled ? &reuse : nullptr, &ap->plan) != RSP_OK) {
         if (reuse.device >= 0) {   // (not taken after all: back into the pool)
             std::lock_guard<std::mutex> lock(g_auto_mu);
@@ -1454,7 +1475,10 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
         std::lock_guard<std::mutex> lock(g_auto_mu);
         if (use) {
             --use->pins;
-            if (use->retired) auto_fence(use, stream);   // retired while this launch was being issued: its event comes now
+            if (use->retired) {   // retired while this launch was being issued: its event comes now
+                RelaxedCaptureMode relaxed;
+                auto_fence(use, stream);
+            }
         }
         if (plan_for) {
             plan_for->planning = false;
@@ -1541,7 +1565,11 @@ int rsp_column_sums_device_form(const int32_t* d_p, int32_t ncol, int64_t nnz, i
             std::this_thread::sleep_for(std::chrono::microseconds(50));
             continue;
         }
-        const hipError_t e = hipEventSynchronize(pl->ev_end);
+        hipError_t e;
+        {
+            RelaxedCaptureMode relaxed;   // (waiting for an event is one of the calls a global-mode capture elsewhere forbids)
+            e = hipEventSynchronize(pl->ev_end);
+        }
         std::lock_guard<std::mutex> lock(g_auto_mu);
         AutoEntry* c = auto_find(device, d_p, ncol, nnz);
         AutoPlan* holder = nullptr;

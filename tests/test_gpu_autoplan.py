@@ -10,6 +10,7 @@ mostly about: offsets changed in place under an adopted plan, captured calls rep
 matrices over two workspaces and streams, offsets that are not a dgCMatrix's at all.  Never a wrong sum, only a slower
 call.  The reference has one synchronous call and no such state (src/example.cpp:26-32): the oracle is its loop."""
 import os
+import threading
 
 import numpy as np
 import pytest
@@ -631,3 +632,56 @@ def test_bit_stable_run_to_run_under_the_defaults(torch_auto):
             assert outs[j].cpu().numpy().tobytes() == want
     torch.cuda.synchronize()
     assert capi.column_sums_device(xt, pt, nrow_for_means=777).cpu().numpy().tobytes() == (oracle.column_sums(x, p) / 777).tobytes()
+
+
+def test_planning_on_one_thread_leaves_another_threads_global_capture_alone(torch_auto):
+    """an allocation, a page-lock or an event query on ANY thread invalidates a stream capture that another
+    thread runs in GLOBAL mode -- and a key's second sighting allocates its plan.  The entries make those few calls with their
+    own thread's capture mode relaxed (hipThreadExchangeStreamCaptureMode): a capture in global mode on another thread
+    survives a first and a second sighting, the settling of another key and a stale round on this thread, and replays."""
+    torch = torch_auto
+    capi.release_cached()
+    mats = []
+    for seed in (95, 96):
+        p, x = short_matrix(150_000, 10, seed=seed)
+        mats.append((p, x, torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda(),
+                     torch.empty(len(p) - 1, dtype=torch.float64, device="cuda"), capi.alloc_workspace(len(p) - 1, len(x))))
+    a = torch.zeros(4096, device="cuda")
+    cap_stream, my_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    started, go_on, errors = threading.Event(), threading.Event(), []
+
+    def capturer():
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="global"):
+                a.add_(1.0)
+                started.set()
+                go_on.wait(30)
+                a.add_(1.0)
+            g.replay()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+            started.set()
+
+    t = threading.Thread(target=capturer)
+    t.start()
+    assert started.wait(30) and not errors, errors
+    made0 = capi.debug_get("auto_plans_made")
+    with torch.cuda.stream(my_stream):                       # (no work on the legacy stream, no torch allocation: those would
+        p, x, xt, pt, out, ws = mats[0]                      #  disturb the capture by themselves)
+        for _ in range(3):                                   # first sighting, second (allocates + inspects), third
+            capi.column_sums_device(xt, pt, out, ws, stream=my_stream)
+        p2, x2, xt2, pt2, out2, ws2 = mats[1]
+        assert capi.column_sums_device_settle(pt2, len(x2), stream=my_stream) == "lean"
+        pt.copy_(pt2[:pt.numel()] if pt2.numel() >= pt.numel() else pt)      # offsets changed in place: a stale round, a retirement
+        for _ in range(4):
+            capi.column_sums_device(xt, pt, out, ws, stream=my_stream)
+        # (no synchronisation from THIS thread while the other one captures: a stream wait is itself one of the forbidden calls)
+    assert capi.debug_get("auto_plans_made") - made0 >= 2
+    go_on.set()
+    t.join(60)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    assert float(a[0]) == 2.0                                # the two captured adds, replayed once
