@@ -228,7 +228,24 @@ using rsp::ShardWorkers;
 using rsp::now_us;
 using rsp::cpu_relax;
 
-void make_device_current(int device) { (void)hipSetDevice(device); }
+// a worker's one-time set-up: its shard's device current for good, and its capture mode relaxed -- the event queries of a
+// call are among the runtime calls that would invalidate a stream capture another thread of the process runs in global mode
+void make_device_current(int device) {
+    (void)hipSetDevice(device);
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError();
+}
+
+struct RelaxedCapture {   // the same for the calling thread, for the duration of a call
+    hipStreamCaptureMode prev = hipStreamCaptureModeRelaxed;
+    bool ok;
+    RelaxedCapture() : ok(hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess) {
+        if (!ok) (void)hipGetLastError();
+    }
+    ~RelaxedCapture() {
+        if (ok && hipThreadExchangeStreamCaptureMode(&prev) != hipSuccess) (void)hipGetLastError();
+    }
+};
 
 struct ShardState {
     rsp::CscView view;        // device, stream, own output of the resident shard
@@ -688,6 +705,7 @@ static int mcsc_columns(rsp_mcsc_t h, double* sums, bool means) {
     }
     ColumnCall call{h, sums, means};
     int rc = RSP_OK;
+    RelaxedCapture relaxed;
     if (h->gather == RSP_GATHER_RCCL) {
         // the launches, then ONE group of sends and receives (a group is issued by one thread), then one copy home
         for (int k = 0; k < G; ++k) {
