@@ -102,9 +102,10 @@ int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol,
  * rsp_column_sums_host_multi.
  *
  * A call creates NOTHING (round 6; before, G - 1 threads were started and joined per call): the handle keeps per shard
- * a stream, an output and a plan, and per handle one page-locked vector of ncol doubles, parked worker threads and,
+ * a stream, an output, a plan and an event, and per handle one page-locked vector of ncol doubles, parked worker threads and,
  * for the RCCL gather, the communicators of one ncclCommInitAll.  Two independent choices, both per handle:
- *   launch  RSP_LAUNCH_SERIAL   the calling thread enqueues shard after shard, then waits for them in order;
+ *   launch  RSP_LAUNCH_SERIAL   the calling thread enqueues every shard's kernels, then every shard's trip home, then
+ *                               polls the shards' events in turn (a shard is handed over when IT is done);
  *           RSP_LAUNCH_WORKERS  shard 0 on the calling thread, shard k on its own thread, which stays parked between
  *                               calls (futex; it spins for RSP_MCSC_SPIN_US microseconds, default 50, after a call so
  *                               that calls in a loop find it awake): enqueues, waits and the copies into `sums` overlap.
