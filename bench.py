@@ -1634,8 +1634,6 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         "x_copies_rotated": H["ncopies"],
         "gather": H["gather_name"],
         "gather_fell_back_to_torch_distributed": H["fell_back"],
-        "rccl_version": rccl.get("version"), "rccl_library": rccl.get("library"),
-        "peer_probe": H.get("peer_probe"),
         "regions_ms": H["regions_ms"],
         "host_stall_suspected": bool(not use_comm and ms_per_step > 1.5 * H["kernel_ms"]),
         "planned": None if plan is None else {k: v for k, v in plan.items() if k != "kernel"},
@@ -1643,6 +1641,10 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
                     "nnz": s["x1"] - s["x0"], "kernel_ms": s["kernel_ms"], "gather_ms": s["gather_ms"],
                     "form": s.get("form", "general")} for s in H["shards"]],
     }
+    if rccl:                                   # (N > 1 or --force-comm: which RCCL really ran)
+        cfg["rccl_version"], cfg["rccl_library"] = rccl.get("version"), rccl.get("library")
+    if world > 1:
+        cfg["peer_probe"] = H.get("peer_probe")
     if comm_rehearsal is not None:
         refused = [("ncclCommInitRank" in s and "error 5" in s) for s in comm_rehearsal]
         cfg["comm_refused_on_ranks"] = int(sum(refused))
@@ -1662,10 +1664,11 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
         "pipelined": H["pipelined"],
         "planned_shards": H["planned_shards"],
         "direct_gather": H["direct_gather"],
-        "host_gather": H.get("host_gather"),
         "roofline": sig(roof),
         "parity": sig(H["parity"]),
     }
+    if world > 1:
+        line["host_gather"] = H.get("host_gather")
     if also:
         line["also"] = also
         line["also_seconds"] = sig(extras.get("also_seconds"))
