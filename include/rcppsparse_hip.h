@@ -162,10 +162,14 @@ int rsp_mcsc_last_call_stamps(rsp_mcsc_t handle, double *us, int capacity);
 /* Measurement: mean device milliseconds of ONE shard's column-sum launches alone (HIP events on its stream). */
 int rsp_mcsc_shard_kernel_ms(rsp_mcsc_t handle, int32_t shard, int reps, float *ms);
 /* The same handle with the row indices kept on the devices (i[] cut like x[]), for the row-wise entries:
- * Matrix::rowSums / rowMeans (RcppSparse.h:138-156).  Every shard sums the rows of its own columns
- * (rsp_csc_row_sums), the partial vectors come back over the shards' own host links and are added on the host
- * in shard order = column order -- the single-process form of rsp_comm_reduce_rows, same sum term for term.
- * `sums` / `means`: nrow doubles, host. */
+ * Matrix::rowSums / rowMeans (RcppSparse.h:138-156).  Every shard sums the rows of its own columns into a vector in
+ * its HBM; the vectors are added in shard order = column order ON THE DEVICES (round 6): the rows are cut into one
+ * slice per shard, device r copies slice r of every other shard's vector to itself (hipMemcpyPeerAsync, every pair of
+ * devices its own xGMI link), adds the pieces in shard order with one kernel and copies its reduced slice home over
+ * its own host link -- the single-process form of rsp_comm_reduce_rows, same sum term for term.  Per device this keeps
+ * nrow + (shards + 1) * nrow / shards doubles of HBM from the first call on.  If that memory cannot be had (or
+ * RSP_MCSC_ROWS=host in the environment) the vectors come back over the host links and the host adds them: the same
+ * bits, nshards * nrow doubles of host memory for the duration of the call.  `sums` / `means`: nrow doubles, host. */
 int rsp_mcsc_upload_csc(const double *x, const int32_t *i, const int32_t *p, int32_t nrow,
                         int32_t ncol, int64_t nnz, const int *devices, int ndevices,
                         rsp_mcsc_t *handle);
@@ -175,8 +179,7 @@ int rsp_mcsc_row_means(rsp_mcsc_t handle, double *means);
 int rsp_mcsc_dims(rsp_mcsc_t handle, int32_t *nrow, int32_t *ncol, int32_t *nshards);
 /* info4 = { first column, one past the last column, column-sum form (rsp_csc_column_form), entries } of a shard */
 int rsp_mcsc_shard_info(rsp_mcsc_t handle, int32_t shard, int32_t *info4);
-/* Memory and threads: the row-wise entries take nshards * nrow doubles of HOST memory for the duration of a
- * call (8 shards x 1e7 rows: 640 MB; nothing is kept between calls).  Calls on one handle must not overlap
+/* Threads: calls on one handle must not overlap
  * (as for rsp_csc_t); different handles may be used from different threads. */
 int rsp_mcsc_free(rsp_mcsc_t handle);
 

@@ -2022,10 +2022,9 @@ int rsp_row_means_device(const double* d_x, const int32_t* d_i, int32_t nrow, in
                        (hipStream_t)stream);
 }
 
-static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
-    if (!h || !host_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
-    DeviceGuard on(h->device);
-    HIP_TRY(on.error());
+// builds the handle's row form on first use and enqueues its row sums (means) on the handle's stream into d_out (nullptr: the
+// handle's own output); the handle's device must be current; nothing waits once the form exists
+static int csc_rows_enqueue(rsp_csc_t h, double* d_out, bool means) {
     if (h->nrow == 0) return RSP_OK;
     if (h->nnz > 0 && !h->d_i)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: rowSums needs the row indices");
@@ -2084,16 +2083,38 @@ static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
         h->row_segments = false;
         h->row_ready = true;
     }
+    double* out = d_out ? d_out : h->d_row_out;
     if (h->row_segments)
         HIP_TRY(rsp::launch_row_segments_reduce(h->d_x, h->d_i, h->nrow, h->ncol, h->seg_layout, h->d_row_persist,
-                                                h->d_row_out, means ? (double)h->ncol : 1.0, means, h->stream));
+                                                out, means ? (double)h->ncol : 1.0, means, h->stream));
     else
-        HIP_TRY(rsp::launch_row_reduce(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout, h->d_row_persist, h->d_row_out,
+        HIP_TRY(rsp::launch_row_reduce(h->d_x, h->d_i, h->nrow, h->nnz, h->row_layout, h->d_row_persist, out,
                                        means ? (double)h->ncol : 1.0, means, make_plan(h->nnz), h->stream));
+    return RSP_OK;
+}
+
+static int csc_rows(rsp_csc_t h, double* host_out, bool means) {
+    if (!h || !host_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    DeviceGuard on(h->device);
+    HIP_TRY(on.error());
+    if (h->nrow == 0) return RSP_OK;
+    if (int rc = csc_rows_enqueue(h, nullptr, means)) return rc;
     HIP_TRY(hipMemcpyAsync(host_out, h->d_row_out, (size_t)h->nrow * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return RSP_OK;
 }
+
+}  // extern "C"
+namespace rsp {
+// the shard's PARTIAL row sums (its own columns' entries) enqueued on its stream into d_out, nrow doubles in its device's HBM
+// (multigpu.cpp: the single-process handle reduces the shards' vectors on the devices); the shard's device must be current
+int csc_enqueue_rows(rsp_csc_t h, double* d_out) {
+    if (!h || !d_out) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    return csc_rows_enqueue(h, d_out, false);
+}
+}  // namespace rsp
+extern "C" {
+
 
 int rsp_csc_row_sums(rsp_csc_t h, double* sums) { return csc_rows(h, sums, false); }
 

@@ -125,6 +125,8 @@ int csc_view(rsp_csc* h, CscView* v);
 // column sums (means) of the shard enqueued on ITS stream into d_out (nullptr: its own output); the shard's device must be
 // the calling thread's current one; nothing waits
 int csc_enqueue_columns(rsp_csc* h, bool means, double* d_out);
+// the shard's partial row sums (nrow doubles) enqueued on its stream into d_out in its device's HBM; its device must be current
+int csc_enqueue_rows(rsp_csc* h, double* d_out);
 // a shard over x / i / p that already live in `device`'s HBM and stay the caller's (never copied, never freed)
 int csc_wrap_device(const double* d_x, const int32_t* d_i, const int32_t* d_p, int32_t nrow, int32_t ncol, int64_t nnz,
                     int device, rsp_csc** handle);

@@ -274,6 +274,17 @@ struct rsp_mcsc {
     std::vector<ncclComm_t> comms;     // RSP_GATHER_RCCL: one ncclCommInitAll over the shards' devices
     double* d_gathered = nullptr;      // ... and the gathered vector on shard 0's device
     double t_call_begin = 0, t_call_end = 0;
+    // row sums reduced ON THE DEVICES (round 6): per shard its partial vector, the slices it receives, its reduced slice
+    struct RowShard {
+        double* d_partial = nullptr;    // nrow doubles: the shard's own columns' row sums
+        double* d_incoming = nullptr;   // G x len: slice k of this shard's rows from every shard's partial vector
+        double* d_reduced = nullptr;    // len: this shard's slice of the result
+        hipEvent_t computed = nullptr, done = nullptr;
+    };
+    std::vector<RowShard> rows;
+    double* h_rows = nullptr;        // page-locked, nrow doubles: the add kernels write their reduced slices straight into it
+    double* d_rows_view = nullptr;   // ... as the devices address it (nullptr: the slices come home by a copy instead)
+    bool rows_ready = false, rows_failed = false;
 };
 
 namespace {
@@ -477,6 +488,16 @@ int rsp_mcsc_free(rsp_mcsc_t h) {
     for (rsp_csc_t s : h->shards) rsp_csc_free(s);   // waits for each shard's stream
     for (ShardState& s : h->st)
         if (s.done) (void)hipEventDestroy(s.done);
+    if (h->h_rows) (void)hipHostFree(h->h_rows);
+    for (size_t k = 0; k < h->rows.size(); ++k) {
+        rsp_mcsc::RowShard& r = h->rows[k];
+        (void)hipSetDevice(h->devices[k]);
+        if (r.d_partial) (void)hipFree(r.d_partial);
+        if (r.d_incoming) (void)hipFree(r.d_incoming);
+        if (r.d_reduced) (void)hipFree(r.d_reduced);
+        if (r.computed) (void)hipEventDestroy(r.computed);
+        if (r.done) (void)hipEventDestroy(r.done);
+    }
     mcsc_release_rccl(h);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (prev >= 0) (void)hipSetDevice(prev);
@@ -842,9 +863,179 @@ int rsp_mcsc_shard_kernel_ms(rsp_mcsc_t h, int32_t shard, int reps, float* ms) {
     return RSP_OK;
 }
 
-// Matrix::rowSums / rowMeans (reference RcppSparse.h:138-156) of the resident shards: every shard's partial row
-// sums come back over its own device's link into a host vector, and the host adds the vectors in SHARD order
-// (= column order) -- the single-process form of rsp_comm_reduce_rows, same sum term for term.
+// Matrix::rowSums / rowMeans (reference RcppSparse.h:138-156) of the resident shards.  A row's sum is its shards' partial
+// sums added in SHARD order (= column order, the order the reference's scatter loop meets the entries in).
+// Round 6: the add happens ON THE DEVICES -- the single-process form of rsp_comm_reduce_rows, same sum term for term:
+//   1. every shard sums the rows of its own columns into a vector of nrow doubles in its HBM;
+//   2. the rows are cut into G slices; device r copies slice r of every other shard's vector to itself (hipMemcpyPeerAsync
+//      on ITS stream behind an event of the source: every pair of devices its own xGMI link), adds the G pieces in shard
+//      order with one kernel (rows_add_partials_kernel) and
+//   3. writes its reduced slice straight into a page-locked host vector over its own host link; the handle's worker
+//      threads copy the slices out into the caller's vector side by side.
+// 8 shards x 1e7 rows: 70 MB in and out of every device over xGMI and 10 MB per host link, instead of 80 MB per host link
+// and 640 MB added by the host.  The buffers (per device: nrow + (G + 1) * nrow / G doubles) are made at the first call and
+// kept; if they cannot be had -- or RSP_MCSC_ROWS=host -- the host-side add below does the call, with the same bits.
+static int64_t reduce_slice_len(int nranks, int32_t nrow);
+
+static bool mcsc_rows_prepare(rsp_mcsc* h) {
+    if (h->rows_ready) return true;
+    if (h->rows_failed) return false;
+    static const bool host_only = [] {
+        const char* e = getenv("RSP_MCSC_ROWS");
+        return e && !strcmp(e, "host");
+    }();
+    const size_t G = h->shards.size();
+    const int64_t len = reduce_slice_len((int)G, h->nrow);
+    bool ok = !host_only;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    if (ok) {
+        try {
+            h->rows.assign(G, rsp_mcsc::RowShard());
+        } catch (...) {
+            ok = false;
+        }
+    }
+    if (ok) {   // (without it the reduced slices are copied home from d_reduced: slower into pageable memory, not wrong)
+        if (hipHostMalloc((void**)&h->h_rows, (size_t)(h->nrow > 0 ? h->nrow : 1) * 8, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+            void* dv = nullptr;
+            if (hipHostGetDevicePointer(&dv, h->h_rows, 0) == hipSuccess) h->d_rows_view = (double*)dv;
+            else (void)hipGetLastError();
+        } else {
+            (void)hipGetLastError();
+            h->h_rows = nullptr;
+        }
+    }
+    for (size_t k = 0; k < G && ok; ++k) {
+        rsp_mcsc::RowShard& r = h->rows[k];
+        hipError_t e = hipSetDevice(h->devices[k]);
+        if (e == hipSuccess) e = hipMalloc((void**)&r.d_partial, (size_t)h->nrow * 8);
+        if (e == hipSuccess && G > 1) e = hipMalloc((void**)&r.d_incoming, G * (size_t)len * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&r.d_reduced, (size_t)len * 8);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r.computed, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (!ok) {   // (what was made is released with the handle; the host-side add takes over for good)
+        h->rows_failed = true;
+        return false;
+    }
+    h->rows_ready = true;
+    return true;
+}
+
+namespace {
+struct RowCall {
+    rsp_mcsc* h;
+    double* out;
+    int64_t len;
+};
+// step 3 for shard k: wait for its reduced slice, copy it home (pageable destination: the runtime stages it)
+void rows_copy_home(void* ctx, int k) noexcept {
+    RowCall* c = (RowCall*)ctx;
+    rsp_mcsc* h = c->h;
+    ShardState& s = h->st[(size_t)k];
+    const int64_t first = (int64_t)k * c->len < h->nrow ? (int64_t)k * c->len : (int64_t)h->nrow;
+    const int64_t next = (int64_t)(k + 1) * c->len < h->nrow ? (int64_t)(k + 1) * c->len : (int64_t)h->nrow;
+    hipError_t e = hipEventSynchronize(h->rows[(size_t)k].done);
+    if (e == hipSuccess && next > first) {
+        if (h->d_rows_view) memcpy(c->out + first, h->h_rows + first, (size_t)(next - first) * 8);   // (the kernel wrote it there)
+        else e = hipMemcpy(c->out + first, h->rows[(size_t)k].d_reduced, (size_t)(next - first) * 8, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) shard_fail(s, RSP_ERR_HIP, "row sums: the reduced slice's way home", hipGetErrorString(e));
+}
+}  // namespace
+
+static int mcsc_rows_on_devices(rsp_mcsc* h, double* out, bool means) {
+    const int G = (int)h->shards.size();
+    const int64_t len = reduce_slice_len(G, h->nrow);
+    auto first = [&](int k) { const int64_t f = (int64_t)k * len; return f < h->nrow ? f : (int64_t)h->nrow; };
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) {
+        (void)hipGetLastError();
+        prev = -1;
+    }
+    RelaxedCapture relaxed;
+    for (int k = 0; k < G; ++k) h->st[(size_t)k].status = RSP_OK;
+    // 1. every shard's partial vector
+    for (int k = 0; k < G; ++k) {
+        ShardState& s = h->st[(size_t)k];
+        hipError_t e = hipSetDevice(h->devices[(size_t)k]);
+        if (e == hipSuccess) {
+            if (h->bounds[(size_t)k + 1] > h->bounds[(size_t)k]) {
+                const int rc = rsp::csc_enqueue_rows(h->shards[(size_t)k], h->rows[(size_t)k].d_partial);
+                if (rc != RSP_OK) shard_fail(s, rc, "row sums", rsp_last_error());
+            } else {   // a shard without columns adds nothing
+                e = hipMemsetAsync(h->rows[(size_t)k].d_partial, 0, (size_t)h->nrow * 8, s.view.stream);
+            }
+        }
+        if (e == hipSuccess) e = hipEventRecord(h->rows[(size_t)k].computed, s.view.stream);
+        if (e != hipSuccess) shard_fail(s, RSP_ERR_HIP, "row sums: enqueue", hipGetErrorString(e));
+    }
+    bool ok = true;
+    for (int k = 0; k < G; ++k) ok = ok && h->st[(size_t)k].status == RSP_OK;
+    // 2. slice r of every vector to device r, added there in shard order
+    for (int r = 0; r < G && ok; ++r) {
+        ShardState& s = h->st[(size_t)r];
+        rsp_mcsc::RowShard& me = h->rows[(size_t)r];
+        const int64_t cnt = first(r + 1) - first(r);
+        hipError_t e = hipSetDevice(h->devices[(size_t)r]);
+        for (int k = 0; k < G && e == hipSuccess && cnt > 0; ++k) {
+            if (k == r) continue;
+            e = hipStreamWaitEvent(s.view.stream, h->rows[(size_t)k].computed, 0);
+            const double* src = h->rows[(size_t)k].d_partial + first(r);
+            double* dst = me.d_incoming + (size_t)k * (size_t)len;
+            if (e == hipSuccess)
+                e = h->devices[(size_t)k] == h->devices[(size_t)r]
+                        ? hipMemcpyAsync(dst, src, (size_t)cnt * 8, hipMemcpyDeviceToDevice, s.view.stream)
+                        : hipMemcpyPeerAsync(dst, h->devices[(size_t)r], src, h->devices[(size_t)k], (size_t)cnt * 8, s.view.stream);
+        }
+        if (e == hipSuccess && cnt > 0)
+            // (the reduced slice: consecutive doubles, written by neighbouring lanes -- straight into the page-locked host vector
+            // where the device can address it, over the device's own host link)
+            e = rsp::launch_add_partials(G > 1 ? me.d_incoming : me.d_partial, G, len, me.d_partial + first(r), r, cnt,
+                                         h->d_rows_view ? h->d_rows_view + first(r) : me.d_reduced, means ? (double)h->ncol : 1.0,
+                                         means, s.view.stream);
+        if (e == hipSuccess) e = hipEventRecord(me.done, s.view.stream);
+        if (e != hipSuccess) {
+            shard_fail(s, RSP_ERR_HIP, "row sums: reduce", hipGetErrorString(e));
+            ok = false;
+        }
+    }
+    // 3. the reduced slices home, side by side where the handle has its workers
+    if (ok) {
+        RowCall call{h, out, len};
+        if (G > 1 && ensure_workers(h)) {
+            (void)hipSetDevice(h->devices[0]);
+            h->workers->run(rows_copy_home, &call);
+        } else {
+            for (int k = 0; k < G; ++k) {
+                (void)hipSetDevice(h->devices[(size_t)k]);
+                rows_copy_home(&call, k);
+            }
+        }
+    }
+    for (int k = 0; k < G; ++k) {   // nothing of a failed call stays in flight
+        if (ok) break;
+        (void)hipSetDevice(h->devices[(size_t)k]);
+        (void)hipStreamSynchronize(h->st[(size_t)k].view.stream);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    for (int k = 0; k < G; ++k)
+        if (h->st[(size_t)k].status != RSP_OK)
+            return fail(h->st[(size_t)k].status, "shard %d on device %d: %s", k, h->devices[(size_t)k], h->st[(size_t)k].message);
+    return RSP_OK;
+}
+
+// The host-side add (until round 6 the only form; now the fall-back): every shard's partial vector comes back over its own
+// device's link into a host vector, and the host adds the vectors in shard order.
 static int mcsc_rows(rsp_mcsc_t h, double* out, bool means) try {
     if (!h || (h->nrow > 0 && !out)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
     if (!h->has_rows)
@@ -852,6 +1043,7 @@ static int mcsc_rows(rsp_mcsc_t h, double* out, bool means) try {
     const int G = (int)h->shards.size();
     const size_t nrow = (size_t)h->nrow;
     if (nrow == 0) return RSP_OK;
+    if (mcsc_rows_prepare(h)) return mcsc_rows_on_devices(h, out, means);
     // shards x nrow doubles for the duration of this call only (8 shards x 1e7 rows: 640 MB), so that the handle
     // holds no host memory between calls and two threads asking the same handle for row sums do not share a buffer
     std::vector<double> partial((size_t)G * nrow);

@@ -49,7 +49,7 @@ def main():
     rng = np.random.default_rng(seed)
     capi.load()
     t0 = last_note = time.time()
-    handles = calls = 0
+    handles = calls = row_handles = 0
     combos = {}
     while time.time() - t0 < seconds:
         p, x, fam = random_matrix(rng)
@@ -86,11 +86,37 @@ def main():
                                   "column": c, "bits_differ": bool(want_bits is not None and got.tobytes() != want_bits)}))
                 sys.exit(1)
         h.close()
+        # every fourth matrix also by row (round 6: the shards' partial vectors are added on the devices): against the scatter
+        # loop's sums, bit-stable, means = sums / ncol, and the SAME bits as the shards' own row sums added in shard order
+        if handles % 4 == 0 and len(x) > 0:
+            nr = int(rng.choice([7, 20_000, 70_000, 300_000]))
+            ii = np.sort(rng.integers(0, nr, size=len(x)).astype(np.int32))   # (any rows: the regrouping forms do not need them ascending per column)
+            hr = capi.MultiDeviceCSC(x, p, (nr, ncol), devices=[0] * G, i=ii)
+            rs, rs2, rm = hr.row_sums(), hr.row_sums(), hr.row_means()
+            hr.close()
+            rref = np.bincount(ii, weights=x, minlength=nr)
+            rscale = np.bincount(ii, weights=np.abs(x), minlength=nr)
+            bounds = capi.partition_columns(p, G)
+            blocked = None
+            for k in range(G):
+                c0, c1 = int(bounds[k]), int(bounds[k + 1])
+                if c1 == c0:
+                    continue
+                hk = capi.DeviceCSC(x[p[c0]:p[c1]], capi.rebase_offsets(p, c0, c1), (nr, c1 - c0), i=ii[p[c0]:p[c1]])
+                part = hk.row_sums()
+                hk.close()
+                blocked = part if blocked is None else blocked + part
+            rows_ok = (np.all(np.abs(rs - rref) <= 1e-12 * rscale) and rs.tobytes() == rs2.tobytes()
+                       and rm.tobytes() == (rs / ncol).tobytes() and (blocked is None or rs.tobytes() == (blocked + 0.0).tobytes()))
+            row_handles += 1
+            if not rows_ok:
+                print(json.dumps({"FAILED": "row sums", "family": fam, "shards": G, "nrow": nr}))
+                sys.exit(1)
         if time.time() - last_note > 60:
             last_note = time.time()
             print(f"[soak_mcsc] {int(last_note - t0)} s: {handles} handles, {calls} calls", file=sys.stderr, flush=True)
     threads = len(os.listdir(f"/proc/{os.getpid()}/task"))
-    print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "handles": handles, "calls_checked": calls,
+    print(json.dumps({"seconds": round(time.time() - t0, 1), "seed": seed, "handles": handles, "calls_checked": calls, "row_sum_handles_checked": row_handles,
                       "launch_gather_combinations": combos, "threads_alive_at_the_end": threads, "mismatches": 0}))
 
 
