@@ -922,6 +922,25 @@ static bool mcsc_rows_prepare(rsp_mcsc* h) {
             ok = false;
         }
     }
+    // the slices travel device to device: let every device reach the others directly where the hardware can (without it
+    // the runtime stages a peer copy through the host); what cannot be enabled simply stays staged
+    for (size_t a = 0; a < G && ok; ++a)
+        for (size_t b = 0; b < G; ++b) {
+            if (h->devices[a] == h->devices[b]) continue;
+            bool seen = false;   // (once per ordered pair of DEVICES, however many shards share them)
+            for (size_t a2 = 0; a2 <= a && !seen; ++a2)
+                for (size_t b2 = 0; b2 < (a2 == a ? b : G) && !seen; ++b2)
+                    seen = h->devices[a2] == h->devices[a] && h->devices[b2] == h->devices[b];
+            if (seen) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, h->devices[a], h->devices[b]) == hipSuccess && can &&
+                hipSetDevice(h->devices[a]) == hipSuccess) {
+                const hipError_t e = hipDeviceEnablePeerAccess(h->devices[b], 0);
+                if (e != hipSuccess) (void)hipGetLastError();   // (already enabled, or not to be had: either is fine)
+            } else {
+                (void)hipGetLastError();
+            }
+        }
     if (prev >= 0) (void)hipSetDevice(prev);
     if (!ok) {   // (what was made is released with the handle; the host-side add takes over for good)
         h->rows_failed = true;
