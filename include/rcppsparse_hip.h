@@ -243,8 +243,8 @@ int rsp_csc_free(rsp_csc_t handle);
  * NOTHING IN THESE ENTRIES WAITS FOR THE DEVICE.  A retired plan's image is given up when an event recorded on every
  * stream it was launched on has completed (looked at only while something is retired) -- given up, not freed: on this
  * runtime hipFree and hipHostFree drain every stream of the device first, so the allocation goes to a pool of at most 8
- * and the next plan that fits takes it (a re-inspection of the same key always fits; only a 9th dead image of a size
- * nobody asks for again is really freed, and that free waits).  A key keeps at most 2 retired images (beyond that it
+ * (and at most 1 GiB in all) and the next plan that fits takes it (a re-inspection of the same key always fits; only what
+ * overflows the pool -- dead images of sizes nobody asks for again -- is really freed, and that free waits).  A key keeps at most 2 retired images (beyond that it
  * stays on the general kernels until one is given up), so HBM use is bounded whatever the caller does with d_p.  Up to 16 keys are remembered per process; keys that never got a plan make room first, a planned key
  * only after 64 calls without a use (its plan is retired, not waited for).  One plan is launched on up to 6 different
  * streams; calls on further streams take the general kernels.  rsp_release_cached() forgets everything (it DOES wait).

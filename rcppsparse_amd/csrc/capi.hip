@@ -1052,6 +1052,7 @@ std::atomic<int> g_auto_recycled{0};                // ... of the made ones, how
 // there and then (the one place where a call of these entries can wait for the device; it takes more than kAutoPoolMax
 // dead images of sizes nobody asks for again)
 constexpr size_t kAutoPoolMax = 8;
+constexpr size_t kAutoPoolMaxBytes = (size_t)1 << 30;   // ... and at most 1 GiB of HBM in all (a larger image is kept alone)
 std::vector<PlanResources> g_plan_pool;
 
 // Another thread of the process may be capturing a stream in GLOBAL mode, which an allocation, an event query or a page-lock
@@ -1121,8 +1122,11 @@ void auto_plan_free(AutoPlan* ap, bool really_free = false) {
             plan_resources_free(r);
         } else if (r.device >= 0) {
             try {
-                if (g_plan_pool.size() >= kAutoPoolMax) {
-                    plan_resources_free(g_plan_pool.front());
+                size_t held = 0;
+                for (const PlanResources& q : g_plan_pool) held += q.d_mem_bytes;
+                while (!g_plan_pool.empty() && (g_plan_pool.size() >= kAutoPoolMax || held + r.d_mem_bytes > kAutoPoolMaxBytes)) {
+                    held -= g_plan_pool.front().d_mem_bytes;
+                    plan_resources_free(g_plan_pool.front());   // (the oldest: really freed, and that waits for the device)
                     g_plan_pool.erase(g_plan_pool.begin());
                 }
                 g_plan_pool.push_back(r);
