@@ -151,6 +151,11 @@ GLOSSARY = {
                                   "the devices: launch + wait only); dest pinned (the handle's vector) | pageable (a malloc'ed vector: "
                                   "what an R NumericVector is).  threads_last_enqueue_us: host clock from a call's entry to the return "
                                   "of the last shard's launch; config.devices_distinct false = a rehearsal on fewer cards than shards",
+    "roofline.mcsc8_*": "default N = 1 line: what the HOST adds to the single-process multi-GPU call (rsp_mcsc_column_sums: the path an R "
+                        "session reaches) -- eight shards of 131072 entries on this device (their kernels take microseconds: what is "
+                        "left of a call IS the host); <launch>_call_us = median wall time of a call, kernels_us = the shards' kernel "
+                        "times added up (each timed alone), <launch>_overhead_us = the difference, <launch>_last_enqueue_us = host clock "
+                        "until the last shard's launch was issued; launch serial | workers",
     "roofline.threads_*": "--parallelism ranks at N > 1: the figures of a `--parallelism threads` CHILD run over the same devices after "
                           "the ranks have finished (threads_value = its `value`); threads_error instead if the child failed",
     "cpu_baseline": "the oracle (kind port: restatement of reference src/example.cpp:26-32), 1 thread, on this box's host on "
@@ -1228,6 +1233,42 @@ def threads_child_figures(args, timeout_s=300):
     return res
 
 
+def mcsc_overhead_figure(torch, capi, synth, shards=8, shard_nnz=131072, shard_ncol=1024, calls=200):
+    """What the HOST adds to the single-process multi-GPU call (rsp_mcsc_column_sums, the path an R session reaches): `shards`
+    tiny shards resident on this device -- their kernels take a few microseconds, what is left of a call's wall time IS the
+    host (launches, events, wake-ups, waits).  Median wall time of `calls` calls minus the sum of the shards' kernel times
+    (each timed alone), in both launch modes; result left in the handle's page-locked vector, gather as the handle chooses."""
+    xs, ps = [], []
+    for k in range(shards):
+        counts = synth.uniform_counts(shard_ncol, shard_nnz, seed=SEED + k, nrow=1_000_000)
+        xt = torch.empty(shard_nnz, dtype=torch.float64, device="cuda")
+        capi.gen_values_device(xt, SEED, k * shard_nnz, 0)
+        xs.append(xt)
+        ps.append(torch.from_numpy(synth.offsets_from_counts(counts)).cuda())
+    torch.cuda.synchronize()
+    h = capi.MultiDeviceCSC.wrap_device(xs, ps, 1_000_000)
+    out = h.result_buffer()
+    kernels_us = sum(h.shard_kernel_ms(k, reps=20) for k in range(shards)) * 1e3
+    fig = {"mcsc8_kernels_us": kernels_us}
+    for launch in ("serial", "workers"):
+        h.set_launch(launch)
+        for _ in range(10):
+            h.column_sums(out=out)
+        wall, enq = [], []
+        for _ in range(calls):
+            h.column_sums(out=out)
+            st = h.last_call_stamps()
+            wall.append(st["call_us"])
+            enq.append(max(st["enqueued_us"]))
+        wall.sort()
+        enq.sort()
+        fig[f"mcsc8_{launch}_call_us"] = wall[len(wall) // 2]
+        fig[f"mcsc8_{launch}_overhead_us"] = wall[len(wall) // 2] - kernels_us
+        fig[f"mcsc8_{launch}_last_enqueue_us"] = enq[len(enq) // 2]
+    h.close()
+    return fig
+
+
 def make_communicator(env, counts, displs, recv, shard_ncol):
     """The C-ABI communicator (rsp_comm_*), checked with a trial gatherv of a known pattern.  If it
     cannot be created or delivers wrong data on any rank, EVERY rank switches to the same gatherv
@@ -1615,6 +1656,8 @@ def assemble_line(args, H, extras, devices=1, rehearsal=False, comm_rehearsal=No
     th = extras.get("threads")
     if th:
         roof.update(th)
+    if extras.get("mcsc"):
+        roof.update(extras["mcsc"])
     for name in ("planned_shards", "direct_gather", "host_gather", "pipelined"):
         fig = H.get(name)
         if fig and fig.get("value") is not None:
@@ -1772,6 +1815,13 @@ def main(argv=None):
                 extras["also"] = [also_record(torch, capi, spec, args, dev, dev_index, s_main,
                                               traffic_now=want_pass and spec in ALSO_TRAFFIC_NOW) for spec in specs]
                 extras["also_seconds"] = time.perf_counter() - t_also
+            if default_c3:
+                # (round 6) the host's share of the single-process multi-GPU call, measured by this very run: eight tiny shards
+                try:
+                    from rcppsparse_amd import synth
+                    extras["mcsc"] = mcsc_overhead_figure(torch, capi, synth)
+                except Exception as e:   # noqa: BLE001  (an extra figure never costs the line)
+                    extras["mcsc"] = {"mcsc8_error": str(e)[:100]}
     if world > 1:
         specs = (ALSO_SHARDED_AUTO if default_c3 and args.partition == "nnz" else ()) if args.also_sharded == "auto" else \
             tuple(t for t in args.also_sharded.split(",") if t and t != "none")

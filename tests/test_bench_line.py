@@ -68,10 +68,14 @@ def test_default_n1_line_fits_the_drivers_tail_and_carries_the_flat_scalars():
     extras = {"traffic": {"bytes": 8032627189.3, "in_run": True, "file": None, "read_bytes": 8020620928.0,
                           "write_bytes": 12148224.0, "seconds": 3.44},
               "read_ceiling": {"GBps": 6941.2, "ms_per_launch": 1.1525, "reps": 5},
-              "also": _also_records(), "also_seconds": 17.1, "cpu_baseline": CPU}
+              "also": _also_records(), "also_seconds": 17.1, "cpu_baseline": CPU,
+              "mcsc": {"mcsc8_kernels_us": 46.12345, "mcsc8_serial_call_us": 63.12345, "mcsc8_serial_overhead_us": 17.0123,
+                       "mcsc8_serial_last_enqueue_us": 24.51234, "mcsc8_workers_call_us": 53.12345,
+                       "mcsc8_workers_overhead_us": 7.012345, "mcsc8_workers_last_enqueue_us": 11.71234}}
     line = bench.assemble_line(_args(), _head(1), extras)
     text = json.dumps(line)
-    assert len(text) < bench.LINE_BYTES_MAX - 800, len(text)          # (headroom: real numbers print longer than round ones)
+    assert len(text) < bench.LINE_BYTES_MAX - 700, len(text)          # (headroom: real numbers print longer than round ones)
+    assert line["roofline"]["mcsc8_workers_overhead_us"] == pytest.approx(7.01235, rel=1e-5) and line["roofline"]["mcsc8_serial_call_us"] > 60
     roof = line["roofline"]
     # what the driver's record keeps: scalars of `roofline` -- every figure of the run has to be one
     for k in ("read_ceiling_GBps", "frac_of_ceiling", "traffic_over_algorithmic", "traffic_measured_in_run"):
