@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX: every soak of the repository (about 27 minutes in all, so in two calls: part 1, part 2); results under
+# Run ON THE GPU BOX: every soak of the repository (about 32 minutes in all, so in two calls: part 1, part 2); results under
 # gpurun_out/.  A step that fails or times out ends the call: no further GPU step is started after it.
 #   bash tools/soak_all.sh 1        bash tools/soak_all.sh 2
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out
@@ -20,4 +20,6 @@ else
   step 300 soak_all_autoplan.log python3 $R/tools/soak_auto_plan.py 150 5
   step 300 soak_all_hostpath.log python3 $R/tools/soak_host_path.py 150 5
   step 300 soak_all_autothreads.log python3 $R/tools/soak_auto_plan_threads.py 120 3 5
+  step 300 soak_all_mcsc.log python3 $R/tools/soak_mcsc.py 120 5
+  step 200 soak_all_rewrites.log python3 $R/tools/soak_auto_plan.py rewrites 10000
 fi
