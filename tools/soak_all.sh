@@ -11,6 +11,8 @@ step() {   # step <seconds> <log> <command...>
 if [ "${1:-1}" = "1" ]; then
   step 700 soak_all_fuzz.log python3 $R/tools/soak_fuzz.py --seconds 500 --mode mixed --seed 77
   step 300 soak_all_next.log python3 $R/tools/soak_fuzz.py --seconds 150 --what next --seed 78
+  step 300 soak_all_mcsc.log python3 $R/tools/soak_mcsc.py 120 5
+  step 200 soak_all_rewrites.log python3 $R/tools/soak_auto_plan.py rewrites 10000
 else
   step 400 soak_all_rowsums.log python3 $R/tools/soak_rowsums.py 200
   step 300 soak_all_segments.log python3 $R/tools/soak_row_segments.py 600 9
@@ -20,6 +22,4 @@ else
   step 300 soak_all_autoplan.log python3 $R/tools/soak_auto_plan.py 150 5
   step 300 soak_all_hostpath.log python3 $R/tools/soak_host_path.py 150 5
   step 300 soak_all_autothreads.log python3 $R/tools/soak_auto_plan_threads.py 120 3 5
-  step 300 soak_all_mcsc.log python3 $R/tools/soak_mcsc.py 120 5
-  step 200 soak_all_rewrites.log python3 $R/tools/soak_auto_plan.py rewrites 10000
 fi
