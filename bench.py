@@ -922,6 +922,101 @@ def host_gather_figure(ctx):
     return fig
 
 
+def rows_parity(got, p, nrow, ncol, kind):
+    """EVERY row of `got` against the oracle's scatter loop over the whole matrix (reference RcppSparse.h:138-144), column slab
+    after column slab in storage order: (max |gpu - ref| / sum|x| over the rows, rows out of the 1e-12 tolerance)."""
+    import numpy as np
+    import oracle
+    ref, scale = np.zeros(nrow), np.zeros(nrow)
+    p64 = np.asarray(p, dtype=np.int64)
+    c0 = 0
+    while c0 < ncol:
+        c1 = int(np.searchsorted(p64, p64[c0] + 40_000_000, side="right")) - 1
+        c1 = min(ncol, max(c1, c0 + 1))
+        lo, hi = int(p64[c0]), int(p64[c1])
+        if hi > lo:
+            xv = oracle.gen_values_threads(hi - lo, SEED, lo, kind, max(1, usable_cores()))
+            iv = oracle.gen_row_indices(p, nrow, SEED, c0, c1)
+            oracle.row_sums_accumulate(xv, iv, ref, scale)
+        c0 = c1
+    err = np.abs(got - ref)
+    nbad = int(np.count_nonzero(~(err <= 1e-12 * scale)))
+    nz = scale > 0
+    worst = float(np.max(err[nz] / scale[nz])) if nz.any() else 0.0
+    return worst, nbad
+
+
+def main_threads_rowsums(args):
+    """--op rowsums --parallelism threads: Matrix::rowSums through the single-process multi-GPU handle (rsp_mcsc_row_sums):
+    every shard sums the rows of its own columns, the partial vectors are added in shard order ON THE DEVICES (slices
+    exchanged device to device, one add kernel per device, reduced slices written into a page-locked host vector) and the
+    call returns when the nrow sums are in the caller's host vector.  Three regions of K synchronous calls, the median counts."""
+    import numpy as np
+    import torch
+    from rcppsparse_amd import capi, sharded
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    capi.load()
+    G = max(1, args.gpus)
+    ndev = torch.cuda.device_count()
+    devices = [k % ndev for k in range(G)]
+    nrow, ncol, nnz, shape, p = build_offsets(args.workload, args.nnz)
+    shards = [sharded.make_shard(p, k, G, balance=args.partition) for k in range(G)]
+    # the rows of the WHOLE matrix (the generator hashes the global element index), made once on device 0, dealt out
+    pg = torch.from_numpy(np.ascontiguousarray(p)).to("cuda:0")
+    i_all = torch.empty(nnz, dtype=torch.int32, device="cuda:0")
+    with torch.cuda.device(0):
+        capi.gen_row_indices_device(i_all, pg, nrow, SEED)
+        torch.cuda.synchronize()
+    xs, ps, its = [], [], []
+    for k, sh in enumerate(shards):
+        with torch.cuda.device(devices[k]):
+            d = f"cuda:{devices[k]}"
+            xt = torch.empty(max(sh.nnz, 2), dtype=torch.float64, device=d)[:sh.nnz]
+            if sh.nnz:
+                capi.gen_values_device(xt, SEED, sh.x0, args.kind)
+            xs.append(xt)
+            ps.append(torch.from_numpy(sh.p_local).to(d))
+            its.append(i_all[sh.x0:sh.x1].to(d, copy=True))
+            torch.cuda.synchronize()
+    del i_all, pg
+    torch.cuda.empty_cache()
+    h = capi.MultiDeviceCSC.wrap_device(xs, ps, nrow, i_ts=its)
+    h.row_sums()                                                    # (builds every shard's row form and the reduce's buffers)
+    out = np.empty(nrow, dtype=np.float64)
+    regions = []
+    for _ in range(args.warmup):
+        h.row_sums_into(out)
+    for _ in range(N_REGIONS_SMALL):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            h.row_sums_into(out)
+        regions.append((time.perf_counter() - t0) / args.steps * 1e3)
+    ms = sorted(regions)[len(regions) // 2]
+    worst, nbad = rows_parity(out, p, nrow, ncol, args.kind)
+    if nbad:
+        raise SystemExit(f"rowSums parity check failed (threads): {nbad} rows out of tolerance (worst {worst:.3e})")
+    forms = [h.shard_info(k)["form"] for k in range(G)]
+    h.close()
+    line = {"metric": "rowSums nnz/s (next row f1: Matrix::rowSums over column-range shards, shard-ordered reduce)",
+            "value": nnz / (ms * 1e-3), "unit": "nnz/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": sig({"workload": f"{args.workload}: {nrow}x{ncol} CSC dgCMatrix, nnz={nnz}, {shape} nnz/column, rows ascending "
+                                       f"and distinct per column (stratified), values kind {args.kind}, seed {SEED}",
+                           "op": "rowsums", "parallelism": "threads", "devices": ndev, "devices_distinct": len(set(devices)) == G,
+                           "reduce": "on the devices: peer copies of row slices + rows_add_partials_kernel, shard order",
+                           "result": "a pageable host vector of nrow doubles", "regions_ms": regions,
+                           "shards": [{"shard": k, "device": devices[k], "c0": sh.c0, "c1": sh.c1, "nnz": sh.nnz, "column_form": forms[k]}
+                                      for k, sh in enumerate(shards)]}),
+            "roofline": sig({"bound": "hbm", "achieved": (12 * nnz + 8 * nrow) / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS * len(set(devices)),
+                             "unit": "GB/s", "frac": (12 * nnz + 8 * nrow) / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * len(set(devices))),
+                             "traffic": None, "kernel": "the whole call (every shard's accumulate pass, the reduce, the result's way to the host)",
+                             "algorithmic_bytes_per_launch": 12 * nnz + 8 * nrow}),
+            "parity": {"max_abs_err_over_l1": worst, "tolerance": 1e-12, "rows_checked": "all", "nrow": nrow, "rows_out_of_tolerance": nbad},
+            "cpu_baseline": None}
+    print(json.dumps(line), flush=True)
+
+
 def main_rowsums(args):
     """bench.py --op rowsums: Matrix::rowSums (reference RcppSparse.h:138-144) over column-range shards.  A step = every rank
     sums the rows of its own columns (rsp_row_sums_device: nrow doubles) and the partial vectors are reduced IN RANK ORDER to
@@ -1020,24 +1115,7 @@ def main_rowsums(args):
     out = None
     if rank == 0:
         got = result.cpu().numpy()
-        # the oracle's scatter loop over the whole matrix, column slab after column slab in storage order
-        import oracle
-        ref, scale = np.zeros(nrow), np.zeros(nrow)
-        p64 = np.asarray(p, dtype=np.int64)
-        c0 = 0
-        while c0 < ncol:
-            c1 = int(np.searchsorted(p64, p64[c0] + 40_000_000, side="right")) - 1
-            c1 = min(ncol, max(c1, c0 + 1))
-            lo, hi = int(p64[c0]), int(p64[c1])
-            if hi > lo:
-                xv = oracle.gen_values_threads(hi - lo, SEED, lo, args.kind, max(1, usable_cores()))
-                iv = oracle.gen_row_indices(p, nrow, SEED, c0, c1)
-                oracle.row_sums_accumulate(xv, iv, ref, scale)
-            c0 = c1
-        err = np.abs(got - ref)
-        nbad = int(np.count_nonzero(~(err <= 1e-12 * scale)))
-        nz = scale > 0
-        worst = float(np.max(err[nz] / scale[nz])) if nz.any() else 0.0
+        worst, nbad = rows_parity(got, p, nrow, ncol, args.kind)
         if nbad:
             raise SystemExit(f"rowSums parity check failed: {nbad} rows out of tolerance (worst {worst:.3e})")
         # one rank's launch: reads its x and i (12 B per entry), writes nrow sums
@@ -1735,7 +1813,7 @@ def main(argv=None):
     if args.peer_probe:
         sys.exit(peer_probe(args))
     if args.parallelism == "threads":
-        return main_threads(args)
+        return main_threads_rowsums(args) if args.op == "rowsums" else main_threads(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 

@@ -418,6 +418,11 @@ class MultiDeviceCSC:
     def row_sums(self) -> np.ndarray:
         return self._out(load().rsp_mcsc_row_sums, self.nrow)
 
+    def row_sums_into(self, out: np.ndarray) -> np.ndarray:
+        """rsp_mcsc_row_sums into a caller's float64 vector of nrow entries (no allocation per call)."""
+        _check(load().rsp_mcsc_row_sums(self._h, _dp(out)))
+        return out
+
     def row_means(self) -> np.ndarray:
         return self._out(load().rsp_mcsc_row_means, self.nrow)
 

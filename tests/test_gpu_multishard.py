@@ -581,3 +581,18 @@ def test_bench_parallelism_threads_line(torch_cuda, gpus, workload):
         assert roof[f"threads_serial_{g0}_pinned_ms" if cfg["launch"] == "workers" else f"threads_workers_{g0}_pinned_ms"] > 0
     if workload == "c4shard":
         assert all(s["form"] == "columns" for s in cfg["shards"]) and 0.2 < roof["frac"] < 1.0
+
+
+@pytest.mark.parametrize("gpus", [1, 3])
+def test_bench_rowsums_through_the_single_process_handle(torch_cuda, gpus):
+    """`bench.py --op rowsums --parallelism threads`: Matrix::rowSums (reference RcppSparse.h:138-144) through rsp_mcsc_row_sums --
+    every shard's partial vector added in shard order ON THE DEVICES (round 6), the result in a host vector; every row against
+    the oracle's scatter loop over the whole matrix."""
+    torch_cuda.cuda.empty_cache()
+    d = _run_bench("--op", "rowsums", "--parallelism", "threads", "--gpus", str(gpus), "--workload", "tinyu", "--steps", "4",
+                   "--warmup", "1")
+    assert d["metric"].startswith("rowSums") and d["n_gpus"] == gpus and d["config"]["parallelism"] == "threads"
+    assert d["config"]["op"] == "rowsums" and len(d["config"]["shards"]) == gpus and len(d["config"]["regions_ms"]) == 3
+    par = d["parity"]
+    assert par["rows_checked"] == "all" and par["rows_out_of_tolerance"] == 0 and par["max_abs_err_over_l1"] <= RTOL
+    assert d["value"] == pytest.approx(4_000_000 / (d["ms_per_step"] * 1e-3), rel=1e-9)
