@@ -123,6 +123,9 @@ int rsp_column_sums_host_multi(const double *x, const int32_t *p, int32_t ncol,
  * Every combination returns the bits of the per-shard device calls (the same launches over the same data).
  * `sums` may be rsp_mcsc_result_buffer(handle) -- the page-locked vector itself, ncol doubles, valid until the next
  * call on the handle or its release: then nothing is copied on the host at all.
+ * fork(): a child process (R's parallel::mclapply) inherits the handle's pointer but neither its worker threads nor a
+ * usable GPU context; the handle's entries fail there with RSP_ERR_BAD_ARG and a message (they do not hang), and
+ * rsp_mcsc_free in the child releases nothing of the parent's.
  */
 typedef struct rsp_mcsc *rsp_mcsc_t;
 #define RSP_GATHER_D2H     0

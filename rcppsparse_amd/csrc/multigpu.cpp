@@ -285,6 +285,9 @@ struct rsp_mcsc {
     double* h_rows = nullptr;        // page-locked, nrow doubles: the add kernels write their reduced slices straight into it
     double* d_rows_view = nullptr;   // ... as the devices address it (nullptr: the slices come home by a copy instead)
     bool rows_ready = false, rows_failed = false;
+    // R code forks (parallel::mclapply): a child inherits this pointer but neither the worker threads nor a usable GPU context.
+    // A call there must fail with a message, not wait for threads that do not exist.
+    pid_t owner = getpid();
 };
 
 namespace {
@@ -478,6 +481,7 @@ extern "C" {
 
 int rsp_mcsc_free(rsp_mcsc_t h) {
     if (!h) return RSP_OK;
+    if (h->owner != getpid()) return RSP_OK;   // (a forked child: nothing here is its to release; the parent's copy lives on)
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) {
         (void)hipGetLastError();
@@ -713,6 +717,9 @@ double* rsp_mcsc_result_buffer(rsp_mcsc_t h) { return h ? h->h_result : nullptr;
 
 static int mcsc_columns(rsp_mcsc_t h, double* sums, bool means) {
     if (!h || (h->ncol > 0 && !sums)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
+    if (h->owner != getpid())
+        return fail(RSP_ERR_BAD_ARG, "this handle was made by process %d and does not survive a fork (neither its threads nor the GPU context do): "
+                                     "make the handle in the process that uses it", (int)h->owner);
     const int G = (int)h->shards.size();
     h->t_call_begin = now_us();
     if (h->ncol == 0) {
@@ -1059,6 +1066,9 @@ static int mcsc_rows(rsp_mcsc_t h, double* out, bool means) try {
     if (!h || (h->nrow > 0 && !out)) return fail(RSP_ERR_BAD_ARG, "null handle or output");
     if (!h->has_rows)
         return fail(RSP_ERR_BAD_ARG, "this handle was uploaded without i[]: use rsp_mcsc_upload_csc for the row-wise entries");
+    if (h->owner != getpid())
+        return fail(RSP_ERR_BAD_ARG, "this handle was made by process %d and does not survive a fork: make the handle in the process that uses it",
+                    (int)h->owner);
     const int G = (int)h->shards.size();
     const size_t nrow = (size_t)h->nrow;
     if (nrow == 0) return RSP_OK;

@@ -199,3 +199,39 @@ def test_two_handles_from_two_threads_and_many_calls(torch_cuda):
     assert not errors, errors
     # the threads of both handles are gone again (nothing of a closed handle stays behind)
     assert nthreads() <= before
+
+
+def test_a_forked_child_gets_an_error_not_a_hang(torch_cuda):
+    """R code forks (parallel::mclapply).  A child inherits the handle's pointer but neither its parked worker threads nor a
+    usable GPU context: a call there must come back with a message at once -- before round 6's fix it would have waited for
+    threads that do not exist -- and releasing the handle in the child must leave the parent's alone."""
+    x, p, nrow, ncol = mixed_matrix(ncol=3000, nnz=300_000, nrow=50_000, seed=21)
+    h = capi.MultiDeviceCSC(x, p, (nrow, ncol), devices=[0] * 3)
+    h.set_launch("workers")
+    want = h.column_sums()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                             # the child: no GPU call of its own before this one
+        os.close(r)
+        msg = b"no error"
+        try:
+            h.column_sums()
+        except capi.RspError as e:
+            msg = str(e).encode()[:200]
+        except BaseException as e:   # noqa: BLE001
+            msg = ("other: " + repr(e)).encode()[:200]
+        try:
+            h.close()
+            os.write(w, msg)
+        finally:
+            os._exit(0)
+    os.close(w)
+    import select
+    ready, _, _ = select.select([r], [], [], 30)
+    assert ready, "the forked child did not answer within 30 s (it hangs)"
+    said = os.read(r, 400).decode()
+    os.close(r)
+    os.waitpid(pid, 0)
+    assert "does not survive a fork" in said, said
+    assert h.column_sums().tobytes() == want.tobytes()       # the parent's handle is untouched
+    h.close()
