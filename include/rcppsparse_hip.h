@@ -55,7 +55,10 @@ extern "C" {
 const char *rsp_version(void);
 /* Message of the last non-OK status returned on this thread ("" if none). */
 const char *rsp_last_error(void);
-/* Number of visible HIP devices; 0 (and RSP_OK) when there are none. */
+/* Number of visible HIP devices; 0 (and RSP_OK) when there are none -- and in a process that was FORKED from one that had
+ * already used the GPU through this library (R's parallel::mclapply): the HIP runtime does not survive a fork, so such a
+ * child is a machine without a device (the host entries answer RSP_ERR_NO_DEVICE without touching the runtime; the Rcpp
+ * layer above the ABI then runs the reference's loop on the host). */
 int rsp_device_count(int *count);
 
 /* ---- one-shot path: replaces reference src/example.cpp:28-30 ------------ */

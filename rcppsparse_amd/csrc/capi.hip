@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <unistd.h>
 
 #include "../../include/rcppsparse_hip.h"
 #include "colsums_kernels.h"
@@ -295,7 +296,22 @@ int check_offsets_host(const int32_t* p, int32_t ncol, int64_t nnz) {
     return RSP_OK;
 }
 
+// R code forks (parallel::mclapply).  A child of a process that has used the HIP runtime inherits neither a usable GPU context
+// nor the runtime's threads; its calls into the runtime may hang.  The host entries therefore remember which process first asked
+// for a device, and answer "no device" in a forked child: the Rcpp layer above the ABI then takes its host loop (the
+// reference's own), exactly as on a machine without a GPU -- a child never touches the runtime at all.
+std::atomic<long> g_hip_pid{0};
+bool forked_child() {
+    const long me = (long)getpid();
+    long seen = g_hip_pid.load(std::memory_order_relaxed);
+    if (seen == 0 && g_hip_pid.compare_exchange_strong(seen, me, std::memory_order_relaxed)) return false;
+    return seen != me;
+}
+
 int require_device(int device) {
+    if (forked_child())
+        return fail(RSP_ERR_NO_DEVICE, "this process was forked from one that had already used the GPU (pid %ld): the HIP runtime does "
+                                       "not survive a fork -- no device here", g_hip_pid.load(std::memory_order_relaxed));
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -450,6 +466,10 @@ const char* rsp_last_error(void) { return g_err; }
 
 int rsp_device_count(int* count) {
     if (!count) return fail(RSP_ERR_BAD_ARG, "count is null");
+    if (forked_child()) {   // (a child of a process that used the runtime: see forked_child)
+        *count = 0;
+        return RSP_OK;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) {
@@ -561,6 +581,7 @@ static int auto_enqueue(const double* d_x, const int32_t* d_p, int32_t ncol, int
 
 }  // extern "C"
 namespace rsp {
+bool process_was_forked_after_gpu_use() { return forked_child(); }   // (multigpu.cpp's host entries ask too)
 // the general kernels, no planning: for the library's own one-shot paths (multigpu.cpp: rsp_column_sums_host_multi sees new
 // offsets at a fresh address in every call -- nothing to remember)
 int column_sums_general(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,

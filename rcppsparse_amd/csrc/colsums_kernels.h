@@ -106,6 +106,8 @@ hipError_t fold_ticket_address(int slot, uint32_t** out);
 // n doubles from HBM into page-locked host memory (its device address) by a kernel, enqueued on `stream`
 hipError_t launch_copy_f64(const double* d_src, double* dst, int64_t n, hipStream_t stream);
 
+// true in a process forked from one that had already asked this library for a device (the HIP runtime does not survive a fork)
+bool process_was_forked_after_gpu_use();
 // rsp_column_sums_device without the entry's own planning (capi.hip): the library's one-shot paths use it
 int column_sums_general(const double* d_x, const int32_t* d_p, int32_t ncol, int64_t nnz, double* d_out, void* d_ws,
                         size_t ws_bytes, hipStream_t stream);

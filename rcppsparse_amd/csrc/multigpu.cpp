@@ -114,6 +114,8 @@ int rsp_column_sums_host_multi(const double* x, const int32_t* p, int32_t ncol, 
     if (!p || (nnz > 0 && !x) || (ncol > 0 && !sums) || ncol < 0 || nnz < 0)
         return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_column_sums_host_multi");
     int visible = 0;
+    if (rsp::process_was_forked_after_gpu_use())
+        return fail(RSP_ERR_NO_DEVICE, "this process was forked from one that had already used the GPU: the HIP runtime does not survive a fork");
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
         (void)hipGetLastError();
         return fail(RSP_ERR_NO_DEVICE, "no HIP device available");
@@ -515,6 +517,8 @@ static int mcsc_upload(const double* x, const int32_t* i, const int32_t* p, int3
     *handle = nullptr;
     if (!p || (nnz > 0 && !x) || ncol < 0 || nnz < 0) return fail(RSP_ERR_BAD_ARG, "bad argument to rsp_mcsc_upload");
     int visible = 0;
+    if (rsp::process_was_forked_after_gpu_use())
+        return fail(RSP_ERR_NO_DEVICE, "this process was forked from one that had already used the GPU: the HIP runtime does not survive a fork");
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
         (void)hipGetLastError();
         return fail(RSP_ERR_NO_DEVICE, "no HIP device available");

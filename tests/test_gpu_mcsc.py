@@ -235,3 +235,42 @@ def test_a_forked_child_gets_an_error_not_a_hang(torch_cuda):
     assert "does not survive a fork" in said, said
     assert h.column_sums().tobytes() == want.tobytes()       # the parent's handle is untouched
     h.close()
+
+
+def test_a_forked_child_is_a_machine_without_a_device(torch_cuda):
+    """The HIP runtime does not survive a fork.  A child of a process that has used the GPU through this library sees no
+    device at the C ABI (rsp_device_count = 0, the host entries RSP_ERR_NO_DEVICE with a message, without touching the runtime)
+    -- which is what lets the Rcpp layer above the ABI answer on the host in an mclapply child, as on a machine without a GPU.
+    The parent is unaffected."""
+    assert capi.device_count() >= 1
+    x, p = np.array([1.0, 2.0, 4.0]), np.array([0, 1, 3], dtype=np.int32)
+    assert capi.column_sums_host(x, p).tolist() == [1.0, 6.0]
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.close(r)
+        said = []
+        try:
+            said.append(f"count={capi.device_count()}")
+            for fn in (lambda: capi.column_sums_host(x, p), lambda: capi.column_sums_host_multi(x, p, devices=[0]),
+                       lambda: capi.DeviceCSC(x, p, (5, 2)), lambda: capi.MultiDeviceCSC(x, p, (5, 2), devices=[0])):
+                try:
+                    fn()
+                    said.append("answered")
+                except capi.RspError as e:
+                    said.append(f"code={e.code} fork={'fork' in str(e)}")
+        except BaseException as e:   # noqa: BLE001
+            said.append("other: " + repr(e)[:80])
+        try:
+            os.write(w, ";".join(said).encode())
+        finally:
+            os._exit(0)
+    os.close(w)
+    import select
+    ready, _, _ = select.select([r], [], [], 30)
+    assert ready, "the forked child did not answer within 30 s"
+    said = os.read(r, 1000).decode()
+    os.close(r)
+    os.waitpid(pid, 0)
+    assert said == "count=0;" + ";".join([f"code={capi.RSP_ERR_NO_DEVICE} fork=True"] * 4), said
+    assert capi.device_count() >= 1 and capi.column_sums_host(x, p).tolist() == [1.0, 6.0]
