@@ -253,9 +253,25 @@ rsp::LaunchPlan make_plan(int64_t nnz, bool planned = false) {
 // The handle entries run on the handle's device: switch to it for the duration of the call and
 // put the calling thread's current device back on every exit path (a torch-hosting process
 // would otherwise find its later allocations on another GPU).
+// R code forks (parallel::mclapply).  A child of a process that has used the HIP runtime inherits neither a usable GPU context
+// nor the runtime's threads; its calls into the runtime may hang.  The host entries therefore remember which process first asked
+// for a device, and answer "no device" in a forked child: the Rcpp layer above the ABI then takes its host loop (the
+// reference's own), exactly as on a machine without a GPU -- a child never touches the runtime at all.
+std::atomic<long> g_hip_pid{0};
+bool forked_child() {
+    const long me = (long)getpid();
+    long seen = g_hip_pid.load(std::memory_order_relaxed);
+    if (seen == 0 && g_hip_pid.compare_exchange_strong(seen, me, std::memory_order_relaxed)) return false;
+    return seen != me;
+}
+
 class DeviceGuard {
 public:
     explicit DeviceGuard(int device) {
+        if (forked_child()) {   // (a handle carried across a fork: fail, do not enter a runtime that may hang)
+            err_ = hipErrorNoDevice;
+            return;
+        }
         if (hipGetDevice(&prev_) != hipSuccess) {
             (void)hipGetLastError();
             prev_ = -1;
@@ -294,18 +310,6 @@ int check_offsets_host(const int32_t* p, int32_t ncol, int64_t nnz) {
     if (p[ncol] != nnz)
         return fail(RSP_ERR_BAD_ARG, "p[ncol] = %d but nnz = %lld", p[ncol], (long long)nnz);
     return RSP_OK;
-}
-
-// R code forks (parallel::mclapply).  A child of a process that has used the HIP runtime inherits neither a usable GPU context
-// nor the runtime's threads; its calls into the runtime may hang.  The host entries therefore remember which process first asked
-// for a device, and answer "no device" in a forked child: the Rcpp layer above the ABI then takes its host loop (the
-// reference's own), exactly as on a machine without a GPU -- a child never touches the runtime at all.
-std::atomic<long> g_hip_pid{0};
-bool forked_child() {
-    const long me = (long)getpid();
-    long seen = g_hip_pid.load(std::memory_order_relaxed);
-    if (seen == 0 && g_hip_pid.compare_exchange_strong(seen, me, std::memory_order_relaxed)) return false;
-    return seen != me;
 }
 
 int require_device(int device) {
@@ -975,6 +979,7 @@ int rsp_column_sums_plan_info(rsp_colsums_plan_t plan, int32_t* info4, double* i
 
 int rsp_column_sums_plan_destroy(rsp_colsums_plan_t plan) {
     if (!plan) return RSP_OK;
+    if (forked_child()) return RSP_OK;   // (the parent's, see rsp_csc_free)
     if (plan->device_built) {   // (records and images live inside d_mem)
         DeviceGuard on(plan->device);
         if (plan->ev_end) (void)hipEventSynchronize(plan->ev_end);   // the inspection may still be writing
@@ -1754,6 +1759,7 @@ int rsp_gen_row_indices_device(int32_t* d_i, const int32_t* d_p, int32_t nrow, i
 
 int rsp_csc_free(rsp_csc_t h) {
     if (!h) return RSP_OK;
+    if (forked_child()) return RSP_OK;   // (a handle carried across a fork is the parent's: nothing to release here, no runtime to enter)
     DeviceGuard on(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->d_x && !h->borrowed) (void)hipFree(h->d_x);
@@ -2294,6 +2300,7 @@ void arena_release(OneShotArena& a) {   // caller holds a.mu and has made the de
 }  // namespace
 
 int rsp_release_cached(void) {
+    if (forked_child()) return RSP_OK;   // (what is cached belongs to the parent process's runtime)
     auto_release_all();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

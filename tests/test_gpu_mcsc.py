@@ -245,6 +245,7 @@ def test_a_forked_child_is_a_machine_without_a_device(torch_cuda):
     assert capi.device_count() >= 1
     x, p = np.array([1.0, 2.0, 4.0]), np.array([0, 1, 3], dtype=np.int32)
     assert capi.column_sums_host(x, p).tolist() == [1.0, 6.0]
+    carried = capi.DeviceCSC(x, p, (5, 2))                   # a single-device handle made BEFORE the fork
     r, w = os.pipe()
     pid = os.fork()
     if pid == 0:
@@ -253,7 +254,8 @@ def test_a_forked_child_is_a_machine_without_a_device(torch_cuda):
         try:
             said.append(f"count={capi.device_count()}")
             for fn in (lambda: capi.column_sums_host(x, p), lambda: capi.column_sums_host_multi(x, p, devices=[0]),
-                       lambda: capi.DeviceCSC(x, p, (5, 2)), lambda: capi.MultiDeviceCSC(x, p, (5, 2), devices=[0])):
+                       lambda: capi.DeviceCSC(x, p, (5, 2)), lambda: capi.MultiDeviceCSC(x, p, (5, 2), devices=[0]),
+                       lambda: carried.column_sums()):
                 try:
                     fn()
                     said.append("answered")
@@ -272,5 +274,8 @@ def test_a_forked_child_is_a_machine_without_a_device(torch_cuda):
     said = os.read(r, 1000).decode()
     os.close(r)
     os.waitpid(pid, 0)
-    assert said == "count=0;" + ";".join([f"code={capi.RSP_ERR_NO_DEVICE} fork=True"] * 4), said
+    want = "count=0;" + ";".join([f"code={capi.RSP_ERR_NO_DEVICE} fork=True"] * 4) + f";code={capi.RSP_ERR_HIP} fork=False"
+    assert said == want, said                                 # (the carried handle: an error from its device guard, no hang)
     assert capi.device_count() >= 1 and capi.column_sums_host(x, p).tolist() == [1.0, 6.0]
+    assert carried.column_sums().tolist() == [1.0, 6.0]      # the parent's handle is untouched
+    carried.close()
