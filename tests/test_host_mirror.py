@@ -265,3 +265,45 @@ def test_host_mirror_under_address_and_ub_sanitizers(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     assert "host selftest ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_in_a_forked_child_the_exported_columnSums_answers_on_the_host():
+    """R's parallel::mclapply forks, and the HIP runtime does not survive a fork.  Round 6: a child of a process that has used
+    the GPU is, to the C ABI, a machine without a device -- so the exported columnSums (the drop-in of reference
+    src/example.cpp:26-32) runs the reference's own loop on the host there, with the reference's bits, instead of entering a
+    runtime that may hang; with a GPU REQUIRED it is an R error.  The parent keeps its GPU."""
+    import select
+    m = synth.rsparsematrix(3000, 800, density=0.05, seed=77)
+    want = oracle.column_sums(m["x"], m["p"])
+    hostseam.columnSums_opt(m, require_gpu=1)
+    assert hostseam.backend(last=True) == "hip"                          # the parent has used the GPU
+    os_ = __import__("os")
+    r, w = os_.pipe()
+    pid = os_.fork()
+    if pid == 0:
+        os_.close(r)
+        said = "?"
+        try:
+            got = hostseam.columnSums_opt2(m, require_gpu=0, min_nnz=0)  # (the threshold would send this matrix to the device)
+            said = f"{hostseam.backend(last=True)};{got.tobytes() == want.tobytes()}"
+            try:
+                hostseam.columnSums_opt(m, require_gpu=1)
+                said += ";answered"
+            except Exception as e:   # noqa: BLE001
+                said += ";error" if "GPU" in str(e) or "device" in str(e) else ";other " + str(e)[:60]
+        except BaseException as e:   # noqa: BLE001
+            said = "failed: " + repr(e)[:100]
+        try:
+            os_.write(w, said.encode())
+        finally:
+            os_._exit(0)
+    os_.close(w)
+    ready, _, _ = select.select([r], [], [], 30)
+    assert ready, "the forked child did not answer within 30 s"
+    said = os_.read(r, 400).decode()
+    os_.close(r)
+    os_.waitpid(pid, 0)
+    assert said == "cpu;True;error", said
+    hostseam.columnSums_opt(m, require_gpu=1)
+    assert hostseam.backend(last=True) == "hip"                          # the parent still computes on its GPU
